@@ -1,0 +1,154 @@
+"""Pins the CPU oracle (oracle/mirage_oracle.py) against golden vectors produced by the reference
+itself (tools/gen_golden.py).  CPU only."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import mirage_oracle as O
+from conftest import load_golden
+
+
+def _t(a):
+    return torch.from_numpy(np.asarray(a))
+
+
+def _sub(t, n):
+    f = t.detach().reshape(-1)
+    step = max(1, f.numel() // n)
+    return f[::step][:n].numpy()
+
+
+def _run_case(name, check_inter=False, check_grads=True, rtol=2e-5):
+    fx, meta = load_golden(name)
+    cfg, B, K = meta["cfg"], meta["B"], meta["K"]
+    sd = {k: v.clone().requires_grad_(O.param_shapes(cfg)[k][1]) for k, v in O.procedural_state_dict(cfg).items()}
+    x = O.synthetic_batch(cfg, B, seed=meta["data_seed"])
+    # masks: bit-exact from the committed noise
+    tm, ids_keep, ids_restore = O.generate_masks_from_noise(fx["p"], [fx[f"u.{d}"] for d in cfg["in_domains"]], fx["g"], K)
+    assert np.array_equal(ids_keep, fx["ids_keep"])
+    assert np.array_equal(ids_restore, fx["ids_restore"])
+    for d, m in zip(cfg["in_domains"], tm):
+        assert np.array_equal(m, fx[f"task_mask.{d}"])
+    ids_keep, ids_restore = _t(ids_keep), _t(ids_restore)
+    if check_inter:
+        toks = O.input_tokens(cfg, sd, {d: x[d] for d in cfg["in_domains"]})
+        layout, T = O.token_layout(cfg)
+        for d, (s, e) in layout.items():
+            np.testing.assert_allclose(toks[:, s:e].detach().numpy(), fx[f"adapter.{d}"], rtol=rtol, atol=2e-5)
+        outs = O.encoder(cfg, sd, O.select_and_append_global(cfg, sd, toks, ids_keep), return_all=True)
+        for i, o in enumerate(outs):
+            np.testing.assert_allclose(o.detach().numpy(), fx[f"block.{i}"], rtol=rtol, atol=5e-5)
+    loss, ls, enc, preds = O.forward_loss(cfg, sd, x, ids_keep, ids_restore)
+    scale = float(np.abs(fx["enc_tokens"]).max()) if "enc_tokens" in fx else 20.0
+    if "enc_tokens" in fx:
+        np.testing.assert_allclose(enc.detach().numpy(), fx["enc_tokens"], rtol=1e-4, atol=1e-5 * scale)
+    else:
+        np.testing.assert_allclose(_sub(enc, 65536), fx["enc_tokens_sub"], rtol=1e-4, atol=1e-5 * scale)
+    assert abs(float(enc.detach().double().norm()) - float(fx["enc_tokens_norm"])) <= 1e-5 * float(fx["enc_tokens_norm"])
+    for d in cfg["out_domains"]:
+        assert abs(float(ls[d]) - float(fx[f"loss.{d}"])) <= 1e-5 * max(1.0, abs(float(fx[f"loss.{d}"])))
+        ps = float(np.abs(fx[f"pred_sub.{d}"]).max())
+        np.testing.assert_allclose(_sub(preds[d], 8192), fx[f"pred_sub.{d}"], rtol=1e-4, atol=2e-5 * ps)
+    assert abs(float(loss) - float(fx["loss"])) <= 1e-5 * abs(float(fx["loss"]))
+    if check_grads:
+        loss.backward()
+        names = [str(n) for n in fx["grad_names"]]
+        norms = fx["grad_norms"]
+        for n, gn in zip(names, norms):
+            g = sd[n].grad
+            assert g is not None, n
+            assert abs(float(g.double().norm()) - gn) <= 2e-4 * max(gn, 1e-6) + 1e-7, (n, float(g.double().norm()), gn)
+            if f"grad.{n}" in fx:
+                np.testing.assert_allclose(g.numpy(), fx[f"grad.{n}"], rtol=2e-3, atol=2e-5 * max(gn, 1e-3))
+        tot = float(torch.sqrt(sum((p.grad.double() ** 2).sum() for p in sd.values() if p.grad is not None)))
+        assert abs(tot - float(fx["grad_total_norm"])) <= 1e-4 * float(fx["grad_total_norm"])
+
+
+def test_tiny3_forward_backward():
+    _run_case("tiny3", check_inter=True)
+
+
+def test_tiny2_forward_backward():
+    _run_case("tiny2", check_inter=True)
+
+
+def test_c2_base_full_size():
+    _run_case("c2_base")
+
+
+@pytest.mark.slow
+def test_c3_base_full_size():
+    _run_case("c3_base", check_grads=False)
+
+
+def test_posemb_quirk_and_tables():
+    fx, _ = load_golden("harness_tiny")
+    assert np.array_equal(O.sincos_posemb_2d(2, 3, 8).numpy(), fx["posemb.2x3x8"])
+    np.testing.assert_allclose(O.sincos_posemb_2d(16, 16, 768).numpy(), fx["posemb.16x16x768"], rtol=0, atol=1e-6)
+    np.testing.assert_allclose(O.sincos_posemb_2d(16, 16, 256).numpy(), fx["posemb.16x16x256"], rtol=0, atol=1e-6)
+
+
+def test_mask_generator_bit_exact():
+    fx, meta = load_golden("harness_tiny")
+    cfg = meta["cfg"]
+    for tag in ("0", "1", "2", "uni"):
+        tm, ik, ir = O.generate_masks_from_noise(fx[f"mask.{tag}.p"], [fx[f"mask.{tag}.u.{d}"] for d in cfg["in_domains"]],
+                                                 fx[f"mask.{tag}.g"], 24)
+        assert np.array_equal(ik, fx[f"mask.{tag}.ids_keep"])
+        assert np.array_equal(ir, fx[f"mask.{tag}.ids_restore"])
+        for d, m in zip(cfg["in_domains"], tm):
+            assert np.array_equal(m, fx[f"mask.{tag}.tm.{d}"])
+            assert m.dtype == np.int64
+        assert ((np.concatenate(tm, 1) == 0).sum(1) == 24).all()
+
+
+def test_schedules_groups_and_state_dict_layout():
+    fx, meta = load_golden("harness_tiny")
+    cfg = meta["cfg"]
+    np.testing.assert_allclose(O.cosine_scheduler(1e-4, 0.0, 10, 7, warmup_epochs=2), fx["sched.a"], rtol=1e-12)
+    np.testing.assert_allclose(O.cosine_scheduler(0.05, 0.05, 10, 7), fx["sched.b"], rtol=1e-12)
+    np.testing.assert_allclose(O.cosine_scheduler(2e-4, 1e-6, 6, 5, warmup_epochs=1, warmup_steps=3), fx["sched.c"], rtol=1e-12)
+    g = O.param_groups(cfg)
+    assert g["decay"] == [str(s) for s in fx["group.decay"]]
+    assert g["no_decay"] == [str(s) for s in fx["group.no_decay"]]
+    assert sorted(O.no_weight_decay_names(cfg)) == [str(s) for s in fx["no_weight_decay"]]
+    shapes = O.param_shapes(cfg)
+    ref_keys = [str(s) for s in fx["state_dict_keys"]]
+    assert sorted(shapes.keys()) == sorted(ref_keys)
+    import json
+    for k, s in zip(ref_keys, fx["state_dict_shapes"]):
+        assert list(shapes[k][0]) == json.loads(str(s)), k
+    assert sorted(n for n, (s, t) in shapes.items() if t) == sorted(str(s) for s in fx["trainable"])
+
+
+def test_train_curve_five_steps():
+    fx, meta = load_golden("tiny3_curve")
+    cfg, B, K, steps = meta["cfg"], meta["B"], meta["K"], meta["steps"]
+    batches, masks = [], []
+    for it in range(steps):
+        batches.append(O.synthetic_batch(cfg, B, seed=500 + it))
+        _, ik, ir = O.generate_masks_from_noise(fx[f"p.{it}"], [fx[f"u.{it}.{d}"] for d in cfg["in_domains"]], fx[f"g.{it}"], K)
+        masks.append((_t(ik), _t(ir)))
+    curve, norms, final = O.train_steps(cfg, O.procedural_state_dict(cfg), batches, masks, fx["lrs"], fx["wds"])
+    np.testing.assert_allclose(curve, fx["curve"], rtol=2e-4)
+    np.testing.assert_allclose(norms, fx["grad_norms"], rtol=2e-3)
+    for n, gn in zip(fx["final_names"], fx["final_norms"]):
+        # k-bias gradients are exactly zero in exact arithmetic (softmax shift invariance), so Adam turns
+        # their roundoff noise into +-lr steps: allow lr*steps*sqrt(numel) of drift on every tensor.
+        slack = 1e-4 * max(gn, 1e-3) + 5 * 1e-3 * float(final[str(n)].numel()) ** 0.5 * 0.2
+        assert abs(float(final[str(n)].double().norm()) - gn) <= slack, n
+
+
+def test_cls_pooled_features():
+    for name in ("tiny_cls",):
+        fx, meta = load_golden(name)
+        cfg, B = meta["cfg"], meta["B"]
+        sd = O.procedural_state_dict(cfg)
+        d = cfg["in_domains"][0]
+        x = O.synthetic_batch(cfg, B, seed=meta["data_seed"])[d]
+        D = cfg["dim"]
+        nw = torch.from_numpy(1.0 + 0.2 * O.procedural_uniform("cls.norm.weight", D))
+        nb = torch.from_numpy(0.04 * O.procedural_uniform("cls.norm.bias", D))
+        with torch.no_grad():
+            pooled = O.cls_global_features(cfg, sd, x, nw, nb)
+        np.testing.assert_allclose(pooled.numpy(), fx["pooled"], rtol=1e-4, atol=2e-5)

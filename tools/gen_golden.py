@@ -1,0 +1,349 @@
+#!/usr/bin/env python3
+"""Generate golden vectors by running the REFERENCE implementation (imported from /root/reference).
+
+Runs only in the build container (the reference never travels).  Outputs small .npz fixtures under
+tests/golden/ that pin the oracle (oracle/mirage_oracle.py) and, through it, the HIP path.
+Nothing from the reference's source text is written to the fixtures -- only numeric inputs/outputs.
+
+    python tools/gen_golden.py            # regenerates every fixture (about a minute on 8 cores)
+"""
+import json
+import os
+import sys
+
+sys.dont_write_bytecode = True
+REF = os.environ.get("MIRAGE_REFERENCE", "/root/reference")
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REF)
+sys.path.insert(0, ROOT)
+
+import argparse
+import contextlib
+import io
+import types
+
+import numpy as np
+import torch
+from torch.distributions.dirichlet import Dirichlet
+
+from oracle import mirage_oracle as O  # config + procedural weights + synthetic data (NOT the math under test)
+
+with contextlib.redirect_stdout(io.StringIO()):
+    from mirage.model import MIRAGEModel
+    from mirage.input_adapters import PatchedInputAdapter, SemSegInputAdapter
+    from mirage.output_adapters import SpatialOutputAdapter
+    from mirage.criterion import MaskedMSELoss, MaskedCrossEntropyLoss
+    from mirage.utils import build_2d_sincos_posemb
+    from mutils.native_scaler import cosine_scheduler, get_grad_norm_
+    from mutils.optim_factory import create_optimizer, get_parameter_groups
+    from mutils.pos_embed import interpolate_pos_embed
+
+OUT = os.path.join(ROOT, "tests", "golden")
+
+
+def build_reference(cfg):
+    """Adapters exactly as run_pretraining.py:380-403 builds them, model as mirage/model.py:43."""
+    args = types.SimpleNamespace()
+    args.input_size = {d: (c["image"], c["image"]) for d, c in cfg["domains"].items()}
+    args.grid_sizes = {d: [c["grid"], c["grid"]] for d, c in cfg["domains"].items()}
+    ia, oa = {}, {}
+    for d in cfg["in_domains"]:
+        c = cfg["domains"][d]
+        if c["kind"] == "semseg":
+            ia[d] = SemSegInputAdapter(num_classes=13, dim_class_emb=64, interpolate_class_emb=False, stride_level=1,
+                                       patch_size_full=(c["patch"], c["patch"]), image_size=(c["image"], c["image"]))
+        else:
+            ia[d] = PatchedInputAdapter(num_channels=1, stride_level=1, patch_size_full=(c["patch"], c["patch"]),
+                                        image_size=(c["image"], c["image"]))
+    for d in cfg["out_domains"]:
+        c = cfg["domains"][d]
+        oa[d] = SpatialOutputAdapter(num_channels=c["channels"], stride_level=1, patch_size_full=(c["patch"], c["patch"]),
+                                     dim_tokens=cfg["decoder_dim"], depth=cfg["decoder_depth"],
+                                     num_heads=cfg["decoder_heads"], use_task_queries=True, task=d,
+                                     context_tasks=list(cfg["in_domains"]), use_xattn=True,
+                                     image_size=(c["image"], c["image"]))
+    model = MIRAGEModel(args, input_adapters=ia, output_adapters=oa if cfg["out_domains"] else None,
+                        num_global_tokens=cfg["num_global_tokens"], dim_tokens=cfg["dim"], depth=cfg["depth"],
+                        num_heads=cfg["heads"])
+    return model
+
+
+def reference_losses(cfg):
+    fns = {}
+    for d in cfg["out_domains"]:
+        c = cfg["domains"][d]
+        if c["kind"] == "semseg":
+            fns[d] = MaskedCrossEntropyLoss(patch_size=(c["patch"], c["patch"]), stride=1, label_smoothing=0.0)
+        else:
+            fns[d] = MaskedMSELoss(patch_size=(c["patch"], c["patch"]), stride=1)
+    return fns
+
+
+def replay_mask_noise(cfg, B, seed, alphas=1.0):
+    """Draw the three random inputs of generate_random_masks in the reference's RNG order
+    (mirage/model.py:207,216,225) so they can be committed next to the reference's integer outputs."""
+    layout, T = O.token_layout(cfg)
+    torch.manual_seed(seed)
+    n = len(cfg["in_domains"])
+    p = Dirichlet(torch.Tensor([alphas] * n)).sample((B,))
+    u = [torch.rand(B, e - s) for (s, e) in layout.values()]
+    g = torch.rand(B, T)
+    return p.numpy(), [x.numpy() for x in u], g.numpy()
+
+
+def subsample(t, n=4096):
+    f = t.detach().reshape(-1)
+    step = max(1, f.numel() // n)
+    return f[::step][:n].numpy().copy(), step
+
+
+def run_case(name, cfg, B, K, data_seed, mask_seed, keep_intermediate=False, full_enc=True, with_grads=True):
+    print(f"== {name}: B={B} K={K}")
+    with contextlib.redirect_stdout(io.StringIO()):
+        model = build_reference(cfg)
+    sd = O.procedural_state_dict(cfg)
+    msg = model.load_state_dict(sd, strict=True)   # proves oracle.param_shapes == the reference's state_dict
+    model.train()
+    x = O.synthetic_batch(cfg, B, seed=data_seed)
+    x_in = {d: x[d] for d in cfg["in_domains"]}
+    p, u, g = replay_mask_noise(cfg, B, mask_seed)
+    fx = {"p": p, "g": g}
+    for d, ud in zip(cfg["in_domains"], u):
+        fx[f"u.{d}"] = ud
+
+    inter = {}
+    hooks = []
+    if keep_intermediate:
+        for d in cfg["in_domains"]:
+            hooks.append(model.input_adapters[d].register_forward_hook(
+                lambda m, i, o, d=d: inter.__setitem__(f"adapter.{d}", o.detach().numpy().copy())))
+        for i, blk in enumerate(model.encoder):
+            hooks.append(blk.register_forward_hook(
+                lambda m, i_, o, i=i: inter.__setitem__(f"block.{i}", o.detach().numpy().copy())))
+    captured = {}
+    if cfg["out_domains"]:
+        first = cfg["out_domains"][0]
+        orig = model.output_adapters[first].forward
+
+        def spy(encoder_tokens, input_info, ids_keep, ids_restore):
+            captured["enc"] = encoder_tokens
+            captured["ids_keep"] = ids_keep
+            captured["ids_restore"] = ids_restore
+            return orig(encoder_tokens=encoder_tokens, input_info=input_info, ids_keep=ids_keep, ids_restore=ids_restore)
+        model.output_adapters[first].forward = spy
+
+    torch.manual_seed(mask_seed)
+    with contextlib.redirect_stdout(io.StringIO()):
+        preds, task_masks = model(x_in, num_encoded_tokens=K, alphas=1.0, sample_tasks_uniformly=False)
+    for h in hooks:
+        h.remove()
+    enc = captured["enc"]
+    fx["ids_keep"] = captured["ids_keep"].numpy()
+    fx["ids_restore"] = captured["ids_restore"].numpy()
+    for d in cfg["in_domains"]:
+        fx[f"task_mask.{d}"] = task_masks[d].numpy()
+    if full_enc:
+        fx["enc_tokens"] = enc.detach().numpy()
+    else:
+        fx["enc_tokens_sub"], fx["enc_tokens_step"] = subsample(enc, 65536)
+    fx["enc_tokens_norm"] = np.float64(enc.detach().double().norm().item())
+    loss_fns = reference_losses(cfg)
+    task_losses = {d: loss_fns[d](preds[d].float(), x[d], mask=task_masks.get(d)) for d in preds}
+    loss = sum(task_losses.values())
+    for d, pr in preds.items():
+        fx[f"pred_sub.{d}"], fx[f"pred_step.{d}"] = subsample(pr, 8192)
+        fx[f"pred_norm.{d}"] = np.float64(pr.detach().double().norm().item())
+        fx[f"loss.{d}"] = np.float64(task_losses[d].item())
+    fx["loss"] = np.float64(loss.item())
+    for k, v in inter.items():
+        fx[k] = v
+    if with_grads:
+        loss.backward()
+        names, norms = [], []
+        for n_, p_ in model.named_parameters():
+            if p_.grad is None:
+                continue
+            names.append(n_)
+            norms.append(p_.grad.double().norm().item())
+            if p_.grad.numel() <= 4096:
+                fx[f"grad.{n_}"] = p_.grad.numpy().copy()
+            else:
+                fx[f"gradsub.{n_}"], _ = subsample(p_.grad, 2048)
+        fx["grad_names"] = np.array(names)
+        fx["grad_norms"] = np.array(norms, dtype=np.float64)
+        fx["grad_total_norm"] = np.float64(get_grad_norm_(model.parameters()).item())
+    fx["meta"] = np.array(json.dumps(dict(cfg=cfg, B=B, K=K, data_seed=data_seed, mask_seed=mask_seed)))
+    np.savez_compressed(os.path.join(OUT, f"{name}.npz"), **fx)
+    print(f"   loss={fx['loss']:.6f}  enc_norm={fx['enc_tokens_norm']:.4f}")
+    return model, x, (fx["ids_keep"], fx["ids_restore"])
+
+
+def run_train_curve(name, cfg, B, K, steps=5):
+    """5-step AdamW curve through the reference's optimizer factory + cosine schedules
+    (run_pretraining.py:496-515,683-742), fp32, no AMP."""
+    print(f"== {name}: train curve")
+    with contextlib.redirect_stdout(io.StringIO()):
+        model = build_reference(cfg)
+    model.load_state_dict(O.procedural_state_dict(cfg), strict=True)
+    model.train()
+    args = types.SimpleNamespace(opt="adamw", weight_decay=0.05, lr=1e-3, opt_eps=1e-8, opt_betas=[0.9, 0.95], momentum=0.9)
+    with contextlib.redirect_stdout(io.StringIO()):
+        opt = create_optimizer(args, model)
+        lrs = cosine_scheduler(args.lr, 0.0, epochs=steps, niter_per_ep=1, warmup_epochs=2)
+        wds = cosine_scheduler(0.05, 0.05, epochs=steps, niter_per_ep=1)
+    loss_fns = reference_losses(cfg)
+    fx = {"lrs": lrs, "wds": wds}
+    curve, norms = [], []
+    for it in range(steps):
+        for gr in opt.param_groups:
+            gr["lr"] = lrs[it] * gr["lr_scale"]
+            if gr["weight_decay"] > 0:
+                gr["weight_decay"] = wds[it]
+        x = O.synthetic_batch(cfg, B, seed=500 + it)
+        p, u, g = replay_mask_noise(cfg, B, 700 + it)
+        fx[f"p.{it}"] = p; fx[f"g.{it}"] = g
+        for d, ud in zip(cfg["in_domains"], u):
+            fx[f"u.{it}.{d}"] = ud
+        torch.manual_seed(700 + it)
+        with contextlib.redirect_stdout(io.StringIO()):
+            preds, masks = model({d: x[d] for d in cfg["in_domains"]}, num_encoded_tokens=K, alphas=1.0)
+        loss = sum(loss_fns[d](preds[d].float(), x[d], mask=masks.get(d)) for d in preds)
+        opt.zero_grad()
+        loss.backward()
+        norms.append(get_grad_norm_(model.parameters()).item())
+        opt.step()
+        curve.append(loss.item())
+    fx["curve"] = np.array(curve, dtype=np.float64)
+    fx["grad_norms"] = np.array(norms, dtype=np.float64)
+    names = [n for n, _ in model.named_parameters()]
+    fx["final_names"] = np.array(names)
+    fx["final_norms"] = np.array([p.detach().double().norm().item() for _, p in model.named_parameters()])
+    fx["final_global_tokens"] = model.global_tokens.detach().numpy().copy()
+    fx["meta"] = np.array(json.dumps(dict(cfg=cfg, B=B, K=K, steps=steps, lr=args.lr)))
+    np.savez_compressed(os.path.join(OUT, f"{name}.npz"), **fx)
+    print("   curve", curve)
+
+
+def run_harness_fixtures(cfg):
+    """Schedules, param groups, posemb quirk, mask generator on its own."""
+    fx = {}
+    with contextlib.redirect_stdout(io.StringIO()):
+        fx["sched.a"] = cosine_scheduler(1e-4, 0.0, 10, 7, warmup_epochs=2)
+        fx["sched.b"] = cosine_scheduler(0.05, 0.05, 10, 7)
+        fx["sched.c"] = cosine_scheduler(2e-4, 1e-6, 6, 5, warmup_epochs=1, warmup_steps=3)
+        model = build_reference(cfg)
+    # param groups by identity
+    id2name = {id(p): n for n, p in model.named_parameters()}
+    groups = get_parameter_groups(model, 0.05, model.no_weight_decay())
+    for gr in groups:
+        key = "decay" if gr["weight_decay"] > 0 else "no_decay"
+        fx[f"group.{key}"] = np.array([id2name[id(p)] for p in gr["params"]])
+    fx["no_weight_decay"] = np.array(sorted(model.no_weight_decay()))
+    fx["state_dict_keys"] = np.array(list(model.state_dict().keys()))
+    fx["state_dict_shapes"] = np.array([json.dumps(list(v.shape)) for v in model.state_dict().values()])
+    fx["trainable"] = np.array([n for n, p in model.named_parameters() if p.requires_grad])
+    # posemb (incl. the non-square axis quirk)
+    fx["posemb.2x3x8"] = build_2d_sincos_posemb(2, 3, 8).numpy()
+    fx["posemb.16x16x768"] = build_2d_sincos_posemb(16, 16, 768).numpy()
+    fx["posemb.16x16x256"] = build_2d_sincos_posemb(16, 16, 256).numpy()
+    # pos-embed checkpoint resampler (mutils/pos_embed.py): 8x8 -> 4x4? use model grid vs a 2x finer table
+    D = cfg["dim"]; gsz = cfg["domains"][cfg["in_domains"][0]]["grid"]
+    ck = {f"input_adapters.{cfg['in_domains'][0]}.pos_emb": build_2d_sincos_posemb(2 * gsz, 2 * gsz, D)}
+    fx["posemb_resample.in"] = ck[f"input_adapters.{cfg['in_domains'][0]}.pos_emb"].numpy().copy()
+    with contextlib.redirect_stdout(io.StringIO()):
+        interpolate_pos_embed(model, ck)
+    fx["posemb_resample.out"] = ck[f"input_adapters.{cfg['in_domains'][0]}.pos_emb"].numpy()
+    # mask generator alone, several seeds, both sampling modes
+    layout, T = O.token_layout(cfg)
+    for seed in (0, 1, 2):
+        B, K = 8, 24
+        p, u, g = replay_mask_noise(cfg, B, seed)
+        toks = {d: torch.zeros(B, e - s, 1) for d, (s, e) in layout.items()}
+        torch.manual_seed(seed)
+        with contextlib.redirect_stdout(io.StringIO()):
+            tm, ik, ir = model.generate_random_masks(toks, K, alphas=1.0, sample_tasks_uniformly=False)
+        fx[f"mask.{seed}.p"] = p; fx[f"mask.{seed}.g"] = g
+        for d, ud in zip(cfg["in_domains"], u):
+            fx[f"mask.{seed}.u.{d}"] = ud
+            fx[f"mask.{seed}.tm.{d}"] = tm[d].numpy()
+        fx[f"mask.{seed}.ids_keep"] = ik.numpy(); fx[f"mask.{seed}.ids_restore"] = ir.numpy()
+    # uniform task pre-sampling (model.py:145-166,205): capture alphas -> Dirichlet sample
+    torch.manual_seed(5)
+    B, K = 8, 24
+    al = model.sample_alphas(B, len(cfg["in_domains"]), alphas=[1.0] * len(cfg["in_domains"]))
+    fx["mask.uni.alphas"] = al.numpy()
+    p = Dirichlet(al).sample()
+    u = [torch.rand(B, e - s) for (s, e) in layout.values()]
+    g = torch.rand(B, T)
+    torch.manual_seed(5)
+    toks = {d: torch.zeros(B, e - s, 1) for d, (s, e) in layout.items()}
+    with contextlib.redirect_stdout(io.StringIO()):
+        tm, ik, ir = model.generate_random_masks(toks, K, alphas=1.0, sample_tasks_uniformly=True)
+    fx["mask.uni.p"] = p.numpy(); fx["mask.uni.g"] = g.numpy()
+    for d, ud in zip(cfg["in_domains"], u):
+        fx[f"mask.uni.u.{d}"] = ud.numpy()
+        fx[f"mask.uni.tm.{d}"] = tm[d].numpy()
+    fx["mask.uni.ids_keep"] = ik.numpy(); fx["mask.uni.ids_restore"] = ir.numpy()
+    fx["meta"] = np.array(json.dumps(dict(cfg=cfg)))
+    np.savez_compressed(os.path.join(OUT, "harness_tiny.npz"), **fx)
+    print("== harness fixtures written")
+
+
+def run_cls_case(name, cfg, B):
+    """Encoder-only feature path (mirage_wrapper.py:208-224 restated around the reference model):
+    model(x, mask_inputs=False) -> LayerNorm -> mean over patch tokens.  Order-invariant pooled output."""
+    print(f"== {name}: encoder-only pooled features")
+    cfg = dict(cfg); cfg["out_domains"] = []
+    with contextlib.redirect_stdout(io.StringIO()):
+        model = build_reference(cfg)
+    sd = O.procedural_state_dict(cfg)
+    model.load_state_dict(sd, strict=True)
+    model.eval()
+    d = cfg["in_domains"][0]
+    x = O.synthetic_batch(cfg, B, seed=4321)[d]
+    D = cfg["dim"]
+    nw = torch.from_numpy(1.0 + 0.2 * O.procedural_uniform("cls.norm.weight", D))
+    nb = torch.from_numpy(0.04 * O.procedural_uniform("cls.norm.bias", D))
+    torch.manual_seed(3)
+    with torch.no_grad(), contextlib.redirect_stdout(io.StringIO()):
+        out, _ = model({d: x}, mask_inputs=False)
+        out = torch.nn.functional.layer_norm(out, (D,), nw, nb, 1e-6)
+        pooled = out[:, :-cfg["num_global_tokens"], :].mean(dim=1)
+        glob = out[:, -cfg["num_global_tokens"]:, :].mean(dim=1)
+    np.savez_compressed(os.path.join(OUT, f"{name}.npz"), pooled=pooled.numpy(), global_=glob.numpy(),
+                        meta=np.array(json.dumps(dict(cfg=cfg, B=B, data_seed=4321))))
+
+
+def tiny_cfg(in_domains, out_domains=None):
+    return O.make_config(model="tiny", in_domains=in_domains, out_domains=out_domains, input_size=64, patch_size=8,
+                         layermap_size=16, layermap_patch=2, decoder_dim=64, decoder_depth=2, decoder_heads=2,
+                         dim=128, depth=2, heads=2)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--only", default="")
+    a = ap.parse_args()
+    os.makedirs(OUT, exist_ok=True)
+    torch.set_num_threads(8)
+    three = ("bscan", "slo", "bscanlayermap")
+    jobs = {
+        "tiny3": lambda: run_case("tiny3", tiny_cfg(three), B=3, K=24, data_seed=11, mask_seed=21, keep_intermediate=True),
+        "tiny2": lambda: run_case("tiny2", tiny_cfg(("bscan", "slo")), B=2, K=32, data_seed=12, mask_seed=22, keep_intermediate=True),
+        "tiny3_curve": lambda: run_train_curve("tiny3_curve", tiny_cfg(three), B=4, K=24, steps=5),
+        "harness": lambda: run_harness_fixtures(tiny_cfg(three)),
+        "tiny_cls": lambda: run_cls_case("tiny_cls", tiny_cfg(("bscan",)), B=3),
+        # BASELINE.json configs at their real shapes, small batch
+        "c2_base": lambda: run_case("c2_base", O.make_config("base", ("bscan", "slo")), B=2, K=128, data_seed=1234, mask_seed=31),
+        "c3_base": lambda: run_case("c3_base", O.make_config("base", three), B=2, K=98, data_seed=1234, mask_seed=32, full_enc=False),
+        "c4_large": lambda: run_case("c4_large", O.make_config("large", three), B=1, K=98, data_seed=1234, mask_seed=33, full_enc=False),
+        "c5_large_cls": lambda: run_cls_case("c5_large_cls", O.make_config("large", ("bscan",), out_domains=()), B=1),
+    }
+    for k, fn in jobs.items():
+        if a.only and k not in a.only.split(","):
+            continue
+        fn()
+
+
+if __name__ == "__main__":
+    main()
