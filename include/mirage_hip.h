@@ -1,0 +1,212 @@
+/* libmirage_hip.so: C ABI of the MI355X (gfx950) kernels behind the MIRAGE MultiMAE pretraining path.
+ *
+ * The reference (j-morano MIRAGE) has no native code and no FFI: its hot path is a chain of aten dispatches
+ * issued from Python nn.Modules.  Each entry point below replaces one group of those dispatches; the
+ * reference call site it stands in for is cited as file:line (paths relative to the reference tree).
+ * Host code (the mirage_amd python package, via ctypes) is the only caller; see INTEGRATION.md for the binding.
+ *
+ * Conventions
+ *   - every function returns int: 0 ok, <0 argument/shape error (mrg_last_error_string() has the text),
+ *     >0 a hipError_t from the launch.  Kernels are asynchronous on `stream` (a hipStream_t).
+ *   - all pointers are DEVICE pointers unless a parameter says "host".  The library owns no memory and
+ *     keeps no state besides the last error string: callers pass workspaces.
+ *   - "bf16" = raw bfloat16 bits (uint16_t), row-major, explicit leading dimensions in ELEMENTS.
+ *   - the library never calls hipSetDevice / hipDeviceSynchronize.
+ */
+#ifndef MIRAGE_HIP_H
+#define MIRAGE_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#ifndef __HIP__
+typedef struct ihipStream_t* hipStream_t;
+#endif
+
+#define MRG_ABI_VERSION 1
+
+enum { MRG_DT_BF16 = 0, MRG_DT_F32 = 1 };
+enum { MRG_OP_KCONTIG = 0, MRG_OP_KSTRIDED = 1 };
+enum { MRG_ACT_NONE = 0, MRG_ACT_GELU = 1, MRG_ACT_GELU_BWD = 2 };
+enum { MRG_LOSS_MSE = 0, MRG_LOSS_CE = 1 };
+#define MRG_MAX_DOMAINS 4
+
+int mrg_version(void);
+const char* mrg_last_error_string(void);
+
+/* ---------------------------------------------------------------------------------------------------
+ * GEMM with fused epilogue:  C[M,N] = A(MxK) * B(NxK)^T  (+bias) (act) (+add_tab) (+resid) ...
+ * Replaces nn.Linear forward (mirage/utils.py:155-157,177,186,209-212,221; output_adapters.py:272,288),
+ * the patch-embedding Conv2d as an im2col GEMM (mirage/input_adapters.py:101,229) and autograd's
+ * dgrad / wgrad `mm`s of all of them.
+ *   a_mode/b_mode  MRG_OP_KCONTIG: element (row,k) at P[row*ld + k];  MRG_OP_KSTRIDED: at P[k*ld + row].
+ *     forward  y = x W^T      : A = x  [M,K]  KCONTIG,  B = W [N,K] KCONTIG
+ *     dgrad    dx = dy W      : A = dy [M,N'] KCONTIG,  B = W [N',K'] KSTRIDED (ldb = K')
+ *     wgrad    dW = dy^T x    : A = dy [m,N'] KSTRIDED, B = x [m,K'] KSTRIDED, K = m (token count)
+ *   a_map   optional int32 gather: KCONTIG -> source row = a_map[row]; KSTRIDED -> source k-row = a_map[k]
+ *   b_map   same for B (KSTRIDED only)
+ *   m_dev   optional device int: effective M = min(M, *m_dev) (data-dependent per-domain token counts)
+ *   k_dev   optional device int: effective K = min(K, *k_dev)
+ *   C       bf16 or fp32 [M,N]; C2 optional bf16 copy; accumulate: fp32 C += result
+ *   bias    fp32 [N]; resid fp32 [M,N] added; act: GELU stores gelu(v) (and pre-activation v to aux_out),
+ *           GELU_BWD multiplies by gelu'(aux_in)
+ *   row_map optional int32 scatter of output rows; add_tab/add_row: v += add_tab[add_row[row]*ldt + col]
+ *           (positional-embedding add of the input adapters, mirage/input_adapters.py:104-108)
+ *   splitk  >1: partial sums to ws [splitk][M][N] fp32, then reduced (bias/accumulate epilogue only)
+ */
+typedef struct mrg_gemm_desc {
+    const void* A; const void* B;
+    int M, N, K, lda, ldb;
+    int a_mode, b_mode;
+    const int* a_map; const int* b_map;
+    const int* m_dev; const int* k_dev;
+    void* C; int ldc; int c_dtype;
+    void* C2; int ldc2;
+    const float* bias;
+    const float* resid; int ldr;
+    int accumulate;
+    int act;
+    void* aux_out; const void* aux_in; int ldaux;
+    const int* row_map;
+    const float* add_tab; const int* add_row; int ldt;
+    int splitk; float* ws;
+} mrg_gemm_desc;
+
+int mrg_gemm(const mrg_gemm_desc* d, hipStream_t stream);
+
+/* ---------------------------------------------------------------------------------------------------
+ * LayerNorm (eps passed by caller; the path uses 1e-6: mirage/model.py:57).  Replaces aten native_layer_norm
+ * and its backward (mirage/utils.py:260-261, mirage/output_adapters.py:279-280).
+ *   fwd: x fp32 [M,D] -> y bf16 and/or fp32, mean/rstd fp32 [M].  D % 4 == 0, D <= 1024.
+ *   bwd: dx = dres + LN'(dy); writes dx fp32 and/or bf16; dgamma/dbeta fp32 [D]; dres_colsum (optional) = column
+ *        sum of dres = bias gradient of the Linear whose output entered the residual stream.
+ *        partials: workspace fp32 [mrg_ln_bwd_nblocks(M)][3][D].
+ */
+int mrg_ln_fwd(const float* x, const float* gamma, const float* beta, void* y_bf16, float* y_f32, float* mean, float* rstd,
+               int M, int D, float eps, hipStream_t stream);
+int mrg_ln_bwd_nblocks(int M);
+int mrg_ln_bwd(const void* dy_bf16, const float* dy_f32, const float* x, const float* mean, const float* rstd,
+               const float* gamma, const float* dres, float* dx_f32, void* dx_bf16, float* partials, float* dgamma,
+               float* dbeta, float* dres_colsum, int M, int D, hipStream_t stream);
+/* out[N] = column sums of x [M,N] (bf16 or fp32), optional row gather and device row count;
+ * partials: workspace fp32 [mrg_colsum_nblocks(M)][N].  Bias gradients of Linear layers. */
+int mrg_colsum_nblocks(int M);
+int mrg_colsum(const void* x, int x_dtype, int M, int N, int ld, const int* row_map, const int* m_dev, float* partials,
+               float* out, hipStream_t stream);
+
+/* ---------------------------------------------------------------------------------------------------
+ * Fused softmax attention.  Replaces F.scaled_dot_product_attention (mirage/utils.py:181 self, :216 cross;
+ * scale = head_dim^-0.5, no mask, dropout 0) and its backward.  All tensors bf16; *_bs / *_rs are batch / row
+ * strides in elements, the head stride is head_dim (heads are adjacent inside a row), so q/k/v may point into the
+ * fused qkv / kv projection outputs and o / d* use the merged-head [B, N, H*hd] layout.
+ *   fwd: o, lse [B,H,Nq] fp32 (lse may be NULL for inference)
+ *   bwd: needs o, d_o, lse; dsum [B,H,Nq] fp32 workspace; writes dq, dk, dv.
+ */
+typedef struct mrg_attn_desc {
+    const void* q; const void* k; const void* v; void* o; float* lse;
+    long q_bs, q_rs, k_bs, k_rs, v_bs, v_rs, o_bs, o_rs;
+    int B, H, Nq, Nk, head_dim;
+    float scale;
+    const void* d_o; long do_bs, do_rs;
+    float* dsum;
+    void* dq; void* dk; void* dv;
+    long dq_bs, dq_rs, dk_bs, dk_rs, dv_bs, dv_rs;
+} mrg_attn_desc;
+int mrg_attn_fwd(const mrg_attn_desc* d, hipStream_t stream);
+int mrg_attn_bwd(const mrg_attn_desc* d, hipStream_t stream);
+
+/* ---------------------------------------------------------------------------------------------------
+ * Gather-then-embed input adapters (mirage/input_adapters.py:87-110 PatchedInputAdapter.forward, :211-238
+ * SemSegInputAdapter.forward, mirage/model.py:384-391 token select + global tokens).
+ *   mrg_embed_plan      ids_keep int64 [B,K] -> per-modality compact lists (cap = B*K entries each):
+ *                       rows (destination row b*N+k), toks (token inside the modality grid), srcb (sample), counts.
+ *                       dom_start: HOST array [ndom+1] of token offsets of the modalities.
+ *   mrg_im2col_image    fp32 image [B,C,H,W] -> bf16 rows [cap, C*P*P] for the kept patches of one modality
+ *   mrg_im2col_layermap int64 labels [B,Hs,Ws] + class_emb fp32 [ncls,E] -> bf16 rows [cap, E*P*P]
+ *   mrg_class_emb_grad  d class_emb [ncls,E] from dA bf16 [cap, E*P*P] (dgrad of the layer-map patch GEMM)
+ *   mrg_fill_global     x[b*N + K + g] = global_tokens[g]
+ * The projection itself is mrg_gemm with m_dev = &counts[d], row_map = rows, add_tab/add_row = posemb/toks.
+ */
+int mrg_embed_plan(const long* ids_keep, int B, int K, int N, int ndom, const int* dom_start_host, int* rows, int* toks,
+                   int* srcb, int* counts, hipStream_t stream);
+int mrg_im2col_image(const float* img, const int* srcb, const int* toks, const int* count_dev, int cap, int C, int H, int W,
+                     int P, void* out_bf16, hipStream_t stream);
+int mrg_im2col_layermap(const long* labels, const float* class_emb, const int* srcb, const int* toks, const int* count_dev,
+                        int cap, int ncls, int E, int Hs, int Ws, int P, void* out_bf16, hipStream_t stream);
+int mrg_class_emb_grad(const void* dA_bf16, const long* labels, const int* srcb, const int* toks, const int* count_dev,
+                       int ncls, int E, int Hs, int Ws, int P, float* out, hipStream_t stream);
+int mrg_fill_global(float* x, const float* global_tokens, int B, int N, int K, int ng, int D, hipStream_t stream);
+
+/* ---------------------------------------------------------------------------------------------------
+ * Decoder query/context assembly (mirage/output_adapters.py:164-246 generate_context_embeddings +
+ * get_queries_and_context) and its backward.  ctx = proj_context(encoder tokens) fp32 [B,N,Dd].
+ * dom_start is a HOST array; task_emb[i] / d_task_emb[i] device pointers per input modality (may be NULL).
+ * partials: fp32 [mrg_dec_assemble_bwd_nblocks()][MRG_MAX_DOMAINS+1][Dd].
+ */
+typedef struct mrg_dec_assemble_desc {
+    const float* ctx; const float* mask_token; const float* task_emb[MRG_MAX_DOMAINS]; const float* pos;
+    const long* ids_keep; const long* ids_restore;
+    int dom_start[MRG_MAX_DOMAINS + 1];
+    int ndom, qdom;
+    const float* q_task_emb;
+    int B, N, K, T, Tq, Dd;
+    float* queries; float* context;
+    const float* d_queries; const float* d_context;
+    float* d_ctx; float* partials;
+    float* d_task_emb[MRG_MAX_DOMAINS]; float* d_mask_token;
+} mrg_dec_assemble_desc;
+int mrg_dec_assemble_fwd(const mrg_dec_assemble_desc* d, hipStream_t stream);
+int mrg_dec_assemble_bwd_nblocks(int B, int N, int Tq);
+int mrg_dec_assemble_bwd(const mrg_dec_assemble_desc* d, hipStream_t stream);
+
+/* ---------------------------------------------------------------------------------------------------
+ * Masked losses (mirage/criterion.py:31-51 CE, :87-117 MSE) on image-layout predictions [B,C,H,W] (bf16 or fp32),
+ * token mask int64 [B,(H/P)*(W/P)] (1 = masked = counted; NULL = plain mean), target fp32 [B,C,H,W] (MSE) or
+ * int64 [B,H,W] (CE).  fwd: loss[1], coef[B] (backward coefficients), per_sample[B] optional.
+ * bwd: dpred (same dtype as pred) = gout * dloss/dpred.  partial: fp32 [mrg_loss_partial_floats(B)].
+ * mrg_patch_rearrange: tokens [B,g*g,C*P*P] <-> image [B,C,g*P,g*P] (mirage/output_adapters.py:291-294).
+ */
+typedef struct mrg_loss_desc {
+    int kind; const void* pred; int pred_dtype; const void* target; const long* mask;
+    int B, C, H, W, P;
+    float* partial; float* loss; float* coef; float* per_sample;
+    const float* gout; void* dpred;
+} mrg_loss_desc;
+int mrg_loss_partial_floats(int B);
+int mrg_masked_loss_fwd(const mrg_loss_desc* d, hipStream_t stream);
+int mrg_masked_loss_bwd(const mrg_loss_desc* d, hipStream_t stream);
+int mrg_patch_rearrange(const void* src, void* dst, int dtype, int to_image, int B, int C, int g, int P, hipStream_t stream);
+
+/* ---------------------------------------------------------------------------------------------------
+ * Mask generation (mirage/model.py:168-239) from explicit noise: p fp32 [B,ndom] Dirichlet shares, u fp32 [B,T]
+ * per-modality noise (modalities concatenated), g fp32 [B,T].  Outputs int64 like the reference.
+ */
+int mrg_maskgen(const float* p, const float* u, const float* g, int B, int T, int K, int ndom, const int* dom_start_host,
+                long* task_mask, long* ids_keep, long* ids_restore, hipStream_t stream);
+
+/* ---------------------------------------------------------------------------------------------------
+ * Step boundary on flat arenas: global grad L2 norm (mutils/native_scaler.py:46-61), AdamW with decoupled decay on
+ * the first n_decay elements (mutils/optim_factory.py:33-92 groups; torch.optim.AdamW update), per-step lr / wd
+ * read from device tables at index *step (run_pretraining.py:683-688), bf16 shadow weights refreshed in the same
+ * pass.  clip_norm / skip_norm <= 0 disable clipping / skipping (native_scaler.py:19-32).
+ */
+typedef struct mrg_adamw_desc {
+    float* p; const float* g; float* m; float* v; void* shadow_bf16;
+    long n, n_decay;
+    const float* lr_table; const float* wd_table; const int* step; int table_len;
+    float lr_scale, beta1, beta2, eps;
+    const float* grad_norm; float clip_norm, skip_norm;
+} mrg_adamw_desc;
+int mrg_sumsq_nblocks(long n);
+int mrg_grad_norm(const float* g, long n, float* partials, float* out, hipStream_t stream);
+int mrg_adamw(const mrg_adamw_desc* d, hipStream_t stream);
+int mrg_step_inc(int* step, hipStream_t stream);
+int mrg_cast_bf16(const float* src, void* dst_bf16, long n, hipStream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MIRAGE_HIP_H */

@@ -1,0 +1,552 @@
+// Fused softmax attention, forward and backward, for the short sequences of the MIRAGE path
+// (encoder N = K+1 in {99,129,257}, hd 64; decoder self N = 256 and cross 256 x N, hd 32).
+// Replaces F.scaled_dot_product_attention (mirage/utils.py:181,216; scale = hd^-0.5, no mask, p = 0) and
+// aten::_scaled_dot_product_*_backward.
+//
+// One workgroup (4 waves) per (batch, head).  The whole K/V of a head fits in LDS (<= 288 keys: 36 KiB each),
+// so forward is "single KV tile": each wave owns 32-query tiles, computes S^T = K Q^T on MFMA 32x32x16 so that a
+// lane owns one query column (row-reductions are in-lane + one cross-half exchange), keeps every key block's
+// scores in registers, and feeds P straight back into the PV MFMAs as the A operand (the accumulator layout of
+// S^T is exactly a k-permuted A-operand layout; V fragments come from LDS with ds_read_b64_tr_b16 using the same
+// k permutation).  Longer sequences loop over KV chunks with an online-softmax rescale.
+// Backward recomputes P from the saved log-sum-exp: a query-owner kernel produces dQ and a key-owner kernel
+// produces dK, dV (no atomics, deterministic).
+//
+// All tensors are bf16 with explicit (batch, row, head) strides in elements so the kernels read q/k/v directly
+// out of the fused qkv / kv projection buffers ([B, N, 3, H, hd] / [B, N, 2, H, hd]) and write the merged-head
+// [B, N, H*hd] layout the proj GEMM consumes: the reference's reshape/permute/transpose copies do not exist.
+#include "common.h"
+#include "mirage_hip.h"
+
+namespace {
+
+constexpr float LOG2E = 1.4426950408889634f;
+
+enum { SWZ_ROW = 0, SWZ_TR = 1 };
+
+// byte offset of 16-B chunk c of row r in a [rows][HD] bf16 LDS tile
+template <int HD, int SWZ>
+__device__ __forceinline__ int tile_off(int r, int c) {
+    if (HD == 64) {
+        if (SWZ == SWZ_ROW) return r * 128 + ((c ^ ((r >> 1) & 7)) << 4);
+        return r * 128 + ((c ^ ((r & 2) << 1)) << 4);
+    } else {
+        if (SWZ == SWZ_ROW) return r * 64 + ((c ^ ((r >> 2) & 3)) << 4);
+        return r * 64 + (c << 4);
+    }
+}
+
+// cooperative global -> LDS copy of `rows` rows (zero-filled beyond nvalid); src row stride in elements
+template <int HD, int SWZ>
+__device__ __forceinline__ void load_rows(char* lds, const bf16_t* __restrict__ src, long row_stride, int rows, int nvalid,
+                                          int tid, int nthreads) {
+    constexpr int CPR = HD / 8;
+    for (int q = tid; q < rows * CPR; q += nthreads) {
+        const int r = q / CPR, c = q % CPR;
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (r < nvalid) v = *reinterpret_cast<const uint4*>(src + (long)r * row_stride + c * 8);
+        *reinterpret_cast<uint4*>(lds + tile_off<HD, SWZ>(r, c)) = v;
+    }
+}
+
+// A/B operand fragment with the contraction along the row (hd) direction: lane -> row (l&31), chunk 2*kk + (l>>5)
+template <int HD, int SWZ>
+__device__ __forceinline__ bf16x8 frag_rows(const char* lds, int row0, int kk, int lane) {
+    const int r = row0 + (lane & 31);
+    return *reinterpret_cast<const bf16x8*>(lds + tile_off<HD, SWZ>(r, kk * 2 + (lane >> 5)));
+}
+
+// B operand fragment with the contraction along the tile's ROW direction (keys / queries), output column = hd index.
+// k-slot order matches an accumulator-layout A operand: slots 0-3 = rows base+0..3, slots 4-7 = rows base+8..11 with
+// base = row0 + 16*mf + 4*(lane>>5).
+template <int HD, int SWZ>
+__device__ __forceinline__ bf16x8 frag_cols_tr(uint32_t lds_base, int row0, int mf, int dj, int lane) {
+    const int i = lane & 15;
+    const int d = dj * 32 + (lane & 16) + ((i & 3) << 2);
+    const int r0 = row0 + 16 * mf + 4 * (lane >> 5) + (i >> 2);
+    const int r1 = r0 + 8;
+    const s16x4 lo = lds_read_tr16(lds_base + tile_off<HD, SWZ>(r0, d >> 3) + ((d & 4) << 1));
+    const s16x4 hi = lds_read_tr16(lds_base + tile_off<HD, SWZ>(r1, d >> 3) + ((d & 4) << 1));
+    bf16x8 f;
+    f[0] = lo[0]; f[1] = lo[1]; f[2] = lo[2]; f[3] = lo[3];
+    f[4] = hi[0]; f[5] = hi[1]; f[6] = hi[2]; f[7] = hi[3];
+    return f;
+}
+
+__device__ __forceinline__ bf16x8 pack8(const f32x16& s, int mf) {
+    bf16x8 f;
+    const int b = mf * 8;
+    uint32_t w0 = pack_bf2(s[b + 0], s[b + 1]), w1 = pack_bf2(s[b + 2], s[b + 3]);
+    uint32_t w2 = pack_bf2(s[b + 4], s[b + 5]), w3 = pack_bf2(s[b + 6], s[b + 7]);
+    f[0] = (short)(w0 & 0xffff); f[1] = (short)(w0 >> 16); f[2] = (short)(w1 & 0xffff); f[3] = (short)(w1 >> 16);
+    f[4] = (short)(w2 & 0xffff); f[5] = (short)(w2 >> 16); f[6] = (short)(w3 & 0xffff); f[7] = (short)(w3 >> 16);
+    return f;
+}
+
+// row index (0..31) of accumulator register r for this lane
+__device__ __forceinline__ int acc_row(int r, int lane) { return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); }
+
+struct AttnArgs {
+    const bf16_t* q; const bf16_t* k; const bf16_t* v;
+    bf16_t* o; float* lse;
+    long q_bs, q_rs, k_bs, k_rs, v_bs, v_rs, o_bs, o_rs;  // batch / row strides (elements); head stride = HD
+    int B, H, Nq, Nk;
+    float scale;
+    // backward
+    const bf16_t* d_o; long do_bs, do_rs;
+    float* dsum;
+    bf16_t* dq; bf16_t* dk; bf16_t* dv;
+    long dq_bs, dq_rs, dk_bs, dk_rs, dv_bs, dv_rs;
+    int chunk_rows;
+};
+
+// ================================================ forward ===============================================
+template <int HD, int CB>
+__global__ __launch_bounds__(256, 1) void attn_fwd_kernel(const AttnArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int KS = HD / 16, DJ = HD / 32, ROWS = CB * 32;
+    char* ldsK = smem;
+    char* ldsV = smem + ROWS * HD * 2;
+    const uint32_t ldsV_u = lds_addr(ldsV);
+    const int h = blockIdx.x, b = blockIdx.y;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const bf16_t* qp = a.q + (long)b * a.q_bs + h * HD;
+    const bf16_t* kp = a.k + (long)b * a.k_bs + h * HD;
+    const bf16_t* vp = a.v + (long)b * a.v_bs + h * HD;
+    const int nqt = (a.Nq + 31) >> 5;
+    const int nchunks = (a.Nk + ROWS - 1) / ROWS;
+    const float sc = a.scale * LOG2E;
+
+    if (nchunks == 1) {
+        load_rows<HD, SWZ_ROW>(ldsK, kp, a.k_rs, ROWS, a.Nk, tid, 256);
+        load_rows<HD, SWZ_TR>(ldsV, vp, a.v_rs, ROWS, a.Nk, tid, 256);
+        __syncthreads();
+    }
+    // uniform rounds so that every wave takes part in the staging barriers of the multi-chunk path
+    const int rounds = (nqt + 3) >> 2;
+    for (int rd = 0; rd < rounds; ++rd) {
+        const int qt = rd * 4 + wave;
+        const bool active = qt < nqt;
+        const int q0 = qt * 32;
+        bf16x8 qf[KS];
+        {
+            const int qr = q0 + (lane & 31);
+#pragma unroll
+            for (int kk = 0; kk < KS; ++kk) {
+                uint4 v = make_uint4(0, 0, 0, 0);
+                if (active && qr < a.Nq) v = *reinterpret_cast<const uint4*>(qp + (long)qr * a.q_rs + kk * 16 + 8 * (lane >> 5));
+                qf[kk] = *reinterpret_cast<bf16x8*>(&v);
+            }
+        }
+        f32x16 o[DJ];
+#pragma unroll
+        for (int dj = 0; dj < DJ; ++dj)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[dj][r] = 0.f;
+        float m_run = -INFINITY, l_run = 0.f;
+
+        for (int ch = 0; ch < nchunks; ++ch) {
+            const int kbase = ch * ROWS;
+            const int kvalid = min(ROWS, a.Nk - kbase);
+            if (nchunks > 1) {
+                __syncthreads();
+                load_rows<HD, SWZ_ROW>(ldsK, kp + (long)kbase * a.k_rs, a.k_rs, ROWS, kvalid, tid, 256);
+                load_rows<HD, SWZ_TR>(ldsV, vp + (long)kbase * a.v_rs, a.v_rs, ROWS, kvalid, tid, 256);
+                __syncthreads();
+            }
+            if (!active) continue;
+            f32x16 s[CB];
+            float mx = -INFINITY;
+#pragma unroll
+            for (int kb = 0; kb < CB; ++kb) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) s[kb][r] = 0.f;
+                if (kb * 32 < kvalid) {
+#pragma unroll
+                    for (int kk = 0; kk < KS; ++kk)
+                        s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows<HD, SWZ_ROW>(ldsK, kb * 32, kk, lane), qf[kk], s[kb], 0, 0, 0);
+                }
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int key = kb * 32 + acc_row(r, lane);
+                    if (key >= kvalid) s[kb][r] = -INFINITY;
+                    mx = fmaxf(mx, s[kb][r]);
+                }
+            }
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            const float m_new = fmaxf(m_run, mx);
+            const float alpha = exp2f((m_run - m_new) * sc);   // first chunk: exp2(-inf) = 0
+            float ls = 0.f;
+#pragma unroll
+            for (int kb = 0; kb < CB; ++kb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float p = exp2f((s[kb][r] - m_new) * sc);
+                    s[kb][r] = p;
+                    ls += p;
+                }
+            ls += __shfl_xor(ls, 32, 64);
+            l_run = l_run * alpha + ls;
+            m_run = m_new;
+            if (ch > 0) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float al = __shfl(alpha, acc_row(r, lane), 64);
+#pragma unroll
+                    for (int dj = 0; dj < DJ; ++dj) o[dj][r] *= al;
+                }
+            }
+#pragma unroll
+            for (int kb = 0; kb < CB; ++kb) {
+                if (kb * 32 < kvalid) {
+#pragma unroll
+                    for (int mf = 0; mf < 2; ++mf) {
+                        const bf16x8 pa = pack8(s[kb], mf);
+#pragma unroll
+                        for (int dj = 0; dj < DJ; ++dj)
+                            o[dj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa, frag_cols_tr<HD, SWZ_TR>(ldsV_u, kb * 32, mf, dj, lane), o[dj], 0, 0, 0);
+                    }
+                }
+            }
+        }
+        if (!active) continue;
+        const float linv = 1.f / l_run;
+        bf16_t* op = a.o + (long)b * a.o_bs + h * HD;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = acc_row(r, lane);
+            const float li = __shfl(linv, row, 64);
+            const int qr = q0 + row;
+            if (qr < a.Nq) {
+#pragma unroll
+                for (int dj = 0; dj < DJ; ++dj) op[(long)qr * a.o_rs + dj * 32 + (lane & 31)] = f2bf(o[dj][r] * li);
+            }
+        }
+        if (a.lse && lane < 32 && q0 + lane < a.Nq)
+            a.lse[((long)b * a.H + h) * a.Nq + q0 + lane] = m_run * a.scale + __logf(l_run);
+    }
+}
+
+// ================================================ backward ==============================================
+// dsum[b,h,q] = sum_d dO * O
+template <int HD>
+__global__ void attn_bwd_prep_kernel(const AttnArgs a) {
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long total = (long)a.B * a.H * a.Nq;
+    if (idx >= total) return;
+    const int q = (int)(idx % a.Nq);
+    const int h = (int)((idx / a.Nq) % a.H);
+    const int b = (int)(idx / ((long)a.Nq * a.H));
+    const bf16_t* op = a.o + (long)b * a.o_bs + (long)q * a.o_rs + h * HD;
+    const bf16_t* dp = a.d_o + (long)b * a.do_bs + (long)q * a.do_rs + h * HD;
+    float s = 0.f;
+#pragma unroll
+    for (int c = 0; c < HD / 8; ++c) {
+        const uint4 x = *reinterpret_cast<const uint4*>(op + c * 8);
+        const uint4 y = *reinterpret_cast<const uint4*>(dp + c * 8);
+        const uint32_t xs[4] = {x.x, x.y, x.z, x.w}, ys[4] = {y.x, y.y, y.z, y.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            s += __uint_as_float(xs[e] << 16) * __uint_as_float(ys[e] << 16) +
+                 __uint_as_float(xs[e] & 0xffff0000u) * __uint_as_float(ys[e] & 0xffff0000u);
+    }
+    a.dsum[idx] = s;
+}
+
+// query-owner pass: dQ.  LDS: K chunk (row + tr reads), V chunk (row reads).
+template <int HD>
+__global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int KS = HD / 16, DJ = HD / 32;
+    const int ROWS = a.chunk_rows;
+    char* ldsK = smem;
+    char* ldsV = smem + ROWS * HD * 2;
+    const uint32_t ldsK_u = lds_addr(ldsK);
+    const int h = blockIdx.x, b = blockIdx.y;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const bf16_t* qp = a.q + (long)b * a.q_bs + h * HD;
+    const bf16_t* kp = a.k + (long)b * a.k_bs + h * HD;
+    const bf16_t* vp = a.v + (long)b * a.v_bs + h * HD;
+    const bf16_t* dop = a.d_o + (long)b * a.do_bs + h * HD;
+    const int nqt = (a.Nq + 31) >> 5;
+    const int nchunks = (a.Nk + ROWS - 1) / ROWS;
+    const int rounds = (nqt + 3) >> 2;
+    const float sc = a.scale * LOG2E;
+    if (nchunks == 1) {
+        load_rows<HD, SWZ_ROW>(ldsK, kp, a.k_rs, ROWS, a.Nk, tid, 256);
+        load_rows<HD, SWZ_ROW>(ldsV, vp, a.v_rs, ROWS, a.Nk, tid, 256);
+        __syncthreads();
+    }
+    for (int rd = 0; rd < rounds; ++rd) {
+        const int qt = rd * 4 + wave;
+        const bool active = qt < nqt;
+        const int q0 = qt * 32;
+        const int qr = q0 + (lane & 31);
+        const bool qok = active && qr < a.Nq;
+        bf16x8 qf[KS], dof[KS];
+#pragma unroll
+        for (int kk = 0; kk < KS; ++kk) {
+            uint4 v = make_uint4(0, 0, 0, 0), w = make_uint4(0, 0, 0, 0);
+            if (qok) {
+                v = *reinterpret_cast<const uint4*>(qp + (long)qr * a.q_rs + kk * 16 + 8 * (lane >> 5));
+                w = *reinterpret_cast<const uint4*>(dop + (long)qr * a.do_rs + kk * 16 + 8 * (lane >> 5));
+            }
+            qf[kk] = *reinterpret_cast<bf16x8*>(&v);
+            dof[kk] = *reinterpret_cast<bf16x8*>(&w);
+        }
+        const long sidx = ((long)b * a.H + h) * a.Nq + qr;
+        const float lse2 = qok ? a.lse[sidx] * LOG2E : INFINITY;   // invalid query -> p = exp2(-inf) = 0
+        const float dsm = qok ? a.dsum[sidx] : 0.f;
+        f32x16 dq[DJ];
+#pragma unroll
+        for (int dj = 0; dj < DJ; ++dj)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) dq[dj][r] = 0.f;
+        for (int ch = 0; ch < nchunks; ++ch) {
+            const int kbase = ch * ROWS;
+            const int kvalid = min(ROWS, a.Nk - kbase);
+            if (nchunks > 1) {
+                __syncthreads();
+                load_rows<HD, SWZ_ROW>(ldsK, kp + (long)kbase * a.k_rs, a.k_rs, ROWS, kvalid, tid, 256);
+                load_rows<HD, SWZ_ROW>(ldsV, vp + (long)kbase * a.v_rs, a.v_rs, ROWS, kvalid, tid, 256);
+                __syncthreads();
+            }
+            if (!active) continue;
+            const int nkb = (kvalid + 31) >> 5;
+            for (int kb = 0; kb < nkb; ++kb) {
+                f32x16 s, dp;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
+#pragma unroll
+                for (int kk = 0; kk < KS; ++kk) {
+                    s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows<HD, SWZ_ROW>(ldsK, kb * 32, kk, lane), qf[kk], s, 0, 0, 0);
+                    dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows<HD, SWZ_ROW>(ldsV, kb * 32, kk, lane), dof[kk], dp, 0, 0, 0);
+                }
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int key = kb * 32 + acc_row(r, lane);
+                    const float p = key < kvalid ? exp2f(s[r] * sc - lse2) : 0.f;
+                    s[r] = p * (dp[r] - dsm) * a.scale;
+                }
+#pragma unroll
+                for (int mf = 0; mf < 2; ++mf) {
+                    const bf16x8 da = pack8(s, mf);
+#pragma unroll
+                    for (int dj = 0; dj < DJ; ++dj)
+                        dq[dj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(da, frag_cols_tr<HD, SWZ_ROW>(ldsK_u, kb * 32, mf, dj, lane), dq[dj], 0, 0, 0);
+                }
+            }
+        }
+        if (!active) continue;
+        bf16_t* dqp = a.dq + (long)b * a.dq_bs + h * HD;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = q0 + acc_row(r, lane);
+            if (row < a.Nq) {
+#pragma unroll
+                for (int dj = 0; dj < DJ; ++dj) dqp[(long)row * a.dq_rs + dj * 32 + (lane & 31)] = f2bf(dq[dj][r]);
+            }
+        }
+    }
+}
+
+// key-owner pass: dK, dV.  LDS: Q chunk and dO chunk (row + tr reads), lse*log2e and dsum per query of the chunk.
+template <int HD>
+__global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const AttnArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int KS = HD / 16, DJ = HD / 32;
+    const int ROWS = a.chunk_rows;
+    char* ldsQ = smem;
+    char* ldsDO = smem + ROWS * HD * 2;
+    float* ldsL = reinterpret_cast<float*>(smem + 2 * ROWS * HD * 2);
+    float* ldsD = ldsL + ROWS;
+    const uint32_t ldsQ_u = lds_addr(ldsQ), ldsDO_u = lds_addr(ldsDO);
+    const int h = blockIdx.x, b = blockIdx.y;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const bf16_t* qp = a.q + (long)b * a.q_bs + h * HD;
+    const bf16_t* kp = a.k + (long)b * a.k_bs + h * HD;
+    const bf16_t* vp = a.v + (long)b * a.v_bs + h * HD;
+    const bf16_t* dop = a.d_o + (long)b * a.do_bs + h * HD;
+    const int nkt = (a.Nk + 31) >> 5;
+    const int nchunks = (a.Nq + ROWS - 1) / ROWS;
+    const int rounds = (nkt + 3) >> 2;
+    const float sc = a.scale * LOG2E;
+    for (int rd = 0; rd < rounds; ++rd) {
+        const int kt = rd * 4 + wave;
+        const bool active = kt < nkt;
+        const int k0 = kt * 32;
+        const int kr = k0 + (lane & 31);
+        const bool kok = active && kr < a.Nk;
+        bf16x8 kf[KS], vf[KS];
+#pragma unroll
+        for (int kk = 0; kk < KS; ++kk) {
+            uint4 v = make_uint4(0, 0, 0, 0), w = make_uint4(0, 0, 0, 0);
+            if (kok) {
+                v = *reinterpret_cast<const uint4*>(kp + (long)kr * a.k_rs + kk * 16 + 8 * (lane >> 5));
+                w = *reinterpret_cast<const uint4*>(vp + (long)kr * a.v_rs + kk * 16 + 8 * (lane >> 5));
+            }
+            kf[kk] = *reinterpret_cast<bf16x8*>(&v);
+            vf[kk] = *reinterpret_cast<bf16x8*>(&w);
+        }
+        f32x16 dk[DJ], dv[DJ];
+#pragma unroll
+        for (int dj = 0; dj < DJ; ++dj)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { dk[dj][r] = 0.f; dv[dj][r] = 0.f; }
+        for (int ch = 0; ch < nchunks; ++ch) {
+            const int qbase = ch * ROWS;
+            const int qvalid = min(ROWS, a.Nq - qbase);
+            if (nchunks > 1 || rd == 0) {
+                __syncthreads();
+                load_rows<HD, SWZ_ROW>(ldsQ, qp + (long)qbase * a.q_rs, a.q_rs, ROWS, qvalid, tid, 256);
+                load_rows<HD, SWZ_ROW>(ldsDO, dop + (long)qbase * a.do_rs, a.do_rs, ROWS, qvalid, tid, 256);
+                for (int i = tid; i < ROWS; i += 256) {
+                    const long sidx = ((long)b * a.H + h) * a.Nq + qbase + i;
+                    ldsL[i] = i < qvalid ? a.lse[sidx] * LOG2E : INFINITY;
+                    ldsD[i] = i < qvalid ? a.dsum[sidx] : 0.f;
+                }
+                __syncthreads();
+            }
+            if (!active) continue;
+            const int nqb = (qvalid + 31) >> 5;
+            for (int qb = 0; qb < nqb; ++qb) {
+                f32x16 s, dp;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
+#pragma unroll
+                for (int kk = 0; kk < KS; ++kk) {
+                    s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows<HD, SWZ_ROW>(ldsQ, qb * 32, kk, lane), kf[kk], s, 0, 0, 0);
+                    dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows<HD, SWZ_ROW>(ldsDO, qb * 32, kk, lane), vf[kk], dp, 0, 0, 0);
+                }
+                f32x16 pr;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int qrow = qb * 32 + 8 * g + 4 * (lane >> 5);
+                    const float4 l4 = *reinterpret_cast<const float4*>(ldsL + qrow);
+                    const float4 d4 = *reinterpret_cast<const float4*>(ldsD + qrow);
+                    const float ls[4] = {l4.x, l4.y, l4.z, l4.w}, ds[4] = {d4.x, d4.y, d4.z, d4.w};
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int r = g * 4 + e;
+                        const float p = exp2f(s[r] * sc - ls[e]);
+                        pr[r] = p;
+                        s[r] = p * (dp[r] - ds[e]) * a.scale;
+                    }
+                }
+#pragma unroll
+                for (int mf = 0; mf < 2; ++mf) {
+                    const bf16x8 pa = pack8(pr, mf);
+                    const bf16x8 da = pack8(s, mf);
+#pragma unroll
+                    for (int dj = 0; dj < DJ; ++dj) {
+                        dv[dj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa, frag_cols_tr<HD, SWZ_ROW>(ldsDO_u, qb * 32, mf, dj, lane), dv[dj], 0, 0, 0);
+                        dk[dj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(da, frag_cols_tr<HD, SWZ_ROW>(ldsQ_u, qb * 32, mf, dj, lane), dk[dj], 0, 0, 0);
+                    }
+                }
+            }
+        }
+        if (!active) continue;
+        bf16_t* dkp = a.dk + (long)b * a.dk_bs + h * HD;
+        bf16_t* dvp = a.dv + (long)b * a.dv_bs + h * HD;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = k0 + acc_row(r, lane);
+            if (row < a.Nk) {
+#pragma unroll
+                for (int dj = 0; dj < DJ; ++dj) {
+                    dkp[(long)row * a.dk_rs + dj * 32 + (lane & 31)] = f2bf(dk[dj][r]);
+                    dvp[(long)row * a.dv_rs + dj * 32 + (lane & 31)] = f2bf(dv[dj][r]);
+                }
+            }
+        }
+    }
+}
+
+template <int HD>
+int launch_fwd(const AttnArgs& a, hipStream_t stream) {
+    const int nkb = (a.Nk + 31) / 32;
+    dim3 grid(a.H, a.B), block(256);
+#define MRG_FWD(CB_) do { const size_t sh = (size_t)(2 * CB_ * 32 * HD * 2); \
+        if (sh > 65536) { static bool once = false; if (!once) { (void)hipFuncSetAttribute((const void*)attn_fwd_kernel<HD, CB_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh); once = true; } } \
+        hipLaunchKernelGGL((attn_fwd_kernel<HD, CB_>), grid, block, sh, stream, a); } while (0)
+    if (nkb <= 4) MRG_FWD(4);
+    else if (nkb == 5) MRG_FWD(5);
+    else if (nkb <= 8) MRG_FWD(8);
+    else if (nkb == 9) MRG_FWD(9);
+    else MRG_FWD(8);  // longer sequences: 256-key chunks with online-softmax rescale
+#undef MRG_FWD
+    return mrg_check_launch("mrg_attn_fwd");
+}
+
+int check_common(const mrg_attn_desc* d, const char* who) {
+    MRG_REQUIRE(d != nullptr, MRG_ERR_ARG, "%s: null descriptor", who);
+    MRG_REQUIRE(d->q && d->k && d->v && d->o, MRG_ERR_ARG, "%s: null tensor", who);
+    MRG_REQUIRE(d->head_dim == 32 || d->head_dim == 64, MRG_ERR_UNSUPPORTED, "%s: head_dim %d not in {32, 64}", who, d->head_dim);
+    MRG_REQUIRE(d->B > 0 && d->H > 0 && d->Nq > 0 && d->Nk > 0, MRG_ERR_SHAPE, "%s: bad shape", who);
+    const long strides[] = {d->q_bs, d->q_rs, d->k_bs, d->k_rs, d->v_bs, d->v_rs, d->o_bs, d->o_rs};
+    for (long s : strides) MRG_REQUIRE(s % 8 == 0, MRG_ERR_SHAPE, "%s: strides must be multiples of 8 elements (16 B)", who);
+    MRG_REQUIRE((((uintptr_t)d->q | (uintptr_t)d->k | (uintptr_t)d->v) & 15) == 0, MRG_ERR_ARG, "%s: q/k/v must be 16-B aligned", who);
+    return 0;
+}
+
+void fill(AttnArgs& a, const mrg_attn_desc* d) {
+    a.q = (const bf16_t*)d->q; a.k = (const bf16_t*)d->k; a.v = (const bf16_t*)d->v; a.o = (bf16_t*)d->o; a.lse = d->lse;
+    a.q_bs = d->q_bs; a.q_rs = d->q_rs; a.k_bs = d->k_bs; a.k_rs = d->k_rs; a.v_bs = d->v_bs; a.v_rs = d->v_rs;
+    a.o_bs = d->o_bs; a.o_rs = d->o_rs;
+    a.B = d->B; a.H = d->H; a.Nq = d->Nq; a.Nk = d->Nk; a.scale = d->scale;
+    a.d_o = (const bf16_t*)d->d_o; a.do_bs = d->do_bs; a.do_rs = d->do_rs; a.dsum = d->dsum;
+    a.dq = (bf16_t*)d->dq; a.dk = (bf16_t*)d->dk; a.dv = (bf16_t*)d->dv;
+    a.dq_bs = d->dq_bs; a.dq_rs = d->dq_rs; a.dk_bs = d->dk_bs; a.dk_rs = d->dk_rs; a.dv_bs = d->dv_bs; a.dv_rs = d->dv_rs;
+    a.chunk_rows = 0;
+}
+
+}  // namespace
+
+extern "C" int mrg_attn_fwd(const mrg_attn_desc* d, hipStream_t stream) {
+    int rc = check_common(d, "mrg_attn_fwd");
+    if (rc) return rc;
+    AttnArgs a;
+    fill(a, d);
+    return d->head_dim == 64 ? launch_fwd<64>(a, stream) : launch_fwd<32>(a, stream);
+}
+
+extern "C" int mrg_attn_bwd(const mrg_attn_desc* d, hipStream_t stream) {
+    int rc = check_common(d, "mrg_attn_bwd");
+    if (rc) return rc;
+    MRG_REQUIRE(d->d_o && d->lse && d->dsum && d->dq && d->dk && d->dv, MRG_ERR_ARG, "mrg_attn_bwd: null tensor");
+    MRG_REQUIRE(d->do_bs % 8 == 0 && d->do_rs % 8 == 0, MRG_ERR_SHAPE, "mrg_attn_bwd: dO strides must be multiples of 8");
+    AttnArgs a;
+    fill(a, d);
+    const int HD = d->head_dim;
+    {
+        const long total = (long)a.B * a.H * a.Nq;
+        dim3 grid((unsigned)((total + 255) / 256)), block(256);
+        if (HD == 64) hipLaunchKernelGGL(attn_bwd_prep_kernel<64>, grid, block, 0, stream, a);
+        else hipLaunchKernelGGL(attn_bwd_prep_kernel<32>, grid, block, 0, stream, a);
+        rc = mrg_check_launch("mrg_attn_bwd/prep");
+        if (rc) return rc;
+    }
+    dim3 grid(a.H, a.B), block(256);
+    {   // dQ: K,V chunk in LDS
+        AttnArgs b = a;
+        b.chunk_rows = ((a.Nk + 31) / 32) * 32;
+        if (b.chunk_rows > 288) b.chunk_rows = 256;
+        const size_t sh = (size_t)2 * b.chunk_rows * HD * 2;
+        if (sh > 65536) (void)hipFuncSetAttribute((const void*)attn_bwd_dq_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
+        if (HD == 64) hipLaunchKernelGGL(attn_bwd_dq_kernel<64>, grid, block, sh, stream, b);
+        else hipLaunchKernelGGL(attn_bwd_dq_kernel<32>, grid, block, sh, stream, b);
+        rc = mrg_check_launch("mrg_attn_bwd/dq");
+        if (rc) return rc;
+    }
+    {   // dK,dV: Q,dO chunk in LDS
+        AttnArgs b = a;
+        b.chunk_rows = ((a.Nq + 31) / 32) * 32;
+        if (b.chunk_rows > 288) b.chunk_rows = 256;
+        const size_t sh = (size_t)2 * b.chunk_rows * HD * 2 + (size_t)2 * b.chunk_rows * 4;
+        if (sh > 65536) (void)hipFuncSetAttribute((const void*)attn_bwd_dkv_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
+        if (HD == 64) hipLaunchKernelGGL(attn_bwd_dkv_kernel<64>, grid, block, sh, stream, b);
+        else hipLaunchKernelGGL(attn_bwd_dkv_kernel<32>, grid, block, sh, stream, b);
+        rc = mrg_check_launch("mrg_attn_bwd/dkv");
+    }
+    return rc;
+}

@@ -1,0 +1,66 @@
+// Shared device/host helpers for libmirage_hip.so (gfx950 / CDNA4 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef uint16_t bf16_t;  // raw bfloat16 bits
+
+typedef __attribute__((ext_vector_type(8))) short bf16x8;
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+
+#define MRG_OK 0
+#define MRG_ERR_ARG (-1)
+#define MRG_ERR_SHAPE (-2)
+#define MRG_ERR_UNSUPPORTED (-3)
+
+// error plumbing (api.cpp)
+extern "C" const char* mrg_last_error_string();
+int mrg_set_error(int code, const char* fmt, ...);
+int mrg_check_launch(const char* what);
+
+#define MRG_REQUIRE(cond, code, ...) do { if (!(cond)) return mrg_set_error((code), __VA_ARGS__); } while (0)
+
+__device__ __forceinline__ float bf2f(bf16_t h) { return __uint_as_float(((uint32_t)h) << 16); }
+// round-to-nearest-even, NaN preserved (quiet)
+__device__ __forceinline__ bf16_t f2bf(float f) {
+    uint32_t u = __float_as_uint(f);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (bf16_t)(u >> 16);
+}
+__device__ __forceinline__ uint32_t pack_bf2(float lo, float hi) { return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16); }
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+// exact-erf GELU and its derivative (reference: nn.GELU() default = erf form, mirage/utils.py:142,156)
+__device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+__device__ __forceinline__ float gelu_grad_f(float x) {
+    const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752f));
+    const float pdf = 0.3989422804014327f * __expf(-0.5f * x * x);
+    return cdf + x * pdf;
+}
+
+// LDS pointer -> 32-bit LDS byte address
+__device__ __forceinline__ uint32_t lds_addr(const void* p) {
+    return (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const void*)p;
+}
+// ds_read_b64_tr_b16: within each 16-lane group the lanes' 8-byte reads form a [4][16] bf16 block
+// (lane i supplies row i>>2, cols 4*(i&3)..+3); lane l receives column (l&15), rows 0..3.
+// (semantics verified on hardware by tools/probe/probe_layout.hip)
+__device__ __forceinline__ s16x4 lds_read_tr16(uint32_t byte_addr) {
+    typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+    return __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(uintptr_t)byte_addr);
+}
+
+static inline int cdiv(int a, int b) { return (a + b - 1) / b; }

@@ -1,0 +1,238 @@
+// Gather-then-embed input adapters.
+//
+// The reference projects ALL T patch tokens of every modality (Conv2d k=s=P, mirage/input_adapters.py:101,229) and
+// then throws 75-87 % of them away with torch.gather (mirage/model.py:384-387).  Here only the K kept tokens per
+// sample are ever read: a plan kernel sorts the kept (sample, slot) pairs by modality, im2col kernels pack just
+// those patches as bf16 GEMM rows (the layer-map adapter fuses the nn.Embedding(13,64) lookup,
+// input_adapters.py:226, into the packing), and the patch GEMM's epilogue adds bias + positional embedding and
+// scatters each row straight to its slot of the encoder input [B, K+ng, D] (global tokens last,
+// mirage/model.py:390-391).  Counts per modality are data-dependent and stay on the device (m_dev / k_dev of
+// mrg_gemm), so the step needs no host synchronisation and is hipGraph-capturable.
+#include "common.h"
+#include "mirage_hip.h"
+
+namespace {
+
+constexpr int MAXDOM = MRG_MAX_DOMAINS;
+
+struct PlanArgs {
+    const long* ids_keep;   // [B, K]
+    int B, K, N, ndom;
+    int dom_start[MAXDOM + 1];
+    int* rows;    // [ndom][cap] destination row b*N + k
+    int* toks;    // [ndom][cap] token index inside the modality grid
+    int* srcb;    // [ndom][cap] sample index
+    int* counts;  // [ndom]
+};
+
+__device__ __forceinline__ int find_dom(const int* dom_start, int ndom, int t) {
+    int d = 0;
+#pragma unroll
+    for (int i = 1; i < MAXDOM; ++i) d += (i < ndom && t >= dom_start[i]) ? 1 : 0;
+    return d;
+}
+
+// single block, 1024 threads: deterministic (flat (b,k) order) compaction per modality
+__global__ __launch_bounds__(1024) void embed_plan_kernel(const PlanArgs a) {
+    __shared__ int cnt[MAXDOM][1024];
+    const int tid = threadIdx.x;
+    const int total = a.B * a.K;
+    const int per = (total + 1023) / 1024;
+    const int beg = min(total, tid * per), end = min(total, beg + per);
+    int c[MAXDOM];
+#pragma unroll
+    for (int d = 0; d < MAXDOM; ++d) c[d] = 0;
+    for (int i = beg; i < end; ++i) {
+        const int dm = find_dom(a.dom_start, a.ndom, (int)a.ids_keep[i]);
+#pragma unroll
+        for (int d = 0; d < MAXDOM; ++d) c[d] += (dm == d) ? 1 : 0;
+    }
+#pragma unroll
+    for (int d = 0; d < MAXDOM; ++d) cnt[d][tid] = c[d];
+    __syncthreads();
+    // inclusive Hillis-Steele scan per modality
+    for (int off = 1; off < 1024; off <<= 1) {
+        int v[MAXDOM];
+#pragma unroll
+        for (int d = 0; d < MAXDOM; ++d) v[d] = tid >= off ? cnt[d][tid - off] : 0;
+        __syncthreads();
+#pragma unroll
+        for (int d = 0; d < MAXDOM; ++d) cnt[d][tid] += v[d];
+        __syncthreads();
+    }
+    int pos[MAXDOM];
+#pragma unroll
+    for (int d = 0; d < MAXDOM; ++d) pos[d] = cnt[d][tid] - c[d];
+    if (tid == 1023) {
+#pragma unroll
+        for (int d = 0; d < MAXDOM; ++d) if (d < a.ndom) a.counts[d] = cnt[d][1023];
+    }
+    const int cap = total;
+    for (int i = beg; i < end; ++i) {
+        const int t = (int)a.ids_keep[i];
+        const int dm = find_dom(a.dom_start, a.ndom, t);
+        const int b = i / a.K, k = i - b * a.K;
+        int p = 0;
+#pragma unroll
+        for (int d = 0; d < MAXDOM; ++d) if (dm == d) { p = pos[d]; pos[d] += 1; }
+        a.rows[dm * cap + p] = b * a.N + k;
+        a.toks[dm * cap + p] = t - a.dom_start[dm];
+        a.srcb[dm * cap + p] = b;
+    }
+}
+
+// image patches: img fp32 [B, C, H, W]; row i = patch (srcb[i], toks[i]) flattened (c, ph, pw) -> bf16 [cap, C*P*P]
+__global__ __launch_bounds__(256) void im2col_image_kernel(const float* __restrict__ img, const int* __restrict__ srcb,
+                                                           const int* __restrict__ toks, const int* __restrict__ count,
+                                                           int C, int H, int W, int P, int G, bf16_t* __restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (i >= *count) return;
+    const int b = srcb[i], t = toks[i];
+    const int ty = t / G, tx = t - ty * G;
+    const int PP = P * P, L = C * PP;
+    bf16_t* o = out + (long)i * L;
+    for (int e = lane * 4; e < L; e += 256) {
+        const int c = e / PP, r = e - c * PP;
+        const int ph = r / P, pw = r - ph * P;
+        const float4 v = *reinterpret_cast<const float4*>(img + (((long)b * C + c) * H + ty * P + ph) * W + tx * P + pw);
+        *reinterpret_cast<uint2*>(o + e) = make_uint2(pack_bf2(v.x, v.y), pack_bf2(v.z, v.w));
+    }
+}
+
+// layer-map patches: labels int64 [B, Hs, Ws]; out[i][ch*PP + ph*P + pw] = class_emb[label][ch]
+__global__ __launch_bounds__(256) void im2col_layermap_kernel(const long* __restrict__ labels, const float* __restrict__ class_emb,
+                                                              const int* __restrict__ srcb, const int* __restrict__ toks,
+                                                              const int* __restrict__ count, int ncls, int E, int Hs, int Ws,
+                                                              int P, int G, bf16_t* __restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* emb = reinterpret_cast<float*>(smem);           // [ncls][E]
+    int* lab = reinterpret_cast<int*>(emb + ncls * E);     // [P*P]
+    const int i = blockIdx.x;
+    if (i >= *count) return;
+    const int PP = P * P;
+    for (int j = threadIdx.x; j < ncls * E; j += 256) emb[j] = class_emb[j];
+    const int b = srcb[i], t = toks[i];
+    const int ty = t / G, tx = t - ty * G;
+    for (int j = threadIdx.x; j < PP; j += 256) {
+        const int ph = j / P, pw = j - ph * P;
+        lab[j] = (int)labels[((long)b * Hs + ty * P + ph) * Ws + tx * P + pw];
+    }
+    __syncthreads();
+    const int L = E * PP;
+    bf16_t* o = out + (long)i * L;
+    for (int e = threadIdx.x * 4; e < L; e += 1024) {
+        const int ch = e / PP, px = e - ch * PP;
+        const float v0 = emb[lab[px] * E + ch], v1 = emb[lab[px + 1] * E + ch];
+        const float v2 = emb[lab[px + 2] * E + ch], v3 = emb[lab[px + 3] * E + ch];
+        *reinterpret_cast<uint2*>(o + e) = make_uint2(pack_bf2(v0, v1), pack_bf2(v2, v3));
+    }
+}
+
+// d class_emb[c][ch] = sum over rows i < count, pixels px with label == c of dA[i][ch*PP + px].
+// grid = E blocks (one per embedding channel); deterministic tree reduction.
+__global__ __launch_bounds__(256) void class_emb_grad_kernel(const bf16_t* __restrict__ dA, const long* __restrict__ labels,
+                                                             const int* __restrict__ srcb, const int* __restrict__ toks,
+                                                             const int* __restrict__ count, int ncls, int E, int Hs, int Ws,
+                                                             int P, int G, float* __restrict__ out) {
+    __shared__ float red[256];
+    const int ch = blockIdx.x;
+    const int PP = P * P;
+    const int groups = 256 / PP > 0 ? 256 / PP : 1;
+    const int px = threadIdx.x % PP, grp = threadIdx.x / PP;
+    const int n = *count;
+    float acc[16];
+#pragma unroll
+    for (int c = 0; c < 16; ++c) acc[c] = 0.f;
+    if (grp < groups && PP <= 256) {
+        const int ph = px / P, pw = px - ph * P;
+        for (int i = grp; i < n; i += groups) {
+            const int b = srcb[i], t = toks[i];
+            const int ty = t / G, tx = t - ty * G;
+            const int lb = (int)labels[((long)b * Hs + ty * P + ph) * Ws + tx * P + pw];
+            const float v = bf2f(dA[(long)i * (E * PP) + ch * PP + px]);
+#pragma unroll
+            for (int c = 0; c < 16; ++c) acc[c] += (lb == c) ? v : 0.f;
+        }
+    }
+    for (int c = 0; c < ncls; ++c) {
+        float mine = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) mine = (k == c) ? acc[k] : mine;
+        red[threadIdx.x] = mine;
+        __syncthreads();
+        for (int s = 128; s > 0; s >>= 1) {
+            if (threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) out[c * E + ch] = red[0];
+        __syncthreads();
+    }
+}
+
+// x[b*N + K + g][:] = global_tokens[g][:]
+__global__ void fill_global_kernel(float* __restrict__ x, const float* __restrict__ glob, int B, int N, int K, int ng, int D) {
+    const long total = (long)B * ng * D;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % D);
+        const int g = (int)((i / D) % ng);
+        const int b = (int)(i / ((long)D * ng));
+        x[((long)b * N + K + g) * D + c] = glob[g * D + c];
+    }
+}
+
+}  // namespace
+
+extern "C" int mrg_embed_plan(const long* ids_keep, int B, int K, int N, int ndom, const int* dom_start_host, int* rows, int* toks,
+                              int* srcb, int* counts, hipStream_t stream) {
+    MRG_REQUIRE(ids_keep && dom_start_host && rows && toks && srcb && counts, MRG_ERR_ARG, "mrg_embed_plan: null pointer");
+    MRG_REQUIRE(ndom >= 1 && ndom <= MAXDOM, MRG_ERR_UNSUPPORTED, "mrg_embed_plan: ndom=%d not in 1..%d", ndom, MAXDOM);
+    MRG_REQUIRE(B > 0 && K > 0 && N >= K, MRG_ERR_SHAPE, "mrg_embed_plan: bad shape");
+    PlanArgs a;
+    a.ids_keep = ids_keep; a.B = B; a.K = K; a.N = N; a.ndom = ndom;
+    for (int i = 0; i <= MAXDOM; ++i) a.dom_start[i] = i <= ndom ? dom_start_host[i] : 0x7fffffff;
+    a.rows = rows; a.toks = toks; a.srcb = srcb; a.counts = counts;
+    hipLaunchKernelGGL(embed_plan_kernel, dim3(1), dim3(1024), 0, stream, a);
+    return mrg_check_launch("mrg_embed_plan");
+}
+
+extern "C" int mrg_im2col_image(const float* img, const int* srcb, const int* toks, const int* count_dev, int cap, int C, int H,
+                                int W, int P, void* out_bf16, hipStream_t stream) {
+    MRG_REQUIRE(img && srcb && toks && count_dev && out_bf16, MRG_ERR_ARG, "mrg_im2col_image: null pointer");
+    MRG_REQUIRE(P > 0 && H % P == 0 && W % P == 0 && P % 4 == 0 && W % 4 == 0, MRG_ERR_SHAPE,
+                "mrg_im2col_image: need H,W divisible by P and P %% 4 == 0 (H=%d W=%d P=%d)", H, W, P);
+    MRG_REQUIRE(((uintptr_t)img & 15) == 0, MRG_ERR_ARG, "mrg_im2col_image: image must be 16-B aligned");
+    hipLaunchKernelGGL(im2col_image_kernel, dim3(cdiv(cap, 4)), dim3(256), 0, stream, img, srcb, toks, count_dev, C, H, W, P, W / P,
+                       (bf16_t*)out_bf16);
+    return mrg_check_launch("mrg_im2col_image");
+}
+
+extern "C" int mrg_im2col_layermap(const long* labels, const float* class_emb, const int* srcb, const int* toks, const int* count_dev,
+                                   int cap, int ncls, int E, int Hs, int Ws, int P, void* out_bf16, hipStream_t stream) {
+    MRG_REQUIRE(labels && class_emb && srcb && toks && count_dev && out_bf16, MRG_ERR_ARG, "mrg_im2col_layermap: null pointer");
+    MRG_REQUIRE(P > 0 && Hs % P == 0 && Ws % P == 0 && (P * P) % 4 == 0, MRG_ERR_SHAPE, "mrg_im2col_layermap: bad patch geometry");
+    MRG_REQUIRE(ncls <= 16, MRG_ERR_UNSUPPORTED, "mrg_im2col_layermap: at most 16 classes");
+    const size_t sh = (size_t)ncls * E * 4 + (size_t)P * P * 4;
+    hipLaunchKernelGGL(im2col_layermap_kernel, dim3(cap), dim3(256), sh, stream, labels, class_emb, srcb, toks, count_dev, ncls, E, Hs,
+                       Ws, P, Ws / P, (bf16_t*)out_bf16);
+    return mrg_check_launch("mrg_im2col_layermap");
+}
+
+extern "C" int mrg_class_emb_grad(const void* dA_bf16, const long* labels, const int* srcb, const int* toks, const int* count_dev,
+                                  int ncls, int E, int Hs, int Ws, int P, float* out, hipStream_t stream) {
+    MRG_REQUIRE(dA_bf16 && labels && srcb && toks && count_dev && out, MRG_ERR_ARG, "mrg_class_emb_grad: null pointer");
+    MRG_REQUIRE(ncls <= 16 && P * P <= 256 && 256 % (P * P) == 0, MRG_ERR_UNSUPPORTED,
+                "mrg_class_emb_grad: need <= 16 classes and P*P dividing 256");
+    hipLaunchKernelGGL(class_emb_grad_kernel, dim3(E), dim3(256), 0, stream, (const bf16_t*)dA_bf16, labels, srcb, toks, count_dev, ncls,
+                       E, Hs, Ws, P, Ws / P, out);
+    return mrg_check_launch("mrg_class_emb_grad");
+}
+
+extern "C" int mrg_fill_global(float* x, const float* global_tokens, int B, int N, int K, int ng, int D, hipStream_t stream) {
+    MRG_REQUIRE(x && global_tokens, MRG_ERR_ARG, "mrg_fill_global: null pointer");
+    MRG_REQUIRE(N == K + ng, MRG_ERR_SHAPE, "mrg_fill_global: N != K + ng");
+    const long total = (long)B * ng * D;
+    hipLaunchKernelGGL(fill_global_kernel, dim3((unsigned)((total + 255) / 256 < 1024 ? (total + 255) / 256 : 1024)), dim3(256), 0,
+                       stream, x, global_tokens, B, N, K, ng, D);
+    return mrg_check_launch("mrg_fill_global");
+}

@@ -1,0 +1,380 @@
+// bf16 MFMA GEMM for gfx950 with fused epilogues.
+//
+//   C[M,N] = A(M x K) * B(N x K)^T   (fp32 accumulate on v_mfma_f32_32x32x16_bf16)
+//
+// Operand modes (per operand):
+//   KCONTIG  : element (row, k) at P[row*ld + k]   -- activations [M,K], weights [out,in]
+//   KSTRIDED : element (row, k) at P[k*ld + row]   -- the "transposed" view needed by dgrad (W as [N',K'])
+//              and wgrad (dY and X both contracted over the token axis).  Fragments come out of LDS with
+//              ds_read_b64_tr_b16, so no transposed copies of weights or activations ever exist in HBM.
+// This replaces the reference's aten addmm / mm dispatches (mirage/utils.py:155-157,177,186,209-221 and
+// autograd mm x186).
+//
+// Tile 128x128x64, 256 threads = 4 waves (2x2), each wave 64x64 = 2x2 MFMA 32x32 tiles, register-staged
+// double-buffered LDS (one barrier per K tile), XOR-swizzled LDS images (conflict-free ds_read_b128 /
+// tr reads), XCD-aware tile order.
+#include "common.h"
+#include "mirage_hip.h"
+
+namespace {
+
+constexpr int BM = 128, BN = 128, BK = 64;
+constexpr int TILE_BYTES = 128 * 64 * 2;  // 16 KiB per operand tile
+
+struct GemmArgs {
+    const bf16_t* A; const bf16_t* B;
+    int M, N, K, lda, ldb;
+    const int* a_map; const int* b_map;
+    const int* m_dev; const int* k_dev;
+    int a_aligned, b_aligned;
+    // epilogue
+    void* C; int ldc; int c_f32;
+    bf16_t* C2; int ldc2;
+    const float* bias;
+    const float* resid; int ldr;
+    int accumulate;
+    int act;
+    bf16_t* aux_out; const bf16_t* aux_in; int ldaux;
+    const int* row_map;
+    const float* add_tab; const int* add_row; int ldt;
+    int splitk; float* ws;
+    int tiles_m, tiles_n;
+};
+
+// ---- global -> register staging -------------------------------------------------------------------
+// KCONTIG tile: [128 rows][64 k]; chunk q (16 B): row = q>>3, c = q&7
+// KSTRIDED tile: [64 k][128 rows]; chunk q: kr = q>>4, c = q&15
+template <int MODE, bool ALIGNED>
+__device__ __forceinline__ void load_tile(uint4 (&r)[4], const bf16_t* __restrict__ P, int ld, int row0, int nrows,
+                                          int k0, int kmax, const int* __restrict__ map, int tid) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int q = tid + 256 * j;
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (MODE == MRG_OP_KCONTIG) {
+            const int row = row0 + (q >> 3);
+            const int k = k0 + ((q & 7) << 3);
+            if (row < nrows && k < kmax) {
+                const long src = (long)(map ? map[row] : row) * ld + k;
+                if (ALIGNED) {
+                    v = *reinterpret_cast<const uint4*>(P + src);
+                } else {
+                    bf16_t e[8];
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) e[i] = (k + i < kmax) ? P[src + i] : (bf16_t)0;
+                    v = make_uint4(e[0] | (e[1] << 16), e[2] | (e[3] << 16), e[4] | (e[5] << 16), e[6] | (e[7] << 16));
+                }
+            }
+        } else {
+            const int k = k0 + (q >> 4);
+            const int row = row0 + ((q & 15) << 3);
+            if (k < kmax && row < nrows) {
+                const long src = (long)(map ? map[k] : k) * ld + row;
+                if (ALIGNED) {
+                    v = *reinterpret_cast<const uint4*>(P + src);
+                } else {
+                    bf16_t e[8];
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) e[i] = (row + i < nrows) ? P[src + i] : (bf16_t)0;
+                    v = make_uint4(e[0] | (e[1] << 16), e[2] | (e[3] << 16), e[4] | (e[5] << 16), e[6] | (e[7] << 16));
+                }
+            }
+        }
+        r[j] = v;
+    }
+}
+
+template <int MODE>
+__device__ __forceinline__ void store_tile(const uint4 (&r)[4], char* lds, int tid) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int q = tid + 256 * j;
+        int off;
+        if (MODE == MRG_OP_KCONTIG) {
+            const int row = q >> 3, c = q & 7;
+            off = row * 128 + ((c ^ ((row >> 1) & 7)) << 4);
+        } else {
+            const int kr = q >> 4, c = q & 15;
+            off = kr * 256 + ((c ^ ((kr & 3) << 2)) << 4);
+        }
+        *reinterpret_cast<uint4*>(lds + off) = r[j];
+    }
+}
+
+// ---- LDS -> MFMA fragment -------------------------------------------------------------------------
+// 32x32x16 operand: lane l holds row (l&31), k-slots 8*(l>>5)..+7 of the 16-deep step kk.
+template <int MODE>
+__device__ __forceinline__ bf16x8 read_frag(const char* lds, uint32_t lds_base, int row_in_tile, int kk, int lane) {
+    if (MODE == MRG_OP_KCONTIG) {
+        const int row = row_in_tile + (lane & 31);
+        const int c = kk * 2 + (lane >> 5);
+        return *reinterpret_cast<const bf16x8*>(lds + row * 128 + ((c ^ ((row >> 1) & 7)) << 4));
+    } else {
+        const int i = lane & 15;
+        const int col = row_in_tile + (lane & 16) + ((i & 3) << 2);
+        const int kr0 = kk * 16 + ((lane >> 5) << 3) + (i >> 2);
+        const int kr1 = kr0 + 4;
+        const uint32_t a0 = lds_base + kr0 * 256 + ((((col >> 3) ^ ((kr0 & 3) << 2))) << 4) + ((col & 4) << 1);
+        const uint32_t a1 = lds_base + kr1 * 256 + ((((col >> 3) ^ ((kr1 & 3) << 2))) << 4) + ((col & 4) << 1);
+        const s16x4 lo = lds_read_tr16(a0);
+        const s16x4 hi = lds_read_tr16(a1);
+        bf16x8 f;
+        f[0] = lo[0]; f[1] = lo[1]; f[2] = lo[2]; f[3] = lo[3];
+        f[4] = hi[0]; f[5] = hi[1]; f[6] = hi[2]; f[7] = hi[3];
+        return f;
+    }
+}
+
+template <int AMODE, int BMODE, bool ALIGNED, bool VEC>
+__global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs g) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    // XCD-aware tile order: block b runs on XCD b%8; give each XCD a contiguous band of logical tiles
+    const int nwg = g.tiles_m * g.tiles_n;
+    int bid = blockIdx.x;
+    {
+        const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int tm = bid / g.tiles_n, tn = bid % g.tiles_n;
+    const int m0 = tm * BM, n0 = tn * BN;
+    const int Meff = g.m_dev ? min(g.M, *g.m_dev) : g.M;
+    const int Keff = g.k_dev ? min(g.K, *g.k_dev) : g.K;
+    if (m0 >= Meff) return;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+
+    const int ntiles = (Keff + BK - 1) / BK;
+    int t0 = 0, t1 = ntiles;
+    if (g.splitk > 1) {
+        const int per = (ntiles + g.splitk - 1) / g.splitk;
+        t0 = blockIdx.y * per;
+        t1 = min(ntiles, t0 + per);
+    }
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const uint32_t sbase = lds_addr(smem);
+
+    uint4 ra[4], rb[4];
+    if (t0 < t1) {
+        load_tile<AMODE, ALIGNED>(ra, g.A, g.lda, m0, Meff, t0 * BK, Keff, g.a_map, tid);
+        load_tile<BMODE, ALIGNED>(rb, g.B, g.ldb, n0, g.N, t0 * BK, Keff, g.b_map, tid);
+        store_tile<AMODE>(ra, smem, tid);
+        store_tile<BMODE>(rb, smem + TILE_BYTES, tid);
+    }
+    __syncthreads();
+    int cur = 0;
+    for (int t = t0; t < t1; ++t) {
+        const bool more = (t + 1 < t1);
+        if (more) {
+            load_tile<AMODE, ALIGNED>(ra, g.A, g.lda, m0, Meff, (t + 1) * BK, Keff, g.a_map, tid);
+            load_tile<BMODE, ALIGNED>(rb, g.B, g.ldb, n0, g.N, (t + 1) * BK, Keff, g.b_map, tid);
+        }
+        const char* la = smem + cur * (2 * TILE_BYTES);
+        const char* lb = la + TILE_BYTES;
+        const uint32_t la_u = sbase + cur * (2 * TILE_BYTES), lb_u = la_u + TILE_BYTES;
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            bf16x8 fa[2], fb[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) fa[i] = read_frag<AMODE>(la, la_u, wm * 64 + i * 32, kk, lane);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) fb[j] = read_frag<BMODE>(lb, lb_u, wn * 64 + j * 32, kk, lane);
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+        }
+        if (more) {
+            store_tile<AMODE>(ra, smem + (cur ^ 1) * (2 * TILE_BYTES), tid);
+            store_tile<BMODE>(rb, smem + (cur ^ 1) * (2 * TILE_BYTES) + TILE_BYTES, tid);
+        }
+        __syncthreads();
+        cur ^= 1;
+    }
+
+    // ---- epilogue through LDS: accumulators (lane = column lane&31, rows (r&3)+8*(r>>2)+4*(lane>>5)) are
+    // parked as a 128x128 fp32 tile, then every thread streams 4 consecutive columns of a row so that bias /
+    // residual / output traffic is 16-byte wide and fully coalesced.
+    float* ct = reinterpret_cast<float*>(smem);
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int cl = wn * 64 + j * 32 + (lane & 31);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int rl = wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                ct[rl * BN + cl] = acc[i][j][r];
+            }
+        }
+    __syncthreads();
+    const int cl = (tid & 31) << 2;
+    const int col = n0 + cl;
+    if (col >= g.N) return;
+    const int nv = min(4, g.N - col);
+    float* ws = g.splitk > 1 ? g.ws + (long)blockIdx.y * g.M * g.N : nullptr;
+    float bv[4] = {0.f, 0.f, 0.f, 0.f};
+    if (g.bias && !ws) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) if (e < nv) bv[e] = g.bias[col + e];
+    }
+#pragma unroll 1
+    for (int it = 0; it < 16; ++it) {
+        const int rl = (tid >> 5) + (it << 3);
+        const int row = m0 + rl;
+        if (row >= Meff) break;
+        const float4 a4 = *reinterpret_cast<const float4*>(ct + rl * BN + cl);
+        float v[4] = {a4.x, a4.y, a4.z, a4.w};
+        if (ws) {
+            float* w = ws + (long)row * g.N + col;
+            if (VEC) *reinterpret_cast<float4*>(w) = a4;
+            else { for (int e = 0; e < nv; ++e) w[e] = v[e]; }
+            continue;
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] += bv[e];
+        if (g.act == MRG_ACT_GELU) {
+            if (g.aux_out) {
+                bf16_t* ao = g.aux_out + (long)row * g.ldaux + col;
+                if (VEC) *reinterpret_cast<uint2*>(ao) = make_uint2(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]));
+                else { for (int e = 0; e < nv; ++e) ao[e] = f2bf(v[e]); }
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = gelu_f(v[e]);
+        } else if (g.act == MRG_ACT_GELU_BWD) {
+            const bf16_t* ai = g.aux_in + (long)row * g.ldaux + col;
+            float x[4] = {0.f, 0.f, 0.f, 0.f};
+            if (VEC) {
+                const uint2 u = *reinterpret_cast<const uint2*>(ai);
+                x[0] = __uint_as_float(u.x << 16); x[1] = __uint_as_float(u.x & 0xffff0000u);
+                x[2] = __uint_as_float(u.y << 16); x[3] = __uint_as_float(u.y & 0xffff0000u);
+            } else { for (int e = 0; e < nv; ++e) x[e] = bf2f(ai[e]); }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] *= gelu_grad_f(x[e]);
+        }
+        if (g.add_tab) {
+            const float* t = g.add_tab + (long)g.add_row[row] * g.ldt + col;
+            if (VEC) { const float4 t4 = *reinterpret_cast<const float4*>(t); v[0] += t4.x; v[1] += t4.y; v[2] += t4.z; v[3] += t4.w; }
+            else { for (int e = 0; e < nv; ++e) v[e] += t[e]; }
+        }
+        if (g.resid) {
+            const float* t = g.resid + (long)row * g.ldr + col;
+            if (VEC) { const float4 t4 = *reinterpret_cast<const float4*>(t); v[0] += t4.x; v[1] += t4.y; v[2] += t4.z; v[3] += t4.w; }
+            else { for (int e = 0; e < nv; ++e) v[e] += t[e]; }
+        }
+        const long orow = g.row_map ? g.row_map[row] : row;
+        if (g.c_f32) {
+            float* c = reinterpret_cast<float*>(g.C) + orow * g.ldc + col;
+            if (VEC) {
+                if (g.accumulate) { const float4 o = *reinterpret_cast<const float4*>(c); v[0] += o.x; v[1] += o.y; v[2] += o.z; v[3] += o.w; }
+                *reinterpret_cast<float4*>(c) = make_float4(v[0], v[1], v[2], v[3]);
+            } else {
+                for (int e = 0; e < nv; ++e) { if (g.accumulate) v[e] += c[e]; c[e] = v[e]; }
+            }
+        } else {
+            bf16_t* c = reinterpret_cast<bf16_t*>(g.C) + orow * g.ldc + col;
+            if (VEC) *reinterpret_cast<uint2*>(c) = make_uint2(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]));
+            else { for (int e = 0; e < nv; ++e) c[e] = f2bf(v[e]); }
+        }
+        if (g.C2) {
+            bf16_t* c = g.C2 + orow * g.ldc2 + col;
+            if (VEC) *reinterpret_cast<uint2*>(c) = make_uint2(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]));
+            else { for (int e = 0; e < nv; ++e) c[e] = f2bf(v[e]); }
+        }
+    }
+}
+
+// split-K finish: C (+)= sum_z ws[z]  (+ bias) ; fp32 out, optional bf16 copy
+__global__ void splitk_reduce_kernel(const float* __restrict__ ws, int splitk, long mn, int N, float* __restrict__ C, int ldc,
+                                     int accumulate, const float* __restrict__ bias, bf16_t* __restrict__ C2, int ldc2,
+                                     int c_f32, void* Cany) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < mn; i += (long)gridDim.x * blockDim.x) {
+        float s = 0.f;
+        for (int z = 0; z < splitk; ++z) s += ws[(long)z * mn + i];
+        const long row = i / N;
+        const int col = (int)(i - row * N);
+        if (bias) s += bias[col];
+        if (c_f32) {
+            float* c = C + row * ldc + col;
+            if (accumulate) s += *c;
+            *c = s;
+        } else {
+            reinterpret_cast<bf16_t*>(Cany)[row * ldc + col] = f2bf(s);
+        }
+        if (C2) C2[row * ldc2 + col] = f2bf(s);
+    }
+}
+
+}  // namespace
+
+extern "C" int mrg_gemm(const mrg_gemm_desc* d, hipStream_t stream) {
+    MRG_REQUIRE(d != nullptr, MRG_ERR_ARG, "mrg_gemm: null descriptor");
+    MRG_REQUIRE(d->A && d->B && d->C, MRG_ERR_ARG, "mrg_gemm: null operand pointer");
+    MRG_REQUIRE(d->M > 0 && d->N > 0 && d->K > 0, MRG_ERR_SHAPE, "mrg_gemm: bad shape M=%d N=%d K=%d", d->M, d->N, d->K);
+    MRG_REQUIRE(d->a_mode == MRG_OP_KCONTIG || d->a_mode == MRG_OP_KSTRIDED, MRG_ERR_ARG, "mrg_gemm: bad a_mode");
+    MRG_REQUIRE(d->b_mode == MRG_OP_KCONTIG || d->b_mode == MRG_OP_KSTRIDED, MRG_ERR_ARG, "mrg_gemm: bad b_mode");
+    MRG_REQUIRE(!(d->a_mode == MRG_OP_KSTRIDED && d->b_mode == MRG_OP_KCONTIG), MRG_ERR_UNSUPPORTED,
+                "mrg_gemm: (A k-strided, B k-contiguous) is not instantiated");
+    MRG_REQUIRE(d->act == MRG_ACT_NONE || d->act == MRG_ACT_GELU || d->act == MRG_ACT_GELU_BWD, MRG_ERR_ARG, "mrg_gemm: bad act");
+    MRG_REQUIRE(d->act != MRG_ACT_GELU_BWD || d->aux_in, MRG_ERR_ARG, "mrg_gemm: gelu_bwd needs aux_in");
+    MRG_REQUIRE(!d->add_tab || d->add_row, MRG_ERR_ARG, "mrg_gemm: add_tab needs add_row");
+    MRG_REQUIRE(!d->accumulate || d->c_dtype == MRG_DT_F32, MRG_ERR_ARG, "mrg_gemm: accumulate needs fp32 C");
+    const int splitk = d->splitk > 1 ? d->splitk : 1;
+    if (splitk > 1) {
+        MRG_REQUIRE(d->ws, MRG_ERR_ARG, "mrg_gemm: split-K needs a workspace");
+        MRG_REQUIRE(d->act == MRG_ACT_NONE && !d->resid && !d->add_tab && !d->row_map && !d->m_dev, MRG_ERR_UNSUPPORTED,
+                    "mrg_gemm: split-K supports only bias/accumulate epilogues");
+    }
+    GemmArgs g;
+    g.A = (const bf16_t*)d->A; g.B = (const bf16_t*)d->B;
+    g.M = d->M; g.N = d->N; g.K = d->K; g.lda = d->lda; g.ldb = d->ldb;
+    g.a_map = d->a_map; g.b_map = d->b_map; g.m_dev = d->m_dev; g.k_dev = d->k_dev;
+    g.a_aligned = (((uintptr_t)d->A & 15) == 0) && (d->lda % 8 == 0);
+    g.b_aligned = (((uintptr_t)d->B & 15) == 0) && (d->ldb % 8 == 0);
+    g.C = d->C; g.ldc = d->ldc; g.c_f32 = (d->c_dtype == MRG_DT_F32);
+    g.C2 = (bf16_t*)d->C2; g.ldc2 = d->ldc2;
+    g.bias = d->bias; g.resid = d->resid; g.ldr = d->ldr; g.accumulate = d->accumulate; g.act = d->act;
+    g.aux_out = (bf16_t*)d->aux_out; g.aux_in = (const bf16_t*)d->aux_in; g.ldaux = d->ldaux;
+    g.row_map = d->row_map; g.add_tab = d->add_tab; g.add_row = d->add_row; g.ldt = d->ldt;
+    g.splitk = splitk; g.ws = d->ws;
+    g.tiles_m = cdiv(d->M, BM); g.tiles_n = cdiv(d->N, BN);
+    dim3 grid(g.tiles_m * g.tiles_n, splitk), block(256);
+    const size_t shmem = 4 * TILE_BYTES;
+    // vector (16 B) loads need 16-B aligned bases, ld % 8 == 0 and whole chunks inside the matrix
+    bool al = g.a_aligned && g.b_aligned && !d->k_dev;
+    if (d->a_mode == MRG_OP_KCONTIG) al = al && (d->K % 8 == 0); else al = al && (d->M % 8 == 0);
+    if (d->b_mode == MRG_OP_KCONTIG) al = al && (d->K % 8 == 0); else al = al && (d->N % 8 == 0);
+    if (d->k_dev && d->a_mode == MRG_OP_KSTRIDED && d->b_mode == MRG_OP_KSTRIDED)   // k rows are whole rows: count may be anything
+        al = g.a_aligned && g.b_aligned && (d->M % 8 == 0) && (d->N % 8 == 0);
+    // 16-byte epilogue accesses need N % 4 == 0 and every touched matrix 16-B (fp32) / 8-B (bf16) aligned per row
+    auto al4 = [](const void* p, int ld, int bytes) { return p == nullptr || ((((uintptr_t)p) % (4 * bytes) == 0) && (ld % 4 == 0)); };
+    const bool vec = (d->N % 4 == 0) && al4(d->C, d->ldc, g.c_f32 ? 4 : 2) && al4(d->C2, d->ldc2, 2) && al4(d->resid, d->ldr, 4) &&
+                     al4(d->add_tab, d->ldt, 4) && al4(d->aux_out, d->ldaux, 2) && al4(d->aux_in, d->ldaux, 2) && al4(d->ws, d->N, 4);
+#define MRG_LAUNCH2(AM, BM_, AL) do { if (vec) hipLaunchKernelGGL((gemm_kernel<AM, BM_, AL, true>), grid, block, shmem, stream, g); \
+                                      else hipLaunchKernelGGL((gemm_kernel<AM, BM_, AL, false>), grid, block, shmem, stream, g); } while (0)
+#define MRG_LAUNCH(AM, BM_, AL) MRG_LAUNCH2(AM, BM_, AL)
+    if (d->a_mode == MRG_OP_KCONTIG && d->b_mode == MRG_OP_KCONTIG) { if (al) MRG_LAUNCH(0, 0, true); else MRG_LAUNCH(0, 0, false); }
+    else if (d->a_mode == MRG_OP_KCONTIG && d->b_mode == MRG_OP_KSTRIDED) { if (al) MRG_LAUNCH(0, 1, true); else MRG_LAUNCH(0, 1, false); }
+    else { if (al) MRG_LAUNCH(1, 1, true); else MRG_LAUNCH(1, 1, false); }
+#undef MRG_LAUNCH
+#undef MRG_LAUNCH2
+    int rc = mrg_check_launch("mrg_gemm");
+    if (rc) return rc;
+    if (splitk > 1) {
+        const long mn = (long)d->M * d->N;
+        const int nb = (int)((mn + 255) / 256 < 2048 ? (mn + 255) / 256 : 2048);
+        hipLaunchKernelGGL(splitk_reduce_kernel, dim3(nb), dim3(256), 0, stream, d->ws, splitk, mn, d->N, (float*)d->C, d->ldc,
+                           d->accumulate, d->bias, (bf16_t*)d->C2, d->ldc2, g.c_f32, d->C);
+        rc = mrg_check_launch("mrg_gemm/splitk_reduce");
+    }
+    return rc;
+}

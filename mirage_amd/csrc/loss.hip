@@ -1,0 +1,222 @@
+// Masked reconstruction losses (mirage/criterion.py:31-51 MaskedCrossEntropyLoss, :87-117 MaskedMSELoss) and the
+// token -> image rearrangement of the decoder output (mirage/output_adapters.py:291-294), forward + backward.
+//
+// Reference semantics: per-pixel loss (MSE averaged over channels / 13-way softmax CE) times the token mask
+// nearest-upsampled to pixels, per-sample sum / per-sample masked-pixel count, then nanmean over samples; a mask
+// with no masked token at all gives 0.  The mask is per token, so no upsampled mask or full-size temporaries are
+// ever built: stage 1 reduces each (sample, row-chunk) deterministically, stage 2 finishes the batch statistics and
+// emits the per-sample backward coefficient, the backward kernel writes dpred in one pass.
+#include "common.h"
+#include "mirage_hip.h"
+
+namespace {
+
+constexpr int LOSS_CHUNKS = 32;  // partial sums per sample
+
+template <typename T> __device__ __forceinline__ float ldf(const T* p, long i);
+template <> __device__ __forceinline__ float ldf<float>(const float* p, long i) { return p[i]; }
+template <> __device__ __forceinline__ float ldf<bf16_t>(const bf16_t* p, long i) { return bf2f(p[i]); }
+template <typename T> __device__ __forceinline__ void stf(T* p, long i, float v);
+template <> __device__ __forceinline__ void stf<float>(float* p, long i, float v) { p[i] = v; }
+template <> __device__ __forceinline__ void stf<bf16_t>(bf16_t* p, long i, float v) { p[i] = f2bf(v); }
+
+__device__ __forceinline__ float block_sum(float v, float* red) {
+    v = wave_sum(v);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) red[wave] = v;
+    __syncthreads();
+    float s = 0.f;
+    if (threadIdx.x == 0) for (int w = 0; w < (int)(blockDim.x >> 6); ++w) s += red[w];
+    __syncthreads();
+    return s;  // valid in thread 0
+}
+
+// grid (LOSS_CHUNKS, B); partial [B][LOSS_CHUNKS][2] = (sum of masked per-pixel loss, masked pixel count)
+template <typename T, bool CE>
+__global__ __launch_bounds__(256) void loss_fwd_kernel(const T* __restrict__ pred, const void* __restrict__ target,
+                                                       const long* __restrict__ mask, int B, int C, int H, int W, int P,
+                                                       float* __restrict__ partial) {
+    __shared__ float red[4];
+    const int b = blockIdx.y, chunk = blockIdx.x;
+    const int nw = W / P;
+    const long HW = (long)H * W;
+    float s = 0.f, n = 0.f;
+    for (long px = (long)chunk * 256 + threadIdx.x; px < HW; px += (long)LOSS_CHUNKS * 256) {
+        const int y = (int)(px / W), x = (int)(px - (long)y * W);
+        const float m = mask ? (float)mask[(long)b * (H / P) * nw + (y / P) * nw + x / P] : 1.f;
+        if (m == 0.f) continue;
+        float l;
+        if (CE) {
+            const int t = (int)reinterpret_cast<const long*>(target)[(long)b * HW + px];
+            float mx = -INFINITY, zt = 0.f;
+            for (int c = 0; c < C; ++c) { const float z = ldf<T>(pred, ((long)b * C + c) * HW + px); mx = fmaxf(mx, z); zt = (c == t) ? z : zt; }
+            float se = 0.f;
+            for (int c = 0; c < C; ++c) se += __expf(ldf<T>(pred, ((long)b * C + c) * HW + px) - mx);
+            l = mx + __logf(se) - zt;
+        } else {
+            float q = 0.f;
+            for (int c = 0; c < C; ++c) {
+                const float d = ldf<T>(pred, ((long)b * C + c) * HW + px) - reinterpret_cast<const float*>(target)[((long)b * C + c) * HW + px];
+                q += d * d;
+            }
+            l = q / (float)C;
+        }
+        s += l * m;
+        n += m;
+    }
+    const float ts = block_sum(s, red);
+    const float tn = block_sum(n, red);
+    if (threadIdx.x == 0) {
+        partial[((long)b * LOSS_CHUNKS + chunk) * 2 + 0] = ts;
+        partial[((long)b * LOSS_CHUNKS + chunk) * 2 + 1] = tn;
+    }
+}
+
+// single block: per-sample loss, nanmean, backward coefficients coef[b] = 1 / (count_b * n_valid)
+__global__ void loss_finish_kernel(const float* __restrict__ partial, int B, float* __restrict__ loss, float* __restrict__ coef,
+                                   float* __restrict__ per_sample) {
+    __shared__ float sl[1024], sn[1024];
+    const int t = threadIdx.x;
+    float tot = 0.f;
+    int nvalid = 0;
+    // B <= 1024 per pass; loop passes for larger B
+    float total_cnt = 0.f;
+    for (int base = 0; base < B; base += 1024) {
+        const int b = base + t;
+        float s = 0.f, n = 0.f;
+        if (b < B)
+            for (int c = 0; c < LOSS_CHUNKS; ++c) { s += partial[((long)b * LOSS_CHUNKS + c) * 2]; n += partial[((long)b * LOSS_CHUNKS + c) * 2 + 1]; }
+        sl[t] = s; sn[t] = n;
+        __syncthreads();
+        if (t == 0) {
+            for (int i = 0; i < min(1024, B - base); ++i) {
+                total_cnt += sn[i];
+                if (sn[i] > 0.f) { tot += sl[i] / sn[i]; ++nvalid; }
+            }
+        }
+        __syncthreads();
+    }
+    __shared__ float s_nvalid;
+    if (t == 0) {
+        // criterion.py:36,103: mask.sum() == 0 -> 0 ; otherwise nanmean over samples (0/0 samples dropped)
+        loss[0] = (total_cnt > 0.f && nvalid > 0) ? tot / (float)nvalid : 0.f;
+        s_nvalid = (float)nvalid;
+    }
+    __syncthreads();
+    for (int b = t; b < B; b += blockDim.x) {
+        float n = 0.f, s = 0.f;
+        for (int c = 0; c < LOSS_CHUNKS; ++c) { s += partial[((long)b * LOSS_CHUNKS + c) * 2]; n += partial[((long)b * LOSS_CHUNKS + c) * 2 + 1]; }
+        coef[b] = (n > 0.f && s_nvalid > 0.f) ? 1.f / (n * s_nvalid) : 0.f;
+        if (per_sample) per_sample[b] = n > 0.f ? s / n : NAN;
+    }
+}
+
+template <typename T, bool CE>
+__global__ __launch_bounds__(256) void loss_bwd_kernel(const T* __restrict__ pred, const void* __restrict__ target,
+                                                       const long* __restrict__ mask, const float* __restrict__ coef,
+                                                       const float* __restrict__ gout, int B, int C, int H, int W, int P,
+                                                       T* __restrict__ dpred) {
+    const long HW = (long)H * W;
+    const long total = (long)B * HW;
+    const int nw = W / P;
+    const float go = gout ? gout[0] : 1.f;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int b = (int)(i / HW);
+        const long px = i - (long)b * HW;
+        const int y = (int)(px / W), x = (int)(px - (long)y * W);
+        const float m = mask ? (float)mask[(long)b * (H / P) * nw + (y / P) * nw + x / P] : 1.f;
+        const float k = go * coef[b] * m;
+        if (CE) {
+            if (k == 0.f) { for (int c = 0; c < C; ++c) stf<T>(dpred, ((long)b * C + c) * HW + px, 0.f); continue; }
+            const int t = (int)reinterpret_cast<const long*>(target)[(long)b * HW + px];
+            float mx = -INFINITY;
+            for (int c = 0; c < C; ++c) mx = fmaxf(mx, ldf<T>(pred, ((long)b * C + c) * HW + px));
+            float se = 0.f;
+            for (int c = 0; c < C; ++c) se += __expf(ldf<T>(pred, ((long)b * C + c) * HW + px) - mx);
+            const float inv = 1.f / se;
+            for (int c = 0; c < C; ++c) {
+                const float p = __expf(ldf<T>(pred, ((long)b * C + c) * HW + px) - mx) * inv;
+                stf<T>(dpred, ((long)b * C + c) * HW + px, k * (p - (c == t ? 1.f : 0.f)));
+            }
+        } else {
+            const float kk = k * 2.f / (float)C;
+            for (int c = 0; c < C; ++c) {
+                const long j = ((long)b * C + c) * HW + px;
+                stf<T>(dpred, j, kk * (ldf<T>(pred, j) - reinterpret_cast<const float*>(target)[j]));
+            }
+        }
+    }
+}
+
+// tokens [B, g*g, C*P*P] <-> image [B, C, g*P, g*P]   (inner token order c, ph, pw)
+template <typename T, bool TO_IMAGE>
+__global__ void patch_rearrange_kernel(const T* __restrict__ src, T* __restrict__ dst, int B, int C, int g, int P) {
+    const int S = g * P;
+    const long total = (long)B * C * S * S;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int x = (int)(i % S);
+        const int y = (int)((i / S) % S);
+        const int c = (int)((i / ((long)S * S)) % C);
+        const int b = (int)(i / ((long)S * S * C));
+        const long tok = ((long)b * g * g + (y / P) * g + x / P) * ((long)C * P * P) + ((long)c * P + y % P) * P + x % P;
+        if (TO_IMAGE) dst[i] = src[tok]; else dst[tok] = src[i];
+    }
+}
+
+int check(const mrg_loss_desc* d, const char* who) {
+    MRG_REQUIRE(d != nullptr, MRG_ERR_ARG, "%s: null descriptor", who);
+    MRG_REQUIRE(d->pred && d->target && d->partial && d->coef, MRG_ERR_ARG, "%s: null pointer", who);
+    MRG_REQUIRE(d->kind == MRG_LOSS_MSE || d->kind == MRG_LOSS_CE, MRG_ERR_ARG, "%s: bad kind", who);
+    MRG_REQUIRE(d->B > 0 && d->C > 0 && d->P > 0 && d->H % d->P == 0 && d->W % d->P == 0, MRG_ERR_SHAPE, "%s: bad geometry", who);
+    MRG_REQUIRE(d->pred_dtype == MRG_DT_BF16 || d->pred_dtype == MRG_DT_F32, MRG_ERR_ARG, "%s: bad dtype", who);
+    return 0;
+}
+
+}  // namespace
+
+extern "C" int mrg_loss_partial_floats(int B) { return B * LOSS_CHUNKS * 2; }
+
+extern "C" int mrg_masked_loss_fwd(const mrg_loss_desc* d, hipStream_t stream) {
+    int rc = check(d, "mrg_masked_loss_fwd");
+    if (rc) return rc;
+    MRG_REQUIRE(d->loss, MRG_ERR_ARG, "mrg_masked_loss_fwd: null loss pointer");
+    dim3 grid(LOSS_CHUNKS, d->B), block(256);
+#define MRG_L(T, CE) hipLaunchKernelGGL((loss_fwd_kernel<T, CE>), grid, block, 0, stream, (const T*)d->pred, d->target, d->mask, d->B, d->C, d->H, d->W, d->P, d->partial)
+    if (d->pred_dtype == MRG_DT_BF16) { if (d->kind == MRG_LOSS_CE) MRG_L(bf16_t, true); else MRG_L(bf16_t, false); }
+    else { if (d->kind == MRG_LOSS_CE) MRG_L(float, true); else MRG_L(float, false); }
+#undef MRG_L
+    rc = mrg_check_launch("mrg_masked_loss_fwd");
+    if (rc) return rc;
+    hipLaunchKernelGGL(loss_finish_kernel, dim3(1), dim3(1024), 0, stream, d->partial, d->B, d->loss, d->coef, d->per_sample);
+    return mrg_check_launch("mrg_masked_loss_fwd/finish");
+}
+
+extern "C" int mrg_masked_loss_bwd(const mrg_loss_desc* d, hipStream_t stream) {
+    int rc = check(d, "mrg_masked_loss_bwd");
+    if (rc) return rc;
+    MRG_REQUIRE(d->dpred, MRG_ERR_ARG, "mrg_masked_loss_bwd: null dpred");
+    const long total = (long)d->B * d->H * d->W;
+    dim3 grid((unsigned)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096)), block(256);
+#define MRG_L(T, CE) hipLaunchKernelGGL((loss_bwd_kernel<T, CE>), grid, block, 0, stream, (const T*)d->pred, d->target, d->mask, d->coef, d->gout, d->B, d->C, d->H, d->W, d->P, (T*)d->dpred)
+    if (d->pred_dtype == MRG_DT_BF16) { if (d->kind == MRG_LOSS_CE) MRG_L(bf16_t, true); else MRG_L(bf16_t, false); }
+    else { if (d->kind == MRG_LOSS_CE) MRG_L(float, true); else MRG_L(float, false); }
+#undef MRG_L
+    return mrg_check_launch("mrg_masked_loss_bwd");
+}
+
+extern "C" int mrg_patch_rearrange(const void* src, void* dst, int dtype, int to_image, int B, int C, int g, int P, hipStream_t stream) {
+    MRG_REQUIRE(src && dst, MRG_ERR_ARG, "mrg_patch_rearrange: null pointer");
+    MRG_REQUIRE(B > 0 && C > 0 && g > 0 && P > 0, MRG_ERR_SHAPE, "mrg_patch_rearrange: bad shape");
+    const long total = (long)B * C * g * P * g * P;
+    dim3 grid((unsigned)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192)), block(256);
+    if (dtype == MRG_DT_BF16) {
+        if (to_image) hipLaunchKernelGGL((patch_rearrange_kernel<bf16_t, true>), grid, block, 0, stream, (const bf16_t*)src, (bf16_t*)dst, B, C, g, P);
+        else hipLaunchKernelGGL((patch_rearrange_kernel<bf16_t, false>), grid, block, 0, stream, (const bf16_t*)src, (bf16_t*)dst, B, C, g, P);
+    } else if (dtype == MRG_DT_F32) {
+        if (to_image) hipLaunchKernelGGL((patch_rearrange_kernel<float, true>), grid, block, 0, stream, (const float*)src, (float*)dst, B, C, g, P);
+        else hipLaunchKernelGGL((patch_rearrange_kernel<float, false>), grid, block, 0, stream, (const float*)src, (float*)dst, B, C, g, P);
+    } else {
+        return mrg_set_error(MRG_ERR_ARG, "mrg_patch_rearrange: bad dtype");
+    }
+    return mrg_check_launch("mrg_patch_rearrange");
+}

@@ -1,0 +1,157 @@
+// Step boundary: fused flat-arena AdamW (+ bf16 shadow weights for the next step's GEMMs), global L2 gradient
+// norm, fp32 -> bf16 cast.  Replaces torch.optim.AdamW's per-tensor kernels (296 Base / 440 Large tensors,
+// mutils/optim_factory.py:180), mutils/native_scaler.py:46-61 get_grad_norm_ and the per-Linear autocast weight
+// casts.  HBM-bound: 4 fp32 streams read, 3 written, + 2 B/param shadow.
+// Hyper-parameters come from device-resident schedule tables indexed by a device step counter, so the whole
+// optimizer step is hipGraph-replayable (run_pretraining.py:683-688 sets lr/wd per step from such arrays).
+#include "common.h"
+#include "mirage_hip.h"
+
+namespace {
+
+__global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g, long n, float* __restrict__ partials) {
+    __shared__ float red[4];
+    float s = 0.f;
+    const long n4 = n >> 2;
+    const float4* g4 = reinterpret_cast<const float4*>(g);
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+        const float4 v = g4[i];
+        s += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) { const float v = g[(n4 << 2) + threadIdx.x]; s += v * v; }
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) partials[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+__global__ __launch_bounds__(256) void sumsq_finish_kernel(const float* __restrict__ partials, int nb, float* __restrict__ out) {
+    __shared__ double red[256];
+    double s = 0.0;
+    for (int i = threadIdx.x; i < nb; i += 256) s += (double)partials[i];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int k = 128; k > 0; k >>= 1) {
+        if (threadIdx.x < k) red[threadIdx.x] += red[threadIdx.x + k];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[0] = (float)sqrt(red[0]);
+}
+
+struct AdamArgs {
+    float* p; const float* g; float* m; float* v; bf16_t* shadow;
+    long n, n_decay;
+    const float* lr_table; const float* wd_table; const int* step; int table_len;
+    float lr_scale, beta1, beta2, eps;
+    const float* grad_norm; float clip_norm, skip_norm;
+};
+
+__global__ __launch_bounds__(256) void adamw_kernel(const AdamArgs a) {
+    __shared__ float hp[5];
+    if (threadIdx.x == 0) {
+        int st = *a.step;
+        const int ti = st < a.table_len ? st : a.table_len - 1;
+        const double t = (double)(st + 1);
+        hp[0] = a.lr_table[ti] * a.lr_scale;
+        hp[1] = a.wd_table[ti];
+        hp[2] = (float)(1.0 / (1.0 - pow((double)a.beta1, t)));
+        hp[3] = (float)(1.0 / sqrt(1.0 - pow((double)a.beta2, t)));
+        float gs = 1.f;
+        if (a.grad_norm) {
+            const float nrm = a.grad_norm[0];
+            if (a.clip_norm > 0.f) gs = fminf(1.f, a.clip_norm / (nrm + 1e-6f));   // torch clip_grad_norm_
+            if (a.skip_norm > 0.f && nrm >= a.skip_norm) gs = -1.f;               // native_scaler.py:24-29: skip the update
+        }
+        hp[4] = gs;
+    }
+    __syncthreads();
+    const float lr = hp[0], wd = hp[1], ibc1 = hp[2], isbc2 = hp[3], gs = hp[4];
+    if (gs < 0.f) return;
+    const float b1 = a.beta1, b2 = a.beta2;
+    const long n4 = a.n >> 2;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+        float4 p = reinterpret_cast<float4*>(a.p)[i];
+        float4 g = reinterpret_cast<const float4*>(a.g)[i];
+        float4 m = reinterpret_cast<float4*>(a.m)[i];
+        float4 v = reinterpret_cast<float4*>(a.v)[i];
+        float* pp = &p.x; float* gp = &g.x; float* mp = &m.x; float* vp = &v.x;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float decay = ((i << 2) + e) < a.n_decay ? wd : 0.f;
+            const float gg = gp[e] * gs;
+            pp[e] *= (1.f - lr * decay);
+            mp[e] = b1 * mp[e] + (1.f - b1) * gg;
+            vp[e] = b2 * vp[e] + (1.f - b2) * gg * gg;
+            const float denom = sqrtf(vp[e]) * isbc2 + a.eps;
+            pp[e] -= lr * ibc1 * (mp[e] / denom);
+        }
+        reinterpret_cast<float4*>(a.p)[i] = p;
+        reinterpret_cast<float4*>(a.m)[i] = m;
+        reinterpret_cast<float4*>(a.v)[i] = v;
+        if (a.shadow) reinterpret_cast<uint2*>(a.shadow)[i] = make_uint2(pack_bf2(p.x, p.y), pack_bf2(p.z, p.w));
+    }
+}
+
+__global__ void step_inc_kernel(int* step) { if (threadIdx.x == 0 && blockIdx.x == 0) step[0] += 1; }
+
+__global__ __launch_bounds__(256) void cast_bf16_kernel(const float* __restrict__ src, bf16_t* __restrict__ dst, long n) {
+    const long n4 = n >> 2;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+        const float4 v = reinterpret_cast<const float4*>(src)[i];
+        reinterpret_cast<uint2*>(dst)[i] = make_uint2(pack_bf2(v.x, v.y), pack_bf2(v.z, v.w));
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) dst[(n4 << 2) + threadIdx.x] = f2bf(src[(n4 << 2) + threadIdx.x]);
+}
+
+}  // namespace
+
+extern "C" int mrg_sumsq_nblocks(long n) {
+    long nb = (n / 4 + 255) / 256;
+    if (nb > 2048) nb = 2048;
+    if (nb < 1) nb = 1;
+    return (int)nb;
+}
+
+extern "C" int mrg_grad_norm(const float* g, long n, float* partials, float* out, hipStream_t stream) {
+    MRG_REQUIRE(g && partials && out && n > 0, MRG_ERR_ARG, "mrg_grad_norm: bad argument");
+    MRG_REQUIRE(((uintptr_t)g & 15) == 0, MRG_ERR_ARG, "mrg_grad_norm: gradient arena must be 16-B aligned");
+    const int nb = mrg_sumsq_nblocks(n);
+    hipLaunchKernelGGL(sumsq_kernel, dim3(nb), dim3(256), 0, stream, g, n, partials);
+    int rc = mrg_check_launch("mrg_grad_norm");
+    if (rc) return rc;
+    hipLaunchKernelGGL(sumsq_finish_kernel, dim3(1), dim3(256), 0, stream, partials, nb, out);
+    return mrg_check_launch("mrg_grad_norm/finish");
+}
+
+extern "C" int mrg_adamw(const mrg_adamw_desc* d, hipStream_t stream) {
+    MRG_REQUIRE(d && d->p && d->g && d->m && d->v && d->lr_table && d->wd_table && d->step, MRG_ERR_ARG, "mrg_adamw: null pointer");
+    MRG_REQUIRE(d->n > 0 && d->n % 4 == 0 && d->n_decay >= 0 && d->n_decay <= d->n && d->table_len > 0, MRG_ERR_SHAPE,
+                "mrg_adamw: n must be a positive multiple of 4 and 0 <= n_decay <= n");
+    MRG_REQUIRE((((uintptr_t)d->p | (uintptr_t)d->g | (uintptr_t)d->m | (uintptr_t)d->v) & 15) == 0, MRG_ERR_ARG,
+                "mrg_adamw: arenas must be 16-B aligned");
+    AdamArgs a;
+    a.p = d->p; a.g = d->g; a.m = d->m; a.v = d->v; a.shadow = (bf16_t*)d->shadow_bf16; a.n = d->n; a.n_decay = d->n_decay;
+    a.lr_table = d->lr_table; a.wd_table = d->wd_table; a.step = d->step; a.table_len = d->table_len;
+    a.lr_scale = d->lr_scale; a.beta1 = d->beta1; a.beta2 = d->beta2; a.eps = d->eps;
+    a.grad_norm = d->grad_norm; a.clip_norm = d->clip_norm; a.skip_norm = d->skip_norm;
+    long nb = (d->n / 4 + 255) / 256;
+    if (nb > 4096) nb = 4096;
+    hipLaunchKernelGGL(adamw_kernel, dim3((unsigned)nb), dim3(256), 0, stream, a);
+    return mrg_check_launch("mrg_adamw");
+}
+
+extern "C" int mrg_step_inc(int* step, hipStream_t stream) {
+    MRG_REQUIRE(step, MRG_ERR_ARG, "mrg_step_inc: null pointer");
+    hipLaunchKernelGGL(step_inc_kernel, dim3(1), dim3(64), 0, stream, step);
+    return mrg_check_launch("mrg_step_inc");
+}
+
+extern "C" int mrg_cast_bf16(const float* src, void* dst_bf16, long n, hipStream_t stream) {
+    MRG_REQUIRE(src && dst_bf16 && n > 0, MRG_ERR_ARG, "mrg_cast_bf16: bad argument");
+    MRG_REQUIRE((((uintptr_t)src & 15) | ((uintptr_t)dst_bf16 & 7)) == 0, MRG_ERR_ARG, "mrg_cast_bf16: misaligned");
+    long nb = (n / 4 + 255) / 256;
+    if (nb > 4096) nb = 4096;
+    if (nb < 1) nb = 1;
+    hipLaunchKernelGGL(cast_bf16_kernel, dim3((unsigned)nb), dim3(256), 0, stream, src, (bf16_t*)dst_bf16, n);
+    return mrg_check_launch("mrg_cast_bf16");
+}
