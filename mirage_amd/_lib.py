@@ -1,0 +1,117 @@
+"""ctypes binding of libmirage_hip.so (the C ABI declared in include/mirage_hip.h).
+
+`import torch` happens first on purpose: the library must bind to the HIP runtime torch has already mapped
+(same soname), otherwise torch's streams / device pointers would be meaningless to the kernels.
+There is no fallback: if the shared library is missing or fails to load, importing this module raises.
+"""
+import ctypes as C
+import os
+
+import torch  # noqa: F401  (must precede CDLL: one HIP runtime per process)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmirage_hip.so")
+
+MRG_DT_BF16, MRG_DT_F32 = 0, 1
+MRG_OP_KCONTIG, MRG_OP_KSTRIDED = 0, 1
+MRG_ACT_NONE, MRG_ACT_GELU, MRG_ACT_GELU_BWD = 0, 1, 2
+MRG_LOSS_MSE, MRG_LOSS_CE = 0, 1
+MRG_MAX_DOMAINS = 4
+
+vp, ci, cl, cf = C.c_void_p, C.c_int, C.c_long, C.c_float
+
+
+class GemmDesc(C.Structure):
+    _fields_ = [("A", vp), ("B", vp), ("M", ci), ("N", ci), ("K", ci), ("lda", ci), ("ldb", ci),
+                ("a_mode", ci), ("b_mode", ci), ("a_map", vp), ("b_map", vp), ("m_dev", vp), ("k_dev", vp),
+                ("C", vp), ("ldc", ci), ("c_dtype", ci), ("C2", vp), ("ldc2", ci), ("bias", vp),
+                ("resid", vp), ("ldr", ci), ("accumulate", ci), ("act", ci),
+                ("aux_out", vp), ("aux_in", vp), ("ldaux", ci), ("row_map", vp),
+                ("add_tab", vp), ("add_row", vp), ("ldt", ci), ("splitk", ci), ("ws", vp)]
+
+
+class AttnDesc(C.Structure):
+    _fields_ = [("q", vp), ("k", vp), ("v", vp), ("o", vp), ("lse", vp),
+                ("q_bs", cl), ("q_rs", cl), ("k_bs", cl), ("k_rs", cl), ("v_bs", cl), ("v_rs", cl), ("o_bs", cl), ("o_rs", cl),
+                ("B", ci), ("H", ci), ("Nq", ci), ("Nk", ci), ("head_dim", ci), ("scale", cf),
+                ("d_o", vp), ("do_bs", cl), ("do_rs", cl), ("dsum", vp),
+                ("dq", vp), ("dk", vp), ("dv", vp),
+                ("dq_bs", cl), ("dq_rs", cl), ("dk_bs", cl), ("dk_rs", cl), ("dv_bs", cl), ("dv_rs", cl)]
+
+
+class DecAssembleDesc(C.Structure):
+    _fields_ = [("ctx", vp), ("mask_token", vp), ("task_emb", vp * MRG_MAX_DOMAINS), ("pos", vp),
+                ("ids_keep", vp), ("ids_restore", vp), ("dom_start", ci * (MRG_MAX_DOMAINS + 1)),
+                ("ndom", ci), ("qdom", ci), ("q_task_emb", vp),
+                ("B", ci), ("N", ci), ("K", ci), ("T", ci), ("Tq", ci), ("Dd", ci),
+                ("queries", vp), ("context", vp), ("d_queries", vp), ("d_context", vp),
+                ("d_ctx", vp), ("partials", vp), ("d_task_emb", vp * MRG_MAX_DOMAINS), ("d_mask_token", vp)]
+
+
+class LossDesc(C.Structure):
+    _fields_ = [("kind", ci), ("pred", vp), ("pred_dtype", ci), ("target", vp), ("mask", vp),
+                ("B", ci), ("C", ci), ("H", ci), ("W", ci), ("P", ci),
+                ("partial", vp), ("loss", vp), ("coef", vp), ("per_sample", vp), ("gout", vp), ("dpred", vp)]
+
+
+class AdamWDesc(C.Structure):
+    _fields_ = [("p", vp), ("g", vp), ("m", vp), ("v", vp), ("shadow_bf16", vp), ("n", cl), ("n_decay", cl),
+                ("lr_table", vp), ("wd_table", vp), ("step", vp), ("table_len", ci),
+                ("lr_scale", cf), ("beta1", cf), ("beta2", cf), ("eps", cf),
+                ("grad_norm", vp), ("clip_norm", cf), ("skip_norm", cf)]
+
+
+# name -> (restype, argtypes); kept in sync with include/mirage_hip.h (tests/test_abi.py checks the exports)
+SIGNATURES = {
+    "mrg_version": (ci, []),
+    "mrg_last_error_string": (C.c_char_p, []),
+    "mrg_gemm": (ci, [C.POINTER(GemmDesc), vp]),
+    "mrg_ln_fwd": (ci, [vp, vp, vp, vp, vp, vp, vp, ci, ci, cf, vp]),
+    "mrg_ln_bwd_nblocks": (ci, [ci]),
+    "mrg_ln_bwd": (ci, [vp] * 13 + [ci, ci, vp]),
+    "mrg_colsum_nblocks": (ci, [ci]),
+    "mrg_colsum": (ci, [vp, ci, ci, ci, ci, vp, vp, vp, vp, vp]),
+    "mrg_attn_fwd": (ci, [C.POINTER(AttnDesc), vp]),
+    "mrg_attn_bwd": (ci, [C.POINTER(AttnDesc), vp]),
+    "mrg_embed_plan": (ci, [vp, ci, ci, ci, ci, C.POINTER(ci), vp, vp, vp, vp, vp]),
+    "mrg_im2col_image": (ci, [vp, vp, vp, vp, ci, ci, ci, ci, ci, vp, vp]),
+    "mrg_im2col_layermap": (ci, [vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, vp, vp]),
+    "mrg_class_emb_grad": (ci, [vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, vp, vp]),
+    "mrg_fill_global": (ci, [vp, vp, ci, ci, ci, ci, ci, vp]),
+    "mrg_dec_assemble_fwd": (ci, [C.POINTER(DecAssembleDesc), vp]),
+    "mrg_dec_assemble_bwd_nblocks": (ci, [ci, ci, ci]),
+    "mrg_dec_assemble_bwd": (ci, [C.POINTER(DecAssembleDesc), vp]),
+    "mrg_loss_partial_floats": (ci, [ci]),
+    "mrg_masked_loss_fwd": (ci, [C.POINTER(LossDesc), vp]),
+    "mrg_masked_loss_bwd": (ci, [C.POINTER(LossDesc), vp]),
+    "mrg_patch_rearrange": (ci, [vp, vp, ci, ci, ci, ci, ci, ci, vp]),
+    "mrg_maskgen": (ci, [vp, vp, vp, ci, ci, ci, ci, C.POINTER(ci), vp, vp, vp, vp]),
+    "mrg_sumsq_nblocks": (ci, [cl]),
+    "mrg_grad_norm": (ci, [vp, cl, vp, vp, vp]),
+    "mrg_adamw": (ci, [C.POINTER(AdamWDesc), vp]),
+    "mrg_step_inc": (ci, [vp, vp]),
+    "mrg_cast_bf16": (ci, [vp, vp, cl, vp]),
+}
+
+if not os.path.exists(LIB_PATH):
+    raise ImportError(
+        f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+        "(hipcc --offload-arch=gfx950).  mirage_amd has no CPU or eager fallback.")
+
+lib = C.CDLL(LIB_PATH)
+for _name, (_res, _args) in SIGNATURES.items():
+    _fn = getattr(lib, _name)
+    _fn.restype = _res
+    _fn.argtypes = _args
+
+ABI_VERSION = lib.mrg_version()
+
+
+def check(rc: int, what: str = "") -> None:
+    if rc != 0:
+        msg = lib.mrg_last_error_string()
+        raise RuntimeError(f"libmirage_hip {what} failed (rc={rc}): {msg.decode() if msg else ''}")
+
+
+def stream_ptr():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)

@@ -1,0 +1,315 @@
+"""Tensor-level launchers for the HIP kernels (one python function per C-ABI entry point).
+
+Everything here takes CUDA(=HIP) torch tensors, passes raw pointers + the current torch stream to
+libmirage_hip.so, and returns torch tensors.  No computation happens in torch.
+"""
+import ctypes as C
+from typing import Optional, Sequence
+
+import torch
+
+from . import _lib as L
+from ._lib import lib, check
+
+BF16, F32 = torch.bfloat16, torch.float32
+_cur = torch.cuda.current_stream
+
+
+def _p(t: Optional[torch.Tensor]):
+    return None if t is None else t.data_ptr()
+
+
+def _s():
+    return C.c_void_p(_cur().cuda_stream)
+
+
+def _need_cuda(t: torch.Tensor, what: str):
+    if not t.is_cuda:
+        raise RuntimeError(f"mirage_amd: {what} must live on the GPU (got {t.device}); there is no CPU path")
+
+
+# ------------------------------------------------------------------------------------------------ GEMM
+_ws_cache = {}
+
+
+def _workspace(nbytes: int, device) -> torch.Tensor:
+    key = (device, torch.cuda.current_stream(device).cuda_stream)
+    ws = _ws_cache.get(key)
+    if ws is None or ws.numel() * 4 < nbytes:
+        ws = torch.empty((max(nbytes, 1 << 20) + 3) // 4, dtype=F32, device=device)
+        _ws_cache[key] = ws
+    return ws
+
+
+def gemm(A: torch.Tensor, B: torch.Tensor, M: int, N: int, K: int, *, a_mode=L.MRG_OP_KCONTIG, b_mode=L.MRG_OP_KCONTIG,
+         lda: Optional[int] = None, ldb: Optional[int] = None, out: Optional[torch.Tensor] = None, out_dtype=BF16,
+         ldc: Optional[int] = None, out2: Optional[torch.Tensor] = None, bias=None, resid=None, accumulate=False,
+         act=L.MRG_ACT_NONE, aux_out=None, aux_in=None, row_map=None, add_tab=None, add_row=None, a_map=None, b_map=None,
+         m_dev=None, k_dev=None, splitk: int = 1) -> torch.Tensor:
+    _need_cuda(A, "GEMM operand")
+    if out is None:
+        out = torch.empty((M, N), dtype=out_dtype, device=A.device)
+    d = L.GemmDesc()
+    d.A, d.B = A.data_ptr(), B.data_ptr()
+    d.M, d.N, d.K = M, N, K
+    d.lda = lda if lda is not None else A.stride(0)
+    d.ldb = ldb if ldb is not None else B.stride(0)
+    d.a_mode, d.b_mode = a_mode, b_mode
+    d.a_map, d.b_map, d.m_dev, d.k_dev = _p(a_map), _p(b_map), _p(m_dev), _p(k_dev)
+    d.C = out.data_ptr()
+    d.ldc = ldc if ldc is not None else out.stride(-2)
+    d.c_dtype = L.MRG_DT_F32 if out.dtype == F32 else L.MRG_DT_BF16
+    if out2 is not None:
+        d.C2, d.ldc2 = out2.data_ptr(), out2.stride(-2)
+    d.bias = _p(bias)
+    if resid is not None:
+        d.resid, d.ldr = resid.data_ptr(), resid.stride(-2)
+    d.accumulate = int(accumulate)
+    d.act = act
+    if aux_out is not None:
+        d.aux_out, d.ldaux = aux_out.data_ptr(), aux_out.stride(-2)
+    if aux_in is not None:
+        d.aux_in, d.ldaux = aux_in.data_ptr(), aux_in.stride(-2)
+    d.row_map = _p(row_map)
+    if add_tab is not None:
+        d.add_tab, d.add_row, d.ldt = add_tab.data_ptr(), add_row.data_ptr(), add_tab.stride(0)
+    d.splitk = splitk
+    if splitk > 1:
+        d.ws = _workspace(splitk * M * N * 4, A.device).data_ptr()
+    check(lib.mrg_gemm(C.byref(d), _s()), "mrg_gemm")
+    return out
+
+
+def pick_splitk(M: int, N: int, K: int, n_cu: int = 256) -> int:
+    """wgrad GEMMs have few output tiles and a long K: split K until there are ~1-2 workgroups per CU."""
+    tiles = ((M + 127) // 128) * ((N + 127) // 128)
+    ktiles = (K + 63) // 64
+    s = 1
+    while tiles * s < n_cu and s * 2 <= ktiles // 4 and s < 32:
+        s *= 2
+    return s
+
+
+# ------------------------------------------------------------------------------------------- LayerNorm
+def ln_fwd(x: torch.Tensor, gamma, beta, eps: float, out_dtype=BF16):
+    _need_cuda(x, "LayerNorm input")
+    D = x.shape[-1]
+    M = x.numel() // D
+    y = torch.empty(x.shape, dtype=out_dtype, device=x.device)
+    mean = torch.empty(M, dtype=F32, device=x.device)
+    rstd = torch.empty(M, dtype=F32, device=x.device)
+    check(lib.mrg_ln_fwd(x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), y.data_ptr() if out_dtype == BF16 else None,
+                         y.data_ptr() if out_dtype == F32 else None, mean.data_ptr(), rstd.data_ptr(), M, D, eps, _s()), "mrg_ln_fwd")
+    return y, mean, rstd
+
+
+def ln_bwd(dy: torch.Tensor, x, mean, rstd, gamma, dres, dgamma, dbeta, dres_colsum=None, want_f32=True, want_bf16=True):
+    D = x.shape[-1]
+    M = x.numel() // D
+    dx32 = torch.empty(x.shape, dtype=F32, device=x.device) if want_f32 else None
+    dx16 = torch.empty(x.shape, dtype=BF16, device=x.device) if want_bf16 else None
+    nb = lib.mrg_ln_bwd_nblocks(M)
+    partials = torch.empty(nb * 3 * D, dtype=F32, device=x.device)
+    check(lib.mrg_ln_bwd(dy.data_ptr() if dy.dtype == BF16 else None, dy.data_ptr() if dy.dtype == F32 else None, x.data_ptr(),
+                         mean.data_ptr(), rstd.data_ptr(), gamma.data_ptr(), _p(dres), _p(dx32), _p(dx16), partials.data_ptr(),
+                         _p(dgamma), _p(dbeta), _p(dres_colsum), M, D, _s()), "mrg_ln_bwd")
+    return dx32, dx16
+
+
+def colsum(x: torch.Tensor, out: torch.Tensor, M: Optional[int] = None, row_map=None, m_dev=None):
+    N = x.shape[-1]
+    M = M if M is not None else x.numel() // N
+    nb = lib.mrg_colsum_nblocks(M)
+    partials = torch.empty(nb * N, dtype=F32, device=x.device)
+    check(lib.mrg_colsum(x.data_ptr(), L.MRG_DT_BF16 if x.dtype == BF16 else L.MRG_DT_F32, M, N, x.stride(-2), _p(row_map),
+                         _p(m_dev), partials.data_ptr(), out.data_ptr(), _s()), "mrg_colsum")
+    return out
+
+
+# ------------------------------------------------------------------------------------------- attention
+def _attn_desc(q, k, v, o, lse, B, H, Nq, Nk, hd, scale, strides):
+    d = L.AttnDesc()
+    d.q, d.k, d.v, d.o, d.lse = q.data_ptr(), k.data_ptr(), v.data_ptr(), o.data_ptr(), _p(lse)
+    (d.q_bs, d.q_rs), (d.k_bs, d.k_rs), (d.v_bs, d.v_rs), (d.o_bs, d.o_rs) = strides
+    d.B, d.H, d.Nq, d.Nk, d.head_dim, d.scale = B, H, Nq, Nk, hd, scale
+    return d
+
+
+def attn_fwd(q, k, v, B, H, Nq, Nk, hd, scale, q_strides, k_strides, v_strides, need_lse=True):
+    """q/k/v: bf16 tensors (possibly views into fused projection buffers); strides = (batch, row) in elements."""
+    _need_cuda(q, "attention input")
+    o = torch.empty((B, Nq, H * hd), dtype=BF16, device=q.device)
+    lse = torch.empty((B, H, Nq), dtype=F32, device=q.device) if need_lse else None
+    d = _attn_desc(q, k, v, o, lse, B, H, Nq, Nk, hd, scale, (q_strides, k_strides, v_strides, (Nq * H * hd, H * hd)))
+    check(lib.mrg_attn_fwd(C.byref(d), _s()), "mrg_attn_fwd")
+    return o, lse
+
+
+def attn_bwd(q, k, v, o, lse, d_o, dq, dk, dv, B, H, Nq, Nk, hd, scale, q_strides, k_strides, v_strides, dq_strides, dk_strides,
+             dv_strides):
+    d = _attn_desc(q, k, v, o, lse, B, H, Nq, Nk, hd, scale, (q_strides, k_strides, v_strides, (Nq * H * hd, H * hd)))
+    dsum = torch.empty((B, H, Nq), dtype=F32, device=q.device)
+    d.d_o, d.do_bs, d.do_rs = d_o.data_ptr(), d_o.stride(0), d_o.stride(1)
+    d.dsum = dsum.data_ptr()
+    d.dq, d.dk, d.dv = dq.data_ptr(), dk.data_ptr(), dv.data_ptr()
+    (d.dq_bs, d.dq_rs), (d.dk_bs, d.dk_rs), (d.dv_bs, d.dv_rs) = dq_strides, dk_strides, dv_strides
+    check(lib.mrg_attn_bwd(C.byref(d), _s()), "mrg_attn_bwd")
+
+
+# ------------------------------------------------------------------------------------------- embedding
+def _int_array(vals: Sequence[int]):
+    return (C.c_int * len(vals))(*vals)
+
+
+def embed_plan(ids_keep: torch.Tensor, N: int, dom_start: Sequence[int]):
+    _need_cuda(ids_keep, "ids_keep")
+    B, K = ids_keep.shape
+    ndom = len(dom_start) - 1
+    cap = B * K
+    dev = ids_keep.device
+    rows = torch.empty((ndom, cap), dtype=torch.int32, device=dev)
+    toks = torch.empty((ndom, cap), dtype=torch.int32, device=dev)
+    srcb = torch.empty((ndom, cap), dtype=torch.int32, device=dev)
+    counts = torch.empty(ndom, dtype=torch.int32, device=dev)
+    check(lib.mrg_embed_plan(ids_keep.data_ptr(), B, K, N, ndom, _int_array(list(dom_start)), rows.data_ptr(), toks.data_ptr(),
+                             srcb.data_ptr(), counts.data_ptr(), _s()), "mrg_embed_plan")
+    return rows, toks, srcb, counts
+
+
+def im2col_image(img: torch.Tensor, srcb, toks, count, cap: int, P: int) -> torch.Tensor:
+    B, Cc, H, W = img.shape
+    out = torch.empty((cap, Cc * P * P), dtype=BF16, device=img.device)
+    check(lib.mrg_im2col_image(img.data_ptr(), srcb.data_ptr(), toks.data_ptr(), count.data_ptr(), cap, Cc, H, W, P, out.data_ptr(), _s()),
+          "mrg_im2col_image")
+    return out
+
+
+def im2col_layermap(labels: torch.Tensor, class_emb: torch.Tensor, srcb, toks, count, cap: int, P: int) -> torch.Tensor:
+    B, Hs, Ws = labels.shape
+    ncls, E = class_emb.shape
+    out = torch.empty((cap, E * P * P), dtype=BF16, device=labels.device)
+    check(lib.mrg_im2col_layermap(labels.data_ptr(), class_emb.data_ptr(), srcb.data_ptr(), toks.data_ptr(), count.data_ptr(), cap, ncls,
+                                  E, Hs, Ws, P, out.data_ptr(), _s()), "mrg_im2col_layermap")
+    return out
+
+
+def class_emb_grad(dA: torch.Tensor, labels, srcb, toks, count, ncls: int, E: int, P: int, out: torch.Tensor):
+    B, Hs, Ws = labels.shape
+    check(lib.mrg_class_emb_grad(dA.data_ptr(), labels.data_ptr(), srcb.data_ptr(), toks.data_ptr(), count.data_ptr(), ncls, E, Hs, Ws, P,
+                                 out.data_ptr(), _s()), "mrg_class_emb_grad")
+    return out
+
+
+def fill_global(x: torch.Tensor, glob: torch.Tensor, B: int, N: int, K: int):
+    ng, D = glob.shape[-2], glob.shape[-1]
+    check(lib.mrg_fill_global(x.data_ptr(), glob.data_ptr(), B, N, K, ng, D, _s()), "mrg_fill_global")
+
+
+# --------------------------------------------------------------------------------------------- decoder
+def dec_assemble_desc(ctx, mask_token, task_embs, pos, ids_keep, ids_restore, dom_start, qdom, B, N, K, T, Tq, Dd, q_task_emb=None):
+    d = L.DecAssembleDesc()
+    d.ctx, d.mask_token, d.pos = _p(ctx), mask_token.data_ptr(), pos.data_ptr()
+    for i, t in enumerate(task_embs):
+        d.task_emb[i] = _p(t)
+    d.ids_keep, d.ids_restore = ids_keep.data_ptr(), ids_restore.data_ptr()
+    for i, v in enumerate(dom_start):
+        d.dom_start[i] = v
+    d.ndom, d.qdom, d.q_task_emb = len(dom_start) - 1, qdom, _p(q_task_emb)
+    d.B, d.N, d.K, d.T, d.Tq, d.Dd = B, N, K, T, Tq, Dd
+    return d
+
+
+def dec_assemble_fwd(d: "L.DecAssembleDesc", device):
+    queries = torch.empty((d.B, d.Tq, d.Dd), dtype=F32, device=device)
+    context = torch.empty((d.B, d.N, d.Dd), dtype=F32, device=device)
+    d.queries, d.context = queries.data_ptr(), context.data_ptr()
+    check(lib.mrg_dec_assemble_fwd(C.byref(d), _s()), "mrg_dec_assemble_fwd")
+    return queries, context
+
+
+def dec_assemble_bwd(d: "L.DecAssembleDesc", d_queries, d_context, d_task_embs, d_mask_token, device):
+    d_ctx = torch.empty((d.B, d.N, d.Dd), dtype=F32, device=device)
+    nb = lib.mrg_dec_assemble_bwd_nblocks(d.B, d.N, d.Tq)
+    partials = torch.empty(nb * (L.MRG_MAX_DOMAINS + 1) * d.Dd, dtype=F32, device=device)
+    d.d_queries, d.d_context, d.d_ctx, d.partials = d_queries.data_ptr(), d_context.data_ptr(), d_ctx.data_ptr(), partials.data_ptr()
+    for i, t in enumerate(d_task_embs):
+        d.d_task_emb[i] = _p(t)
+    d.d_mask_token = _p(d_mask_token)
+    check(lib.mrg_dec_assemble_bwd(C.byref(d), _s()), "mrg_dec_assemble_bwd")
+    return d_ctx
+
+
+# ---------------------------------------------------------------------------------------------- losses
+def loss_desc(kind, pred, target, mask, P):
+    _need_cuda(pred, "loss input")
+    d = L.LossDesc()
+    B, Cc, H, W = pred.shape
+    d.kind, d.pred, d.pred_dtype = kind, pred.data_ptr(), (L.MRG_DT_BF16 if pred.dtype == BF16 else L.MRG_DT_F32)
+    d.target, d.mask = target.data_ptr(), _p(mask)
+    d.B, d.C, d.H, d.W, d.P = B, Cc, H, W, P
+    return d
+
+
+def masked_loss_fwd(d: "L.LossDesc", device):
+    partial = torch.empty(lib.mrg_loss_partial_floats(d.B), dtype=F32, device=device)
+    loss = torch.empty((), dtype=F32, device=device)
+    coef = torch.empty(d.B, dtype=F32, device=device)
+    d.partial, d.loss, d.coef = partial.data_ptr(), loss.data_ptr(), coef.data_ptr()
+    check(lib.mrg_masked_loss_fwd(C.byref(d), _s()), "mrg_masked_loss_fwd")
+    return loss, coef, partial
+
+
+def masked_loss_bwd(d: "L.LossDesc", coef, partial, gout, pred):
+    dpred = torch.empty_like(pred)
+    d.coef, d.partial, d.gout, d.dpred = coef.data_ptr(), partial.data_ptr(), _p(gout), dpred.data_ptr()
+    check(lib.mrg_masked_loss_bwd(C.byref(d), _s()), "mrg_masked_loss_bwd")
+    return dpred
+
+
+def patch_rearrange(src: torch.Tensor, to_image: bool, B: int, Cc: int, g: int, P: int) -> torch.Tensor:
+    shape = (B, Cc, g * P, g * P) if to_image else (B, g * g, Cc * P * P)
+    dst = torch.empty(shape, dtype=src.dtype, device=src.device)
+    check(lib.mrg_patch_rearrange(src.data_ptr(), dst.data_ptr(), L.MRG_DT_BF16 if src.dtype == BF16 else L.MRG_DT_F32, int(to_image),
+                                  B, Cc, g, P, _s()), "mrg_patch_rearrange")
+    return dst
+
+
+# --------------------------------------------------------------------------------------------- maskgen
+def maskgen(p: torch.Tensor, u: torch.Tensor, g: torch.Tensor, K: int, dom_start: Sequence[int]):
+    _need_cuda(p, "mask noise")
+    B, T = g.shape
+    dev = g.device
+    task_mask = torch.empty((B, T), dtype=torch.int64, device=dev)
+    ids_keep = torch.empty((B, K), dtype=torch.int64, device=dev)
+    ids_restore = torch.empty((B, T), dtype=torch.int64, device=dev)
+    check(lib.mrg_maskgen(p.data_ptr(), u.data_ptr(), g.data_ptr(), B, T, K, len(dom_start) - 1, _int_array(list(dom_start)),
+                          task_mask.data_ptr(), ids_keep.data_ptr(), ids_restore.data_ptr(), _s()), "mrg_maskgen")
+    return task_mask, ids_keep, ids_restore
+
+
+# ------------------------------------------------------------------------------------------- optimizer
+def grad_norm(g: torch.Tensor, out: torch.Tensor):
+    n = g.numel()
+    partials = torch.empty(lib.mrg_sumsq_nblocks(n), dtype=F32, device=g.device)
+    check(lib.mrg_grad_norm(g.data_ptr(), n, partials.data_ptr(), out.data_ptr(), _s()), "mrg_grad_norm")
+    return out
+
+
+def adamw(p, g, m, v, shadow, n_decay, lr_table, wd_table, step, beta1, beta2, eps, lr_scale=1.0, grad_norm_t=None, clip_norm=0.0,
+          skip_norm=0.0):
+    d = L.AdamWDesc()
+    d.p, d.g, d.m, d.v, d.shadow_bf16 = p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), _p(shadow)
+    d.n, d.n_decay = p.numel(), n_decay
+    d.lr_table, d.wd_table, d.step, d.table_len = lr_table.data_ptr(), wd_table.data_ptr(), step.data_ptr(), lr_table.numel()
+    d.lr_scale, d.beta1, d.beta2, d.eps = lr_scale, beta1, beta2, eps
+    d.grad_norm, d.clip_norm, d.skip_norm = _p(grad_norm_t), clip_norm or 0.0, skip_norm or 0.0
+    check(lib.mrg_adamw(C.byref(d), _s()), "mrg_adamw")
+
+
+def step_inc(step: torch.Tensor):
+    check(lib.mrg_step_inc(step.data_ptr(), _s()), "mrg_step_inc")
+
+
+def cast_bf16(src: torch.Tensor, dst: torch.Tensor):
+    check(lib.mrg_cast_bf16(src.data_ptr(), dst.data_ptr(), src.numel(), _s()), "mrg_cast_bf16")
+    return dst
