@@ -107,10 +107,16 @@ for _name, (_res, _args) in SIGNATURES.items():
 ABI_VERSION = lib.mrg_version()
 
 
+_SYNC_DEBUG = os.environ.get("MRG_SYNC_DEBUG", "0") == "1"
+
+
 def check(rc: int, what: str = "") -> None:
     if rc != 0:
         msg = lib.mrg_last_error_string()
         raise RuntimeError(f"libmirage_hip {what} failed (rc={rc}): {msg.decode() if msg else ''}")
+    if _SYNC_DEBUG:   # debugging aid: surface asynchronous faults at the launch that caused them
+        print(f"[mrg] {what}", flush=True)
+        torch.cuda.synchronize()
 
 
 def stream_ptr():

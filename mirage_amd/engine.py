@@ -1,0 +1,421 @@
+"""Forward / backward orchestration of the hot path on top of the HIP kernels.
+
+Each stage (gather-then-embed, encoder block, decoders, masked loss) is an explicit forward function that returns the
+activations its hand-written backward needs, plus a torch.autograd.Function shell so that callers keep the
+reference's `loss.backward()` protocol (run_pretraining.py:735-742 -> mutils/native_scaler.py:17).
+Parameter gradients are written IN PLACE (overwrite) into each Parameter's fp32 `.grad` buffer (an arena view for
+arena-backed models); the Functions return None for parameters.
+
+Dtype map (mirrors the reference's autocast map, SURVEY.md Appendix B, with bf16 instead of fp16): fp32 residual
+stream / LayerNorm statistics / softmax / accumulators / parameters / gradients; bf16 GEMM operands and outputs.
+"""
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import torch
+
+from . import _lib as L
+from . import kernels as K
+from .arena import grad_buffer, shadow
+
+BF16, F32 = torch.bfloat16, torch.float32
+KS = L.MRG_OP_KSTRIDED
+
+
+# ------------------------------------------------------------------------------------------- linear helpers
+def lin_fwd(x16: torch.Tensor, lin, *, out_dtype=BF16, resid: Optional[torch.Tensor] = None, want_bf16_copy: bool = False,
+            gelu: bool = False, save_pre: bool = False):
+    """y = x W^T + b with fused epilogue.  x16: bf16 [..., K].  Returns y (and bf16 copy / pre-activation if asked)."""
+    W = shadow(lin.weight)
+    N = W.shape[0]
+    Kin = W.numel() // N
+    M = x16.numel() // Kin
+    oshape = x16.shape[:-1] + (N,)
+    out = torch.empty(oshape, dtype=out_dtype, device=x16.device)
+    out2 = torch.empty(oshape, dtype=BF16, device=x16.device) if want_bf16_copy else None
+    pre = torch.empty(oshape, dtype=BF16, device=x16.device) if (gelu and save_pre) else None
+    K.gemm(x16, W, M, N, Kin, lda=Kin, ldb=Kin, out=out, ldc=N, out2=out2, bias=lin.bias,
+           resid=resid, act=L.MRG_ACT_GELU if gelu else L.MRG_ACT_NONE, aux_out=pre)
+    return out, out2, pre
+
+
+def lin_bwd(dy16: torch.Tensor, x16: torch.Tensor, lin, *, need_dx: bool = True, gelu_pre: Optional[torch.Tensor] = None,
+            dx_dtype=BF16, dx_bf16_copy: bool = False, bias_grad: bool = True, a_map=None, k_dev=None, m_rows: Optional[int] = None,
+            dx_accumulate_into: Optional[torch.Tensor] = None):
+    """Backward of y = x W^T + b given dy (bf16 [M, N]) and x (bf16 [M, K]).
+    Writes dW (and db) in place; returns dx (bf16 or fp32, optionally both) or None."""
+    Wp = lin.weight
+    W = shadow(Wp)
+    N = W.shape[0]
+    Kin = W.numel() // N
+    M = m_rows if m_rows is not None else dy16.numel() // N
+    if Wp.requires_grad:
+        gw = grad_buffer(Wp)
+        K.gemm(dy16, x16, N, Kin, M, a_mode=KS, b_mode=KS, lda=N, ldb=Kin, out=gw.view(N, Kin), ldc=Kin,
+               a_map=a_map, k_dev=k_dev, splitk=K.pick_splitk(N, Kin, M))
+    if bias_grad and lin.bias is not None and lin.bias.requires_grad:
+        K.colsum(dy16, grad_buffer(lin.bias), M=M, row_map=a_map, m_dev=k_dev)
+    if not need_dx:
+        return None, None
+    dshape = dy16.shape[:-1] + (Kin,)
+    if dx_accumulate_into is not None:
+        dx = dx_accumulate_into
+        acc = True
+    else:
+        dx = torch.empty(dshape, dtype=dx_dtype, device=dy16.device)
+        acc = False
+    dx2 = torch.empty(dshape, dtype=BF16, device=dy16.device) if dx_bf16_copy else None
+    K.gemm(dy16, W, M, Kin, N, b_mode=KS, lda=N, ldb=Kin, out=dx, ldc=Kin, out2=dx2, accumulate=acc,
+           act=L.MRG_ACT_GELU_BWD if gelu_pre is not None else L.MRG_ACT_NONE, aux_in=gelu_pre)
+    return dx, dx2
+
+
+def to_bf16(x32: torch.Tensor) -> torch.Tensor:
+    out = torch.empty(x32.shape, dtype=BF16, device=x32.device)
+    K.cast_bf16(x32, out)
+    return out
+
+
+# ------------------------------------------------------------------------------------------- transformer block
+def block_fwd(blk, x32: torch.Tensor, save: bool, want_bf16_out: bool = False):
+    """Block.forward (mirage/utils.py:259-262): x + attn(norm1(x)); x + mlp(norm2(x)).  x32: fp32 [B, N, D]."""
+    B, N, D = x32.shape
+    H = blk.attn.num_heads
+    hd = D // H
+    eps = blk.norm1.eps
+    ln1, mean1, rstd1 = K.ln_fwd(x32, blk.norm1.weight, blk.norm1.bias, eps)
+    qkv, _, _ = lin_fwd(ln1, blk.attn.qkv)
+    st = (N * 3 * D, 3 * D)
+    o, lse = K.attn_fwd(qkv[..., :D], qkv[..., D:2 * D], qkv[..., 2 * D:], B, H, N, N, hd, blk.attn.scale, st, st, st, need_lse=save)
+    x_mid, _, _ = lin_fwd(o, blk.attn.proj, out_dtype=F32, resid=x32)
+    ln2, mean2, rstd2 = K.ln_fwd(x_mid, blk.norm2.weight, blk.norm2.bias, blk.norm2.eps)
+    h_act, _, h_pre = lin_fwd(ln2, blk.mlp.fc1, gelu=True, save_pre=save)
+    x_out, x_out16, _ = lin_fwd(h_act, blk.mlp.fc2, out_dtype=F32, resid=x_mid, want_bf16_copy=want_bf16_out)
+    saved = (x32, ln1, mean1, rstd1, qkv, o, lse, x_mid, ln2, mean2, rstd2, h_pre, h_act) if save else None
+    return x_out, x_out16, saved
+
+
+def block_bwd(blk, saved, dx32: torch.Tensor, dx16: Optional[torch.Tensor]):
+    """Returns (dx_in fp32, dx_in bf16).  fc2 / proj bias gradients come out of the LayerNorm backward kernels
+    (column sums of the residual-stream gradient)."""
+    x_in, ln1, mean1, rstd1, qkv, o, lse, x_mid, ln2, mean2, rstd2, h_pre, h_act = saved
+    B, N, D = x_in.shape
+    H = blk.attn.num_heads
+    hd = D // H
+    if dx16 is None:
+        dx16 = to_bf16(dx32)
+    d_pre, _ = lin_bwd(dx16, h_act, blk.mlp.fc2, gelu_pre=h_pre, bias_grad=False)
+    d_ln2, _ = lin_bwd(d_pre, ln2, blk.mlp.fc1)
+    dx_mid32, dx_mid16 = K.ln_bwd(d_ln2, x_mid, mean2, rstd2, blk.norm2.weight, dx32, grad_buffer(blk.norm2.weight),
+                                  grad_buffer(blk.norm2.bias), grad_buffer(blk.mlp.fc2.bias))
+    d_o, _ = lin_bwd(dx_mid16, o, blk.attn.proj, bias_grad=False)
+    d_qkv = torch.empty_like(qkv)
+    st = (N * 3 * D, 3 * D)
+    K.attn_bwd(qkv[..., :D], qkv[..., D:2 * D], qkv[..., 2 * D:], o, lse, d_o, d_qkv[..., :D], d_qkv[..., D:2 * D], d_qkv[..., 2 * D:],
+               B, H, N, N, hd, blk.attn.scale, st, st, st, st, st, st)
+    d_ln1, _ = lin_bwd(d_qkv, ln1, blk.attn.qkv)
+    dx_in32, dx_in16 = K.ln_bwd(d_ln1, x_in, mean1, rstd1, blk.norm1.weight, dx_mid32, grad_buffer(blk.norm1.weight),
+                                grad_buffer(blk.norm1.bias), grad_buffer(blk.attn.proj.bias))
+    return dx_in32, dx_in16
+
+
+class BlockFn(torch.autograd.Function):
+    """Stand-alone Block (mirage/utils.py:226-262) for callers that use the module directly."""
+
+    @staticmethod
+    def forward(ctx, x, blk, save, *params):
+        x32 = x.contiguous().float()
+        out, _, saved = block_fwd(blk, x32, save)
+        ctx.blk, ctx.saved = blk, saved
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        dx32, _ = block_bwd(ctx.blk, ctx.saved, dout.contiguous().float(), None)
+        ctx.saved = None
+        return (dx32, None, None) + (None,) * 12
+
+
+class EncoderFn(torch.autograd.Function):
+    """nn.Sequential(Block x depth) (mirage/model.py:82-94,409) as one node: the (fp32, bf16) gradient pair flows
+    between blocks without touching autograd."""
+
+    @staticmethod
+    def forward(ctx, x, blocks, save, want_bf16, *params):
+        x32 = x
+        saved_all = []
+        x16 = None
+        n = len(blocks)
+        for i, blk in enumerate(blocks):
+            x32, x16, sv = block_fwd(blk, x32, save, want_bf16_out=(want_bf16 and i == n - 1))
+            saved_all.append(sv)
+        ctx.blocks, ctx.saved = blocks, saved_all
+        if want_bf16:
+            ctx.mark_non_differentiable(x16)
+            return x32, x16
+        return x32, None
+
+    @staticmethod
+    def backward(ctx, dout, _unused):
+        dx32 = dout.contiguous()
+        dx16 = None
+        for blk, sv in zip(reversed(ctx.blocks), reversed(ctx.saved)):
+            dx32, dx16 = block_bwd(blk, sv, dx32, dx16)
+        ctx.saved = None
+        # hand the bf16 twin of the returned gradient to the embedding backward: keyed by the tensor OBJECT (identity
+        # is checked on lookup, so a recycled address can never alias); at most one entry is alive
+        _TWINS.clear()
+        _TWINS[dx32.data_ptr()] = (dx32, dx16)
+        return (dx32, None, None, None) + (None,) * (len(ctx.needs_input_grad) - 4)
+
+
+# fp32 gradient tensor -> its bf16 twin, valid only while the fp32 tensor object itself is alive and identical
+_TWINS: Dict[int, Tuple[torch.Tensor, torch.Tensor]] = {}
+
+
+def _twin_of(g32: torch.Tensor) -> Optional[torch.Tensor]:
+    ent = _TWINS.pop(g32.data_ptr(), None)
+    if ent is not None and ent[0] is g32:
+        return ent[1]
+    return None
+
+
+# ------------------------------------------------------------------------------------------- input adapters
+def _pos_tokens(adapter) -> torch.Tensor:
+    """[1, D, h, w] frozen table -> token-major fp32 [h*w, D], cached (F.interpolate at identical size is an
+    identity: input_adapters.py:104,232, output_adapters.py:176,221)."""
+    pe = adapter.pos_emb
+    cache = getattr(adapter, "_mrg_pos_tok", None)
+    if cache is None or cache[0] != (pe.data_ptr(), pe._version):
+        _, D, h, w = pe.shape
+        tok = pe.detach()[0].permute(1, 2, 0).reshape(h * w, D).contiguous().float()
+        adapter._mrg_pos_tok = ((pe.data_ptr(), pe._version), tok)
+        return tok
+    return cache[1]
+
+
+def embed_fwd(model, x: Dict[str, torch.Tensor], ids_keep: torch.Tensor, save: bool):
+    """input adapters (mirage/input_adapters.py:87-110, 211-238) + token select + global tokens
+    (mirage/model.py:384-391), computing only the kept tokens."""
+    doms = list(model.input_adapters.keys())
+    B, Kk = ids_keep.shape
+    ng = model.num_global_tokens
+    N = Kk + ng
+    D = model.global_tokens.shape[-1]
+    dev = ids_keep.device
+    dom_start = model._dom_start(doms)
+    rows, toks, srcb, counts = K.embed_plan(ids_keep, N, dom_start)
+    cap = B * Kk
+    x0 = torch.empty((B, N, D), dtype=F32, device=dev)
+    saved = []
+    for d, dom in enumerate(doms):
+        ad = model.input_adapters[dom]
+        inp = x[dom]
+        if ad.kind == "semseg":
+            A = K.im2col_layermap(inp.contiguous(), ad.class_emb.weight, srcb[d], toks[d], counts[d:d + 1], cap, ad.P_H)
+        else:
+            A = K.im2col_image(inp.contiguous().float(), srcb[d], toks[d], counts[d:d + 1], cap, ad.P_H)
+        W = shadow(ad.proj.weight)
+        Kp = A.shape[1]
+        K.gemm(A, W, cap, D, Kp, lda=Kp, ldb=Kp, out=x0, ldc=D, bias=ad.proj.bias, row_map=rows[d], add_tab=_pos_tokens(ad),
+               add_row=toks[d], m_dev=counts[d:d + 1])
+        saved.append(A if save else None)
+    K.fill_global(x0, model.global_tokens, B, N, Kk)
+    plan = (rows, toks, srcb, counts)
+    return x0, (plan, saved, {k: x[k] for k in doms}) if save else None
+
+
+def embed_bwd(model, saved_all, dx32: torch.Tensor, dx16: Optional[torch.Tensor]):
+    (rows, toks, srcb, counts), A_list, inputs = saved_all
+    doms = list(model.input_adapters.keys())
+    B, N, D = dx32.shape
+    ng = model.num_global_tokens
+    Kk = N - ng
+    cap = B * Kk
+    if dx16 is None:
+        dx16 = to_bf16(dx32)
+    for d, dom in enumerate(doms):
+        ad = model.input_adapters[dom]
+        A = A_list[d]
+        Kp = A.shape[1]
+        cnt = counts[d:d + 1]
+        if ad.proj.weight.requires_grad:
+            gw = grad_buffer(ad.proj.weight)
+            K.gemm(dx16, A, D, Kp, cap, a_mode=KS, b_mode=KS, lda=D, ldb=Kp, out=gw.view(D, Kp), ldc=Kp, a_map=rows[d], k_dev=cnt,
+                   splitk=K.pick_splitk(D, Kp, max(cap // len(doms), 64)))
+        if ad.proj.bias.requires_grad:
+            K.colsum(dx32.view(B * N, D), grad_buffer(ad.proj.bias), M=cap, row_map=rows[d], m_dev=cnt)
+        if ad.kind == "semseg" and ad.class_emb.weight.requires_grad:
+            W = shadow(ad.proj.weight)
+            dA = torch.empty((cap, Kp), dtype=BF16, device=dx32.device)
+            K.gemm(dx16, W, cap, Kp, D, b_mode=KS, lda=D, ldb=Kp, out=dA, ldc=Kp, a_map=rows[d], m_dev=cnt)
+            ncls, E = ad.class_emb.weight.shape
+            K.class_emb_grad(dA, inputs[dom].contiguous(), srcb[d], toks[d], cnt, ncls, E, ad.P_H, grad_buffer(ad.class_emb.weight))
+    if model.global_tokens.requires_grad:
+        gg = grad_buffer(model.global_tokens).view(ng, D)
+        flat = dx32.view(B * N, D)
+        for g in range(ng):
+            rm = model._global_rows(B, N, Kk + g, dx32.device)
+            K.colsum(flat, gg[g], M=B, row_map=rm)
+
+
+class EmbedFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, model, x, ids_keep, save, *params):
+        x0, saved = embed_fwd(model, x, ids_keep, save)
+        ctx.model, ctx.saved = model, saved
+        return x0
+
+    @staticmethod
+    def backward(ctx, dx):
+        dx = dx.contiguous()
+        embed_bwd(ctx.model, ctx.saved, dx, _twin_of(dx))
+        ctx.saved = None
+        return (None,) * len(ctx.needs_input_grad)
+
+
+# ------------------------------------------------------------------------------------------- output adapters
+def decoder_fwd(ad, enc32: torch.Tensor, enc16: torch.Tensor, ids_keep, ids_restore, dom_names: Sequence[str],
+                dom_start: Sequence[int], ng: int, save: bool):
+    """SpatialOutputAdapter.forward (mirage/output_adapters.py:248-296)."""
+    B, N, D = enc32.shape
+    Kk = N - ng
+    T = dom_start[-1]
+    Dd = ad.dim_tokens
+    H = ad.decoder.num_heads
+    hd = Dd // H
+    dev = enc32.device
+    ctx, _, _ = lin_fwd(enc16, ad.proj_context, out_dtype=F32)                           # :272
+    qdom = dom_names.index(ad.task) if (ad.use_task_queries and ad.task in dom_names) else -1
+    task_embs = [ad.task_embeddings[n] if (ad.task_embeddings is not None and n in ad.task_embeddings) else None for n in dom_names]
+    pos = _pos_tokens(ad)
+    Tq = pos.shape[0]
+    q_te = None
+    if qdom < 0 and ad.task_embeddings is not None and ad.task in ad.task_embeddings:
+        q_te = ad.task_embeddings[ad.task]
+    desc = K.dec_assemble_desc(ctx, ad.mask_token, task_embs, pos, ids_keep, ids_restore, dom_start, qdom, B, N, Kk, T, Tq, Dd, q_te)
+    queries, context = K.dec_assemble_fwd(desc, dev)                                     # :188-246
+    eps = ad.query_norm.eps
+    qn, mq, rq = K.ln_fwd(queries, ad.query_norm.weight, ad.query_norm.bias, eps)
+    cn, mc, rc = K.ln_fwd(context, ad.context_norm.weight, ad.context_norm.bias, eps)
+    qp, _, _ = lin_fwd(qn, ad.decoder.q)
+    kv, _, _ = lin_fwd(cn, ad.decoder.kv)
+    sq, skv = (Tq * Dd, Dd), (N * 2 * Dd, 2 * Dd)
+    o, lse = K.attn_fwd(qp, kv[..., :Dd], kv[..., Dd:], B, H, Tq, N, hd, ad.decoder.scale, sq, skv, skv, need_lse=save)
+    x1, _, _ = lin_fwd(o, ad.decoder.proj, out_dtype=F32)                                # :279 (no residual)
+    on, mo, ro = K.ln_fwd(x1, ad.out_norm.weight, ad.out_norm.bias, eps)
+    h_act, _, h_pre = lin_fwd(on, ad.mlp.fc1, gelu=True, save_pre=save)
+    blocks = list(ad.decoder_transformer) if isinstance(ad.decoder_transformer, torch.nn.Sequential) else []
+    x2, x16, _ = lin_fwd(h_act, ad.mlp.fc2, out_dtype=F32, resid=x1, want_bf16_copy=(len(blocks) == 0))   # :280
+    blk_saved = []
+    xx = x2
+    for i, blk in enumerate(blocks):                                                     # :285
+        xx, x16, sv = block_fwd(blk, xx, save, want_bf16_out=(i == len(blocks) - 1))
+        blk_saved.append(sv)
+    y, _, _ = lin_fwd(x16, ad.out_proj)                                                  # :288
+    g = ad.image_size[0] // (ad.stride_level * ad.P_H)
+    img = K.patch_rearrange(y.view(B, Tq, -1), True, B, ad.num_channels, g, ad.P_H)      # :291-294
+    saved = None
+    if save:
+        saved = (desc, task_embs, queries, context, qn, mq, rq, cn, mc, rc, qp, kv, o, lse, x1, on, mo, ro, h_pre, h_act, x2,
+                 blk_saved, x16, enc16, (B, N, Tq, Dd, H, hd, g))
+    return img, saved
+
+
+def decoder_bwd(ad, saved, d_img: torch.Tensor, d_enc32: torch.Tensor, first: bool):
+    """Accumulates this adapter's contribution into d_enc32 (overwrites it if `first`)."""
+    (desc, task_embs, queries, context, qn, mq, rq, cn, mc, rc, qp, kv, o, lse, x1, on, mo, ro, h_pre, h_act, x2, blk_saved, x16,
+     enc16, (B, N, Tq, Dd, H, hd, g)) = saved
+    dev = d_img.device
+    blocks = list(ad.decoder_transformer) if isinstance(ad.decoder_transformer, torch.nn.Sequential) else []
+    d_y = K.patch_rearrange(d_img.contiguous(), False, B, ad.num_channels, g, ad.P_H).view(B * Tq, -1)
+    if d_y.dtype != BF16:
+        d_y = to_bf16(d_y)
+    dx32, dx16 = lin_bwd(d_y, x16, ad.out_proj, dx_dtype=F32, dx_bf16_copy=True)
+    dx32 = dx32.view(B, Tq, Dd)
+    dx16 = dx16.view(B, Tq, Dd)
+    for blk, sv in zip(reversed(blocks), reversed(blk_saved)):
+        dx32, dx16 = block_bwd(blk, sv, dx32, dx16)
+    d_pre, _ = lin_bwd(dx16, h_act, ad.mlp.fc2, gelu_pre=h_pre, bias_grad=False)
+    d_on, _ = lin_bwd(d_pre, on, ad.mlp.fc1)
+    dx1_32, dx1_16 = K.ln_bwd(d_on, x1, mo, ro, ad.out_norm.weight, dx32, grad_buffer(ad.out_norm.weight),
+                              grad_buffer(ad.out_norm.bias), grad_buffer(ad.mlp.fc2.bias))
+    d_o, _ = lin_bwd(dx1_16, o, ad.decoder.proj, bias_grad=False)
+    K.colsum(dx1_32.view(B * Tq, Dd), grad_buffer(ad.decoder.proj.bias))
+    dq = torch.empty_like(qp)
+    dkv = torch.empty_like(kv)
+    sq, skv = (Tq * Dd, Dd), (N * 2 * Dd, 2 * Dd)
+    K.attn_bwd(qp, kv[..., :Dd], kv[..., Dd:], o, lse, d_o, dq, dkv[..., :Dd], dkv[..., Dd:], B, H, Tq, N, hd, ad.decoder.scale,
+               sq, skv, skv, sq, skv, skv)
+    d_qn, _ = lin_bwd(dq, qn, ad.decoder.q)
+    d_cn, _ = lin_bwd(dkv, cn, ad.decoder.kv)
+    d_queries, _ = K.ln_bwd(d_qn, queries, mq, rq, ad.query_norm.weight, None, grad_buffer(ad.query_norm.weight),
+                            grad_buffer(ad.query_norm.bias), None, want_bf16=False)
+    d_context, _ = K.ln_bwd(d_cn, context, mc, rc, ad.context_norm.weight, None, grad_buffer(ad.context_norm.weight),
+                            grad_buffer(ad.context_norm.bias), None, want_bf16=False)
+    d_te = [grad_buffer(t) if t is not None else None for t in task_embs]
+    d_ctx = K.dec_assemble_bwd(desc, d_queries, d_context, d_te, grad_buffer(ad.mask_token), dev)
+    d_ctx16 = to_bf16(d_ctx)
+    # proj_context: wgrad + bias + dgrad accumulated into the shared encoder-output gradient
+    Wp = ad.proj_context
+    D = enc16.shape[-1]
+    if Wp.weight.requires_grad:
+        K.gemm(d_ctx16, enc16, Dd, D, B * N, a_mode=KS, b_mode=KS, lda=Dd, ldb=D, out=grad_buffer(Wp.weight), ldc=D,
+               splitk=K.pick_splitk(Dd, D, B * N))
+    if Wp.bias.requires_grad:
+        K.colsum(d_ctx.view(B * N, Dd), grad_buffer(Wp.bias))
+    K.gemm(d_ctx16, shadow(Wp.weight), B * N, D, Dd, b_mode=KS, lda=Dd, ldb=D, out=d_enc32, ldc=D, accumulate=not first)
+
+
+class DecodersFn(torch.autograd.Function):
+    """One or more output adapters in one node: their proj_context dgrads accumulate straight into one d_enc buffer."""
+
+    @staticmethod
+    def forward(ctx, enc32, enc16, adapters, dom_names, dom_start, ng, ids_keep, ids_restore, save, *params):
+        enc32 = enc32.contiguous().float()
+        if enc16 is None:
+            enc16 = to_bf16(enc32)
+        imgs, saved = [], []
+        for ad in adapters:
+            img, sv = decoder_fwd(ad, enc32, enc16, ids_keep, ids_restore, list(dom_names), list(dom_start), ng, save)
+            imgs.append(img)
+            saved.append(sv)
+        ctx.adapters, ctx.saved, ctx.shape = adapters, saved, enc32.shape
+        return tuple(imgs)
+
+    @staticmethod
+    def backward(ctx, *d_imgs):
+        dev = next(d for d in d_imgs if d is not None).device
+        d_enc = torch.empty(ctx.shape, dtype=F32, device=dev)
+        first = True
+        for ad, sv, d_img in zip(ctx.adapters, ctx.saved, d_imgs):
+            if d_img is None:
+                continue
+            decoder_bwd(ad, sv, d_img, d_enc, first)
+            first = False
+        ctx.saved = None
+        return (d_enc,) + (None,) * (len(ctx.needs_input_grad) - 1)
+
+
+# ------------------------------------------------------------------------------------------- losses
+class MaskedLossFn(torch.autograd.Function):
+    """MaskedMSELoss / MaskedCrossEntropyLoss (mirage/criterion.py:31-51, 87-117)."""
+
+    @staticmethod
+    def forward(ctx, pred, target, mask, kind, patch):
+        pred = pred.contiguous()
+        target = target.contiguous()
+        if kind == L.MRG_LOSS_MSE:
+            target = target.float()
+        if mask is not None:
+            mask = mask.contiguous().long()
+        d = K.loss_desc(kind, pred, target, mask, patch)
+        loss, coef, partial = K.masked_loss_fwd(d, pred.device)
+        ctx.d, ctx.keep = d, (pred, target, mask, coef, partial)
+        return loss
+
+    @staticmethod
+    def backward(ctx, gout):
+        pred, target, mask, coef, partial = ctx.keep
+        dpred = K.masked_loss_bwd(ctx.d, coef, partial, gout.contiguous().float(), pred)
+        ctx.keep = None
+        return dpred, None, None, None, None

@@ -216,6 +216,8 @@ def dec_assemble_desc(ctx, mask_token, task_embs, pos, ids_keep, ids_restore, do
         d.dom_start[i] = v
     d.ndom, d.qdom, d.q_task_emb = len(dom_start) - 1, qdom, _p(q_task_emb)
     d.B, d.N, d.K, d.T, d.Tq, d.Dd = B, N, K, T, Tq, Dd
+    # the descriptor outlives this call (it is reused by the backward pass): keep the tensors behind its raw pointers alive
+    d._refs = (ctx, mask_token, list(task_embs), pos, ids_keep, ids_restore, q_task_emb)
     return d
 
 
@@ -247,6 +249,7 @@ def loss_desc(kind, pred, target, mask, P):
     d.kind, d.pred, d.pred_dtype = kind, pred.data_ptr(), (L.MRG_DT_BF16 if pred.dtype == BF16 else L.MRG_DT_F32)
     d.target, d.mask = target.data_ptr(), _p(mask)
     d.B, d.C, d.H, d.W, d.P = B, Cc, H, W, P
+    d._refs = (pred, target, mask)
     return d
 
 

@@ -1,0 +1,310 @@
+"""Transformer building blocks with the reference's names, constructor arguments and state_dict layout
+(mirage/utils.py: pair :12, build_2d_sincos_posemb :24, trunc_normal_ :85, DropPath :124, Mlp :137,
+Attention :162, CrossAttention :191, Block :226).  Parameters are ordinary fp32 nn.Parameters; every forward runs
+on the HIP kernels (no torch math), so inputs and parameters must be on the GPU.
+"""
+import math
+import warnings
+from typing import Callable
+
+import torch
+import torch.nn as nn
+
+from . import _lib as L
+from . import engine as E
+from . import kernels as K
+from .arena import grad_buffer, shadow
+
+BF16, F32 = torch.bfloat16, torch.float32
+
+
+def pair(t):
+    if t is None:
+        return None
+    if isinstance(t, tuple):
+        return t
+    if isinstance(t, list):
+        return tuple(t)
+    return (t, t)
+
+
+def build_2d_sincos_posemb(h, w, embed_dim=1024, temperature=10000.0):
+    """Fixed 2-D sin-cos table [1, D, h, w] (mirage/utils.py:24-41), including the reference's axis convention: the
+    token at flat index m = row*w + col is given "w-coordinate" m // h and "h-coordinate" m % h."""
+    assert embed_dim % 4 == 0, "Embed dimension must be divisible by 4 for 2D sin-cos position embedding"
+    pos_dim = embed_dim // 4
+    omega = torch.arange(pos_dim, dtype=torch.float32) / pos_dim
+    omega = 1.0 / (temperature ** omega)
+    m = torch.arange(h * w, dtype=torch.float32)
+    cw = torch.div(m, h, rounding_mode="floor")
+    ch = m - cw * h
+    out_w = cw[:, None] * omega[None, :]
+    out_h = ch[:, None] * omega[None, :]
+    tab = torch.cat([torch.sin(out_w), torch.cos(out_w), torch.sin(out_h), torch.cos(out_h)], dim=1)
+    return tab.reshape(1, h, w, embed_dim).permute(0, 3, 1, 2).contiguous()
+
+
+def trunc_normal_(tensor, mean=0.0, std=1.0, a=-2.0, b=2.0):
+    """Truncated normal init by inverse-CDF sampling (same algorithm and RNG consumption as mirage/utils.py:44-100)."""
+    def norm_cdf(x):
+        return (1.0 + math.erf(x / math.sqrt(2.0))) / 2.0
+    if (mean < a - 2 * std) or (mean > b + 2 * std):
+        warnings.warn("mean is more than 2 std from [a, b] in trunc_normal_.", stacklevel=2)
+    with torch.no_grad():
+        lo, up = norm_cdf((a - mean) / std), norm_cdf((b - mean) / std)
+        tensor.uniform_(2 * lo - 1, 2 * up - 1)
+        tensor.erfinv_()
+        tensor.mul_(std * math.sqrt(2.0))
+        tensor.add_(mean)
+        tensor.clamp_(min=a, max=b)
+    return tensor
+
+
+class DropPath(nn.Module):
+    """Stochastic depth (mirage/utils.py:124-134).  Every configuration on the pretraining path uses p = 0
+    (run_pretraining.py:150), where the reference installs nn.Identity; p > 0 is not implemented on the HIP path."""
+
+    def __init__(self, drop_prob=0.0):
+        super().__init__()
+        self.drop_prob = drop_prob
+
+    def forward(self, x):
+        if self.drop_prob == 0.0 or not self.training:
+            return x
+        raise NotImplementedError("mirage_amd: DropPath with p > 0 is not implemented (no BASELINE config uses it)")
+
+    def extra_repr(self):
+        return "p={}".format(self.drop_prob)
+
+
+def _check_no_dropout(p, what):
+    if p and p > 0.0:
+        raise NotImplementedError(f"mirage_amd: {what} > 0 is not implemented on the HIP path (the pretraining configs use 0)")
+
+
+# ------------------------------------------------------------------------- generic stand-alone ops (autograd)
+class _LinearFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, lin, gelu, weight, bias):
+        x16 = x if x.dtype == BF16 else E.to_bf16(x.contiguous().float())
+        save = torch.is_grad_enabled() or True
+        y, _, pre = E.lin_fwd(x16.contiguous(), lin, out_dtype=F32 if x.dtype != BF16 else BF16, gelu=gelu, save_pre=gelu)
+        ctx.lin, ctx.x16, ctx.pre, ctx.in_dtype = lin, x16, pre, x.dtype
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        dy = dy.contiguous()
+        lin = ctx.lin
+        if ctx.pre is not None:
+            # dy is w.r.t. gelu(pre): fold gelu' in with an elementwise pass through the GEMM-free path
+            raise NotImplementedError
+        dy16 = dy if dy.dtype == BF16 else E.to_bf16(dy.float())
+        dx, _ = E.lin_bwd(dy16.view(-1, dy16.shape[-1]), ctx.x16.view(-1, ctx.x16.shape[-1]), lin,
+                          dx_dtype=F32 if ctx.in_dtype != BF16 else BF16)
+        return dx.view(ctx.x16.shape), None, None, None, None
+
+
+class Linear(nn.Linear):
+    """nn.Linear whose forward/backward run on the bf16 MFMA GEMM (fp32 master weights, bf16 operands)."""
+
+    def forward(self, x):
+        return _LinearFn.apply(x, self, False, self.weight, self.bias)
+
+
+class _LayerNormFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, ln, weight, bias):
+        x32 = x.contiguous().float()
+        y, mean, rstd = K.ln_fwd(x32, ln.weight, ln.bias, ln.eps, out_dtype=F32)
+        ctx.ln, ctx.keep = ln, (x32, mean, rstd)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x32, mean, rstd = ctx.keep
+        ln = ctx.ln
+        dx, _ = K.ln_bwd(dy.contiguous().float(), x32, mean, rstd, ln.weight, None, grad_buffer(ln.weight), grad_buffer(ln.bias),
+                         None, want_bf16=False)
+        return dx, None, None, None
+
+
+class LayerNorm(nn.LayerNorm):
+    """nn.LayerNorm on the wave-per-row HIP kernel (fp32 statistics)."""
+
+    def forward(self, x):
+        return _LayerNormFn.apply(x, self, self.weight, self.bias)
+
+
+class _MlpFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, mlp, *params):
+        x16 = E.to_bf16(x.contiguous().float())
+        h_act, _, h_pre = E.lin_fwd(x16, mlp.fc1, gelu=True, save_pre=True)
+        y, _, _ = E.lin_fwd(h_act, mlp.fc2, out_dtype=F32)
+        ctx.mlp, ctx.keep = mlp, (x16, h_pre, h_act)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x16, h_pre, h_act = ctx.keep
+        mlp = ctx.mlp
+        dy16 = E.to_bf16(dy.contiguous().float())
+        d_pre, _ = E.lin_bwd(dy16, h_act, mlp.fc2, gelu_pre=h_pre)
+        dx, _ = E.lin_bwd(d_pre, x16, mlp.fc1, dx_dtype=F32)
+        return (dx, None) + (None,) * 4
+
+
+class Mlp(nn.Module):
+    """fc1 -> exact-erf GELU -> fc2 (mirage/utils.py:137-159); GELU is fused into the fc1 epilogue."""
+
+    def __init__(self, in_features, hidden_features=None, out_features=None, act_layer=nn.GELU, drop=0.0):
+        super().__init__()
+        out_features = out_features or in_features
+        hidden_features = hidden_features or in_features
+        if act_layer is not nn.GELU:
+            raise NotImplementedError("mirage_amd.Mlp: only the exact-erf nn.GELU of the reference is fused")
+        _check_no_dropout(drop, "Mlp drop")
+        self.fc1 = Linear(in_features, hidden_features)
+        self.act = act_layer()
+        self.fc2 = Linear(hidden_features, out_features)
+        self.drop = nn.Dropout(drop)
+
+    def forward(self, x):
+        return _MlpFn.apply(x, self, self.fc1.weight, self.fc1.bias, self.fc2.weight, self.fc2.bias)
+
+
+class _AttentionFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, att, *params):
+        B, N, C = x.shape
+        H = att.num_heads
+        hd = C // H
+        x16 = E.to_bf16(x.contiguous().float())
+        qkv, _, _ = E.lin_fwd(x16, att.qkv)
+        st = (N * 3 * C, 3 * C)
+        o, lse = K.attn_fwd(qkv[..., :C], qkv[..., C:2 * C], qkv[..., 2 * C:], B, H, N, N, hd, att.scale, st, st, st)
+        y, _, _ = E.lin_fwd(o, att.proj, out_dtype=F32)
+        ctx.att, ctx.keep = att, (x16, qkv, o, lse)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x16, qkv, o, lse = ctx.keep
+        att = ctx.att
+        B, N, C = x16.shape
+        H = att.num_heads
+        hd = C // H
+        dy16 = E.to_bf16(dy.contiguous().float())
+        d_o, _ = E.lin_bwd(dy16, o, att.proj)
+        d_qkv = torch.empty_like(qkv)
+        st = (N * 3 * C, 3 * C)
+        K.attn_bwd(qkv[..., :C], qkv[..., C:2 * C], qkv[..., 2 * C:], o, lse, d_o, d_qkv[..., :C], d_qkv[..., C:2 * C], d_qkv[..., 2 * C:],
+                   B, H, N, N, hd, att.scale, st, st, st, st, st, st)
+        dx, _ = E.lin_bwd(d_qkv, x16, att.qkv, dx_dtype=F32)
+        return (dx, None) + (None,) * 4
+
+
+class Attention(nn.Module):
+    """Fused-QKV self attention (mirage/utils.py:162-188)."""
+
+    def __init__(self, dim, num_heads=8, qkv_bias=False, attn_drop=0.0, proj_drop=0.0):
+        super().__init__()
+        _check_no_dropout(attn_drop, "attn_drop")
+        _check_no_dropout(proj_drop, "proj_drop")
+        self.num_heads = num_heads
+        head_dim = dim // num_heads
+        if head_dim not in (32, 64):
+            raise NotImplementedError(f"mirage_amd.Attention: head_dim {head_dim} not in (32, 64)")
+        self.scale = head_dim ** -0.5
+        self.qkv = Linear(dim, dim * 3, bias=qkv_bias)
+        self.attn_drop = attn_drop
+        self.proj = Linear(dim, dim)
+        self.proj_drop = nn.Dropout(proj_drop)
+
+    def forward(self, x):
+        return _AttentionFn.apply(x, self, self.qkv.weight, self.qkv.bias, self.proj.weight, self.proj.bias)
+
+
+class _CrossAttentionFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, context, att, *params):
+        B, N, C = x.shape
+        M = context.shape[1]
+        H = att.num_heads
+        hd = C // H
+        x16 = E.to_bf16(x.contiguous().float())
+        c16 = E.to_bf16(context.contiguous().float())
+        q, _, _ = E.lin_fwd(x16, att.q)
+        kv, _, _ = E.lin_fwd(c16, att.kv)
+        sq, skv = (N * C, C), (M * 2 * C, 2 * C)
+        o, lse = K.attn_fwd(q, kv[..., :C], kv[..., C:], B, H, N, M, hd, att.scale, sq, skv, skv)
+        y, _, _ = E.lin_fwd(o, att.proj, out_dtype=F32)
+        ctx.att, ctx.keep = att, (x16, c16, q, kv, o, lse)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x16, c16, q, kv, o, lse = ctx.keep
+        att = ctx.att
+        B, N, C = x16.shape
+        M = c16.shape[1]
+        H = att.num_heads
+        hd = C // H
+        dy16 = E.to_bf16(dy.contiguous().float())
+        d_o, _ = E.lin_bwd(dy16, o, att.proj)
+        dq = torch.empty_like(q)
+        dkv = torch.empty_like(kv)
+        sq, skv = (N * C, C), (M * 2 * C, 2 * C)
+        K.attn_bwd(q, kv[..., :C], kv[..., C:], o, lse, d_o, dq, dkv[..., :C], dkv[..., C:], B, H, N, M, hd, att.scale, sq, skv, skv,
+                   sq, skv, skv)
+        dx, _ = E.lin_bwd(dq, x16, att.q, dx_dtype=F32)
+        dc, _ = E.lin_bwd(dkv, c16, att.kv, dx_dtype=F32)
+        return (dx, dc, None) + (None,) * 6
+
+
+class CrossAttention(nn.Module):
+    """Query / context attention (mirage/utils.py:191-223)."""
+
+    def __init__(self, dim, num_heads=8, qkv_bias=False, attn_drop=0.0, proj_drop=0.0):
+        super().__init__()
+        _check_no_dropout(attn_drop, "attn_drop")
+        _check_no_dropout(proj_drop, "proj_drop")
+        self.num_heads = num_heads
+        head_dim = dim // num_heads
+        if head_dim not in (32, 64):
+            raise NotImplementedError(f"mirage_amd.CrossAttention: head_dim {head_dim} not in (32, 64)")
+        self.scale = head_dim ** -0.5
+        self.q = Linear(dim, dim, bias=qkv_bias)
+        self.kv = Linear(dim, dim * 2, bias=qkv_bias)
+        self.attn_drop = attn_drop
+        self.proj = Linear(dim, dim)
+        self.proj_drop = nn.Dropout(proj_drop)
+
+    def forward(self, x, context):
+        return _CrossAttentionFn.apply(x, context, self, self.q.weight, self.q.bias, self.kv.weight, self.kv.bias, self.proj.weight,
+                                       self.proj.bias)
+
+
+class Block(nn.Module):
+    """Pre-LN transformer block (mirage/utils.py:226-262)."""
+
+    def __init__(self, dim: int, num_heads: int, mlp_ratio: float = 4.0, qkv_bias: bool = False, drop: float = 0.0,
+                 attn_drop: float = 0.0, drop_path: float = 0.0, act_layer: Callable = nn.GELU, norm_layer: Callable = LayerNorm):
+        super().__init__()
+        self.norm1 = norm_layer(dim)
+        self.attn = Attention(dim, num_heads=num_heads, qkv_bias=qkv_bias, attn_drop=attn_drop, proj_drop=drop)
+        self.drop_path = DropPath(drop_path) if drop_path > 0.0 else nn.Identity()
+        self.norm2 = norm_layer(dim)
+        self.mlp = Mlp(in_features=dim, hidden_features=int(dim * mlp_ratio), act_layer=act_layer, drop=drop)
+        if not (qkv_bias and isinstance(self.norm1, nn.LayerNorm)):
+            raise NotImplementedError("mirage_amd.Block: needs qkv_bias=True and a LayerNorm norm_layer (the reference's defaults)")
+        if drop_path > 0.0:
+            raise NotImplementedError("mirage_amd.Block: drop_path > 0 is not implemented (pretraining uses 0.0)")
+
+    def _params(self):
+        return (self.norm1.weight, self.norm1.bias, self.attn.qkv.weight, self.attn.qkv.bias, self.attn.proj.weight, self.attn.proj.bias,
+                self.norm2.weight, self.norm2.bias, self.mlp.fc1.weight, self.mlp.fc1.bias, self.mlp.fc2.weight, self.mlp.fc2.bias)
+
+    def forward(self, x):
+        return E.BlockFn.apply(x, self, torch.is_grad_enabled(), *self._params())

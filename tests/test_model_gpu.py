@@ -1,0 +1,169 @@
+"""End-to-end parity of the HIP path against the CPU oracle and the reference-generated golden vectors. GPU only.
+
+Tolerances (bf16 compute vs the fp32 reference):
+  * mask indices / ids_keep / ids_restore: bit-exact;
+  * loss (per task and summed): relative error <= 1e-3 (BASELINE.json north_star) -- except where the REFERENCE ITSELF,
+    run under bf16 autocast on the same weights / inputs / masks, is not within 1e-3/3 of its own fp32 run: every fixture
+    carries that measured noise floor (`floor.*`, tools/ref_bf16_floor.py) and the bound is max(1e-3, 3 x floor).
+    (These fixtures use untrained hash-derived weights; rounding the weights to bf16 is a fixed perturbation of the
+    model, so the floor is larger than for a trained model.  Measured floors: per-task 0.8e-4 .. 1.9e-3.)
+  * encoder tokens: rel-RMS <= 1e-2 (floor 3.9e-3 .. 5.6e-3), cosine >= 0.9999;
+  * gradients: every parameter within max(4e-2, 3 x floor) of the whole-gradient scale, total norm within
+    max(1e-2, 3 x floor).
+"""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _build(cfg, with_decoders=True):
+    from mirage_amd import builder
+    from oracle import mirage_oracle as O
+    dom = cfg["domains"]
+    img = next((d for d in cfg["in_domains"] if dom[d]["kind"] == "image"), None)
+    lm = next((d for d in dom if dom[d]["kind"] == "semseg"), None)
+    args = builder.make_args(cfg["in_domains"], cfg["out_domains"], input_size=dom[img]["image"] if img else 512,
+                             patch_size=dom[img]["patch"] if img else 32, layermap_size=dom[lm]["image"] if lm else 128,
+                             layermap_patch=dom[lm]["patch"] if lm else 8, decoder_dim=cfg["decoder_dim"],
+                             decoder_depth=cfg["decoder_depth"], decoder_num_heads=cfg["decoder_heads"])
+    model = builder.get_model(args, with_decoders=with_decoders and bool(cfg["out_domains"]), dim_tokens=cfg["dim"], depth=cfg["depth"],
+                              num_heads=cfg["heads"])
+    sd = O.procedural_state_dict(cfg)
+    missing = model.load_state_dict(sd, strict=True)
+    return model.to(DEV), args, sd
+
+
+def rel_rms(a, b):
+    a, b = a.double().flatten(), b.double().flatten()
+    return float((a - b).norm() / (b.norm() + 1e-30))
+
+
+def _case(name, grads=True):
+    from mirage_amd import builder
+    from oracle import mirage_oracle as O
+    fx, meta = load_golden(name)
+    cfg, B, Kk = meta["cfg"], meta["B"], meta["K"]
+    model, args, sd = _build(cfg)
+    model.train()
+    x = O.synthetic_batch(cfg, B, seed=meta["data_seed"])
+    xg = {d: t.to(DEV) for d, t in x.items()}
+    doms = cfg["in_domains"]
+    p = torch.from_numpy(fx["p"]).to(DEV)
+    u = torch.cat([torch.from_numpy(fx[f"u.{d}"]) for d in doms], 1).to(DEV)
+    g = torch.from_numpy(fx["g"]).to(DEV)
+    # masks: bit-exact from the committed noise, through the model's own generator
+    tm, ids_keep, ids_restore = model.generate_random_masks_from_noise(p, u, g, Kk, doms)
+    assert torch.equal(ids_keep.cpu(), torch.from_numpy(fx["ids_keep"]))
+    assert torch.equal(ids_restore.cpu(), torch.from_numpy(fx["ids_restore"]))
+    for d in doms:
+        assert torch.equal(tm[d].cpu(), torch.from_numpy(fx[f"task_mask.{d}"]))
+    # encoder tokens (decoders switched off) vs golden
+    oa = model.output_adapters
+    model.output_adapters = None
+    with torch.no_grad():
+        enc, _ = model({d: xg[d] for d in doms}, num_encoded_tokens=Kk, mask_noise=(p, u, g))
+    model.output_adapters = oa
+    enc = enc.float().cpu()
+    if "enc_tokens" in fx:
+        ref = torch.from_numpy(fx["enc_tokens"])
+        assert rel_rms(enc, ref) <= 1e-2, rel_rms(enc, ref)
+        cos = float(torch.nn.functional.cosine_similarity(enc.flatten().double(), ref.flatten().double(), dim=0))
+        assert cos >= 0.9999, cos
+    assert abs(float(enc.double().norm()) - float(fx["enc_tokens_norm"])) <= 5e-3 * float(fx["enc_tokens_norm"])
+    # full forward + masked losses
+    loss_fns = builder.get_losses(args)
+    preds, masks = model({d: xg[d] for d in doms}, num_encoded_tokens=Kk, mask_noise=(p, u, g))
+    losses = {d: loss_fns[d](preds[d], xg[d], mask=masks.get(d)) for d in preds}
+    total = sum(losses.values())
+    for d in preds:
+        want = float(fx[f"loss.{d}"])
+        tol = max(1e-3, 3.0 * float(fx[f"floor.loss.{d}"]))
+        assert abs(float(losses[d]) - want) <= tol * max(1.0, abs(want)), (d, float(losses[d]), want, tol)
+        assert abs(float(preds[d].float().double().norm()) - float(fx[f"pred_norm.{d}"])) <= 1e-2 * float(fx[f"pred_norm.{d}"])
+    tol = max(1e-3, 3.0 * float(fx["floor.loss"]))
+    assert abs(float(total) - float(fx["loss"])) <= tol * abs(float(fx["loss"])), (float(total), float(fx["loss"]), tol)
+    if not grads:
+        return
+    total.backward()
+    names = [str(n) for n in fx["grad_names"]]
+    params = dict(model.named_parameters())
+    tot2 = 0.0
+    worst = (0.0, "")
+    gtol = max(4e-2, 3.0 * float(fx["floor.grad_worst_rel"]))
+    for n, gn in zip(names, fx["grad_norms"]):
+        gr = params[n].grad
+        assert gr is not None, n
+        mine = float(gr.double().norm())
+        tot2 += mine * mine
+        # parameters whose true gradient is ~0 (softmax-shift-invariant k-bias) carry only noise: compare on the scale
+        # of the whole gradient instead of their own
+        scale = max(gn, 1e-3 * float(fx["grad_total_norm"]))
+        err = abs(mine - gn) / scale
+        if err > worst[0]:
+            worst = (err, n)
+        if f"grad.{n}" in fx:
+            ref = torch.from_numpy(fx[f"grad.{n}"]).double()
+            assert float((gr.cpu().double() - ref).norm()) <= gtol * scale + 1e-7, (n, float((gr.cpu().double() - ref).norm()), scale)
+    assert worst[0] <= gtol, worst
+    ttol = max(1e-2, 3.0 * float(fx["floor.grad_total_norm"]))
+    assert abs(tot2 ** 0.5 - float(fx["grad_total_norm"])) <= ttol * float(fx["grad_total_norm"])
+
+
+def test_tiny3_end_to_end():
+    _case("tiny3")
+
+
+def test_tiny2_end_to_end():
+    _case("tiny2")
+
+
+def test_c2_base_end_to_end():
+    _case("c2_base")
+
+
+def test_c3_base_end_to_end():
+    _case("c3_base")
+
+
+def test_c4_large_end_to_end():
+    _case("c4_large")
+
+
+def test_init_matches_reference_distribution_and_state_dict_layout():
+    from oracle import mirage_oracle as O
+    fx, meta = load_golden("harness_tiny")
+    cfg = meta["cfg"]
+    torch.manual_seed(0)
+    model, args, _ = _build(cfg)
+    keys = list(model.state_dict().keys())
+    assert keys == [str(k) for k in fx["state_dict_keys"]]
+    import json
+    for k, s in zip(keys, fx["state_dict_shapes"]):
+        assert list(model.state_dict()[k].shape) == json.loads(str(s))
+    assert sorted(model.no_weight_decay()) == [str(s) for s in fx["no_weight_decay"]]
+    assert sorted(n for n, p in model.named_parameters() if p.requires_grad) == sorted(str(s) for s in fx["trainable"])
+
+
+def test_encoder_only_pooled_features():
+    """Config-5 style path (mirage_wrapper.py:208-224): encoder over all tokens in random order -> LN -> mean pool."""
+    from oracle import mirage_oracle as O
+    for name in ("tiny_cls", "c5_large_cls"):
+        fx, meta = load_golden(name)
+        cfg, B = meta["cfg"], meta["B"]
+        model, args, sd = _build(cfg, with_decoders=False)
+        model.eval()
+        d = cfg["in_domains"][0]
+        x = O.synthetic_batch(cfg, B, seed=meta["data_seed"])[d].to(DEV)
+        D = cfg["dim"]
+        nw = torch.from_numpy(1.0 + 0.2 * O.procedural_uniform("cls.norm.weight", D)).to(DEV)
+        nb = torch.from_numpy(0.04 * O.procedural_uniform("cls.norm.bias", D)).to(DEV)
+        with torch.no_grad():
+            out, _ = model({d: x}, mask_inputs=False)
+            out = torch.nn.functional.layer_norm(out, (D,), nw, nb, 1e-6)
+            pooled = out[:, :-1].mean(1)
+        assert rel_rms(pooled.cpu(), torch.from_numpy(fx["pooled"])) <= 1e-2
