@@ -1,0 +1,271 @@
+#!/usr/bin/env python3
+"""Headline benchmark: MIRAGE pretraining images/sec on N MI355X of one node (BASELINE.json metric).
+
+A "step" is one full optimizer step of the pretraining hot path on one batch of synthetic device-resident inputs:
+mask generation -> gather-then-embed -> encoder -> decoders -> masked losses -> backward -> [grad all-reduce] ->
+global grad-norm + fused AdamW.  Nothing is skipped inside the timed region.
+
+    python bench.py --gpus 1 --steps 20 --warmup 5                      # C2: Base 512/32 bscan+slo, B=64, K=128
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 ... bench.py --gpus 8 ...
+
+Prints ONE JSON line on rank 0 (see README / the driver contract) with `roofline` (dominant kernel, measured live with
+events on the launch stream in an instrumented eager step) and, at N=1, `cpu_baseline` (the CPU oracle timed on the
+host cores on a bounded sample of the same workload).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+MFMA_BF16_PEAK = 2.5e15      # dense bf16 MFMA peak, FLOP/s (MI355X_MICROARCH.md)
+
+CONFIGS = {
+    #        model             in_domains                              B    K    train
+    "c2": ("miragepre_base", ("bscan", "slo"), 64, 128, True),
+    "c3": ("miragepre_base", ("bscan", "slo", "bscanlayermap"), 64, 98, True),
+    "c4": ("miragepre_large", ("bscan", "slo", "bscanlayermap"), 64, 98, True),
+    "c5": ("miragepre_large", ("bscan",), 256, 256, False),
+}
+DIMS = {"miragepre_base": (768, 12, 12), "miragepre_large": (1024, 24, 16)}
+
+
+def flops_per_image(model_name, doms, K, train):
+    """Algorithmic matmul FLOPs per image (SURVEY.md section 8d / BASELINE.md section 3): encoder over N = K+1 tokens,
+    patch-embed for the K kept tokens only (expected share K/T per modality), one decoder per output domain."""
+    D, L, _ = DIMS[model_name]
+    N = K + 1
+    Dd, Tq = 256, 256
+    f_enc = L * (24 * N * D * D + 4 * N * N * D)
+    T = 256 * len(doms)
+    f_emb_img = f_emb_lm = 0.0
+    for d in doms:
+        kept = K * 256 / T
+        if d == "bscanlayermap":
+            f_emb_lm += kept * 2 * 4096 * D
+        else:
+            f_emb_img += kept * 2 * 1024 * D
+    if not train:
+        return f_enc + f_emb_img + f_emb_lm
+    f_dec = 0.0
+    for d in doms:
+        out = 832 if d == "bscanlayermap" else 1024
+        f_dec += (2 * N * D * Dd + 4 * Tq * Dd * Dd + 4 * N * Dd * Dd + 4 * Tq * N * Dd + 16 * Tq * Dd * Dd
+                  + 2 * (24 * Tq * Dd * Dd + 4 * Tq * Tq * Dd) + 2 * Tq * Dd * out)
+    return 3 * (f_enc + f_dec) + 2 * f_emb_img + 3 * f_emb_lm
+
+
+def synth_batches(doms, B, n, seed, device):
+    rng = np.random.default_rng(seed)
+    pool = []
+    for _ in range(n):
+        b = {}
+        for d in doms:
+            if d == "bscanlayermap":
+                b[d] = torch.from_numpy(rng.integers(0, 13, (B, 128, 128), dtype=np.int64)).to(device)
+            else:
+                b[d] = torch.from_numpy(rng.random((B, 1, 512, 512), dtype=np.float32)).to(device)
+        pool.append(b)
+    return pool
+
+
+def cpu_baseline(model_name, doms, K, train, budget_s=25.0):
+    """CPU oracle (parity-pinned restatement of the reference) on the host cores; bounded sample of the same workload."""
+    from oracle import mirage_oracle as O
+    n_threads = min(os.cpu_count() or 1, 32)   # more threads than this only oversubscribe the small CPU matmuls
+    torch.set_num_threads(n_threads)
+    cfg = O.make_config("base" if model_name.endswith("base") else "large", in_domains=doms, out_domains=doms if train else ())
+    sd = {k: v.clone().requires_grad_(O.param_shapes(cfg)[k][1]) for k, v in O.procedural_state_dict(cfg).items()}
+    B = 16 if train else 8
+    x = O.synthetic_batch(cfg, B, seed=1234)
+    _, _, ids_keep, ids_restore = O.synthetic_masks(cfg, B, K, seed=99)
+    times = []
+    t_start = time.perf_counter()
+    it = 0
+    while True:
+        t0 = time.perf_counter()
+        if train:
+            for p in sd.values():
+                p.grad = None
+            loss, _, _, _ = O.forward_loss(cfg, sd, x, ids_keep, ids_restore)
+            loss.backward()
+        else:
+            with torch.no_grad():
+                O.forward(cfg, sd, {d: x[d] for d in doms}, ids_keep, ids_restore, decode=False)
+        dt = time.perf_counter() - t0
+        it += 1
+        if it > 1:
+            times.append(dt)
+        if len(times) >= 3 or (time.perf_counter() - t_start > budget_s and len(times) >= 1):
+            break
+    best = min(times)
+    return {"value": round(B / best, 3), "unit": "images/sec", "cores": n_threads, "kind": "port",
+            "sample": f"CPU oracle fp32, B={B}, {'fwd+loss+bwd' if train else 'fwd'}, 1 warm-up + {len(times)} timed iterations (best)"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--config", default="c2", choices=sorted(CONFIGS))
+    ap.add_argument("--batch", type=int, default=None, help="per-GPU batch override (debug)")
+    ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    a = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    assert world == a.gpus or world == 1, f"--gpus {a.gpus} but WORLD_SIZE={world}"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=dev)
+
+    from mirage_amd import builder, kernels as K, optim
+    from mirage_amd import _lib as L
+    from mirage_amd.dp import GradReducer, broadcast_params
+    from mirage_amd.trainer import TrainStep
+
+    model_name, doms, B, Kk, train = CONFIGS[a.config]
+    if a.batch:
+        B = a.batch
+    args = builder.make_args(doms, doms if train else ())
+    torch.manual_seed(0)
+    model = builder.get_model(args, model_name, with_decoders=train).to(dev)
+    model.train(train)
+    pool = synth_batches(doms, B, 4, 1234 + rank, dev)
+
+    if train:
+        total_steps = a.steps + a.warmup + 64
+        lr = 1e-4 * (B * world) / 256                      # run_pretraining.py:497 with the global batch
+        lrs = optim.cosine_scheduler(lr, 0.0, 1, total_steps, warmup_epochs=1, warmup_steps=max(1, total_steps // 10))
+        wds = optim.cosine_scheduler(0.05, 0.05, 1, total_steps)
+        opt = optim.FusedAdamW(model, lrs, wds, betas=(0.9, 0.95), eps=1e-8)
+        broadcast_params(opt.arena.flat_p)
+        opt.arena.refresh_shadow(force=True)
+        reducer = GradReducer(opt.arena.flat_g) if world > 1 else None
+        loss_fns = builder.get_losses(args)
+        ts = TrainStep(model, loss_fns, opt, pool[0], Kk, use_graph=not a.no_graph, reducer=reducer)
+        ts.load(pool[0])
+        ts.warmup_and_capture()
+
+        def run_step(i):
+            ts.step(pool[i % len(pool)])
+    else:
+        static = {d: torch.empty_like(pool[0][d]) for d in doms}
+        graph = None
+
+        def fwd():
+            with torch.no_grad():
+                return model(static, mask_inputs=False)[0]
+
+        for d in doms:
+            static[d].copy_(pool[0][d])
+        fwd()
+        torch.cuda.synchronize()
+        if not a.no_graph:
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                out_static = fwd()
+
+        def run_step(i):
+            for d in doms:
+                static[d].copy_(pool[i % len(pool)][d], non_blocking=True)
+            if graph is not None:
+                graph.replay()
+            else:
+                fwd()
+
+    for i in range(a.warmup):
+        run_step(i)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(a.steps):
+        run_step(a.warmup + i)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    ms_per_step = 1e3 * elapsed / a.steps
+    value = B * world * a.steps / elapsed
+    fpi = flops_per_image(model_name, doms, Kk, train)
+
+    result = None
+    if rank == 0:
+        # ---- roofline of the dominant kernel: instrumented eager step, events on the launch stream -------------
+        recs = []
+        orig_gemm = K.gemm
+
+        def timed_gemm(A, Bm, M, N, Kd, **kw):
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s.record()
+            out = orig_gemm(A, Bm, M, N, Kd, **kw)
+            e.record()
+            recs.append(((kw.get("a_mode", 0), kw.get("b_mode", 0)), 2.0 * M * N * Kd, s, e, kw.get("splitk", 1) > 1))
+            return out
+
+        K.gemm = timed_gemm
+        try:
+            if train:
+                ts._eager()
+            else:
+                fwd()
+        finally:
+            K.gemm = orig_gemm
+        torch.cuda.synchronize()
+        groups = {}
+        for mode, fl, s, e, split in recs:
+            g = groups.setdefault(mode, [0.0, 0.0, 0])
+            g[0] += fl; g[1] += s.elapsed_time(e) * 1e-3; g[2] += 1
+        names = {(0, 0): "gemm_kernel<KCONTIG,KCONTIG> (forward x*W^T)", (0, 1): "gemm_kernel<KCONTIG,KSTRIDED> (dgrad dy*W)",
+                 (1, 1): "gemm_kernel<KSTRIDED,KSTRIDED> (wgrad dy^T*x)"}
+        dom_mode = max(groups, key=lambda m: groups[m][1])
+        fl, tsec, n = groups[dom_mode]
+        all_fl = sum(g[0] for g in groups.values()); all_t = sum(g[1] for g in groups.values())
+        roofline = {"bound": "mfma", "kernel": names[dom_mode], "achieved": round(fl / tsec / 1e12, 2), "peak": MFMA_BF16_PEAK / 1e12,
+                    "unit": "TFLOP/s", "frac": round(fl / tsec / MFMA_BF16_PEAK, 4), "traffic": None,
+                    "launches_per_step": n, "avg_launch_us": round(1e6 * tsec / n, 2),
+                    "all_gemm_achieved": round(all_fl / all_t / 1e12, 2),
+                    "whole_step_achieved": round(value / world * fpi / 1e12, 2),
+                    "whole_step_frac": round(value / world * fpi / MFMA_BF16_PEAK, 4)}
+        result = {
+            "metric": "pretrain images/sec (node) MIRAGE-Base 512/32 bscan+slo; MFMA % of peak" if a.config == "c2" else f"images/sec (node) {a.config}",
+            "value": round(value, 2), "unit": "images/sec", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": f"{a.config}: {model_name} 512/32 {'+'.join(doms)}, per-GPU batch {B}, {Kk} of {256 * len(doms)} tokens encoded, "
+                                   f"{'fwd+loss+bwd+AdamW' if train else 'encoder forward only'}",
+                       "global_batch": B * world, "parallelism": f"dp{world}", "hipgraph": not a.no_graph,
+                       "gflop_per_image": round(fpi / 1e9, 2)},
+            "mfma_frac_of_peak": round(value / world * fpi / MFMA_BF16_PEAK, 4),
+            "roofline": roofline,
+        }
+        if world == 1 and not a.no_cpu_baseline:
+            result["cpu_baseline"] = cpu_baseline(model_name, doms, Kk, train)
+        if train:
+            result["final_loss"] = round(float(ts.loss), 5)
+        print(json.dumps(result), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,89 @@
+"""Data-parallel layer (new work: the reference is single-process).
+
+One process per GPU; every rank holds a full replica and its own shard of the batch; after backward the flat
+gradient arena is averaged with a handful of large all-reduces (RCCL over xGMI when the backend is "nccl").
+Buckets are contiguous slices of the arena (no packing copies); they are issued on a side stream so the reduction
+of early buckets overlaps whatever still runs on the compute stream; the optimizer waits on the last bucket's event.
+xGMI is point-to-point (7 links per GPU), so buckets are large (default 64 MiB) -- per-call latency, not bandwidth,
+is what many small buckets would pay for.
+"""
+from typing import List, Optional, Tuple
+
+import torch
+import torch.distributed as dist
+
+
+def bucket_ranges(n: int, bucket_elems: int, align: int = 64) -> List[Tuple[int, int]]:
+    """Split [0, n) into contiguous ranges of ~bucket_elems (multiples of `align`)."""
+    if n <= 0:
+        return []
+    step = max(align, (bucket_elems // align) * align)
+    out, s = [], 0
+    while s < n:
+        e = min(n, s + step)
+        out.append((s, e))
+        s = e
+    return out
+
+
+class GradReducer:
+    """Averages a flat fp32 gradient buffer across ranks."""
+
+    def __init__(self, flat_grad: torch.Tensor, bucket_bytes: int = 64 << 20, process_group=None):
+        self.flat = flat_grad
+        self.group = process_group
+        self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        self.ranges = bucket_ranges(flat_grad.numel(), bucket_bytes // 4)
+        self.backend = dist.get_backend(process_group) if dist.is_initialized() else None
+        self.side = torch.cuda.Stream(device=flat_grad.device) if flat_grad.is_cuda else None
+        self._done = None
+
+    def reduce_async(self):
+        """Launch the bucket all-reduces (side stream on GPU).  Call wait() before reading the gradients."""
+        if self.world == 1:
+            return
+        use_avg = self.backend == "nccl"
+        op = dist.ReduceOp.AVG if use_avg else dist.ReduceOp.SUM
+        if self.side is not None:
+            ready = torch.cuda.Event()
+            ready.record(torch.cuda.current_stream(self.flat.device))
+            with torch.cuda.stream(self.side):
+                self.side.wait_event(ready)
+                for s, e in reversed(self.ranges):   # arena tail (decoders / last blocks) finishes first in backward
+                    dist.all_reduce(self.flat[s:e], op=op, group=self.group)
+                self._done = torch.cuda.Event()
+                self._done.record(self.side)
+        else:
+            for s, e in self.ranges:
+                dist.all_reduce(self.flat[s:e], op=op, group=self.group)
+        if not use_avg:
+            if self.side is not None:
+                with torch.cuda.stream(self.side):
+                    self.flat.div_(self.world)
+                    self._done = torch.cuda.Event()
+                    self._done.record(self.side)
+            else:
+                self.flat.div_(self.world)
+
+    def wait(self):
+        if self._done is not None:
+            torch.cuda.current_stream(self.flat.device).wait_event(self._done)
+            self._done = None
+
+    def reduce(self):
+        self.reduce_async()
+        self.wait()
+
+
+def broadcast_params(flat_param: torch.Tensor, src: int = 0, process_group=None):
+    """Initial weight broadcast from rank 0 (all ranks then hold identical replicas)."""
+    if dist.is_initialized() and dist.get_world_size(process_group) > 1:
+        dist.broadcast(flat_param, src=src, group=process_group)
+
+
+def all_reduce_scalar_mean(t: torch.Tensor, process_group=None) -> torch.Tensor:
+    """Logging only: mean of a scalar (loss, grad-norm) over ranks."""
+    if dist.is_initialized() and dist.get_world_size(process_group) > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=process_group)
+        t = t / dist.get_world_size(process_group)
+    return t

@@ -131,11 +131,22 @@ class MIRAGEModel(nn.Module):
         return v
 
     # ------------------------------------------------------------------------------------ masking
+    def _const(self, key, build):
+        """Device constants are created once (no host->device copies inside a captured step)."""
+        v = self._mrg_cache.get(key)
+        if v is None:
+            v = build()
+            self._mrg_cache[key] = v
+        return v
+
     def sample_alphas(self, B: int, n_tasks: int, alphas: Union[float, List[float], Tensor] = 1.0, eps: float = 1e-5, device=None):
         """Uniformly choose a non-empty subset of tasks per sample, alphas = choice * alpha + eps (mirage/model.py:145-166)."""
-        valid = torch.tensor([list(i) for i in itertools.product([0, 1], repeat=n_tasks)][1:], dtype=torch.float32, device=device)
+        al = tuple(float(a) for a in (alphas if isinstance(alphas, (list, tuple)) else [alphas] * n_tasks))
+        valid = self._const(("valid_choices", n_tasks, str(device)), lambda: torch.tensor(
+            [list(i) for i in itertools.product([0, 1], repeat=n_tasks)][1:], dtype=torch.float32, device=device))
+        alt = self._const(("alphas", al, str(device)), lambda: torch.tensor(al, dtype=torch.float32, device=device))
         choice = torch.randint(0, len(valid), (B,), device=device)
-        return torch.index_select(valid, 0, choice) * torch.as_tensor(alphas, dtype=torch.float32, device=device) + eps
+        return torch.index_select(valid, 0, choice) * alt + eps
 
     def generate_random_masks_from_noise(self, p: Tensor, u: Tensor, g: Tensor, num_encoded_tokens: int, doms: Sequence[str]):
         """Pure function of the three random inputs: Dirichlet shares p [B, n], per-task noise
@@ -159,7 +170,9 @@ class MIRAGEModel(nn.Module):
         if sample_tasks_uniformly:
             conc = self.sample_alphas(B, n, alphas=alphas, device=device)
         else:
-            conc = torch.as_tensor(alphas, dtype=torch.float32, device=device).expand(B, n).contiguous()
+            al = tuple(float(a) for a in alphas)
+            conc = self._const(("conc", al, B, str(device)),
+                               lambda: torch.tensor(al, dtype=torch.float32, device=device).expand(B, n).contiguous())
         p = torch._sample_dirichlet(conc)                      # model.py:205-207 (device-side draw)
         u = torch.rand(B, T, device=device)                     # model.py:216 (one draw covering all tasks)
         g = torch.rand(B, T, device=device)                     # model.py:225
