@@ -125,6 +125,68 @@ __device__ __forceinline__ bf16x8 read_frag(const char* lds, uint32_t lds_base, 
     }
 }
 
+// one output row segment (4 consecutive columns) of the fused epilogue
+template <bool VEC>
+__device__ __forceinline__ void epi_row(const GemmArgs& g, const float4 a4, const float (&bv)[4], float* ws, int row, int col, int nv) {
+        float v[4] = {a4.x, a4.y, a4.z, a4.w};
+        if (ws) {
+            float* w = ws + (long)row * g.N + col;
+            if (VEC) *reinterpret_cast<float4*>(w) = a4;
+            else { for (int e = 0; e < nv; ++e) w[e] = v[e]; }
+            return;
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] += bv[e];
+        if (g.act == MRG_ACT_GELU) {
+            if (g.aux_out) {
+                bf16_t* ao = g.aux_out + (long)row * g.ldaux + col;
+                if (VEC) *reinterpret_cast<uint2*>(ao) = make_uint2(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]));
+                else { for (int e = 0; e < nv; ++e) ao[e] = f2bf(v[e]); }
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = gelu_f(v[e]);
+        } else if (g.act == MRG_ACT_GELU_BWD) {
+            const bf16_t* ai = g.aux_in + (long)row * g.ldaux + col;
+            float x[4] = {0.f, 0.f, 0.f, 0.f};
+            if (VEC) {
+                const uint2 u = *reinterpret_cast<const uint2*>(ai);
+                x[0] = __uint_as_float(u.x << 16); x[1] = __uint_as_float(u.x & 0xffff0000u);
+                x[2] = __uint_as_float(u.y << 16); x[3] = __uint_as_float(u.y & 0xffff0000u);
+            } else { for (int e = 0; e < nv; ++e) x[e] = bf2f(ai[e]); }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] *= gelu_grad_f(x[e]);
+        }
+        if (g.add_tab) {
+            const float* t = g.add_tab + (long)g.add_row[row] * g.ldt + col;
+            if (VEC) { const float4 t4 = *reinterpret_cast<const float4*>(t); v[0] += t4.x; v[1] += t4.y; v[2] += t4.z; v[3] += t4.w; }
+            else { for (int e = 0; e < nv; ++e) v[e] += t[e]; }
+        }
+        if (g.resid) {
+            const float* t = g.resid + (long)row * g.ldr + col;
+            if (VEC) { const float4 t4 = *reinterpret_cast<const float4*>(t); v[0] += t4.x; v[1] += t4.y; v[2] += t4.z; v[3] += t4.w; }
+            else { for (int e = 0; e < nv; ++e) v[e] += t[e]; }
+        }
+        const long orow = g.row_map ? g.row_map[row] : row;
+        if (g.c_f32) {
+            float* c = reinterpret_cast<float*>(g.C) + orow * g.ldc + col;
+            if (VEC) {
+                if (g.accumulate) { const float4 o = *reinterpret_cast<const float4*>(c); v[0] += o.x; v[1] += o.y; v[2] += o.z; v[3] += o.w; }
+                *reinterpret_cast<float4*>(c) = make_float4(v[0], v[1], v[2], v[3]);
+            } else {
+                for (int e = 0; e < nv; ++e) { if (g.accumulate) v[e] += c[e]; c[e] = v[e]; }
+            }
+        } else {
+            bf16_t* c = reinterpret_cast<bf16_t*>(g.C) + orow * g.ldc + col;
+            if (VEC) *reinterpret_cast<uint2*>(c) = make_uint2(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]));
+            else { for (int e = 0; e < nv; ++e) c[e] = f2bf(v[e]); }
+        }
+        if (g.C2) {
+            bf16_t* c = g.C2 + orow * g.ldc2 + col;
+            if (VEC) *reinterpret_cast<uint2*>(c) = make_uint2(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]));
+            else { for (int e = 0; e < nv; ++e) c[e] = f2bf(v[e]); }
+        }
+}
+
 template <int AMODE, int BMODE, bool ALIGNED, bool VEC>
 __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs g) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -233,62 +295,157 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs g) {
         const int row = m0 + rl;
         if (row >= Meff) break;
         const float4 a4 = *reinterpret_cast<const float4*>(ct + rl * BN + cl);
-        float v[4] = {a4.x, a4.y, a4.z, a4.w};
-        if (ws) {
-            float* w = ws + (long)row * g.N + col;
-            if (VEC) *reinterpret_cast<float4*>(w) = a4;
-            else { for (int e = 0; e < nv; ++e) w[e] = v[e]; }
-            continue;
-        }
+        epi_row<VEC>(g, a4, bv, ws, row, col, nv);
+    }
+}
+
+// =====================================================================================================
+// Fast path: aligned operands, no gather maps.  Operand tiles go HBM/L2 -> LDS directly with
+// global_load_lds (16 B per lane, LDS destination = wave-uniform base + lane*16), so the XOR swizzle is applied to
+// the per-lane SOURCE address while the LDS image stays linear; out-of-range rows / k read a zero page instead of
+// branching.  One 32 KiB LDS stage per workgroup (A + B tile), ~130 VGPRs -> 3 workgroups per CU hide the
+// load -> barrier -> MFMA latency chain; the epilogue reuses the stage in two 64-row passes.
+__device__ __attribute__((aligned(16))) unsigned int g_zero_page[64];
+
+__device__ __forceinline__ void glds16(const bf16_t* src, char* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                     (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+
+// per-thread source pointer + per-tile increment for LDS block b (1 KiB) of an operand tile
+template <int MODE>
+__device__ __forceinline__ void glds_setup(const bf16_t* P, int ld, int row0, int nrows, int k_first, int b, int lane,
+                                           const bf16_t*& ptr, long& inc, int& koff) {
+    const bf16_t* zero = reinterpret_cast<const bf16_t*>(g_zero_page);
+    if (MODE == MRG_OP_KCONTIG) {
+        const int r = b * 8 + (lane >> 3);
+        const int c = (lane & 7) ^ ((r >> 1) & 7);
+        const int row = row0 + r;
+        koff = c << 3;
+        if (row < nrows) { ptr = P + (long)row * ld + k_first + koff; inc = BK; }
+        else { ptr = zero; inc = 0; koff = -(1 << 30); }
+    } else {
+        const int kr = b * 4 + (lane >> 4);
+        const int c = (lane & 15) ^ ((kr & 3) << 2);
+        const int row = row0 + (c << 3);
+        koff = kr;
+        if (row < nrows) { ptr = P + (long)(k_first + kr) * ld + row; inc = (long)BK * ld; }
+        else { ptr = zero; inc = 0; koff = -(1 << 30); }
+    }
+}
+
+template <int AMODE, int BMODE, bool VEC>
+__global__ __launch_bounds__(256, 3) void gemm_glds_kernel(const GemmArgs g) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int nwg = g.tiles_m * g.tiles_n;
+    int bid = blockIdx.x;
+    {
+        const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int tm = bid / g.tiles_n, tn = bid % g.tiles_n;
+    const int m0 = tm * BM, n0 = tn * BN;
+    const int Meff = g.m_dev ? min(g.M, *g.m_dev) : g.M;
+    const int Keff = g.k_dev ? min(g.K, *g.k_dev) : g.K;
+    if (m0 >= Meff) return;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int ntiles = (Keff + BK - 1) / BK;
+    int t0 = 0, t1 = ntiles;
+    if (g.splitk > 1) {
+        const int per = (ntiles + g.splitk - 1) / g.splitk;
+        t0 = blockIdx.y * per;
+        t1 = min(ntiles, t0 + per);
+    }
+    f32x16 acc[2][2];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] += bv[e];
-        if (g.act == MRG_ACT_GELU) {
-            if (g.aux_out) {
-                bf16_t* ao = g.aux_out + (long)row * g.ldaux + col;
-                if (VEC) *reinterpret_cast<uint2*>(ao) = make_uint2(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]));
-                else { for (int e = 0; e < nv; ++e) ao[e] = f2bf(v[e]); }
-            }
+    for (int i = 0; i < 2; ++i)
 #pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = gelu_f(v[e]);
-        } else if (g.act == MRG_ACT_GELU_BWD) {
-            const bf16_t* ai = g.aux_in + (long)row * g.ldaux + col;
-            float x[4] = {0.f, 0.f, 0.f, 0.f};
-            if (VEC) {
-                const uint2 u = *reinterpret_cast<const uint2*>(ai);
-                x[0] = __uint_as_float(u.x << 16); x[1] = __uint_as_float(u.x & 0xffff0000u);
-                x[2] = __uint_as_float(u.y << 16); x[3] = __uint_as_float(u.y & 0xffff0000u);
-            } else { for (int e = 0; e < nv; ++e) x[e] = bf2f(ai[e]); }
+        for (int j = 0; j < 2; ++j)
 #pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] *= gelu_grad_f(x[e]);
-        }
-        if (g.add_tab) {
-            const float* t = g.add_tab + (long)g.add_row[row] * g.ldt + col;
-            if (VEC) { const float4 t4 = *reinterpret_cast<const float4*>(t); v[0] += t4.x; v[1] += t4.y; v[2] += t4.z; v[3] += t4.w; }
-            else { for (int e = 0; e < nv; ++e) v[e] += t[e]; }
-        }
-        if (g.resid) {
-            const float* t = g.resid + (long)row * g.ldr + col;
-            if (VEC) { const float4 t4 = *reinterpret_cast<const float4*>(t); v[0] += t4.x; v[1] += t4.y; v[2] += t4.z; v[3] += t4.w; }
-            else { for (int e = 0; e < nv; ++e) v[e] += t[e]; }
-        }
-        const long orow = g.row_map ? g.row_map[row] : row;
-        if (g.c_f32) {
-            float* c = reinterpret_cast<float*>(g.C) + orow * g.ldc + col;
-            if (VEC) {
-                if (g.accumulate) { const float4 o = *reinterpret_cast<const float4*>(c); v[0] += o.x; v[1] += o.y; v[2] += o.z; v[3] += o.w; }
-                *reinterpret_cast<float4*>(c) = make_float4(v[0], v[1], v[2], v[3]);
-            } else {
-                for (int e = 0; e < nv; ++e) { if (g.accumulate) v[e] += c[e]; c[e] = v[e]; }
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    char* ldsA = smem;
+    char* ldsB = smem + TILE_BYTES;
+    const uint32_t la_u = lds_addr(ldsA), lb_u = lds_addr(ldsB);
+    const bf16_t* pa[4]; const bf16_t* pb[4];
+    long ia[4], ib[4];
+    int ka[4], kb[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        glds_setup<AMODE>(g.A, g.lda, m0, Meff, t0 * BK, wave * 4 + j, lane, pa[j], ia[j], ka[j]);
+        glds_setup<BMODE>(g.B, g.ldb, n0, g.N, t0 * BK, wave * 4 + j, lane, pb[j], ib[j], kb[j]);
+    }
+    const bf16_t* zero = reinterpret_cast<const bf16_t*>(g_zero_page);
+    for (int t = t0; t < t1; ++t) {
+        const int krem = Keff - t * BK;           // valid k in this tile (>= BK except for the last, partial tile)
+        if (t > t0) __syncthreads();              // everyone finished reading the previous tile
+        if (krem >= BK) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                glds16(pa[j], ldsA + (wave * 4 + j) * 1024);
+                glds16(pb[j], ldsB + (wave * 4 + j) * 1024);
             }
         } else {
-            bf16_t* c = reinterpret_cast<bf16_t*>(g.C) + orow * g.ldc + col;
-            if (VEC) *reinterpret_cast<uint2*>(c) = make_uint2(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]));
-            else { for (int e = 0; e < nv; ++e) c[e] = f2bf(v[e]); }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                glds16(ka[j] < krem ? pa[j] : zero, ldsA + (wave * 4 + j) * 1024);
+                glds16(kb[j] < krem ? pb[j] : zero, ldsB + (wave * 4 + j) * 1024);
+            }
         }
-        if (g.C2) {
-            bf16_t* c = g.C2 + orow * g.ldc2 + col;
-            if (VEC) *reinterpret_cast<uint2*>(c) = make_uint2(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]));
-            else { for (int e = 0; e < nv; ++e) c[e] = f2bf(v[e]); }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { pa[j] += ia[j]; pb[j] += ib[j]; }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            bf16x8 fa[2], fb[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) fa[i] = read_frag<AMODE>(ldsA, la_u, wm * 64 + i * 32, kk, lane);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) fb[j] = read_frag<BMODE>(ldsB, lb_u, wn * 64 + j * 32, kk, lane);
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+        }
+    }
+    // ---- epilogue in two passes of 64 rows x 128 cols fp32 (32 KiB)
+    float* ct = reinterpret_cast<float*>(smem);
+    const int cl = (tid & 31) << 2;
+    const int col = n0 + cl;
+    const int nv = min(4, g.N - col);
+    float* ws = g.splitk > 1 ? g.ws + (long)blockIdx.y * g.M * g.N : nullptr;
+    float bv[4] = {0.f, 0.f, 0.f, 0.f};
+    if (g.bias && !ws && col < g.N) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) if (e < nv) bv[e] = g.bias[col + e];
+    }
+#pragma unroll
+    for (int pss = 0; pss < 2; ++pss) {
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int c2 = wn * 64 + j * 32 + (lane & 31);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int rl = wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                ct[rl * BN + c2] = acc[pss][j][r];
+            }
+        }
+        __syncthreads();
+        if (col < g.N) {
+#pragma unroll 1
+            for (int it = 0; it < 8; ++it) {
+                const int rl = (tid >> 5) + (it << 3);                       // 0..63
+                const int row = m0 + (rl >> 5) * 64 + pss * 32 + (rl & 31);
+                if (row < Meff) {
+                    const float4 a4 = *reinterpret_cast<const float4*>(ct + rl * BN + cl);
+                    epi_row<VEC>(g, a4, bv, ws, row, col, nv);
+                }
+            }
         }
     }
 }
@@ -359,8 +516,12 @@ extern "C" int mrg_gemm(const mrg_gemm_desc* d, hipStream_t stream) {
     auto al4 = [](const void* p, int ld, int bytes) { return p == nullptr || ((((uintptr_t)p) % (4 * bytes) == 0) && (ld % 4 == 0)); };
     const bool vec = (d->N % 4 == 0) && al4(d->C, d->ldc, g.c_f32 ? 4 : 2) && al4(d->C2, d->ldc2, 2) && al4(d->resid, d->ldr, 4) &&
                      al4(d->add_tab, d->ldt, 4) && al4(d->aux_out, d->ldaux, 2) && al4(d->aux_in, d->ldaux, 2) && al4(d->ws, d->N, 4);
-#define MRG_LAUNCH2(AM, BM_, AL) do { if (vec) hipLaunchKernelGGL((gemm_kernel<AM, BM_, AL, true>), grid, block, shmem, stream, g); \
-                                      else hipLaunchKernelGGL((gemm_kernel<AM, BM_, AL, false>), grid, block, shmem, stream, g); } while (0)
+    const bool fast = al && !d->a_map && !d->b_map;
+#define MRG_LAUNCH2(AM, BM_, AL) do { \
+        if (fast) { if (vec) hipLaunchKernelGGL((gemm_glds_kernel<AM, BM_, true>), grid, block, (size_t)(2 * TILE_BYTES), stream, g); \
+                    else hipLaunchKernelGGL((gemm_glds_kernel<AM, BM_, false>), grid, block, (size_t)(2 * TILE_BYTES), stream, g); } \
+        else if (vec) hipLaunchKernelGGL((gemm_kernel<AM, BM_, AL, true>), grid, block, shmem, stream, g); \
+        else hipLaunchKernelGGL((gemm_kernel<AM, BM_, AL, false>), grid, block, shmem, stream, g); } while (0)
 #define MRG_LAUNCH(AM, BM_, AL) MRG_LAUNCH2(AM, BM_, AL)
     if (d->a_mode == MRG_OP_KCONTIG && d->b_mode == MRG_OP_KCONTIG) { if (al) MRG_LAUNCH(0, 0, true); else MRG_LAUNCH(0, 0, false); }
     else if (d->a_mode == MRG_OP_KCONTIG && d->b_mode == MRG_OP_KSTRIDED) { if (al) MRG_LAUNCH(0, 1, true); else MRG_LAUNCH(0, 1, false); }
