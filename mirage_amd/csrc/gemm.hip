@@ -334,8 +334,8 @@ __device__ __forceinline__ void glds_setup(const bf16_t* P, int ld, int row0, in
     }
 }
 
-template <int AMODE, int BMODE, bool VEC>
-__global__ __launch_bounds__(256, 3) void gemm_glds_kernel(const GemmArgs g) {
+template <int AMODE, int BMODE, bool VEC, int OCC>
+__global__ __launch_bounds__(256, OCC) void gemm_glds_kernel(const GemmArgs g) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int nwg = g.tiles_m * g.tiles_n;
     int bid = blockIdx.x;
@@ -517,9 +517,13 @@ extern "C" int mrg_gemm(const mrg_gemm_desc* d, hipStream_t stream) {
     const bool vec = (d->N % 4 == 0) && al4(d->C, d->ldc, g.c_f32 ? 4 : 2) && al4(d->C2, d->ldc2, 2) && al4(d->resid, d->ldr, 4) &&
                      al4(d->add_tab, d->ldt, 4) && al4(d->aux_out, d->ldaux, 2) && al4(d->aux_in, d->ldaux, 2) && al4(d->ws, d->N, 4);
     const bool fast = al && !d->a_map && !d->b_map;
+    // 4 workgroups per CU (<= 128 VGPRs) pay off only when there are enough tiles to fill them (measured: +13..18 % at
+    // >= ~1500 tiles, -3..-15 % below and for the wgrad layout)
+    const bool occ4 = fast && d->a_mode == MRG_OP_KCONTIG && (g.tiles_m * g.tiles_n >= 1400) && splitk == 1;
+#define MRG_FAST(AM, BM_, V) do { if (occ4) hipLaunchKernelGGL((gemm_glds_kernel<AM, BM_, V, 4>), grid, block, (size_t)(2 * TILE_BYTES), stream, g); \
+                                  else hipLaunchKernelGGL((gemm_glds_kernel<AM, BM_, V, 3>), grid, block, (size_t)(2 * TILE_BYTES), stream, g); } while (0)
 #define MRG_LAUNCH2(AM, BM_, AL) do { \
-        if (fast) { if (vec) hipLaunchKernelGGL((gemm_glds_kernel<AM, BM_, true>), grid, block, (size_t)(2 * TILE_BYTES), stream, g); \
-                    else hipLaunchKernelGGL((gemm_glds_kernel<AM, BM_, false>), grid, block, (size_t)(2 * TILE_BYTES), stream, g); } \
+        if (fast) { if (vec) MRG_FAST(AM, BM_, true); else MRG_FAST(AM, BM_, false); } \
         else if (vec) hipLaunchKernelGGL((gemm_kernel<AM, BM_, AL, true>), grid, block, shmem, stream, g); \
         else hipLaunchKernelGGL((gemm_kernel<AM, BM_, AL, false>), grid, block, shmem, stream, g); } while (0)
 #define MRG_LAUNCH(AM, BM_, AL) MRG_LAUNCH2(AM, BM_, AL)
@@ -528,6 +532,7 @@ extern "C" int mrg_gemm(const mrg_gemm_desc* d, hipStream_t stream) {
     else { if (al) MRG_LAUNCH(1, 1, true); else MRG_LAUNCH(1, 1, false); }
 #undef MRG_LAUNCH
 #undef MRG_LAUNCH2
+#undef MRG_FAST
     int rc = mrg_check_launch("mrg_gemm");
     if (rc) return rc;
     if (splitk > 1) {

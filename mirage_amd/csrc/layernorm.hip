@@ -63,57 +63,71 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
     }
 }
 
-// dx32 = dres + LN'(dy); dx16 = bf16(dx32).  partials [gridDim.x][3][D]: dgamma, dbeta, colsum(dres)
-__global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ dy16, const float* __restrict__ dy32,
-                                                     const float* __restrict__ x, const float* __restrict__ mean,
-                                                     const float* __restrict__ rstd, const float* __restrict__ gamma,
-                                                     const float* __restrict__ dres, float* __restrict__ dx32,
-                                                     bf16_t* __restrict__ dx16, float* __restrict__ partials, int M, int D) {
-    __shared__ __attribute__((aligned(16))) float buf[4][1024];
+// dx32 = dres + LN'(dy); dx16 = bf16(dx32).  partials [gridDim.x][3][D]: dgamma, dbeta, colsum(dres).
+// Templated on the row width (NV float4 chunks per lane) and on the optional operands so that the row loop is
+// straight-line code: all loads of a row are issued back to back and registers are sized for the real D.
+constexpr int LNB_WAVES = 4;
+template <int NV, bool DY16, bool HAS_RES>
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const void* __restrict__ dyp, const float* __restrict__ x,
+                                                     const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                     const float* __restrict__ gamma, const float* __restrict__ dres,
+                                                     float* __restrict__ dx32, bf16_t* __restrict__ dx16,
+                                                     float* __restrict__ partials, int M, int D) {
+    __shared__ __attribute__((aligned(16))) float buf[LNB_WAVES][NV * 256];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int nv = D >> 2;
-    float4 ag[LN_MAX_V], ab[LN_MAX_V], ar[LN_MAX_V], gm[LN_MAX_V];
+    const float invD = 1.f / (float)D;
+    float4 ag[NV], ab[NV], ar[NV], gm[NV];
     const float4* g4 = reinterpret_cast<const float4*>(gamma);
 #pragma unroll
-    for (int j = 0; j < LN_MAX_V; ++j) {
+    for (int j = 0; j < NV; ++j) {
         ag[j] = ab[j] = ar[j] = make_float4(0.f, 0.f, 0.f, 0.f);
         const int c = lane + 64 * j;
         gm[j] = c < nv ? g4[c] : make_float4(0.f, 0.f, 0.f, 0.f);
     }
-    for (int row = blockIdx.x * 4 + wave; row < M; row += gridDim.x * 4) {
+    const bf16_t* dy16 = reinterpret_cast<const bf16_t*>(dyp);
+    const float* dy32 = reinterpret_cast<const float*>(dyp);
+    for (int row = blockIdx.x * LNB_WAVES + wave; row < M; row += gridDim.x * LNB_WAVES) {
+        float4 xv[NV], dyv[NV], rv[NV];
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+            const int c = lane + 64 * j;
+            const bool ok = c < nv;
+            const int cc = ok ? c : 0;
+            xv[j] = reinterpret_cast<const float4*>(x + (long)row * D)[cc];
+            if (DY16) dyv[j] = bf4_to_f4(reinterpret_cast<const uint2*>(dy16 + (long)row * D)[cc]);
+            else dyv[j] = reinterpret_cast<const float4*>(dy32 + (long)row * D)[cc];
+            if (HAS_RES) rv[j] = reinterpret_cast<const float4*>(dres + (long)row * D)[cc];
+            if (!ok) { xv[j] = dyv[j] = make_float4(0.f, 0.f, 0.f, 0.f); if (HAS_RES) rv[j] = xv[j]; }
+        }
         const float mu = mean[row], rs = rstd[row];
-        float4 xh[LN_MAX_V], dyv[LN_MAX_V];
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-        for (int j = 0; j < LN_MAX_V; ++j) {
-            const int c = lane + 64 * j;
-            if (c < nv) {
-                const float4 xv = reinterpret_cast<const float4*>(x + (long)row * D)[c];
-                const float4 d = dy16 ? bf4_to_f4(reinterpret_cast<const uint2*>(dy16 + (long)row * D)[c])
-                                      : reinterpret_cast<const float4*>(dy32 + (long)row * D)[c];
-                xh[j] = make_float4((xv.x - mu) * rs, (xv.y - mu) * rs, (xv.z - mu) * rs, (xv.w - mu) * rs);
-                dyv[j] = d;
-                const float w0 = d.x * gm[j].x, w1 = d.y * gm[j].y, w2 = d.z * gm[j].z, w3 = d.w * gm[j].w;
-                s1 += (w0 + w1) + (w2 + w3);
-                s2 += (w0 * xh[j].x + w1 * xh[j].y) + (w2 * xh[j].z + w3 * xh[j].w);
-                ag[j].x += d.x * xh[j].x; ag[j].y += d.y * xh[j].y; ag[j].z += d.z * xh[j].z; ag[j].w += d.w * xh[j].w;
-                ab[j].x += d.x; ab[j].y += d.y; ab[j].z += d.z; ab[j].w += d.w;
-            }
+        for (int j = 0; j < NV; ++j) {
+            const bool ok = (lane + 64 * j) < nv;
+            float4 xh = make_float4((xv[j].x - mu) * rs, (xv[j].y - mu) * rs, (xv[j].z - mu) * rs, (xv[j].w - mu) * rs);
+            if (!ok) xh = make_float4(0.f, 0.f, 0.f, 0.f);
+            xv[j] = xh;
+            const float4 d = dyv[j];
+            const float w0 = d.x * gm[j].x, w1 = d.y * gm[j].y, w2 = d.z * gm[j].z, w3 = d.w * gm[j].w;
+            s1 += (w0 + w1) + (w2 + w3);
+            s2 += (w0 * xh.x + w1 * xh.y) + (w2 * xh.z + w3 * xh.w);
+            ag[j].x += d.x * xh.x; ag[j].y += d.y * xh.y; ag[j].z += d.z * xh.z; ag[j].w += d.w * xh.w;
+            ab[j].x += d.x; ab[j].y += d.y; ab[j].z += d.z; ab[j].w += d.w;
         }
-        const float m1 = wave_sum(s1) / (float)D, m2 = wave_sum(s2) / (float)D;
+        const float m1 = wave_sum(s1) * invD, m2 = wave_sum(s2) * invD;
 #pragma unroll
-        for (int j = 0; j < LN_MAX_V; ++j) {
+        for (int j = 0; j < NV; ++j) {
             const int c = lane + 64 * j;
             if (c < nv) {
                 float4 o;
-                o.x = rs * (dyv[j].x * gm[j].x - m1 - xh[j].x * m2);
-                o.y = rs * (dyv[j].y * gm[j].y - m1 - xh[j].y * m2);
-                o.z = rs * (dyv[j].z * gm[j].z - m1 - xh[j].z * m2);
-                o.w = rs * (dyv[j].w * gm[j].w - m1 - xh[j].w * m2);
-                if (dres) {
-                    const float4 r = reinterpret_cast<const float4*>(dres + (long)row * D)[c];
-                    o.x += r.x; o.y += r.y; o.z += r.z; o.w += r.w;
-                    ar[j].x += r.x; ar[j].y += r.y; ar[j].z += r.z; ar[j].w += r.w;
+                o.x = rs * (dyv[j].x * gm[j].x - m1 - xv[j].x * m2);
+                o.y = rs * (dyv[j].y * gm[j].y - m1 - xv[j].y * m2);
+                o.z = rs * (dyv[j].z * gm[j].z - m1 - xv[j].z * m2);
+                o.w = rs * (dyv[j].w * gm[j].w - m1 - xv[j].w * m2);
+                if (HAS_RES) {
+                    o.x += rv[j].x; o.y += rv[j].y; o.z += rv[j].z; o.w += rv[j].w;
+                    ar[j].x += rv[j].x; ar[j].y += rv[j].y; ar[j].z += rv[j].z; ar[j].w += rv[j].w;
                 }
                 if (dx32) reinterpret_cast<float4*>(dx32 + (long)row * D)[c] = o;
                 if (dx16) reinterpret_cast<uint2*>(dx16 + (long)row * D)[c] = make_uint2(pack_bf2(o.x, o.y), pack_bf2(o.z, o.w));
@@ -124,7 +138,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ 
 #pragma unroll 1
     for (int qn = 0; qn < 3; ++qn) {
 #pragma unroll
-        for (int j = 0; j < LN_MAX_V; ++j) {
+        for (int j = 0; j < NV; ++j) {
             const int c = lane + 64 * j;
             if (c < nv) reinterpret_cast<float4*>(&buf[wave][0])[c] = qn == 0 ? ag[j] : (qn == 1 ? ab[j] : ar[j]);
         }
@@ -134,25 +148,85 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ 
     }
 }
 
-// out_q[c] = sum_b partials[b][q][c]; grid (ceil(D/64), nq), 256 threads: lane = column, 4 waves split the blocks
-__global__ __launch_bounds__(256) void colsum_partials_kernel(const float* __restrict__ partials, int nblocks, int nq, int D,
-                                                              float* o0, float* o1, float* o2) {
-    __shared__ float red[4][64];
+// out_q[c] = sum_b partials[b][q][c]; grid (ceil(D/64), nq), 1024 threads: lane = column, 16 waves split the rows
+__global__ __launch_bounds__(1024) void colsum_partials_kernel(const float* __restrict__ partials, int nblocks, int nq, int D,
+                                                               float* o0, float* o1, float* o2) {
+    __shared__ float red[16][64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int c = blockIdx.x * 64 + lane, q = blockIdx.y;
     float* out = q == 0 ? o0 : (q == 1 ? o1 : o2);
     if (out == nullptr) return;
-    float s = 0.f;
-    if (c < D)
-        for (int b = wave; b < nblocks; b += 4) s += partials[((long)b * nq + q) * D + c];
-    red[wave][lane] = s;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    if (c < D) {
+        int b = wave;
+        for (; b + 48 < nblocks; b += 64) {
+            s0 += partials[((long)b * nq + q) * D + c];
+            s1 += partials[((long)(b + 16) * nq + q) * D + c];
+            s2 += partials[((long)(b + 32) * nq + q) * D + c];
+            s3 += partials[((long)(b + 48) * nq + q) * D + c];
+        }
+        for (; b < nblocks; b += 16) s0 += partials[((long)b * nq + q) * D + c];
+    }
+    red[wave][lane] = (s0 + s1) + (s2 + s3);
     __syncthreads();
-    if (wave == 0 && c < D) out[c] = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
+    if (wave == 0 && c < D) {
+        float s = 0.f;
+#pragma unroll
+        for (int w = 0; w < 16; ++w) s += red[w][lane];
+        out[c] = s;
+    }
 }
 
 // generic column sum of a [M, N] matrix (bf16 or fp32) with optional row gather map and device row count:
-// partials [gridDim.y][N]; finish with colsum_partials (nq = 1).  Used for the bias gradients that are not a
+// partials [gridDim.x][N]; finish with colsum_partials (nq = 1).  Used for the bias gradients that are not a
 // by-product of a LayerNorm backward (qkv / fc1 / kv / q / out_proj / patch-embed biases).
+// Each thread owns 8 consecutive columns (16-B bf16 / 2x16-B fp32 loads): a wave reads 1 KiB+ contiguous per row.
+template <bool IS_BF16>
+__global__ __launch_bounds__(256) void colsum_wide_kernel(const void* __restrict__ xin, int M, int N, int ld,
+                                                          const int* __restrict__ row_map, const int* __restrict__ m_dev,
+                                                          float* __restrict__ partials) {
+    extern __shared__ __attribute__((aligned(16))) float red[];   // [rowlanes][ncg*8]
+    const int ncg = N >> 3;                                        // column groups of 8
+    const int Meff = m_dev ? min(M, *m_dev) : M;
+    const int per_row = ncg < 256 ? ncg : 256;                     // threads along columns
+    const int rowlanes = 256 / per_row;                            // >= 1
+    const int cgl = threadIdx.x % per_row, rl = threadIdx.x / per_row;
+    for (int cg0 = 0; cg0 < ncg; cg0 += per_row) {
+        const int cg = cg0 + cgl;
+        float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        if (cg < ncg && rl < rowlanes) {
+            for (int r = blockIdx.x * rowlanes + rl; r < Meff; r += gridDim.x * rowlanes) {
+                const long src = (long)(row_map ? row_map[r] : r) * ld + (cg << 3);
+                if (IS_BF16) {
+                    const uint4 u = *reinterpret_cast<const uint4*>(reinterpret_cast<const bf16_t*>(xin) + src);
+                    a[0] += __uint_as_float(u.x << 16); a[1] += __uint_as_float(u.x & 0xffff0000u);
+                    a[2] += __uint_as_float(u.y << 16); a[3] += __uint_as_float(u.y & 0xffff0000u);
+                    a[4] += __uint_as_float(u.z << 16); a[5] += __uint_as_float(u.z & 0xffff0000u);
+                    a[6] += __uint_as_float(u.w << 16); a[7] += __uint_as_float(u.w & 0xffff0000u);
+                } else {
+                    const float4 v0 = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(xin) + src);
+                    const float4 v1 = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(xin) + src + 4);
+                    a[0] += v0.x; a[1] += v0.y; a[2] += v0.z; a[3] += v0.w; a[4] += v1.x; a[5] += v1.y; a[6] += v1.z; a[7] += v1.w;
+                }
+            }
+        }
+        if (rl < rowlanes && cg < ncg) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) red[(rl * per_row + cgl) * 8 + e] = a[e];
+        }
+        __syncthreads();
+        if (rl == 0 && cg < ncg) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                float s = 0.f;
+                for (int q = 0; q < rowlanes; ++q) s += red[(q * per_row + cgl) * 8 + e];
+                partials[(long)blockIdx.x * N + (cg << 3) + e] = s;
+            }
+        }
+        __syncthreads();
+    }
+}
+
 __global__ __launch_bounds__(256) void colsum_kernel(const bf16_t* __restrict__ x16, const float* __restrict__ x32, int M, int N,
                                                      int ld, const int* __restrict__ row_map, const int* __restrict__ m_dev,
                                                      float* __restrict__ partials) {
@@ -183,8 +257,8 @@ extern "C" int mrg_ln_fwd(const float* x, const float* gamma, const float* beta,
 }
 
 extern "C" int mrg_ln_bwd_nblocks(int M) {
-    int nb = cdiv(M, 16);  // >= 4 rows per wave
-    if (nb > 512) nb = 512;
+    int nb = cdiv(M, 8);   // 2 rows per wave (4 waves per workgroup)
+    if (nb > 1024) nb = 1024;
     if (nb < 1) nb = 1;
     return nb;
 }
@@ -197,18 +271,25 @@ extern "C" int mrg_ln_bwd(const void* dy_bf16, const float* dy_f32, const float*
     MRG_REQUIRE(M > 0 && D > 0 && D % 4 == 0 && D <= 1024, MRG_ERR_SHAPE, "mrg_ln_bwd: need D %% 4 == 0 and D <= 1024 (D=%d)", D);
     MRG_REQUIRE(!dres_colsum || dres, MRG_ERR_ARG, "mrg_ln_bwd: dres_colsum without dres");
     const int nb = mrg_ln_bwd_nblocks(M);
-    hipLaunchKernelGGL(ln_bwd_kernel, dim3(nb), dim3(256), 0, stream, (const bf16_t*)dy_bf16, dy_f32, x, mean, rstd, gamma, dres,
-                       dx_f32, (bf16_t*)dx_bf16, partials, M, D);
+    const void* dyp = dy_bf16 ? dy_bf16 : (const void*)dy_f32;
+    const int NVr = (D + 255) / 256;
+#define MRG_LNB(NV_, D16, RES) hipLaunchKernelGGL((ln_bwd_kernel<NV_, D16, RES>), dim3(nb), dim3(256), 0, stream, dyp, x, mean, rstd, \
+                                                   gamma, dres, dx_f32, (bf16_t*)dx_bf16, partials, M, D)
+#define MRG_LNB2(NV_) do { if (dy_bf16) { if (dres) MRG_LNB(NV_, true, true); else MRG_LNB(NV_, true, false); } \
+                           else { if (dres) MRG_LNB(NV_, false, true); else MRG_LNB(NV_, false, false); } } while (0)
+    if (NVr == 1) MRG_LNB2(1); else if (NVr == 2) MRG_LNB2(2); else if (NVr == 3) MRG_LNB2(3); else MRG_LNB2(4);
+#undef MRG_LNB2
+#undef MRG_LNB
     int rc = mrg_check_launch("mrg_ln_bwd");
     if (rc) return rc;
-    hipLaunchKernelGGL(colsum_partials_kernel, dim3(cdiv(D, 64), 3), dim3(256), 0, stream, partials, nb, 3, D, dgamma, dbeta,
+    hipLaunchKernelGGL(colsum_partials_kernel, dim3(cdiv(D, 64), 3), dim3(1024), 0, stream, partials, nb, 3, D, dgamma, dbeta,
                        dres_colsum);
     return mrg_check_launch("mrg_ln_bwd/colsum_partials");
 }
 
 extern "C" int mrg_colsum_nblocks(int M) {
-    int nb = cdiv(M, 64);
-    if (nb > 256) nb = 256;
+    int nb = cdiv(M, 16);
+    if (nb > 512) nb = 512;
     if (nb < 1) nb = 1;
     return nb;
 }
@@ -218,11 +299,21 @@ extern "C" int mrg_colsum(const void* x, int x_dtype, int M, int N, int ld, cons
     MRG_REQUIRE(x && partials && out, MRG_ERR_ARG, "mrg_colsum: null pointer");
     MRG_REQUIRE(M > 0 && N > 0, MRG_ERR_SHAPE, "mrg_colsum: bad shape");
     const int nb = mrg_colsum_nblocks(M);
-    hipLaunchKernelGGL(colsum_kernel, dim3(cdiv(N, 64), nb), dim3(256), 0, stream, x_dtype == MRG_DT_BF16 ? (const bf16_t*)x : nullptr,
-                       x_dtype == MRG_DT_F32 ? (const float*)x : nullptr, M, N, ld, row_map, m_dev, partials);
+    const bool is16 = x_dtype == MRG_DT_BF16;
+    const bool wide = (N % 8 == 0) && (ld % 8 == 0) && (((uintptr_t)x & 15) == 0);
+    if (wide) {
+        const int ncg = N / 8;
+        const size_t sh = (size_t)256 * 8 * 4;
+        (void)ncg;
+        if (is16) hipLaunchKernelGGL((colsum_wide_kernel<true>), dim3(nb), dim3(256), sh, stream, x, M, N, ld, row_map, m_dev, partials);
+        else hipLaunchKernelGGL((colsum_wide_kernel<false>), dim3(nb), dim3(256), sh, stream, x, M, N, ld, row_map, m_dev, partials);
+    } else {
+        hipLaunchKernelGGL(colsum_kernel, dim3(cdiv(N, 64), nb), dim3(256), 0, stream, is16 ? (const bf16_t*)x : nullptr,
+                           !is16 ? (const float*)x : nullptr, M, N, ld, row_map, m_dev, partials);
+    }
     int rc = mrg_check_launch("mrg_colsum");
     if (rc) return rc;
-    hipLaunchKernelGGL(colsum_partials_kernel, dim3(cdiv(N, 64), 1), dim3(256), 0, stream, partials, nb, 1, N, out, (float*)nullptr,
+    hipLaunchKernelGGL(colsum_partials_kernel, dim3(cdiv(N, 64), 1), dim3(1024), 0, stream, partials, nb, 1, N, out, (float*)nullptr,
                        (float*)nullptr);
     return mrg_check_launch("mrg_colsum/colsum_partials");
 }
