@@ -1,0 +1,76 @@
+"""Host-side logic that needs no GPU: module surface / state_dict layout / init stream / schedules / parameter groups
+against fixtures captured from the reference (tools/gen_golden.py)."""
+import json
+
+import numpy as np
+import torch
+
+from conftest import load_golden
+
+
+def _tiny_model(seed=None):
+    from mirage_amd import builder
+    fx, meta = load_golden("harness_tiny")
+    cfg = meta["cfg"]
+    args = builder.make_args(cfg["in_domains"], cfg["out_domains"], input_size=64, patch_size=8, layermap_size=16, layermap_patch=2,
+                             decoder_dim=64, decoder_depth=2, decoder_num_heads=2)
+    if seed is not None:
+        torch.manual_seed(seed)
+    return builder.get_model(args, dim_tokens=128, depth=2, num_heads=2), fx, cfg
+
+
+def test_state_dict_layout_matches_reference():
+    model, fx, cfg = _tiny_model()
+    sd = model.state_dict()
+    assert list(sd.keys()) == [str(k) for k in fx["state_dict_keys"]]
+    for k, s in zip(sd.keys(), fx["state_dict_shapes"]):
+        assert list(sd[k].shape) == json.loads(str(s)), k
+    assert sorted(n for n, p in model.named_parameters() if p.requires_grad) == sorted(str(s) for s in fx["trainable"])
+    assert sorted(model.no_weight_decay()) == [str(s) for s in fx["no_weight_decay"]]
+    assert model.get_num_layers() == 2
+
+
+def test_init_stream_matches_reference_bit_for_bit():
+    """Same seed -> same weights as the reference constructor (mirage/model.py:95-121): module registration order and
+    init calls consume the torch RNG identically."""
+    model, fx, cfg = _tiny_model(seed=1234)
+    sd = model.state_dict()
+    names = [str(n) for n in fx["init.names"]]
+    for n, nrm, sm in zip(names, fx["init.norms"], fx["init.sums"]):
+        assert abs(float(sd[n].double().norm()) - nrm) <= 1e-12 + 1e-9 * abs(nrm), n
+        assert abs(float(sd[n].double().sum()) - sm) <= 1e-9 + 1e-9 * abs(sm), n
+    assert np.array_equal(sd["global_tokens"].numpy(), fx["init.global_tokens"])
+    assert np.array_equal(sd["encoder.0.attn.qkv.weight"][:4, :8].numpy(), fx["init.enc0_qkv_w_head"])
+
+
+def test_posemb_tables_and_quirk():
+    from mirage_amd.utils import build_2d_sincos_posemb
+    fx, _ = load_golden("harness_tiny")
+    assert np.array_equal(build_2d_sincos_posemb(2, 3, 8).numpy(), fx["posemb.2x3x8"])
+    np.testing.assert_allclose(build_2d_sincos_posemb(16, 16, 768).numpy(), fx["posemb.16x16x768"], atol=1e-6)
+
+
+def test_schedules_and_parameter_groups():
+    from mirage_amd import optim
+    model, fx, cfg = _tiny_model()
+    np.testing.assert_allclose(optim.cosine_scheduler(1e-4, 0.0, 10, 7, warmup_epochs=2), fx["sched.a"], rtol=1e-12)
+    np.testing.assert_allclose(optim.cosine_scheduler(0.05, 0.05, 10, 7), fx["sched.b"], rtol=1e-12)
+    np.testing.assert_allclose(optim.cosine_scheduler(2e-4, 1e-6, 6, 5, warmup_epochs=1, warmup_steps=3), fx["sched.c"], rtol=1e-12)
+    groups = optim.get_parameter_groups(model, 0.05, model.no_weight_decay())
+    by = {("decay" if g["weight_decay"] > 0 else "no_decay"): g["names"] for g in groups}
+    assert by["decay"] == [str(s) for s in fx["group.decay"]]
+    assert by["no_decay"] == [str(s) for s in fx["group.no_decay"]]
+
+
+def test_factory_and_make_mask():
+    from mirage_amd.model import MIRAGEModel, model_factory
+    assert set(model_factory) >= {"miragepre_base", "miragepre_large"}
+    m = MIRAGEModel.make_mask(4, 4, {"bscan": [(0, 1), (2, 3)], "slo": []}, full_tasks=["slo"], device="cpu")
+    assert m["bscan"].shape == (1, 16) and float(m["bscan"].sum()) == 14 and float(m["slo"].sum()) == 0
+
+
+def test_bucket_ranges_cover_exactly():
+    from mirage_amd.dp import bucket_ranges
+    for n, b in ((1000, 256), (64, 64), (98_000_000, 16 << 20), (5, 64)):
+        r = bucket_ranges(n, b)
+        assert r[0][0] == 0 and r[-1][1] == n and all(a[1] == c[0] for a, c in zip(r, r[1:]))

@@ -284,6 +284,16 @@ def run_harness_fixtures(cfg):
         fx[f"mask.uni.u.{d}"] = ud.numpy()
         fx[f"mask.uni.tm.{d}"] = tm[d].numpy()
     fx["mask.uni.ids_keep"] = ik.numpy(); fx["mask.uni.ids_restore"] = ir.numpy()
+    # initialisation parity: reference model built under a fixed seed (mirage/model.py:95-121 init sequence)
+    torch.manual_seed(1234)
+    with contextlib.redirect_stdout(io.StringIO()):
+        m2 = build_reference(cfg)
+    sd2 = m2.state_dict()
+    fx["init.names"] = np.array(list(sd2.keys()))
+    fx["init.norms"] = np.array([float(v.double().norm()) for v in sd2.values()])
+    fx["init.sums"] = np.array([float(v.double().sum()) for v in sd2.values()])
+    fx["init.global_tokens"] = sd2["global_tokens"].numpy().copy()
+    fx["init.enc0_qkv_w_head"] = sd2["encoder.0.attn.qkv.weight"][:4, :8].numpy().copy()
     fx["meta"] = np.array(json.dumps(dict(cfg=cfg)))
     np.savez_compressed(os.path.join(OUT, "harness_tiny.npz"), **fx)
     print("== harness fixtures written")
@@ -333,6 +343,9 @@ def main():
         "tiny3_curve": lambda: run_train_curve("tiny3_curve", tiny_cfg(three), B=4, K=24, steps=5),
         "harness": lambda: run_harness_fixtures(tiny_cfg(three)),
         "tiny_cls": lambda: run_cls_case("tiny_cls", tiny_cfg(("bscan",)), B=3),
+        # BASELINE.json config 1: Base, 128/8, bscan only, B=2 (the reference's own CPU-runnable case), K=98 (run_pretraining.py:97)
+        "c1_base": lambda: run_case("c1_base", O.make_config("base", ("bscan",), input_size=128, patch_size=8), B=2, K=98,
+                                    data_seed=1234, mask_seed=30, full_enc=False),
         # BASELINE.json configs at their real shapes, small batch
         "c2_base": lambda: run_case("c2_base", O.make_config("base", ("bscan", "slo")), B=2, K=128, data_seed=1234, mask_seed=31),
         "c3_base": lambda: run_case("c3_base", O.make_config("base", three), B=2, K=98, data_seed=1234, mask_seed=32, full_enc=False),
