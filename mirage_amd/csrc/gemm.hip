@@ -15,6 +15,7 @@
 // tr reads), XCD-aware tile order.
 #include "common.h"
 #include "mirage_hip.h"
+#include <cstdlib>
 
 namespace {
 
@@ -343,7 +344,18 @@ __global__ __launch_bounds__(256, OCC) void gemm_glds_kernel(const GemmArgs g) {
         const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
         bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
     }
-    const int tm = bid / g.tiles_n, tn = bid % g.tiles_n;
+    // grouped rasterisation inside the XCD's band: GROUP_M row panels x all column tiles, column-major within the group,
+    // so a B (weight) tile is reused by GROUP_M consecutive workgroups while their A panels stay L2-resident
+    constexpr int GROUP_M = 8;
+    int tm, tn;
+    {
+        const int per_group = GROUP_M * g.tiles_n;
+        const int grp = bid / per_group, in_grp = bid - grp * per_group;
+        const int first = grp * GROUP_M;
+        const int rows = min(GROUP_M, g.tiles_m - first);
+        tm = first + in_grp % rows;
+        tn = in_grp / rows;
+    }
     const int m0 = tm * BM, n0 = tn * BN;
     const int Meff = g.m_dev ? min(g.M, *g.m_dev) : g.M;
     const int Keff = g.k_dev ? min(g.K, *g.k_dev) : g.K;
@@ -450,6 +462,137 @@ __global__ __launch_bounds__(256, OCC) void gemm_glds_kernel(const GemmArgs g) {
     }
 }
 
+// LDS-DMA issued from inline asm: invisible to hipcc's s_waitcnt bookkeeping, so the compiler does not drain the
+// in-flight tile (vmcnt(0)) in front of the ds_reads of the tile being multiplied; completion is waited for by hand.
+__device__ __forceinline__ void glds16_asm(const bf16_t* src, uint32_t lds_wave_base) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(src), "s"(lds_wave_base) : "memory");
+}
+
+// Two-stage ring, 64 KiB LDS, 2 workgroups per CU: the DMA of tile t+1 flies while tile t is on the MFMA pipe;
+// one raw s_barrier per k-tile.
+template <int AMODE, int BMODE, bool VEC>
+__global__ __launch_bounds__(256, 2) void gemm_pipe_kernel(const GemmArgs g) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int nwg = g.tiles_m * g.tiles_n;
+    int bid = blockIdx.x;
+    {
+        const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    constexpr int GROUP_M = 8;
+    int tm, tn;
+    {
+        const int per_group = GROUP_M * g.tiles_n;
+        const int grp = bid / per_group, in_grp = bid - grp * per_group;
+        const int first = grp * GROUP_M;
+        const int rows = min(GROUP_M, g.tiles_m - first);
+        tm = first + in_grp % rows;
+        tn = in_grp / rows;
+    }
+    const int m0 = tm * BM, n0 = tn * BN;
+    const int Meff = g.m_dev ? min(g.M, *g.m_dev) : g.M;
+    const int Keff = g.k_dev ? min(g.K, *g.k_dev) : g.K;
+    if (m0 >= Meff) return;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int ntiles = (Keff + BK - 1) / BK;
+    int t0 = 0, t1 = ntiles;
+    if (g.splitk > 1) {
+        const int per = (ntiles + g.splitk - 1) / g.splitk;
+        t0 = blockIdx.y * per;
+        t1 = min(ntiles, t0 + per);
+    }
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    const uint32_t sbase = __builtin_amdgcn_readfirstlane(lds_addr(smem));
+    const bf16_t* pa[4]; const bf16_t* pb[4];
+    long ia[4], ib[4];
+    int ka[4], kb[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        glds_setup<AMODE>(g.A, g.lda, m0, Meff, t0 * BK, wave * 4 + j, lane, pa[j], ia[j], ka[j]);
+        glds_setup<BMODE>(g.B, g.ldb, n0, g.N, t0 * BK, wave * 4 + j, lane, pb[j], ib[j], kb[j]);
+    }
+    const bf16_t* zero = reinterpret_cast<const bf16_t*>(g_zero_page);
+    auto issue = [&](int t, int buf) {
+        const uint32_t la = sbase + buf * (2 * TILE_BYTES) + wave * 4096;
+        const uint32_t lb = la + TILE_BYTES;
+        const int krem = Keff - t * BK;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            glds16_asm((krem >= BK || ka[j] < krem) ? pa[j] : zero, la + j * 1024);
+            glds16_asm((krem >= BK || kb[j] < krem) ? pb[j] : zero, lb + j * 1024);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { pa[j] += ia[j]; pb[j] += ib[j]; }
+    };
+    if (t0 < t1) issue(t0, 0);
+    for (int t = t0; t < t1; ++t) {
+        const int cur = (t - t0) & 1;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        if (t + 1 < t1) issue(t + 1, cur ^ 1);
+        const char* ldsA = smem + cur * (2 * TILE_BYTES);
+        const char* ldsB = ldsA + TILE_BYTES;
+        const uint32_t la_u = sbase + cur * (2 * TILE_BYTES), lb_u = la_u + TILE_BYTES;
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            bf16x8 fa[2], fb[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) fa[i] = read_frag<AMODE>(ldsA, la_u, wm * 64 + i * 32, kk, lane);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) fb[j] = read_frag<BMODE>(ldsB, lb_u, wn * 64 + j * 32, kk, lane);
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+        }
+    }
+    // ---- epilogue: one pass through a 128x128 fp32 tile (64 KiB ring is free once every wave passed the barrier)
+    __syncthreads();
+    float* ct = reinterpret_cast<float*>(smem);
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int c2 = wn * 64 + j * 32 + (lane & 31);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int rl = wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                ct[rl * BN + c2] = acc[i][j][r];
+            }
+        }
+    __syncthreads();
+    const int cl = (tid & 31) << 2;
+    const int col = n0 + cl;
+    if (col >= g.N) return;
+    const int nv = min(4, g.N - col);
+    float* ws = g.splitk > 1 ? g.ws + (long)blockIdx.y * g.M * g.N : nullptr;
+    float bv[4] = {0.f, 0.f, 0.f, 0.f};
+    if (g.bias && !ws) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) if (e < nv) bv[e] = g.bias[col + e];
+    }
+#pragma unroll 1
+    for (int it = 0; it < 16; ++it) {
+        const int rl = (tid >> 5) + (it << 3);
+        const int row = m0 + rl;
+        if (row >= Meff) break;
+        const float4 a4 = *reinterpret_cast<const float4*>(ct + rl * BN + cl);
+        epi_row<VEC>(g, a4, bv, ws, row, col, nv);
+    }
+}
+
 // split-K finish: C (+)= sum_z ws[z]  (+ bias) ; fp32 out, optional bf16 copy
 __global__ void splitk_reduce_kernel(const float* __restrict__ ws, int splitk, long mn, int N, float* __restrict__ C, int ldc,
                                      int accumulate, const float* __restrict__ bias, bf16_t* __restrict__ C2, int ldc2,
@@ -519,8 +662,14 @@ extern "C" int mrg_gemm(const mrg_gemm_desc* d, hipStream_t stream) {
     const bool fast = al && !d->a_map && !d->b_map;
     // 4 workgroups per CU (<= 128 VGPRs) pay off only when there are enough tiles to fill them (measured: +13..18 % at
     // >= ~1500 tiles, -3..-15 % below and for the wgrad layout)
+    // kernel choice (measured, tools/bench_gemm.py): long K loops (>= 24 k-tiles per workgroup) run the pipelined two-stage
+    // kernel (+5..40 %), short ones the single-stage kernel at 3-4 workgroups/CU (+10..20 % there).  MRG_GEMM_PIPE=0/1 forces.
+    static const int force_pipe = [] { const char* e = getenv("MRG_GEMM_PIPE"); return e ? (e[0] == '1' ? 1 : 0) : -1; }();
+    const int ktiles_per_wg = cdiv(cdiv(d->K, BK), splitk);
+    const bool use_pipe = force_pipe >= 0 ? (force_pipe == 1) : (ktiles_per_wg >= 24);
     const bool occ4 = fast && d->a_mode == MRG_OP_KCONTIG && (g.tiles_m * g.tiles_n >= 1400) && splitk == 1;
-#define MRG_FAST(AM, BM_, V) do { if (occ4) hipLaunchKernelGGL((gemm_glds_kernel<AM, BM_, V, 4>), grid, block, (size_t)(2 * TILE_BYTES), stream, g); \
+#define MRG_FAST(AM, BM_, V) do { if (use_pipe) hipLaunchKernelGGL((gemm_pipe_kernel<AM, BM_, V>), grid, block, (size_t)(4 * TILE_BYTES), stream, g); \
+                                  else if (occ4) hipLaunchKernelGGL((gemm_glds_kernel<AM, BM_, V, 4>), grid, block, (size_t)(2 * TILE_BYTES), stream, g); \
                                   else hipLaunchKernelGGL((gemm_glds_kernel<AM, BM_, V, 3>), grid, block, (size_t)(2 * TILE_BYTES), stream, g); } while (0)
 #define MRG_LAUNCH2(AM, BM_, AL) do { \
         if (fast) { if (vec) MRG_FAST(AM, BM_, true); else MRG_FAST(AM, BM_, false); } \
