@@ -102,7 +102,7 @@ struct AttnArgs {
 
 // ================================================ forward ===============================================
 template <int HD, int CB>
-__global__ __launch_bounds__(256, 1) void attn_fwd_kernel(const AttnArgs a) {
+__global__ __launch_bounds__(512, 2) void attn_fwd_kernel(const AttnArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int KS = HD / 16, DJ = HD / 32, ROWS = CB * 32;
     char* ldsK = smem;
@@ -110,6 +110,7 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_kernel(const AttnArgs a) {
     const uint32_t ldsV_u = lds_addr(ldsV);
     const int h = blockIdx.x, b = blockIdx.y;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int nthr = blockDim.x, nwav = nthr >> 6;
     const bf16_t* qp = a.q + (long)b * a.q_bs + h * HD;
     const bf16_t* kp = a.k + (long)b * a.k_bs + h * HD;
     const bf16_t* vp = a.v + (long)b * a.v_bs + h * HD;
@@ -118,14 +119,14 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_kernel(const AttnArgs a) {
     const float sc = a.scale * LOG2E;
 
     if (nchunks == 1) {
-        load_rows<HD, SWZ_ROW>(ldsK, kp, a.k_rs, ROWS, a.Nk, tid, 256);
-        load_rows<HD, SWZ_TR>(ldsV, vp, a.v_rs, ROWS, a.Nk, tid, 256);
+        load_rows<HD, SWZ_ROW>(ldsK, kp, a.k_rs, ROWS, a.Nk, tid, nthr);
+        load_rows<HD, SWZ_TR>(ldsV, vp, a.v_rs, ROWS, a.Nk, tid, nthr);
         __syncthreads();
     }
     // uniform rounds so that every wave takes part in the staging barriers of the multi-chunk path
-    const int rounds = (nqt + 3) >> 2;
+    const int rounds = (nqt + nwav - 1) / nwav;
     for (int rd = 0; rd < rounds; ++rd) {
-        const int qt = rd * 4 + wave;
+        const int qt = rd * nwav + wave;
         const bool active = qt < nqt;
         const int q0 = qt * 32;
         bf16x8 qf[KS];
@@ -150,8 +151,8 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_kernel(const AttnArgs a) {
             const int kvalid = min(ROWS, a.Nk - kbase);
             if (nchunks > 1) {
                 __syncthreads();
-                load_rows<HD, SWZ_ROW>(ldsK, kp + (long)kbase * a.k_rs, a.k_rs, ROWS, kvalid, tid, 256);
-                load_rows<HD, SWZ_TR>(ldsV, vp + (long)kbase * a.v_rs, a.v_rs, ROWS, kvalid, tid, 256);
+                load_rows<HD, SWZ_ROW>(ldsK, kp + (long)kbase * a.k_rs, a.k_rs, ROWS, kvalid, tid, nthr);
+                load_rows<HD, SWZ_TR>(ldsV, vp + (long)kbase * a.v_rs, a.v_rs, ROWS, kvalid, tid, nthr);
                 __syncthreads();
             }
             if (!active) continue;
@@ -175,13 +176,13 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_kernel(const AttnArgs a) {
             }
             mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
             const float m_new = fmaxf(m_run, mx);
-            const float alpha = exp2f((m_run - m_new) * sc);   // first chunk: exp2(-inf) = 0
+            const float alpha = fast_exp2((m_run - m_new) * sc);   // first chunk: exp2(-inf) = 0
             float ls = 0.f;
 #pragma unroll
             for (int kb = 0; kb < CB; ++kb)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const float p = exp2f((s[kb][r] - m_new) * sc);
+                    const float p = fast_exp2((s[kb][r] - m_new) * sc);
                     s[kb][r] = p;
                     ls += p;
                 }
@@ -198,6 +199,7 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_kernel(const AttnArgs a) {
             }
 #pragma unroll
             for (int kb = 0; kb < CB; ++kb) {
+                __builtin_amdgcn_sched_barrier(0);   // keep the V fragments of later key blocks from being hoisted (VGPR budget)
                 if (kb * 32 < kvalid) {
 #pragma unroll
                     for (int mf = 0; mf < 2; ++mf) {
@@ -255,7 +257,7 @@ __global__ void attn_bwd_prep_kernel(const AttnArgs a) {
 
 // query-owner pass: dQ.  LDS: K chunk (row + tr reads), V chunk (row reads).
 template <int HD>
-__global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnArgs a) {
+__global__ __launch_bounds__(512, 2) void attn_bwd_dq_kernel(const AttnArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int KS = HD / 16, DJ = HD / 32;
     const int ROWS = a.chunk_rows;
@@ -264,21 +266,22 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnArgs a) {
     const uint32_t ldsK_u = lds_addr(ldsK);
     const int h = blockIdx.x, b = blockIdx.y;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int nthr = blockDim.x, nwav = nthr >> 6;
     const bf16_t* qp = a.q + (long)b * a.q_bs + h * HD;
     const bf16_t* kp = a.k + (long)b * a.k_bs + h * HD;
     const bf16_t* vp = a.v + (long)b * a.v_bs + h * HD;
     const bf16_t* dop = a.d_o + (long)b * a.do_bs + h * HD;
     const int nqt = (a.Nq + 31) >> 5;
     const int nchunks = (a.Nk + ROWS - 1) / ROWS;
-    const int rounds = (nqt + 3) >> 2;
+    const int rounds = (nqt + nwav - 1) / nwav;
     const float sc = a.scale * LOG2E;
     if (nchunks == 1) {
-        load_rows<HD, SWZ_ROW>(ldsK, kp, a.k_rs, ROWS, a.Nk, tid, 256);
-        load_rows<HD, SWZ_ROW>(ldsV, vp, a.v_rs, ROWS, a.Nk, tid, 256);
+        load_rows<HD, SWZ_ROW>(ldsK, kp, a.k_rs, ROWS, a.Nk, tid, nthr);
+        load_rows<HD, SWZ_ROW>(ldsV, vp, a.v_rs, ROWS, a.Nk, tid, nthr);
         __syncthreads();
     }
     for (int rd = 0; rd < rounds; ++rd) {
-        const int qt = rd * 4 + wave;
+        const int qt = rd * nwav + wave;
         const bool active = qt < nqt;
         const int q0 = qt * 32;
         const int qr = q0 + (lane & 31);
@@ -307,8 +310,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnArgs a) {
             const int kvalid = min(ROWS, a.Nk - kbase);
             if (nchunks > 1) {
                 __syncthreads();
-                load_rows<HD, SWZ_ROW>(ldsK, kp + (long)kbase * a.k_rs, a.k_rs, ROWS, kvalid, tid, 256);
-                load_rows<HD, SWZ_ROW>(ldsV, vp + (long)kbase * a.v_rs, a.v_rs, ROWS, kvalid, tid, 256);
+                load_rows<HD, SWZ_ROW>(ldsK, kp + (long)kbase * a.k_rs, a.k_rs, ROWS, kvalid, tid, nthr);
+                load_rows<HD, SWZ_ROW>(ldsV, vp + (long)kbase * a.v_rs, a.v_rs, ROWS, kvalid, tid, nthr);
                 __syncthreads();
             }
             if (!active) continue;
@@ -325,7 +328,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnArgs a) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int key = kb * 32 + acc_row(r, lane);
-                    const float p = key < kvalid ? exp2f(s[r] * sc - lse2) : 0.f;
+                    const float p = key < kvalid ? fast_exp2(s[r] * sc - lse2) : 0.f;
                     s[r] = p * (dp[r] - dsm) * a.scale;
                 }
 #pragma unroll
@@ -352,7 +355,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnArgs a) {
 
 // key-owner pass: dK, dV.  LDS: Q chunk and dO chunk (row + tr reads), lse*log2e and dsum per query of the chunk.
 template <int HD>
-__global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const AttnArgs a) {
+__global__ __launch_bounds__(512, 2) void attn_bwd_dkv_kernel(const AttnArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int KS = HD / 16, DJ = HD / 32;
     const int ROWS = a.chunk_rows;
@@ -363,16 +366,17 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const AttnArgs a) 
     const uint32_t ldsQ_u = lds_addr(ldsQ), ldsDO_u = lds_addr(ldsDO);
     const int h = blockIdx.x, b = blockIdx.y;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int nthr = blockDim.x, nwav = nthr >> 6;
     const bf16_t* qp = a.q + (long)b * a.q_bs + h * HD;
     const bf16_t* kp = a.k + (long)b * a.k_bs + h * HD;
     const bf16_t* vp = a.v + (long)b * a.v_bs + h * HD;
     const bf16_t* dop = a.d_o + (long)b * a.do_bs + h * HD;
     const int nkt = (a.Nk + 31) >> 5;
     const int nchunks = (a.Nq + ROWS - 1) / ROWS;
-    const int rounds = (nkt + 3) >> 2;
+    const int rounds = (nkt + nwav - 1) / nwav;
     const float sc = a.scale * LOG2E;
     for (int rd = 0; rd < rounds; ++rd) {
-        const int kt = rd * 4 + wave;
+        const int kt = rd * nwav + wave;
         const bool active = kt < nkt;
         const int k0 = kt * 32;
         const int kr = k0 + (lane & 31);
@@ -398,9 +402,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const AttnArgs a) 
             const int qvalid = min(ROWS, a.Nq - qbase);
             if (nchunks > 1 || rd == 0) {
                 __syncthreads();
-                load_rows<HD, SWZ_ROW>(ldsQ, qp + (long)qbase * a.q_rs, a.q_rs, ROWS, qvalid, tid, 256);
-                load_rows<HD, SWZ_ROW>(ldsDO, dop + (long)qbase * a.do_rs, a.do_rs, ROWS, qvalid, tid, 256);
-                for (int i = tid; i < ROWS; i += 256) {
+                load_rows<HD, SWZ_ROW>(ldsQ, qp + (long)qbase * a.q_rs, a.q_rs, ROWS, qvalid, tid, nthr);
+                load_rows<HD, SWZ_ROW>(ldsDO, dop + (long)qbase * a.do_rs, a.do_rs, ROWS, qvalid, tid, nthr);
+                for (int i = tid; i < ROWS; i += nthr) {
                     const long sidx = ((long)b * a.H + h) * a.Nq + qbase + i;
                     ldsL[i] = i < qvalid ? a.lse[sidx] * LOG2E : INFINITY;
                     ldsD[i] = i < qvalid ? a.dsum[sidx] : 0.f;
@@ -428,7 +432,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const AttnArgs a) 
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         const int r = g * 4 + e;
-                        const float p = exp2f(s[r] * sc - ls[e]);
+                        const float p = fast_exp2(s[r] * sc - ls[e]);
                         pr[r] = p;
                         s[r] = p * (dp[r] - ds[e]) * a.scale;
                     }
@@ -462,18 +466,25 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const AttnArgs a) 
     }
 }
 
+// waves per workgroup so that every wave owns the same number of 32-row tiles: ceil(tiles / ceil(tiles / 8))
+static int waves_for(int ntiles) {
+    const int rounds = (ntiles + 7) / 8;
+    int w = (ntiles + rounds - 1) / rounds;
+    return w < 1 ? 1 : w;
+}
+
 template <int HD>
 int launch_fwd(const AttnArgs& a, hipStream_t stream) {
     const int nkb = (a.Nk + 31) / 32;
-    dim3 grid(a.H, a.B), block(256);
+    dim3 grid(a.H, a.B), block(64 * waves_for((a.Nq + 31) / 32));
 #define MRG_FWD(CB_) do { const size_t sh = (size_t)(2 * CB_ * 32 * HD * 2); \
         if (sh > 65536) { static bool once = false; if (!once) { (void)hipFuncSetAttribute((const void*)attn_fwd_kernel<HD, CB_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh); once = true; } } \
         hipLaunchKernelGGL((attn_fwd_kernel<HD, CB_>), grid, block, sh, stream, a); } while (0)
+    // all scores of a chunk of CB key blocks stay in registers; longer rows run several chunks with an online-softmax rescale
     if (nkb <= 4) MRG_FWD(4);
-    else if (nkb == 5) MRG_FWD(5);
-    else if (nkb <= 8) MRG_FWD(8);
-    else if (nkb == 9) MRG_FWD(9);
-    else MRG_FWD(8);  // longer sequences: 256-key chunks with online-softmax rescale
+    else if (nkb == 5 || nkb == 9 || nkb == 10) MRG_FWD(5);
+    else if (HD == 32 && nkb <= 8) MRG_FWD(8);
+    else MRG_FWD(4);
 #undef MRG_FWD
     return mrg_check_launch("mrg_attn_fwd");
 }
@@ -526,8 +537,9 @@ extern "C" int mrg_attn_bwd(const mrg_attn_desc* d, hipStream_t stream) {
         rc = mrg_check_launch("mrg_attn_bwd/prep");
         if (rc) return rc;
     }
-    dim3 grid(a.H, a.B), block(256);
+    dim3 grid(a.H, a.B);
     {   // dQ: K,V chunk in LDS
+        dim3 block(64 * waves_for((a.Nq + 31) / 32));
         AttnArgs b = a;
         b.chunk_rows = ((a.Nk + 31) / 32) * 32;
         if (b.chunk_rows > 288) b.chunk_rows = 256;
@@ -539,6 +551,7 @@ extern "C" int mrg_attn_bwd(const mrg_attn_desc* d, hipStream_t stream) {
         if (rc) return rc;
     }
     {   // dK,dV: Q,dO chunk in LDS
+        dim3 block(64 * waves_for((a.Nk + 31) / 32));
         AttnArgs b = a;
         b.chunk_rows = ((a.Nq + 31) / 32) * 32;
         if (b.chunk_rows > 288) b.chunk_rows = 256;

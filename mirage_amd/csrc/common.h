@@ -23,14 +23,18 @@ int mrg_check_launch(const char* what);
 #define MRG_REQUIRE(cond, code, ...) do { if (!(cond)) return mrg_set_error((code), __VA_ARGS__); } while (0)
 
 __device__ __forceinline__ float bf2f(bf16_t h) { return __uint_as_float(((uint32_t)h) << 16); }
-// round-to-nearest-even, NaN preserved (quiet)
-__device__ __forceinline__ bf16_t f2bf(float f) {
-    uint32_t u = __float_as_uint(f);
-    if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);
-    u += 0x7fffu + ((u >> 16) & 1u);
-    return (bf16_t)(u >> 16);
+// fp32 -> bf16 with the hardware converter (v_cvt_pk_bf16_f32: round-to-nearest-even, NaN-safe); emitted by the compiler
+// from a vector fptrunc so that it also places the VALU->MFMA operand wait states itself.
+typedef __bf16 mrg_bf16x2 __attribute__((ext_vector_type(2)));
+typedef float mrg_f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t pack_bf2(float lo, float hi) {
+    const mrg_f32x2 v = {lo, hi};
+    const mrg_bf16x2 r = __builtin_convertvector(v, mrg_bf16x2);
+    return *reinterpret_cast<const uint32_t*>(&r);
 }
-__device__ __forceinline__ uint32_t pack_bf2(float lo, float hi) { return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16); }
+__device__ __forceinline__ bf16_t f2bf(float f) { return (bf16_t)(pack_bf2(f, 0.f) & 0xffffu); }
+// 2^x on the raw transcendental unit (v_exp_f32): callers guarantee x <= ~0 or a bounded range; denormal results flush
+__device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
 
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
