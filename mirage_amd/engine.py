@@ -21,6 +21,45 @@ BF16, F32 = torch.bfloat16, torch.float32
 KS = L.MRG_OP_KSTRIDED
 
 
+# ------------------------------------------------------------------------------------------- side stream for wgrad
+class _Side:
+    """Weight / bias gradients are off the critical path of the backward pass (nothing downstream reads them until the
+    optimizer), while the dgrad chain is a sequence of mostly latency-bound launches.  They are therefore issued on a second
+    HIP stream and overlap the chain; `join()` (called at the end of the backward pass and by the optimizer) makes the main
+    stream wait for them.  Works under hipGraph capture (fork / join through events)."""
+    enabled = True
+    stream = None
+    keep = []          # tensors read by side-stream kernels stay referenced until the join
+    pending = False
+
+    @classmethod
+    def run(cls, fn, *tensors):
+        if not cls.enabled:
+            fn()
+            return
+        main = torch.cuda.current_stream()
+        if cls.stream is None or cls.stream.device != main.device:
+            cls.stream = torch.cuda.Stream(device=main.device)
+        ev = torch.cuda.Event()
+        ev.record(main)
+        with torch.cuda.stream(cls.stream):
+            cls.stream.wait_event(ev)
+            fn()
+        cls.keep.extend(tensors)
+        cls.pending = True
+
+    @classmethod
+    def join(cls):
+        if cls.pending:
+            torch.cuda.current_stream().wait_stream(cls.stream)
+            cls.keep.clear()
+            cls.pending = False
+
+
+def join_side_stream():
+    _Side.join()
+
+
 # ------------------------------------------------------------------------------------------- linear helpers
 def lin_fwd(x16: torch.Tensor, lin, *, out_dtype=BF16, resid: Optional[torch.Tensor] = None, want_bf16_copy: bool = False,
             gelu: bool = False, save_pre: bool = False):
@@ -48,12 +87,14 @@ def lin_bwd(dy16: torch.Tensor, x16: torch.Tensor, lin, *, need_dx: bool = True,
     N = W.shape[0]
     Kin = W.numel() // N
     M = m_rows if m_rows is not None else dy16.numel() // N
-    if Wp.requires_grad:
-        gw = grad_buffer(Wp)
-        K.gemm(dy16, x16, N, Kin, M, a_mode=KS, b_mode=KS, lda=N, ldb=Kin, out=gw.view(N, Kin), ldc=Kin,
-               a_map=a_map, k_dev=k_dev, splitk=K.pick_splitk(N, Kin, M))
-    if bias_grad and lin.bias is not None and lin.bias.requires_grad:
-        K.colsum(dy16, grad_buffer(lin.bias), M=M, row_map=a_map, m_dev=k_dev)
+    def _param_grads():
+        if Wp.requires_grad:
+            gw = grad_buffer(Wp)
+            K.gemm(dy16, x16, N, Kin, M, a_mode=KS, b_mode=KS, lda=N, ldb=Kin, out=gw.view(N, Kin), ldc=Kin,
+                   a_map=a_map, k_dev=k_dev, splitk=K.pick_splitk(N, Kin, M))
+        if bias_grad and lin.bias is not None and lin.bias.requires_grad:
+            K.colsum(dy16, grad_buffer(lin.bias), M=M, row_map=a_map, m_dev=k_dev)
+    _Side.run(_param_grads, dy16, x16, a_map, k_dev)
     if not need_dx:
         return None, None
     dshape = dy16.shape[:-1] + (Kin,)
@@ -132,6 +173,7 @@ class BlockFn(torch.autograd.Function):
     def backward(ctx, dout):
         dx32, _ = block_bwd(ctx.blk, ctx.saved, dout.contiguous().float(), None)
         ctx.saved = None
+        _Side.join()
         return (dx32, None, None) + (None,) * 12
 
 
@@ -140,7 +182,8 @@ class EncoderFn(torch.autograd.Function):
     between blocks without touching autograd."""
 
     @staticmethod
-    def forward(ctx, x, blocks, save, want_bf16, *params):
+    def forward(ctx, x, blocks, save, want_bf16, defer_join, *params):
+        ctx.defer_join = defer_join
         x32 = x
         saved_all = []
         x16 = None
@@ -165,7 +208,9 @@ class EncoderFn(torch.autograd.Function):
         # is checked on lookup, so a recycled address can never alias); at most one entry is alive
         _TWINS.clear()
         _TWINS[dx32.data_ptr()] = (dx32, dx16)
-        return (dx32, None, None, None) + (None,) * (len(ctx.needs_input_grad) - 4)
+        if not ctx.defer_join:
+            _Side.join()
+        return (dx32,) + (None,) * (len(ctx.needs_input_grad) - 1)
 
 
 # fp32 gradient tensor -> its bf16 twin, valid only while the fp32 tensor object itself is alive and identical
@@ -270,6 +315,7 @@ class EmbedFn(torch.autograd.Function):
         dx = dx.contiguous()
         embed_bwd(ctx.model, ctx.saved, dx, _twin_of(dx))
         ctx.saved = None
+        _Side.join()       # the embedding backward is the last node of the graph: parameter gradients are complete after this
         return (None,) * len(ctx.needs_input_grad)
 
 
@@ -358,11 +404,13 @@ def decoder_bwd(ad, saved, d_img: torch.Tensor, d_enc32: torch.Tensor, first: bo
     # proj_context: wgrad + bias + dgrad accumulated into the shared encoder-output gradient
     Wp = ad.proj_context
     D = enc16.shape[-1]
-    if Wp.weight.requires_grad:
-        K.gemm(d_ctx16, enc16, Dd, D, B * N, a_mode=KS, b_mode=KS, lda=Dd, ldb=D, out=grad_buffer(Wp.weight), ldc=D,
-               splitk=K.pick_splitk(Dd, D, B * N))
-    if Wp.bias.requires_grad:
-        K.colsum(d_ctx.view(B * N, Dd), grad_buffer(Wp.bias))
+    def _pc_grads():
+        if Wp.weight.requires_grad:
+            K.gemm(d_ctx16, enc16, Dd, D, B * N, a_mode=KS, b_mode=KS, lda=Dd, ldb=D, out=grad_buffer(Wp.weight), ldc=D,
+                   splitk=K.pick_splitk(Dd, D, B * N))
+        if Wp.bias.requires_grad:
+            K.colsum(d_ctx.view(B * N, Dd), grad_buffer(Wp.bias))
+    _Side.run(_pc_grads, d_ctx16, enc16, d_ctx)
     K.gemm(d_ctx16, shadow(Wp.weight), B * N, D, Dd, b_mode=KS, lda=Dd, ldb=D, out=d_enc32, ldc=D, accumulate=not first)
 
 
@@ -370,7 +418,8 @@ class DecodersFn(torch.autograd.Function):
     """One or more output adapters in one node: their proj_context dgrads accumulate straight into one d_enc buffer."""
 
     @staticmethod
-    def forward(ctx, enc32, enc16, adapters, dom_names, dom_start, ng, ids_keep, ids_restore, save, *params):
+    def forward(ctx, enc32, enc16, adapters, dom_names, dom_start, ng, ids_keep, ids_restore, save, defer_join, *params):
+        ctx.defer_join = defer_join
         enc32 = enc32.contiguous().float()
         if enc16 is None:
             enc16 = to_bf16(enc32)
@@ -393,6 +442,8 @@ class DecodersFn(torch.autograd.Function):
             decoder_bwd(ad, sv, d_img, d_enc, first)
             first = False
         ctx.saved = None
+        if not ctx.defer_join:
+            _Side.join()
         return (d_enc,) + (None,) * (len(ctx.needs_input_grad) - 1)
 
 

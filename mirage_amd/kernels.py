@@ -80,12 +80,13 @@ def gemm(A: torch.Tensor, B: torch.Tensor, M: int, N: int, K: int, *, a_mode=L.M
     return out
 
 
-def pick_splitk(M: int, N: int, K: int, n_cu: int = 256) -> int:
-    """wgrad GEMMs have few output tiles and a long K: split K until there are ~1-2 workgroups per CU."""
+def pick_splitk(M: int, N: int, K: int, target_wgs: int = 320) -> int:
+    """wgrad GEMMs have few output tiles and a long K (= tokens): split K until there are ~2 workgroups per CU
+    (the pipelined kernel runs 2 per CU), keeping >= 8 k-tiles per workgroup."""
     tiles = ((M + 127) // 128) * ((N + 127) // 128)
     ktiles = (K + 63) // 64
     s = 1
-    while tiles * s < n_cu and s * 2 <= ktiles // 4 and s < 32:
+    while tiles * s < target_wgs and (ktiles // (s * 2)) >= 8 and s < 32:
         s *= 2
     return s
 

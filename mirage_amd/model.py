@@ -273,7 +273,7 @@ class MIRAGEModel(nn.Module):
             return features
 
         want16 = self.output_adapters is not None
-        enc32, enc16 = E.EncoderFn.apply(x0, blocks, save, want16, *self._encoder_params())
+        enc32, enc16 = E.EncoderFn.apply(x0, blocks, save, want16, True, *self._encoder_params())
         if self.output_adapters is None:
             if reshape:
                 gs = self.args.grid_sizes["bscan"]
@@ -282,7 +282,7 @@ class MIRAGEModel(nn.Module):
 
         ads = list(self.output_adapters.values())
         imgs = E.DecodersFn.apply(enc32, enc16, ads, doms, dom_start, self.num_global_tokens, ids_keep.contiguous(),
-                                  ids_restore.contiguous(), save, *self._decoder_params())
+                                  ids_restore.contiguous(), save, True, *self._decoder_params())
         preds = {name: img for name, img in zip(self.output_adapters.keys(), imgs)}
         return preds, task_masks
 

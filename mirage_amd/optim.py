@@ -91,6 +91,8 @@ class FusedAdamW:
 
     def step(self):
         """global grad norm (native_scaler.py:46-61) -> AdamW (+clip / skip) -> step counter + 1."""
+        from .engine import join_side_stream
+        join_side_stream()
         a = self.arena
         g = a.flat_g
         K.grad_norm(g, self.grad_norm)

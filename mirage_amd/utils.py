@@ -102,6 +102,7 @@ class _LinearFn(torch.autograd.Function):
         dy16 = dy if dy.dtype == BF16 else E.to_bf16(dy.float())
         dx, _ = E.lin_bwd(dy16.view(-1, dy16.shape[-1]), ctx.x16.view(-1, ctx.x16.shape[-1]), lin,
                           dx_dtype=F32 if ctx.in_dtype != BF16 else BF16)
+        E.join_side_stream()
         return dx.view(ctx.x16.shape), None, None, None, None
 
 
@@ -152,6 +153,7 @@ class _MlpFn(torch.autograd.Function):
         dy16 = E.to_bf16(dy.contiguous().float())
         d_pre, _ = E.lin_bwd(dy16, h_act, mlp.fc2, gelu_pre=h_pre)
         dx, _ = E.lin_bwd(d_pre, x16, mlp.fc1, dx_dtype=F32)
+        E.join_side_stream()
         return (dx, None) + (None,) * 4
 
 
@@ -202,6 +204,7 @@ class _AttentionFn(torch.autograd.Function):
         K.attn_bwd(qkv[..., :C], qkv[..., C:2 * C], qkv[..., 2 * C:], o, lse, d_o, d_qkv[..., :C], d_qkv[..., C:2 * C], d_qkv[..., 2 * C:],
                    B, H, N, N, hd, att.scale, st, st, st, st, st, st)
         dx, _ = E.lin_bwd(d_qkv, x16, att.qkv, dx_dtype=F32)
+        E.join_side_stream()
         return (dx, None) + (None,) * 4
 
 
@@ -260,6 +263,7 @@ class _CrossAttentionFn(torch.autograd.Function):
                    sq, skv, skv)
         dx, _ = E.lin_bwd(dq, x16, att.q, dx_dtype=F32)
         dc, _ = E.lin_bwd(dkv, c16, att.kv, dx_dtype=F32)
+        E.join_side_stream()
         return (dx, dc, None) + (None,) * 6
 
 
