@@ -126,17 +126,27 @@ __global__ __launch_bounds__(256) void dec_assemble_bwd_kernel(const AsmArgs a) 
 
 struct FinArgs { const float* partials; int nblocks, Dd; float* out[MAXDOM + 1]; };
 
-__global__ void dec_assemble_fin_kernel(const FinArgs f) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+// grid (ceil(Dd/64), MAXDOM+1), 1024 threads: lane = column, 16 waves split the partial rows
+__global__ __launch_bounds__(1024) void dec_assemble_fin_kernel(const FinArgs f) {
+    __shared__ float red[16][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + lane;
     const int q = blockIdx.y;
-    if (c >= f.Dd) return;
     float* o = nullptr;
 #pragma unroll
     for (int d = 0; d <= MAXDOM; ++d) if (d == q) o = f.out[d];
     if (!o) return;
     float s = 0.f;
-    for (int b = 0; b < f.nblocks; ++b) s += f.partials[((long)b * (MAXDOM + 1) + q) * f.Dd + c];
-    o[c] = s;
+    if (c < f.Dd)
+        for (int b = wave; b < f.nblocks; b += 16) s += f.partials[((long)b * (MAXDOM + 1) + q) * f.Dd + c];
+    red[wave][lane] = s;
+    __syncthreads();
+    if (wave == 0 && c < f.Dd) {
+        float t = 0.f;
+#pragma unroll
+        for (int w = 0; w < 16; ++w) t += red[w][lane];
+        o[c] = t;
+    }
 }
 
 int fill(AsmArgs& a, const mrg_dec_assemble_desc* d, const char* who) {
@@ -188,6 +198,6 @@ extern "C" int mrg_dec_assemble_bwd(const mrg_dec_assemble_desc* d, hipStream_t 
     f.partials = d->partials; f.nblocks = nb; f.Dd = a.Dd;
     for (int i = 0; i < MAXDOM; ++i) f.out[i] = i < d->ndom ? d->d_task_emb[i] : nullptr;
     f.out[MAXDOM] = d->d_mask_token;
-    hipLaunchKernelGGL(dec_assemble_fin_kernel, dim3(cdiv(a.Dd, 64), MAXDOM + 1), dim3(64), 0, stream, f);
+    hipLaunchKernelGGL(dec_assemble_fin_kernel, dim3(cdiv(a.Dd, 64), MAXDOM + 1), dim3(1024), 0, stream, f);
     return mrg_check_launch("mrg_dec_assemble_bwd/fin");
 }

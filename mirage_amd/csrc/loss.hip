@@ -148,18 +148,84 @@ __global__ __launch_bounds__(256) void loss_bwd_kernel(const T* __restrict__ pre
     }
 }
 
-// tokens [B, g*g, C*P*P] <-> image [B, C, g*P, g*P]   (inner token order c, ph, pw)
-template <typename T, bool TO_IMAGE>
+// ---- single-channel bf16 MSE fast path: 8 consecutive pixels (16 B of predictions, 32 B of targets) per thread
+__global__ __launch_bounds__(256) void mse1_fwd_vec_kernel(const bf16_t* __restrict__ pred, const float* __restrict__ target,
+                                                           const long* __restrict__ mask, int B, int H, int W, int P,
+                                                           float* __restrict__ partial) {
+    __shared__ float red[4];
+    const int b = blockIdx.y, chunk = blockIdx.x;
+    const int nw = W / P;
+    const long HW8 = (long)H * W / 8;
+    float s = 0.f, n = 0.f;
+    for (long v = (long)chunk * 256 + threadIdx.x; v < HW8; v += (long)LOSS_CHUNKS * 256) {
+        const long px = v * 8;
+        const int y = (int)(px / W), x = (int)(px - (long)y * W);
+        const float m = mask ? (float)mask[(long)b * (H / P) * nw + (y / P) * nw + x / P] : 1.f;
+        if (m == 0.f) continue;
+        const uint4 p = *reinterpret_cast<const uint4*>(pred + (long)b * H * W + px);
+        const float4 t0 = *reinterpret_cast<const float4*>(target + (long)b * H * W + px);
+        const float4 t1 = *reinterpret_cast<const float4*>(target + (long)b * H * W + px + 4);
+        const float d0 = __uint_as_float(p.x << 16) - t0.x, d1 = __uint_as_float(p.x & 0xffff0000u) - t0.y;
+        const float d2 = __uint_as_float(p.y << 16) - t0.z, d3 = __uint_as_float(p.y & 0xffff0000u) - t0.w;
+        const float d4 = __uint_as_float(p.z << 16) - t1.x, d5 = __uint_as_float(p.z & 0xffff0000u) - t1.y;
+        const float d6 = __uint_as_float(p.w << 16) - t1.z, d7 = __uint_as_float(p.w & 0xffff0000u) - t1.w;
+        s += ((d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3)) + ((d4 * d4 + d5 * d5) + (d6 * d6 + d7 * d7));
+        n += 8.f;
+    }
+    const float ts = block_sum(s, red);
+    const float tn = block_sum(n, red);
+    if (threadIdx.x == 0) {
+        partial[((long)b * LOSS_CHUNKS + chunk) * 2 + 0] = ts;
+        partial[((long)b * LOSS_CHUNKS + chunk) * 2 + 1] = tn;
+    }
+}
+
+__global__ __launch_bounds__(256) void mse1_bwd_vec_kernel(const bf16_t* __restrict__ pred, const float* __restrict__ target,
+                                                           const long* __restrict__ mask, const float* __restrict__ coef,
+                                                           const float* __restrict__ gout, int B, int H, int W, int P,
+                                                           bf16_t* __restrict__ dpred) {
+    const long HW = (long)H * W;
+    const long total8 = (long)B * HW / 8;
+    const int nw = W / P;
+    const float go = gout ? gout[0] : 1.f;
+    for (long v = (long)blockIdx.x * blockDim.x + threadIdx.x; v < total8; v += (long)gridDim.x * blockDim.x) {
+        const long i = v * 8;
+        const int b = (int)(i / HW);
+        const long px = i - (long)b * HW;
+        const int y = (int)(px / W), x = (int)(px - (long)y * W);
+        const float m = mask ? (float)mask[(long)b * (H / P) * nw + (y / P) * nw + x / P] : 1.f;
+        const float k = 2.f * go * coef[b] * m;
+        uint4 o = make_uint4(0, 0, 0, 0);
+        if (k != 0.f) {
+            const uint4 p = *reinterpret_cast<const uint4*>(pred + i);
+            const float4 t0 = *reinterpret_cast<const float4*>(target + i);
+            const float4 t1 = *reinterpret_cast<const float4*>(target + i + 4);
+            o.x = pack_bf2(k * (__uint_as_float(p.x << 16) - t0.x), k * (__uint_as_float(p.x & 0xffff0000u) - t0.y));
+            o.y = pack_bf2(k * (__uint_as_float(p.y << 16) - t0.z), k * (__uint_as_float(p.y & 0xffff0000u) - t0.w));
+            o.z = pack_bf2(k * (__uint_as_float(p.z << 16) - t1.x), k * (__uint_as_float(p.z & 0xffff0000u) - t1.y));
+            o.w = pack_bf2(k * (__uint_as_float(p.w << 16) - t1.z), k * (__uint_as_float(p.w & 0xffff0000u) - t1.w));
+        }
+        *reinterpret_cast<uint4*>(dpred + i) = o;
+    }
+}
+
+// tokens [B, g*g, C*P*P] <-> image [B, C, g*P, g*P]   (inner token order c, ph, pw).  V consecutive x per thread:
+// both layouts are contiguous along pw, so every access is a V-element vector (16 B when P % V == 0).
+template <typename T, bool TO_IMAGE, int V>
 __global__ void patch_rearrange_kernel(const T* __restrict__ src, T* __restrict__ dst, int B, int C, int g, int P) {
     const int S = g * P;
-    const long total = (long)B * C * S * S;
+    const int SV = S / V;
+    const long total = (long)B * C * S * SV;
+    struct alignas(sizeof(T) * V) Vec { T v[V]; };
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-        const int x = (int)(i % S);
-        const int y = (int)((i / S) % S);
-        const int c = (int)((i / ((long)S * S)) % C);
-        const int b = (int)(i / ((long)S * S * C));
+        const int x = (int)(i % SV) * V;
+        const int y = (int)((i / SV) % S);
+        const int c = (int)((i / ((long)SV * S)) % C);
+        const int b = (int)(i / ((long)SV * S * C));
+        const long img = (((long)b * C + c) * S + y) * S + x;
         const long tok = ((long)b * g * g + (y / P) * g + x / P) * ((long)C * P * P) + ((long)c * P + y % P) * P + x % P;
-        if (TO_IMAGE) dst[i] = src[tok]; else dst[tok] = src[i];
+        if (TO_IMAGE) *reinterpret_cast<Vec*>(dst + img) = *reinterpret_cast<const Vec*>(src + tok);
+        else *reinterpret_cast<Vec*>(dst + tok) = *reinterpret_cast<const Vec*>(src + img);
     }
 }
 
@@ -181,10 +247,17 @@ extern "C" int mrg_masked_loss_fwd(const mrg_loss_desc* d, hipStream_t stream) {
     if (rc) return rc;
     MRG_REQUIRE(d->loss, MRG_ERR_ARG, "mrg_masked_loss_fwd: null loss pointer");
     dim3 grid(LOSS_CHUNKS, d->B), block(256);
+    const bool vec_mse = d->kind == MRG_LOSS_MSE && d->C == 1 && d->pred_dtype == MRG_DT_BF16 && d->P % 8 == 0 && d->W % 8 == 0 &&
+                         (((uintptr_t)d->pred | (uintptr_t)d->target) & 15) == 0;
+    if (vec_mse) {
+        hipLaunchKernelGGL(mse1_fwd_vec_kernel, grid, block, 0, stream, (const bf16_t*)d->pred, (const float*)d->target, d->mask, d->B, d->H,
+                           d->W, d->P, d->partial);
+    } else {
 #define MRG_L(T, CE) hipLaunchKernelGGL((loss_fwd_kernel<T, CE>), grid, block, 0, stream, (const T*)d->pred, d->target, d->mask, d->B, d->C, d->H, d->W, d->P, d->partial)
     if (d->pred_dtype == MRG_DT_BF16) { if (d->kind == MRG_LOSS_CE) MRG_L(bf16_t, true); else MRG_L(bf16_t, false); }
     else { if (d->kind == MRG_LOSS_CE) MRG_L(float, true); else MRG_L(float, false); }
 #undef MRG_L
+    }
     rc = mrg_check_launch("mrg_masked_loss_fwd");
     if (rc) return rc;
     hipLaunchKernelGGL(loss_finish_kernel, dim3(1), dim3(1024), 0, stream, d->partial, d->B, d->loss, d->coef, d->per_sample);
@@ -197,6 +270,13 @@ extern "C" int mrg_masked_loss_bwd(const mrg_loss_desc* d, hipStream_t stream) {
     MRG_REQUIRE(d->dpred, MRG_ERR_ARG, "mrg_masked_loss_bwd: null dpred");
     const long total = (long)d->B * d->H * d->W;
     dim3 grid((unsigned)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096)), block(256);
+    const bool vec_mse = d->kind == MRG_LOSS_MSE && d->C == 1 && d->pred_dtype == MRG_DT_BF16 && d->P % 8 == 0 && d->W % 8 == 0 &&
+                         (((uintptr_t)d->pred | (uintptr_t)d->target | (uintptr_t)d->dpred) & 15) == 0;
+    if (vec_mse) {
+        hipLaunchKernelGGL(mse1_bwd_vec_kernel, dim3((unsigned)((total / 8 + 255) / 256 < 4096 ? (total / 8 + 255) / 256 : 4096)), block, 0, stream,
+                           (const bf16_t*)d->pred, (const float*)d->target, d->mask, d->coef, d->gout, d->B, d->H, d->W, d->P, (bf16_t*)d->dpred);
+        return mrg_check_launch("mrg_masked_loss_bwd");
+    }
 #define MRG_L(T, CE) hipLaunchKernelGGL((loss_bwd_kernel<T, CE>), grid, block, 0, stream, (const T*)d->pred, d->target, d->mask, d->coef, d->gout, d->B, d->C, d->H, d->W, d->P, (T*)d->dpred)
     if (d->pred_dtype == MRG_DT_BF16) { if (d->kind == MRG_LOSS_CE) MRG_L(bf16_t, true); else MRG_L(bf16_t, false); }
     else { if (d->kind == MRG_LOSS_CE) MRG_L(float, true); else MRG_L(float, false); }
@@ -207,16 +287,16 @@ extern "C" int mrg_masked_loss_bwd(const mrg_loss_desc* d, hipStream_t stream) {
 extern "C" int mrg_patch_rearrange(const void* src, void* dst, int dtype, int to_image, int B, int C, int g, int P, hipStream_t stream) {
     MRG_REQUIRE(src && dst, MRG_ERR_ARG, "mrg_patch_rearrange: null pointer");
     MRG_REQUIRE(B > 0 && C > 0 && g > 0 && P > 0, MRG_ERR_SHAPE, "mrg_patch_rearrange: bad shape");
-    const long total = (long)B * C * g * P * g * P;
+    const int esz = dtype == MRG_DT_BF16 ? 2 : 4;
+    int V = 16 / esz;                                  // 16-byte vectors when the patch width allows it
+    while (V > 1 && (P % V != 0 || (((uintptr_t)src | (uintptr_t)dst) % (V * esz)) != 0)) V >>= 1;
+    const long total = (long)B * C * g * P * g * P / V;
     dim3 grid((unsigned)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192)), block(256);
-    if (dtype == MRG_DT_BF16) {
-        if (to_image) hipLaunchKernelGGL((patch_rearrange_kernel<bf16_t, true>), grid, block, 0, stream, (const bf16_t*)src, (bf16_t*)dst, B, C, g, P);
-        else hipLaunchKernelGGL((patch_rearrange_kernel<bf16_t, false>), grid, block, 0, stream, (const bf16_t*)src, (bf16_t*)dst, B, C, g, P);
-    } else if (dtype == MRG_DT_F32) {
-        if (to_image) hipLaunchKernelGGL((patch_rearrange_kernel<float, true>), grid, block, 0, stream, (const float*)src, (float*)dst, B, C, g, P);
-        else hipLaunchKernelGGL((patch_rearrange_kernel<float, false>), grid, block, 0, stream, (const float*)src, (float*)dst, B, C, g, P);
-    } else {
-        return mrg_set_error(MRG_ERR_ARG, "mrg_patch_rearrange: bad dtype");
-    }
+#define MRG_PR(T, V_) do { if (to_image) hipLaunchKernelGGL((patch_rearrange_kernel<T, true, V_>), grid, block, 0, stream, (const T*)src, (T*)dst, B, C, g, P); \
+                           else hipLaunchKernelGGL((patch_rearrange_kernel<T, false, V_>), grid, block, 0, stream, (const T*)src, (T*)dst, B, C, g, P); } while (0)
+    if (dtype == MRG_DT_BF16) { if (V == 8) MRG_PR(bf16_t, 8); else if (V == 4) MRG_PR(bf16_t, 4); else if (V == 2) MRG_PR(bf16_t, 2); else MRG_PR(bf16_t, 1); }
+    else if (dtype == MRG_DT_F32) { if (V == 4) MRG_PR(float, 4); else if (V == 2) MRG_PR(float, 2); else MRG_PR(float, 1); }
+    else return mrg_set_error(MRG_ERR_ARG, "mrg_patch_rearrange: bad dtype");
+#undef MRG_PR
     return mrg_check_launch("mrg_patch_rearrange");
 }
