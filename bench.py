@@ -267,6 +267,12 @@ def main():
             result["cpu_baseline"] = cpu_baseline(model_name, doms, Kk, train)
         if train:
             result["final_loss"] = round(float(ts.loss), 5)
+        if os.environ.get("MRG_TUNE_LOG") == "1":
+            names = {1: "glds3", 2: "glds4", 3: "pipe128", 4: "pipe256"}
+            for key, (v, sk), us in K.TUNE["log"]:
+                am, bm, M_, N_, K_ = key[:5]
+                print(f"tune mode=({am},{bm}) {M_}x{N_}x{K_} act={key[5]} -> {names.get(v, v)} splitk={sk} {us:.1f} us {2.0 * M_ * N_ * K_ / us / 1e6:.0f} TF/s",
+                      file=sys.stderr)
         print(json.dumps(result), flush=True)
     if world > 1:
         dist.barrier()

@@ -56,6 +56,8 @@ const char* mrg_last_error_string(void);
  *   row_map optional int32 scatter of output rows; add_tab/add_row: v += add_tab[add_row[row]*ldt + col]
  *           (positional-embedding add of the input adapters, mirage/input_adapters.py:104-108)
  *   splitk  >1: partial sums to ws [splitk][M][N] fp32, then reduced (bias/accumulate epilogue only)
+ *   variant kernel variant for aligned, map-free problems: single-stage LDS-DMA kernel at 3 or 4 workgroups/CU,
+ *           two-stage pipelined 128x128 kernel, two-stage pipelined 256x128 kernel (8 waves); 0 picks by shape
  */
 typedef struct mrg_gemm_desc {
     const void* A; const void* B;
@@ -73,7 +75,9 @@ typedef struct mrg_gemm_desc {
     const int* row_map;
     const float* add_tab; const int* add_row; int ldt;
     int splitk; float* ws;
+    int variant;   /* 0 = heuristic choice; 1..4 force a kernel variant (see MRG_GEMM_* below); used by the host-side autotuner */
 } mrg_gemm_desc;
+enum { MRG_GEMM_AUTO = 0, MRG_GEMM_GLDS3 = 1, MRG_GEMM_GLDS4 = 2, MRG_GEMM_PIPE128 = 3, MRG_GEMM_PIPE256 = 4 };
 
 int mrg_gemm(const mrg_gemm_desc* d, hipStream_t stream);
 

@@ -593,6 +593,139 @@ __global__ __launch_bounds__(256, 2) void gemm_pipe_kernel(const GemmArgs g) {
     }
 }
 
+// 256 x 128 output tile = two stacked 128 x 128 sub-tiles that share one B tile (87 instead of 64 flop per byte moved
+// from L2 to LDS); 8 waves (4 x 2), two-stage ring of 48 KiB stages, one workgroup per CU.
+template <int AMODE, int BMODE, bool VEC>
+__global__ __launch_bounds__(512, 2) void gemm_pipe256_kernel(const GemmArgs g) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int STAGE = 3 * TILE_BYTES;
+    const int tiles_m = (g.M + 255) / 256;
+    const int nwg = tiles_m * g.tiles_n;
+    int bid = blockIdx.x;
+    {
+        const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    constexpr int GROUP_M = 4;
+    int tm, tn;
+    {
+        const int per_group = GROUP_M * g.tiles_n;
+        const int grp = bid / per_group, in_grp = bid - grp * per_group;
+        const int first = grp * GROUP_M;
+        const int rows = min(GROUP_M, tiles_m - first);
+        tm = first + in_grp % rows;
+        tn = in_grp / rows;
+    }
+    const int m0 = tm * 256, n0 = tn * BN;
+    const int Meff = g.m_dev ? min(g.M, *g.m_dev) : g.M;
+    const int Keff = g.k_dev ? min(g.K, *g.k_dev) : g.K;
+    if (m0 >= Meff) return;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int half = wave >> 2, wl = wave & 3;          // sub-tile, wave inside the sub-tile
+    const int wm = wl >> 1, wn = wl & 1;
+    const int ntiles = (Keff + BK - 1) / BK;
+    int t0 = 0, t1 = ntiles;
+    if (g.splitk > 1) {
+        const int per = (ntiles + g.splitk - 1) / g.splitk;
+        t0 = blockIdx.y * per;
+        t1 = min(ntiles, t0 + per);
+    }
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    const uint32_t sbase = __builtin_amdgcn_readfirstlane(lds_addr(smem));
+    const bf16_t* pa[4]; const bf16_t* pb[2];
+    long ia[4], ib[2];
+    int ka[4], kb[2];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) glds_setup<AMODE>(g.A, g.lda, m0 + half * 128, Meff, t0 * BK, wl * 4 + j, lane, pa[j], ia[j], ka[j]);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) glds_setup<BMODE>(g.B, g.ldb, n0, g.N, t0 * BK, wave * 2 + j, lane, pb[j], ib[j], kb[j]);
+    const bf16_t* zero = reinterpret_cast<const bf16_t*>(g_zero_page);
+    auto issue = [&](int t, int buf) {
+        const uint32_t la = sbase + buf * STAGE + half * TILE_BYTES + wl * 4096;
+        const uint32_t lb = sbase + buf * STAGE + 2 * TILE_BYTES + wave * 2048;
+        const int krem = Keff - t * BK;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) glds16_asm((krem >= BK || ka[j] < krem) ? pa[j] : zero, la + j * 1024);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) glds16_asm((krem >= BK || kb[j] < krem) ? pb[j] : zero, lb + j * 1024);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) pa[j] += ia[j];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) pb[j] += ib[j];
+    };
+    if (t0 < t1) issue(t0, 0);
+    for (int t = t0; t < t1; ++t) {
+        const int cur = (t - t0) & 1;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        if (t + 1 < t1) issue(t + 1, cur ^ 1);
+        const char* ldsA = smem + cur * STAGE + half * TILE_BYTES;
+        const char* ldsB = smem + cur * STAGE + 2 * TILE_BYTES;
+        const uint32_t la_u = sbase + cur * STAGE + half * TILE_BYTES, lb_u = sbase + cur * STAGE + 2 * TILE_BYTES;
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            bf16x8 fa[2], fb[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) fa[i] = read_frag<AMODE>(ldsA, la_u, wm * 64 + i * 32, kk, lane);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) fb[j] = read_frag<BMODE>(ldsB, lb_u, wn * 64 + j * 32, kk, lane);
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+        }
+    }
+    // ---- epilogue: the two 128 x 128 sub-tiles go through a 64 KiB fp32 staging tile one after the other
+    float* ct = reinterpret_cast<float*>(smem);
+    const int cl = (tid & 31) << 2;
+    const int col = n0 + cl;
+    const int nv = min(4, g.N - col);
+    float* ws = g.splitk > 1 ? g.ws + (long)blockIdx.y * g.M * g.N : nullptr;
+    float bv[4] = {0.f, 0.f, 0.f, 0.f};
+    if (g.bias && !ws && col < g.N) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) if (e < nv) bv[e] = g.bias[col + e];
+    }
+#pragma unroll 1
+    for (int h = 0; h < 2; ++h) {
+        __syncthreads();
+        if (half == h) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const int c2 = wn * 64 + j * 32 + (lane & 31);
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int rl = wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                        ct[rl * BN + c2] = acc[i][j][r];
+                    }
+                }
+        }
+        __syncthreads();
+        if (col < g.N) {
+#pragma unroll 1
+            for (int it = 0; it < 8; ++it) {
+                const int rl = (tid >> 5) + (it << 4);                  // 0..127 (16 row-lanes of 32 threads)
+                const int row = m0 + h * 128 + rl;
+                if (row < Meff) {
+                    const float4 a4 = *reinterpret_cast<const float4*>(ct + rl * BN + cl);
+                    epi_row<VEC>(g, a4, bv, ws, row, col, nv);
+                }
+            }
+        }
+    }
+}
+
 // split-K finish: C (+)= sum_z ws[z]  (+ bias) ; fp32 out, optional bf16 copy
 __global__ void splitk_reduce_kernel(const float* __restrict__ ws, int splitk, long mn, int N, float* __restrict__ C, int ldc,
                                      int accumulate, const float* __restrict__ bias, bf16_t* __restrict__ C2, int ldc2,
@@ -646,6 +779,7 @@ extern "C" int mrg_gemm(const mrg_gemm_desc* d, hipStream_t stream) {
     g.aux_out = (bf16_t*)d->aux_out; g.aux_in = (const bf16_t*)d->aux_in; g.ldaux = d->ldaux;
     g.row_map = d->row_map; g.add_tab = d->add_tab; g.add_row = d->add_row; g.ldt = d->ldt;
     g.splitk = splitk; g.ws = d->ws;
+    MRG_REQUIRE(d->variant >= 0 && d->variant <= MRG_GEMM_PIPE256, MRG_ERR_ARG, "mrg_gemm: bad variant");
     g.tiles_m = cdiv(d->M, BM); g.tiles_n = cdiv(d->N, BN);
     dim3 grid(g.tiles_m * g.tiles_n, splitk), block(256);
     const size_t shmem = 4 * TILE_BYTES;
@@ -664,11 +798,20 @@ extern "C" int mrg_gemm(const mrg_gemm_desc* d, hipStream_t stream) {
     // >= ~1500 tiles, -3..-15 % below and for the wgrad layout)
     // kernel choice (measured, tools/bench_gemm.py): long K loops (>= 24 k-tiles per workgroup) run the pipelined two-stage
     // kernel (+5..40 %), short ones the single-stage kernel at 3-4 workgroups/CU (+10..20 % there).  MRG_GEMM_PIPE=0/1 forces.
-    static const int force_pipe = [] { const char* e = getenv("MRG_GEMM_PIPE"); return e ? (e[0] == '1' ? 1 : 0) : -1; }();
+    // kernel choice: an explicit variant (host autotuner) wins; otherwise measured heuristics (tools/bench_gemm.py):
+    // long K loops run the pipelined two-stage kernels, short K with many tiles the single-stage kernel at 4 WG/CU.
     const int ktiles_per_wg = cdiv(cdiv(d->K, BK), splitk);
-    const bool use_pipe = force_pipe >= 0 ? (force_pipe == 1) : (ktiles_per_wg >= 24);
-    const bool occ4 = fast && d->a_mode == MRG_OP_KCONTIG && (g.tiles_m * g.tiles_n >= 1400) && splitk == 1;
-#define MRG_FAST(AM, BM_, V) do { if (use_pipe) hipLaunchKernelGGL((gemm_pipe_kernel<AM, BM_, V>), grid, block, (size_t)(4 * TILE_BYTES), stream, g); \
+    bool use_pipe = ktiles_per_wg >= 24;
+    bool occ4 = fast && d->a_mode == MRG_OP_KCONTIG && (g.tiles_m * g.tiles_n >= 1400) && splitk == 1;
+    bool use_big = false;
+    if (d->variant == MRG_GEMM_GLDS3) { use_pipe = false; occ4 = false; }
+    else if (d->variant == MRG_GEMM_GLDS4) { use_pipe = false; occ4 = true; }
+    else if (d->variant == MRG_GEMM_PIPE128) { use_pipe = true; }
+    else if (d->variant == MRG_GEMM_PIPE256) { use_big = fast && d->M > 128; use_pipe = true; }
+#define MRG_BIG(AM, BM_, V) do { const void* fn = (const void*)gemm_pipe256_kernel<AM, BM_, V>; \
+        (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 6 * TILE_BYTES); \
+        hipLaunchKernelGGL((gemm_pipe256_kernel<AM, BM_, V>), dim3(cdiv(d->M, 256) * g.tiles_n, splitk), dim3(512), (size_t)(6 * TILE_BYTES), stream, g); } while (0)
+#define MRG_FAST(AM, BM_, V) do { if (use_big) MRG_BIG(AM, BM_, V); else if (use_pipe) hipLaunchKernelGGL((gemm_pipe_kernel<AM, BM_, V>), grid, block, (size_t)(4 * TILE_BYTES), stream, g); \
                                   else if (occ4) hipLaunchKernelGGL((gemm_glds_kernel<AM, BM_, V, 4>), grid, block, (size_t)(2 * TILE_BYTES), stream, g); \
                                   else hipLaunchKernelGGL((gemm_glds_kernel<AM, BM_, V, 3>), grid, block, (size_t)(2 * TILE_BYTES), stream, g); } while (0)
 #define MRG_LAUNCH2(AM, BM_, AL) do { \
@@ -682,6 +825,7 @@ extern "C" int mrg_gemm(const mrg_gemm_desc* d, hipStream_t stream) {
 #undef MRG_LAUNCH
 #undef MRG_LAUNCH2
 #undef MRG_FAST
+#undef MRG_BIG
     int rc = mrg_check_launch("mrg_gemm");
     if (rc) return rc;
     if (splitk > 1) {

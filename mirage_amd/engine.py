@@ -91,7 +91,7 @@ def lin_bwd(dy16: torch.Tensor, x16: torch.Tensor, lin, *, need_dx: bool = True,
         if Wp.requires_grad:
             gw = grad_buffer(Wp)
             K.gemm(dy16, x16, N, Kin, M, a_mode=KS, b_mode=KS, lda=N, ldb=Kin, out=gw.view(N, Kin), ldc=Kin,
-                   a_map=a_map, k_dev=k_dev, splitk=K.pick_splitk(N, Kin, M))
+                   a_map=a_map, k_dev=k_dev, splitk=K.pick_splitk(N, Kin, M), tune_split=True)
         if bias_grad and lin.bias is not None and lin.bias.requires_grad:
             K.colsum(dy16, grad_buffer(lin.bias), M=M, row_map=a_map, m_dev=k_dev)
     _Side.run(_param_grads, dy16, x16, a_map, k_dev)

@@ -41,11 +41,53 @@ def _workspace(nbytes: int, device) -> torch.Tensor:
     return ws
 
 
+_tune_cache = {}
+TUNE = {"enabled": True, "log": []}
+
+
+def _gemm_launch(d, splitk, variant, dev):
+    d.splitk = splitk
+    d.variant = variant
+    if splitk > 1:
+        d.ws = _workspace(splitk * d.M * d.N * 4, dev).data_ptr()
+    check(lib.mrg_gemm(C.byref(d), _s()), "mrg_gemm")
+
+
+def _autotune(d, key, splitk, allow_split, dev):
+    """Time the kernel variants (and, for wgrad-like problems, neighbouring split-K factors) once per problem shape and
+    remember the fastest.  Runs only outside hipGraph capture; every candidate recomputes the same (idempotent) result."""
+    cands = []
+    splits = [splitk]
+    if allow_split:
+        kt = (d.K + 63) // 64
+        splits = sorted({s for s in (1, 2, 4, 8, 16, 32) if s == 1 or kt // s >= 4})
+    for v in (L.MRG_GEMM_GLDS3, L.MRG_GEMM_GLDS4, L.MRG_GEMM_PIPE128, L.MRG_GEMM_PIPE256):
+        if v == L.MRG_GEMM_PIPE256 and d.M <= 128:
+            continue
+        for s_ in splits:
+            cands.append((v, s_))
+    best, best_t = (L.MRG_GEMM_AUTO, splitk), float("inf")
+    for v, s_ in cands:
+        _gemm_launch(d, s_, v, dev)
+        st, en = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        st.record()
+        for _ in range(3):
+            _gemm_launch(d, s_, v, dev)
+        en.record()
+        en.synchronize()
+        t = st.elapsed_time(en)
+        if t < best_t:
+            best, best_t = (v, s_), t
+    _tune_cache[key] = best
+    TUNE["log"].append((key, best, best_t / 3 * 1e3))
+    return best
+
+
 def gemm(A: torch.Tensor, B: torch.Tensor, M: int, N: int, K: int, *, a_mode=L.MRG_OP_KCONTIG, b_mode=L.MRG_OP_KCONTIG,
          lda: Optional[int] = None, ldb: Optional[int] = None, out: Optional[torch.Tensor] = None, out_dtype=BF16,
          ldc: Optional[int] = None, out2: Optional[torch.Tensor] = None, bias=None, resid=None, accumulate=False,
          act=L.MRG_ACT_NONE, aux_out=None, aux_in=None, row_map=None, add_tab=None, add_row=None, a_map=None, b_map=None,
-         m_dev=None, k_dev=None, splitk: int = 1) -> torch.Tensor:
+         m_dev=None, k_dev=None, splitk: int = 1, tune_split: bool = False) -> torch.Tensor:
     _need_cuda(A, "GEMM operand")
     if out is None:
         out = torch.empty((M, N), dtype=out_dtype, device=A.device)
@@ -73,10 +115,16 @@ def gemm(A: torch.Tensor, B: torch.Tensor, M: int, N: int, K: int, *, a_mode=L.M
     d.row_map = _p(row_map)
     if add_tab is not None:
         d.add_tab, d.add_row, d.ldt = add_tab.data_ptr(), add_row.data_ptr(), add_tab.stride(0)
-    d.splitk = splitk
-    if splitk > 1:
-        d.ws = _workspace(splitk * M * N * 4, A.device).data_ptr()
-    check(lib.mrg_gemm(C.byref(d), _s()), "mrg_gemm")
+    variant = L.MRG_GEMM_AUTO
+    tunable = TUNE["enabled"] and a_map is None and b_map is None and m_dev is None and k_dev is None and not accumulate and M * N >= (1 << 16)
+    if tunable:
+        key = (a_mode, b_mode, M, N, K, act, resid is not None, out.dtype == F32, tune_split)
+        hit = _tune_cache.get(key)
+        if hit is None and not torch.cuda.is_current_stream_capturing():
+            hit = _autotune(d, key, splitk, tune_split, A.device)
+        if hit is not None:
+            variant, splitk = hit
+    _gemm_launch(d, splitk, variant, A.device)
     return out
 
 
