@@ -28,7 +28,7 @@ class GemmDesc(C.Structure):
                 ("C", vp), ("ldc", ci), ("c_dtype", ci), ("C2", vp), ("ldc2", ci), ("bias", vp),
                 ("resid", vp), ("ldr", ci), ("accumulate", ci), ("act", ci),
                 ("aux_out", vp), ("aux_in", vp), ("ldaux", ci), ("row_map", vp),
-                ("add_tab", vp), ("add_row", vp), ("ldt", ci), ("splitk", ci), ("ws", vp), ("variant", ci)]
+                ("add_tab", vp), ("add_row", vp), ("ldt", ci), ("splitk", ci), ("ws", vp), ("variant", ci), ("ev_start", vp), ("ev_stop", vp)]
 
 
 class AttnDesc(C.Structure):

@@ -794,6 +794,7 @@ extern "C" int mrg_gemm(const mrg_gemm_desc* d, hipStream_t stream) {
     const bool vec = (d->N % 4 == 0) && al4(d->C, d->ldc, g.c_f32 ? 4 : 2) && al4(d->C2, d->ldc2, 2) && al4(d->resid, d->ldr, 4) &&
                      al4(d->add_tab, d->ldt, 4) && al4(d->aux_out, d->ldaux, 2) && al4(d->aux_in, d->ldaux, 2) && al4(d->ws, d->N, 4);
     const bool fast = al && !d->a_map && !d->b_map;
+    if (d->ev_start) (void)hipEventRecord((hipEvent_t)d->ev_start, stream);
     // 4 workgroups per CU (<= 128 VGPRs) pay off only when there are enough tiles to fill them (measured: +13..18 % at
     // >= ~1500 tiles, -3..-15 % below and for the wgrad layout)
     // kernel choice (measured, tools/bench_gemm.py): long K loops (>= 24 k-tiles per workgroup) run the pipelined two-stage
@@ -826,6 +827,7 @@ extern "C" int mrg_gemm(const mrg_gemm_desc* d, hipStream_t stream) {
 #undef MRG_LAUNCH2
 #undef MRG_FAST
 #undef MRG_BIG
+    if (d->ev_stop) (void)hipEventRecord((hipEvent_t)d->ev_stop, stream);
     int rc = mrg_check_launch("mrg_gemm");
     if (rc) return rc;
     if (splitk > 1) {

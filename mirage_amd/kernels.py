@@ -4,6 +4,8 @@ Everything here takes CUDA(=HIP) torch tensors, passes raw pointers + the curren
 libmirage_hip.so, and returns torch tensors.  No computation happens in torch.
 """
 import ctypes as C
+import json
+import os
 from typing import Optional, Sequence
 
 import torch
@@ -43,6 +45,26 @@ def _workspace(nbytes: int, device) -> torch.Tensor:
 
 _tune_cache = {}
 TUNE = {"enabled": True, "log": []}
+_TUNE_FILE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "gemm_tune_gfx950.json")
+
+
+def load_tune_cache(path: str = _TUNE_FILE) -> int:
+    """Pre-tuned (variant, split-K) choices for the BASELINE shapes, measured on MI355X (like a BLAS library's tuned table);
+    shapes that are not in the table are tuned on first use."""
+    if not os.path.exists(path):
+        return 0
+    with open(path) as f:
+        for k, v in json.load(f).items():
+            _tune_cache[tuple(json.loads(k))] = tuple(v)
+    return len(_tune_cache)
+
+
+def save_tune_cache(path: str = _TUNE_FILE) -> None:
+    with open(path, "w") as f:
+        json.dump({json.dumps([int(x) if not isinstance(x, bool) else x for x in k]): list(v) for k, v in sorted(_tune_cache.items())}, f, indent=0)
+
+
+TIMING = {"on": False, "records": []}     # bench.py: (kernel variant, mode, flops, start event, stop event) per GEMM launch
 
 
 def _gemm_launch(d, splitk, variant, dev):
@@ -124,8 +146,16 @@ def gemm(A: torch.Tensor, B: torch.Tensor, M: int, N: int, K: int, *, a_mode=L.M
             hit = _autotune(d, key, splitk, tune_split, A.device)
         if hit is not None:
             variant, splitk = hit
+    if TIMING["on"]:
+        st, en = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        st.record(); en.record()                                   # creates the underlying hipEvent_t handles
+        d.ev_start, d.ev_stop = st.cuda_event, en.cuda_event
+        TIMING["records"].append((variant, (a_mode, b_mode), 2.0 * M * N * K, st, en))
     _gemm_launch(d, splitk, variant, A.device)
     return out
+
+
+load_tune_cache()
 
 
 def pick_splitk(M: int, N: int, K: int, target_wgs: int = 320) -> int:
