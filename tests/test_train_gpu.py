@@ -107,3 +107,50 @@ def test_driver_artifacts_and_resume(tmp_path):
     R.main(R.get_args(argv2))
     lines = [json.loads(l) for l in open(os.path.join(d, "log.txt"))]
     assert [l["epoch"] for l in lines] == [0, 1, 2]
+
+
+def test_wrappers_and_checkpoint_compat(tmp_path):
+    """Reference-format checkpoint -> MIRAGEWrapper / MIRAGEClsGlobal (mirage_wrapper.py) + pos-emb resampling (mutils/pos_embed.py)."""
+    import types
+    from mirage_amd import mirage_wrapper as W, checkpoint as CK
+    from oracle import mirage_oracle as O
+    import test_model_gpu as T
+    fx, meta = load_golden("tiny_cls")
+    cfg, B = meta["cfg"], meta["B"]
+    cfg_full = dict(cfg); cfg_full["out_domains"] = ["bscan"]
+    cfg_full = O.make_config(model="tiny", in_domains=("bscan",), input_size=64, patch_size=8, decoder_dim=64, decoder_depth=2,
+                             decoder_heads=2, dim=128, depth=2, heads=2)
+    sd = O.procedural_state_dict(cfg_full)
+    args = types.SimpleNamespace(model="tiny", dim_tokens=128, depth=2, num_heads=2, out_domains=["bscan"], decoder_dim=64, decoder_depth=2,
+                                 decoder_num_heads=2, decoder_use_task_queries=True, decoder_use_xattn=True, num_global_tokens=1,
+                                 drop_path=0.0)
+    path = str(tmp_path / "checkpoint-0.pth")
+    torch.save({"model": sd, "args": args, "epoch": 0, "optimizer": {}, "scaler": {}}, path)
+    # classification wrapper: encoder + LN + mean pool + head
+    cls = W.miragecls_factory["global"](num_classes=5, input_size=64, patch_size=8, modalities="bscan", weights=path, device=DEV)
+    cls.eval()
+    D = 128
+    with torch.no_grad():
+        cls.norm.weight.copy_(torch.from_numpy(1.0 + 0.2 * O.procedural_uniform("cls.norm.weight", D)))
+        cls.norm.bias.copy_(torch.from_numpy(0.04 * O.procedural_uniform("cls.norm.bias", D)))
+    x = O.synthetic_batch(cfg, B, seed=meta["data_seed"])["bscan"].to(DEV)
+    with torch.no_grad():
+        out, _ = cls.model({"bscan": x}, mask_inputs=False)
+        pooled = cls.pool(cls.norm(out))
+        logits = cls(x)
+    ref = torch.from_numpy(fx["pooled"])
+    assert float((pooled.cpu() - ref).norm() / ref.norm()) < 1e-2
+    want = pooled @ cls.head.weight.t() + cls.head.bias
+    assert float((logits - want).norm() / want.norm()) < 2e-2
+    # reconstruction wrapper (B = 1 path with user masks)
+    wr = W.MIRAGEWrapper(input_size=64, patch_size=8, modalities="bscan", weights=path, device=DEV)
+    wr.eval()
+    with torch.no_grad():
+        preds = wr({"bscan": x[:1].cpu()})
+    assert preds["bscan"].shape == (1, 1, 64, 64) and torch.isfinite(preds["bscan"].float()).all()
+    # pos-emb resampling against the reference's output
+    fh, _ = load_golden("harness_tiny")
+    model, _, _ = T._build(load_golden("harness_tiny")[1]["cfg"])
+    ck = {"input_adapters.bscan.pos_emb": torch.from_numpy(fh["posemb_resample.in"])}
+    CK.interpolate_pos_embed(model, ck)
+    np.testing.assert_allclose(ck["input_adapters.bscan.pos_emb"].numpy(), fh["posemb_resample.out"], rtol=1e-5, atol=1e-5)
