@@ -257,8 +257,10 @@ extern "C" int mrg_ln_fwd(const float* x, const float* gamma, const float* beta,
 }
 
 extern "C" int mrg_ln_bwd_nblocks(int M) {
-    int nb = cdiv(M, 8);   // 2 rows per wave (4 waves per workgroup)
-    if (nb > 1024) nb = 1024;
+    // one resident round: at most 3 workgroups (of 4 waves, <= 168 VGPRs) per CU x 256 CUs; callers size the partial
+    // buffer with this upper bound, the launch itself may use fewer workgroups for wide rows (see mrg_ln_bwd)
+    int nb = cdiv(M, 8);
+    if (nb > 768) nb = 768;
     if (nb < 1) nb = 1;
     return nb;
 }
@@ -270,9 +272,10 @@ extern "C" int mrg_ln_bwd(const void* dy_bf16, const float* dy_f32, const float*
                 "mrg_ln_bwd: null pointer");
     MRG_REQUIRE(M > 0 && D > 0 && D % 4 == 0 && D <= 1024, MRG_ERR_SHAPE, "mrg_ln_bwd: need D %% 4 == 0 and D <= 1024 (D=%d)", D);
     MRG_REQUIRE(!dres_colsum || dres, MRG_ERR_ARG, "mrg_ln_bwd: dres_colsum without dres");
-    const int nb = mrg_ln_bwd_nblocks(M);
+    int nb = mrg_ln_bwd_nblocks(M);
     const void* dyp = dy_bf16 ? dy_bf16 : (const void*)dy_f32;
     const int NVr = (D + 255) / 256;
+    if (NVr >= 4 && nb > 512) nb = 512;   // 4-chunk rows need > 168 VGPRs: 2 workgroups per CU
 #define MRG_LNB(NV_, D16, RES) hipLaunchKernelGGL((ln_bwd_kernel<NV_, D16, RES>), dim3(nb), dim3(256), 0, stream, dyp, x, mean, rstd, \
                                                    gamma, dres, dx_f32, (bf16_t*)dx_bf16, partials, M, D)
 #define MRG_LNB2(NV_) do { if (dy_bf16) { if (dres) MRG_LNB(NV_, true, true); else MRG_LNB(NV_, true, false); } \

@@ -367,8 +367,9 @@ def decoder_fwd(ad, enc32: torch.Tensor, enc16: torch.Tensor, ids_keep, ids_rest
     return img, saved
 
 
-def decoder_bwd(ad, saved, d_img: torch.Tensor, d_enc32: torch.Tensor, first: bool):
-    """Accumulates this adapter's contribution into d_enc32 (overwrites it if `first`)."""
+def decoder_bwd(ad, saved, d_img: torch.Tensor):
+    """Backward of one adapter down to d(proj_context output); returns it in bf16.  The caller folds the proj_context dgrads of
+    all adapters into one shared d_enc buffer (decoder_bwd_finish) after the per-adapter streams have joined."""
     (desc, task_embs, queries, context, qn, mq, rq, cn, mc, rc, qp, kv, o, lse, x1, on, mo, ro, h_pre, h_act, x2, blk_saved, x16,
      enc16, (B, N, Tq, Dd, H, hd, g)) = saved
     dev = d_img.device
@@ -411,7 +412,48 @@ def decoder_bwd(ad, saved, d_img: torch.Tensor, d_enc32: torch.Tensor, first: bo
         if Wp.bias.requires_grad:
             K.colsum(d_ctx.view(B * N, Dd), grad_buffer(Wp.bias))
     _Side.run(_pc_grads, d_ctx16, enc16, d_ctx)
-    K.gemm(d_ctx16, shadow(Wp.weight), B * N, D, Dd, b_mode=KS, lda=Dd, ldb=D, out=d_enc32, ldc=D, accumulate=not first)
+    return d_ctx16
+
+
+def decoder_bwd_finish(ad, d_ctx16: torch.Tensor, d_enc32: torch.Tensor, first: bool):
+    B, N, Dd = d_ctx16.shape
+    D = d_enc32.shape[-1]
+    K.gemm(d_ctx16, shadow(ad.proj_context.weight), B * N, D, Dd, b_mode=KS, lda=Dd, ldb=D, out=d_enc32, ldc=D, accumulate=not first)
+
+
+class _Lanes:
+    """Independent output adapters run on their own HIP streams (fork from / join into the calling stream): each adapter is a
+    chain of ~25 short launches on [B*256, 256]-sized problems that cannot fill 256 CUs on its own."""
+    streams = []
+
+    @classmethod
+    def get(cls, i, device):
+        while len(cls.streams) <= i:
+            cls.streams.append(torch.cuda.Stream(device=device))
+        if cls.streams[i].device != device:
+            cls.streams[i] = torch.cuda.Stream(device=device)
+        return cls.streams[i]
+
+    @classmethod
+    def run_all(cls, jobs, device):
+        """jobs: list of zero-arg callables; job 0 runs on the current stream, the others on lane streams."""
+        main = torch.cuda.current_stream(device)
+        if len(jobs) == 1:
+            return [jobs[0]()]
+        ev = torch.cuda.Event()
+        ev.record(main)
+        out = [None] * len(jobs)
+        lanes = []
+        for i, job in enumerate(jobs[1:], start=1):
+            st = cls.get(i - 1, device)
+            st.wait_event(ev)
+            with torch.cuda.stream(st):
+                out[i] = job()
+            lanes.append(st)
+        out[0] = jobs[0]()
+        for st in lanes:
+            main.wait_stream(st)
+        return out
 
 
 class DecodersFn(torch.autograd.Function):
@@ -423,11 +465,11 @@ class DecodersFn(torch.autograd.Function):
         enc32 = enc32.contiguous().float()
         if enc16 is None:
             enc16 = to_bf16(enc32)
-        imgs, saved = [], []
-        for ad in adapters:
-            img, sv = decoder_fwd(ad, enc32, enc16, ids_keep, ids_restore, list(dom_names), list(dom_start), ng, save)
-            imgs.append(img)
-            saved.append(sv)
+        doms_l, start_l = list(dom_names), list(dom_start)
+        jobs = [(lambda ad=ad: decoder_fwd(ad, enc32, enc16, ids_keep, ids_restore, doms_l, start_l, ng, save)) for ad in adapters]
+        res = _Lanes.run_all(jobs, enc32.device)
+        imgs = [r[0] for r in res]
+        saved = [r[1] for r in res]
         ctx.adapters, ctx.saved, ctx.shape = adapters, saved, enc32.shape
         return tuple(imgs)
 
@@ -435,12 +477,11 @@ class DecodersFn(torch.autograd.Function):
     def backward(ctx, *d_imgs):
         dev = next(d for d in d_imgs if d is not None).device
         d_enc = torch.empty(ctx.shape, dtype=F32, device=dev)
-        first = True
-        for ad, sv, d_img in zip(ctx.adapters, ctx.saved, d_imgs):
-            if d_img is None:
-                continue
-            decoder_bwd(ad, sv, d_img, d_enc, first)
-            first = False
+        todo = [(ad, sv, d_img) for ad, sv, d_img in zip(ctx.adapters, ctx.saved, d_imgs) if d_img is not None]
+        jobs = [(lambda ad=ad, sv=sv, d_img=d_img: decoder_bwd(ad, sv, d_img)) for ad, sv, d_img in todo]
+        d_ctxs = _Lanes.run_all(jobs, dev)
+        for i, ((ad, _, _), d_ctx16) in enumerate(zip(todo, d_ctxs)):
+            decoder_bwd_finish(ad, d_ctx16, d_enc, i == 0)
         ctx.saved = None
         if not ctx.defer_join:
             _Side.join()
