@@ -75,11 +75,11 @@ typedef struct mrg_gemm_desc {
     const int* row_map;
     const float* add_tab; const int* add_row; int ldt;
     int splitk; float* ws;
-    int variant;   /* 0 = heuristic choice; 1..4 force a kernel variant (see MRG_GEMM_* below); used by the host-side autotuner */
+    int variant;   /* 0 = heuristic choice; 1..5 force a kernel variant (see MRG_GEMM_* below); used by the host-side autotuner */
     void* ev_start; void* ev_stop;   /* optional hipEvent_t pair recorded on `stream` around the main GEMM kernel only (not the
                                         split-K finishing kernel): lets a benchmark time exactly what rocprofv3 reports per kernel */
 } mrg_gemm_desc;
-enum { MRG_GEMM_AUTO = 0, MRG_GEMM_GLDS3 = 1, MRG_GEMM_GLDS4 = 2, MRG_GEMM_PIPE128 = 3, MRG_GEMM_PIPE256 = 4 };
+enum { MRG_GEMM_AUTO = 0, MRG_GEMM_GLDS3 = 1, MRG_GEMM_GLDS4 = 2, MRG_GEMM_PIPE128 = 3, MRG_GEMM_PIPE256 = 4, MRG_GEMM_PIPE256X3 = 5 };
 
 int mrg_gemm(const mrg_gemm_desc* d, hipStream_t stream);
 

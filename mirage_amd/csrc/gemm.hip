@@ -40,6 +40,7 @@ struct GemmArgs {
     const float* add_tab; const int* add_row; int ldt;
     int splitk; float* ws;
     int tiles_m, tiles_n;
+    int ablate;   // MRG_GEMM_ABLATE (256x128 kernel only, for roofline analysis): 1 = no DMA, 2 = DMA only, 3 = DMA + LDS reads, no MFMA
 };
 
 // ---- global -> register staging -------------------------------------------------------------------
@@ -595,7 +596,7 @@ __global__ __launch_bounds__(256, 2) void gemm_pipe_kernel(const GemmArgs g) {
 
 // 256 x 128 output tile = two stacked 128 x 128 sub-tiles that share one B tile (87 instead of 64 flop per byte moved
 // from L2 to LDS); 8 waves (4 x 2), two-stage ring of 48 KiB stages, one workgroup per CU.
-template <int AMODE, int BMODE, bool VEC>
+template <int AMODE, int BMODE, bool VEC, int STAGES>
 __global__ __launch_bounds__(512, 2) void gemm_pipe256_kernel(const GemmArgs g) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int STAGE = 3 * TILE_BYTES;
@@ -660,13 +661,18 @@ __global__ __launch_bounds__(512, 2) void gemm_pipe256_kernel(const GemmArgs g) 
 #pragma unroll
         for (int j = 0; j < 2; ++j) pb[j] += ib[j];
     };
+    // ring of STAGES stages: STAGES-1 tiles are in flight while one is multiplied (the DMA latency under load is several
+    // k-tile compute times, so the depth of the ring, not the barrier count, sets the rate)
     if (t0 < t1) issue(t0, 0);
+    if (STAGES == 3 && t0 + 1 < t1) issue(t0 + 1, 1);
+    int cur = 0;
     for (int t = t0; t < t1; ++t) {
-        const int cur = (t - t0) & 1;
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (STAGES == 3 && t + 1 < t1) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");   // tile t landed, tile t+1 may still fly
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
-        if (t + 1 < t1) issue(t + 1, cur ^ 1);
+        if (t + STAGES - 1 < t1 && g.ablate != 1) issue(t + STAGES - 1, (cur + STAGES - 1) % STAGES);
+        if (g.ablate == 2) { cur = (cur + 1 == STAGES) ? 0 : cur + 1; continue; }
         const char* ldsA = smem + cur * STAGE + half * TILE_BYTES;
         const char* ldsB = smem + cur * STAGE + 2 * TILE_BYTES;
         const uint32_t la_u = sbase + cur * STAGE + half * TILE_BYTES, lb_u = sbase + cur * STAGE + 2 * TILE_BYTES;
@@ -677,12 +683,17 @@ __global__ __launch_bounds__(512, 2) void gemm_pipe256_kernel(const GemmArgs g) 
             for (int i = 0; i < 2; ++i) fa[i] = read_frag<AMODE>(ldsA, la_u, wm * 64 + i * 32, kk, lane);
 #pragma unroll
             for (int j = 0; j < 2; ++j) fb[j] = read_frag<BMODE>(ldsB, lb_u, wn * 64 + j * 32, kk, lane);
+            if (g.ablate == 3) {
+                asm volatile("" :: "v"(fa[0]), "v"(fa[1]), "v"(fb[0]), "v"(fb[1]));
+                continue;
+            }
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
                 for (int j = 0; j < 2; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
         }
+        cur = (cur + 1 == STAGES) ? 0 : cur + 1;
     }
     // ---- epilogue: the two 128 x 128 sub-tiles go through a 64 KiB fp32 staging tile one after the other
     float* ct = reinterpret_cast<float*>(smem);
@@ -779,8 +790,9 @@ extern "C" int mrg_gemm(const mrg_gemm_desc* d, hipStream_t stream) {
     g.aux_out = (bf16_t*)d->aux_out; g.aux_in = (const bf16_t*)d->aux_in; g.ldaux = d->ldaux;
     g.row_map = d->row_map; g.add_tab = d->add_tab; g.add_row = d->add_row; g.ldt = d->ldt;
     g.splitk = splitk; g.ws = d->ws;
-    MRG_REQUIRE(d->variant >= 0 && d->variant <= MRG_GEMM_PIPE256, MRG_ERR_ARG, "mrg_gemm: bad variant");
+    MRG_REQUIRE(d->variant >= 0 && d->variant <= MRG_GEMM_PIPE256X3, MRG_ERR_ARG, "mrg_gemm: bad variant");
     g.tiles_m = cdiv(d->M, BM); g.tiles_n = cdiv(d->N, BN);
+    { static const int abl = [] { const char* e = getenv("MRG_GEMM_ABLATE"); return e ? atoi(e) : 0; }(); g.ablate = abl; }
     dim3 grid(g.tiles_m * g.tiles_n, splitk), block(256);
     const size_t shmem = 4 * TILE_BYTES;
     // vector (16 B) loads need 16-B aligned bases, ld % 8 == 0 and whole chunks inside the matrix
@@ -808,10 +820,14 @@ extern "C" int mrg_gemm(const mrg_gemm_desc* d, hipStream_t stream) {
     if (d->variant == MRG_GEMM_GLDS3) { use_pipe = false; occ4 = false; }
     else if (d->variant == MRG_GEMM_GLDS4) { use_pipe = false; occ4 = true; }
     else if (d->variant == MRG_GEMM_PIPE128) { use_pipe = true; }
-    else if (d->variant == MRG_GEMM_PIPE256) { use_big = fast && d->M > 128; use_pipe = true; }
-#define MRG_BIG(AM, BM_, V) do { const void* fn = (const void*)gemm_pipe256_kernel<AM, BM_, V>; \
+    else if (d->variant == MRG_GEMM_PIPE256 || d->variant == MRG_GEMM_PIPE256X3) { use_big = fast && d->M > 128; use_pipe = true; }
+    const bool big3 = d->variant == MRG_GEMM_PIPE256X3;
+#define MRG_BIG(AM, BM_, V) do { if (big3) { const void* fn = (const void*)gemm_pipe256_kernel<AM, BM_, V, 3>; \
+        (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 9 * TILE_BYTES); \
+        hipLaunchKernelGGL((gemm_pipe256_kernel<AM, BM_, V, 3>), dim3(cdiv(d->M, 256) * g.tiles_n, splitk), dim3(512), (size_t)(9 * TILE_BYTES), stream, g); } \
+      else { const void* fn = (const void*)gemm_pipe256_kernel<AM, BM_, V, 2>; \
         (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 6 * TILE_BYTES); \
-        hipLaunchKernelGGL((gemm_pipe256_kernel<AM, BM_, V>), dim3(cdiv(d->M, 256) * g.tiles_n, splitk), dim3(512), (size_t)(6 * TILE_BYTES), stream, g); } while (0)
+        hipLaunchKernelGGL((gemm_pipe256_kernel<AM, BM_, V, 2>), dim3(cdiv(d->M, 256) * g.tiles_n, splitk), dim3(512), (size_t)(6 * TILE_BYTES), stream, g); } } while (0)
 #define MRG_FAST(AM, BM_, V) do { if (use_big) MRG_BIG(AM, BM_, V); else if (use_pipe) hipLaunchKernelGGL((gemm_pipe_kernel<AM, BM_, V>), grid, block, (size_t)(4 * TILE_BYTES), stream, g); \
                                   else if (occ4) hipLaunchKernelGGL((gemm_glds_kernel<AM, BM_, V, 4>), grid, block, (size_t)(2 * TILE_BYTES), stream, g); \
                                   else hipLaunchKernelGGL((gemm_glds_kernel<AM, BM_, V, 3>), grid, block, (size_t)(2 * TILE_BYTES), stream, g); } while (0)

@@ -6,6 +6,14 @@ import torch
 from mirage_amd import kernels as K, _lib as L
 
 dev = "cuda:0"
+import os as _os
+if _os.environ.get("MRG_FORCE_VARIANT"):
+    K.TUNE["enabled"] = False
+    _v = int(_os.environ["MRG_FORCE_VARIANT"])
+    _orig = K._gemm_launch
+    K._gemm_launch = lambda d, splitk, variant, dev_: _orig(d, splitk, _v, dev_)
+elif _os.environ.get("MRG_NO_TUNE"):
+    K.TUNE["enabled"] = False
 def bench(fn, iters=20):
     for _ in range(3): fn()
     torch.cuda.synchronize()
