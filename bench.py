@@ -272,7 +272,7 @@ def main():
         if os.environ.get("MRG_TUNE_SAVE") == "1":
             K.save_tune_cache()
         if os.environ.get("MRG_TUNE_LOG") == "1":
-            names = {1: "glds3", 2: "glds4", 3: "pipe128", 4: "pipe256"}
+            names = {1: "glds3", 2: "glds4", 3: "pipe128", 4: "pipe256", 5: "pipe256x3", 6: "pipe256sq"}
             for key, (v, sk), us in K.TUNE["log"]:
                 am, bm, M_, N_, K_ = key[:5]
                 print(f"tune mode=({am},{bm}) {M_}x{N_}x{K_} act={key[5]} -> {names.get(v, v)} splitk={sk} {us:.1f} us {2.0 * M_ * N_ * K_ / us / 1e6:.0f} TF/s",

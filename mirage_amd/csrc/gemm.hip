@@ -737,6 +737,140 @@ __global__ __launch_bounds__(512, 2) void gemm_pipe256_kernel(const GemmArgs g) 
     }
 }
 
+// 256 x 256 output tile (128 flop per operand byte): 8 waves as 2 (M) x 4 (N), each 128 x 64 (8 accumulator tiles), operands as
+// 2 + 2 standard [128][64] sub-tiles per stage, two stages = 128 KiB.  Only pays when there are enough 256 x 256 tiles to fill
+// 256 CUs (large M: the encoder-only configuration, Large-model MLP shapes).
+template <int AMODE, int BMODE, bool VEC>
+__global__ __launch_bounds__(512, 2) void gemm_pipe256sq_kernel(const GemmArgs g) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int STAGE = 4 * TILE_BYTES;
+    const int tiles_m = (g.M + 255) / 256, tiles_n = (g.N + 255) / 256;
+    const int nwg = tiles_m * tiles_n;
+    int bid = blockIdx.x;
+    {
+        const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    constexpr int GROUP_M = 4;
+    int tm, tn;
+    {
+        const int per_group = GROUP_M * tiles_n;
+        const int grp = bid / per_group, in_grp = bid - grp * per_group;
+        const int first = grp * GROUP_M;
+        const int rows = min(GROUP_M, tiles_m - first);
+        tm = first + in_grp % rows;
+        tn = in_grp / rows;
+    }
+    const int m0 = tm * 256, n0 = tn * 256;
+    const int Meff = g.m_dev ? min(g.M, *g.m_dev) : g.M;
+    const int Keff = g.k_dev ? min(g.K, *g.k_dev) : g.K;
+    if (m0 >= Meff) return;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 2, wn = wave & 3;             // rows wm*128.., cols wn*64..
+    const int hsub = wave >> 2, wl = wave & 3;           // DMA assignment: sub-tile index, 4-block group inside it
+    const int ntiles = (Keff + BK - 1) / BK;
+    int t0 = 0, t1 = ntiles;
+    if (g.splitk > 1) {
+        const int per = (ntiles + g.splitk - 1) / g.splitk;
+        t0 = blockIdx.y * per;
+        t1 = min(ntiles, t0 + per);
+    }
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    const uint32_t sbase = __builtin_amdgcn_readfirstlane(lds_addr(smem));
+    const bf16_t* pa[4]; const bf16_t* pb[4];
+    long ia[4], ib[4];
+    int ka[4], kb[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        glds_setup<AMODE>(g.A, g.lda, m0 + hsub * 128, Meff, t0 * BK, wl * 4 + j, lane, pa[j], ia[j], ka[j]);
+        glds_setup<BMODE>(g.B, g.ldb, n0 + hsub * 128, g.N, t0 * BK, wl * 4 + j, lane, pb[j], ib[j], kb[j]);
+    }
+    const bf16_t* zero = reinterpret_cast<const bf16_t*>(g_zero_page);
+    auto issue = [&](int t, int buf) {
+        const uint32_t la = sbase + buf * STAGE + hsub * TILE_BYTES + wl * 4096;
+        const uint32_t lb = la + 2 * TILE_BYTES;
+        const int krem = Keff - t * BK;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            glds16_asm((krem >= BK || ka[j] < krem) ? pa[j] : zero, la + j * 1024);
+            glds16_asm((krem >= BK || kb[j] < krem) ? pb[j] : zero, lb + j * 1024);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { pa[j] += ia[j]; pb[j] += ib[j]; }
+    };
+    if (t0 < t1) issue(t0, 0);
+    for (int t = t0; t < t1; ++t) {
+        const int cur = (t - t0) & 1;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        if (t + 1 < t1) issue(t + 1, cur ^ 1);
+        const char* ldsA = smem + cur * STAGE + wm * TILE_BYTES;
+        const char* ldsB = smem + cur * STAGE + (2 + (wn >> 1)) * TILE_BYTES;
+        const uint32_t la_u = sbase + cur * STAGE + wm * TILE_BYTES, lb_u = sbase + cur * STAGE + (2 + (wn >> 1)) * TILE_BYTES;
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            bf16x8 fa[4], fb[2];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) fa[i] = read_frag<AMODE>(ldsA, la_u, i * 32, kk, lane);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) fb[j] = read_frag<BMODE>(ldsB, lb_u, (wn & 1) * 64 + j * 32, kk, lane);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+        }
+    }
+    // ---- epilogue: four 64-row x 256-col slabs through a 64 KiB fp32 staging tile
+    float* ct = reinterpret_cast<float*>(smem);
+    const int cl = (tid & 63) << 2;
+    const int col = n0 + cl;
+    const int nv = min(4, g.N - col);
+    float* ws = g.splitk > 1 ? g.ws + (long)blockIdx.y * g.M * g.N : nullptr;
+    float bv[4] = {0.f, 0.f, 0.f, 0.f};
+    if (g.bias && !ws && col < g.N) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) if (e < nv) bv[e] = g.bias[col + e];
+    }
+#pragma unroll
+    for (int sl = 0; sl < 4; ++sl) {
+        __syncthreads();
+        if (wm == (sl >> 1)) {
+#pragma unroll
+            for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const int c2 = wn * 64 + j * 32 + (lane & 31);
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int rl = ii * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                        ct[rl * 256 + c2] = acc[2 * (sl & 1) + ii][j][r];
+                    }
+                }
+        }
+        __syncthreads();
+        if (col < g.N) {
+#pragma unroll 1
+            for (int it = 0; it < 8; ++it) {
+                const int rl = (tid >> 6) + (it << 3);                  // 0..63
+                const int row = m0 + sl * 64 + rl;
+                if (row < Meff) {
+                    const float4 a4 = *reinterpret_cast<const float4*>(ct + rl * 256 + cl);
+                    epi_row<VEC>(g, a4, bv, ws, row, col, nv);
+                }
+            }
+        }
+    }
+}
+
 // split-K finish: C (+)= sum_z ws[z]  (+ bias) ; fp32 out, optional bf16 copy
 __global__ void splitk_reduce_kernel(const float* __restrict__ ws, int splitk, long mn, int N, float* __restrict__ C, int ldc,
                                      int accumulate, const float* __restrict__ bias, bf16_t* __restrict__ C2, int ldc2,
@@ -790,7 +924,7 @@ extern "C" int mrg_gemm(const mrg_gemm_desc* d, hipStream_t stream) {
     g.aux_out = (bf16_t*)d->aux_out; g.aux_in = (const bf16_t*)d->aux_in; g.ldaux = d->ldaux;
     g.row_map = d->row_map; g.add_tab = d->add_tab; g.add_row = d->add_row; g.ldt = d->ldt;
     g.splitk = splitk; g.ws = d->ws;
-    MRG_REQUIRE(d->variant >= 0 && d->variant <= MRG_GEMM_PIPE256X3, MRG_ERR_ARG, "mrg_gemm: bad variant");
+    MRG_REQUIRE(d->variant >= 0 && d->variant <= MRG_GEMM_PIPE256SQ, MRG_ERR_ARG, "mrg_gemm: bad variant");
     g.tiles_m = cdiv(d->M, BM); g.tiles_n = cdiv(d->N, BN);
     { static const int abl = [] { const char* e = getenv("MRG_GEMM_ABLATE"); return e ? atoi(e) : 0; }(); g.ablate = abl; }
     dim3 grid(g.tiles_m * g.tiles_n, splitk), block(256);
@@ -821,6 +955,7 @@ extern "C" int mrg_gemm(const mrg_gemm_desc* d, hipStream_t stream) {
     else if (d->variant == MRG_GEMM_GLDS4) { use_pipe = false; occ4 = true; }
     else if (d->variant == MRG_GEMM_PIPE128) { use_pipe = true; }
     else if (d->variant == MRG_GEMM_PIPE256 || d->variant == MRG_GEMM_PIPE256X3) { use_big = fast && d->M > 128; use_pipe = true; }
+    const bool use_sq = fast && d->variant == MRG_GEMM_PIPE256SQ && d->M > 128 && d->N > 128;
     const bool big3 = d->variant == MRG_GEMM_PIPE256X3;
 #define MRG_BIG(AM, BM_, V) do { if (big3) { const void* fn = (const void*)gemm_pipe256_kernel<AM, BM_, V, 3>; \
         (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 9 * TILE_BYTES); \
@@ -828,7 +963,10 @@ extern "C" int mrg_gemm(const mrg_gemm_desc* d, hipStream_t stream) {
       else { const void* fn = (const void*)gemm_pipe256_kernel<AM, BM_, V, 2>; \
         (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 6 * TILE_BYTES); \
         hipLaunchKernelGGL((gemm_pipe256_kernel<AM, BM_, V, 2>), dim3(cdiv(d->M, 256) * g.tiles_n, splitk), dim3(512), (size_t)(6 * TILE_BYTES), stream, g); } } while (0)
-#define MRG_FAST(AM, BM_, V) do { if (use_big) MRG_BIG(AM, BM_, V); else if (use_pipe) hipLaunchKernelGGL((gemm_pipe_kernel<AM, BM_, V>), grid, block, (size_t)(4 * TILE_BYTES), stream, g); \
+#define MRG_SQ(AM, BM_, V) do { const void* fn = (const void*)gemm_pipe256sq_kernel<AM, BM_, V>; \
+        (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 8 * TILE_BYTES); \
+        hipLaunchKernelGGL((gemm_pipe256sq_kernel<AM, BM_, V>), dim3(cdiv(d->M, 256) * cdiv(d->N, 256), splitk), dim3(512), (size_t)(8 * TILE_BYTES), stream, g); } while (0)
+#define MRG_FAST(AM, BM_, V) do { if (use_sq) MRG_SQ(AM, BM_, V); else if (use_big) MRG_BIG(AM, BM_, V); else if (use_pipe) hipLaunchKernelGGL((gemm_pipe_kernel<AM, BM_, V>), grid, block, (size_t)(4 * TILE_BYTES), stream, g); \
                                   else if (occ4) hipLaunchKernelGGL((gemm_glds_kernel<AM, BM_, V, 4>), grid, block, (size_t)(2 * TILE_BYTES), stream, g); \
                                   else hipLaunchKernelGGL((gemm_glds_kernel<AM, BM_, V, 3>), grid, block, (size_t)(2 * TILE_BYTES), stream, g); } while (0)
 #define MRG_LAUNCH2(AM, BM_, AL) do { \
@@ -843,6 +981,7 @@ extern "C" int mrg_gemm(const mrg_gemm_desc* d, hipStream_t stream) {
 #undef MRG_LAUNCH2
 #undef MRG_FAST
 #undef MRG_BIG
+#undef MRG_SQ
     if (d->ev_stop) (void)hipEventRecord((hipEvent_t)d->ev_stop, stream);
     int rc = mrg_check_launch("mrg_gemm");
     if (rc) return rc;
