@@ -229,14 +229,22 @@ def main():
         finally:
             K.TIMING["on"] = False
         torch.cuda.synchronize()
-        vname = {0: "auto", 1: "gemm_glds_kernel<*,*,*,3>", 2: "gemm_glds_kernel<*,*,*,4>", 3: "gemm_pipe_kernel", 4: "gemm_pipe256_kernel"}
+        vname = {0: "auto", 1: "gemm_glds_kernel<*,*,*,3>", 2: "gemm_glds_kernel<*,*,*,4>", 3: "gemm_pipe_kernel", 4: "gemm_pipe256_kernel",
+                 5: "gemm_pipe256_kernel", 6: "gemm_pipe256sq_kernel"}
         mname = {(0, 0): "forward x*W^T", (0, 1): "dgrad dy*W", (1, 1): "wgrad dy^T*x"}
         groups = {}
-        for variant, mode, fl, s, e in K.TIMING["records"]:
+        shapes = {}
+        for variant, mode, fl, s, e, shp in K.TIMING["records"]:
+            sg = shapes.setdefault((mode, shp, variant), [0.0, 0])
+            sg[0] += s.elapsed_time(e) * 1e-3; sg[1] += 1
             g = groups.setdefault(vname.get(variant, "auto"), [0.0, 0.0, 0, {}])
             dt = s.elapsed_time(e) * 1e-3
             g[0] += fl; g[1] += dt; g[2] += 1
             g[3][mname[mode]] = g[3].get(mname[mode], 0) + 1
+        if os.environ.get("MRG_GEMM_TABLE") == "1":                   # per-shape GEMM time of one (multi-stream, eager) step
+            for (mode, shp, variant), (tt, n) in sorted(shapes.items(), key=lambda kv: -kv[1][0]):
+                print(f"gemm {mname[mode]:14s} {shp[0]:6d}x{shp[1]:5d}x{shp[2]:6d} sk={shp[3]:2d} v={variant} n={n:3d} total {tt * 1e3:7.3f} ms "
+                      f"avg {tt / n * 1e6:7.1f} us {2.0 * shp[0] * shp[1] * shp[2] * n / tt / 1e12:6.0f} TF/s", file=sys.stderr)
         dom = max(groups, key=lambda m: groups[m][1])
         fl, tsec, n, modes = groups[dom]
         all_fl = sum(g[0] for g in groups.values()); all_t = sum(g[1] for g in groups.values())

@@ -155,7 +155,7 @@ def gemm(A: torch.Tensor, B: torch.Tensor, M: int, N: int, K: int, *, a_mode=L.M
         st, en = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         st.record(); en.record()                                   # creates the underlying hipEvent_t handles
         d.ev_start, d.ev_stop = st.cuda_event, en.cuda_event
-        TIMING["records"].append((variant, (a_mode, b_mode), 2.0 * M * N * K, st, en))
+        TIMING["records"].append((variant, (a_mode, b_mode), 2.0 * M * N * K, st, en, (M, N, K, splitk)))
     _gemm_launch(d, splitk, variant, A.device)
     return out
 
