@@ -36,16 +36,30 @@ __device__ __forceinline__ int tile_off(int r, int c) {
     }
 }
 
-// cooperative global -> LDS copy of `rows` rows (zero-filled beyond nvalid); src row stride in elements
-template <int HD, int SWZ>
-__device__ __forceinline__ void load_rows(char* lds, const bf16_t* __restrict__ src, long row_stride, int rows, int nvalid,
-                                          int tid, int nthreads) {
+// cooperative global -> LDS copy of `rows` rows of two tensors (zero-filled beyond nvalid); src row strides in elements.
+// Loads are issued in branch-free batches of 4 + 4 before the first LDS store so that the whole tile costs one or two memory
+// round trips (a plain load -> store loop is compiled into one serialized round trip per 16 B).
+template <int HD, int SWZ_A, int SWZ_B>
+__device__ __forceinline__ void load_rows2(char* ldsA, const bf16_t* __restrict__ srcA, long strideA,
+                                           char* ldsB, const bf16_t* __restrict__ srcB, long strideB,
+                                           int rows, int nvalid, int tid, int nthreads) {
+    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
     constexpr int CPR = HD / 8;
-    for (int q = tid; q < rows * CPR; q += nthreads) {
-        const int r = q / CPR, c = q % CPR;
-        uint4 v = make_uint4(0, 0, 0, 0);
-        if (r < nvalid) v = *reinterpret_cast<const uint4*>(src + (long)r * row_stride + c * 8);
-        *reinterpret_cast<uint4*>(lds + tile_off<HD, SWZ>(r, c)) = v;
+    const int total = rows * CPR;
+    for (int q0 = tid; q0 < total; q0 += 4 * nthreads) {
+        const int qa = q0, qb = q0 + nthreads, qc = q0 + 2 * nthreads, qd = q0 + 3 * nthreads;
+#define MRG_LD(Q, VA, VB) const int r##Q = Q / CPR, c##Q = Q % CPR; const bool ok##Q = Q < total && r##Q < nvalid; \
+        const long o##Q = ok##Q ? (long)r##Q : 0l; \
+        u32x4 VA = *reinterpret_cast<const u32x4*>(srcA + o##Q * strideA + c##Q * 8); \
+        u32x4 VB = *reinterpret_cast<const u32x4*>(srcB + o##Q * strideB + c##Q * 8);
+        MRG_LD(qa, a0, b0) MRG_LD(qb, a1, b1) MRG_LD(qc, a2, b2) MRG_LD(qd, a3, b3)
+#undef MRG_LD
+        const u32x4 z = {0u, 0u, 0u, 0u};
+#define MRG_ST(Q, VA, VB) if (Q < total) { \
+            *reinterpret_cast<u32x4*>(ldsA + tile_off<HD, SWZ_A>(r##Q, c##Q)) = ok##Q ? VA : z; \
+            *reinterpret_cast<u32x4*>(ldsB + tile_off<HD, SWZ_B>(r##Q, c##Q)) = ok##Q ? VB : z; }
+        MRG_ST(qa, a0, b0) MRG_ST(qb, a1, b1) MRG_ST(qc, a2, b2) MRG_ST(qd, a3, b3)
+#undef MRG_ST
     }
 }
 
@@ -119,8 +133,7 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_kernel(const AttnArgs a) {
     const float sc = a.scale * LOG2E;
 
     if (nchunks == 1) {
-        load_rows<HD, SWZ_ROW>(ldsK, kp, a.k_rs, ROWS, a.Nk, tid, nthr);
-        load_rows<HD, SWZ_TR>(ldsV, vp, a.v_rs, ROWS, a.Nk, tid, nthr);
+        load_rows2<HD, SWZ_ROW, SWZ_TR>(ldsK, kp, a.k_rs, ldsV, vp, a.v_rs, ROWS, a.Nk, tid, nthr);
         __syncthreads();
     }
     // uniform rounds so that every wave takes part in the staging barriers of the multi-chunk path
@@ -151,8 +164,7 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_kernel(const AttnArgs a) {
             const int kvalid = min(ROWS, a.Nk - kbase);
             if (nchunks > 1) {
                 __syncthreads();
-                load_rows<HD, SWZ_ROW>(ldsK, kp + (long)kbase * a.k_rs, a.k_rs, ROWS, kvalid, tid, nthr);
-                load_rows<HD, SWZ_TR>(ldsV, vp + (long)kbase * a.v_rs, a.v_rs, ROWS, kvalid, tid, nthr);
+                load_rows2<HD, SWZ_ROW, SWZ_TR>(ldsK, kp + (long)kbase * a.k_rs, a.k_rs, ldsV, vp + (long)kbase * a.v_rs, a.v_rs, ROWS, kvalid, tid, nthr);
                 __syncthreads();
             }
             if (!active) continue;
@@ -276,8 +288,7 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dq_kernel(const AttnArgs a) {
     const int rounds = (nqt + nwav - 1) / nwav;
     const float sc = a.scale * LOG2E;
     if (nchunks == 1) {
-        load_rows<HD, SWZ_ROW>(ldsK, kp, a.k_rs, ROWS, a.Nk, tid, nthr);
-        load_rows<HD, SWZ_ROW>(ldsV, vp, a.v_rs, ROWS, a.Nk, tid, nthr);
+        load_rows2<HD, SWZ_ROW, SWZ_ROW>(ldsK, kp, a.k_rs, ldsV, vp, a.v_rs, ROWS, a.Nk, tid, nthr);
         __syncthreads();
     }
     for (int rd = 0; rd < rounds; ++rd) {
@@ -310,8 +321,7 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dq_kernel(const AttnArgs a) {
             const int kvalid = min(ROWS, a.Nk - kbase);
             if (nchunks > 1) {
                 __syncthreads();
-                load_rows<HD, SWZ_ROW>(ldsK, kp + (long)kbase * a.k_rs, a.k_rs, ROWS, kvalid, tid, nthr);
-                load_rows<HD, SWZ_ROW>(ldsV, vp + (long)kbase * a.v_rs, a.v_rs, ROWS, kvalid, tid, nthr);
+                load_rows2<HD, SWZ_ROW, SWZ_ROW>(ldsK, kp + (long)kbase * a.k_rs, a.k_rs, ldsV, vp + (long)kbase * a.v_rs, a.v_rs, ROWS, kvalid, tid, nthr);
                 __syncthreads();
             }
             if (!active) continue;
@@ -402,8 +412,7 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dkv_kernel(const AttnArgs a) 
             const int qvalid = min(ROWS, a.Nq - qbase);
             if (nchunks > 1 || rd == 0) {
                 __syncthreads();
-                load_rows<HD, SWZ_ROW>(ldsQ, qp + (long)qbase * a.q_rs, a.q_rs, ROWS, qvalid, tid, nthr);
-                load_rows<HD, SWZ_ROW>(ldsDO, dop + (long)qbase * a.do_rs, a.do_rs, ROWS, qvalid, tid, nthr);
+                load_rows2<HD, SWZ_ROW, SWZ_ROW>(ldsQ, qp + (long)qbase * a.q_rs, a.q_rs, ldsDO, dop + (long)qbase * a.do_rs, a.do_rs, ROWS, qvalid, tid, nthr);
                 for (int i = tid; i < ROWS; i += nthr) {
                     const long sidx = ((long)b * a.H + h) * a.Nq + qbase + i;
                     ldsL[i] = i < qvalid ? a.lse[sidx] * LOG2E : INFINITY;
