@@ -79,6 +79,9 @@ typedef struct mrg_gemm_desc {
     int variant;   /* 0 = heuristic choice; 1..6 force a kernel variant (see MRG_GEMM_* below); used by the host-side autotuner */
     void* ev_start; void* ev_stop;   /* optional hipEvent_t pair recorded on `stream` around the main GEMM kernel only (not the
                                         split-K finishing kernel): lets a benchmark time exactly what rocprofv3 reports per kernel */
+    const float* row_scale;          /* optional [M]: (acc + bias -> act) is multiplied by row_scale[row] before add_tab / resid are
+                                        added -- stochastic depth, x + drop_path(f(x)) (mirage/utils.py:103-118,259-262);
+                                        not combinable with splitk > 1 */
 } mrg_gemm_desc;
 enum { MRG_GEMM_AUTO = 0, MRG_GEMM_GLDS3 = 1, MRG_GEMM_GLDS4 = 2, MRG_GEMM_PIPE128 = 3, MRG_GEMM_PIPE256 = 4, MRG_GEMM_PIPE256X3 = 5, MRG_GEMM_PIPE256SQ = 6 };
 
@@ -212,6 +215,9 @@ int mrg_grad_norm(const float* g, long n, float* partials, float* out, hipStream
 int mrg_adamw(const mrg_adamw_desc* d, hipStream_t stream);
 int mrg_step_inc(int* step, hipStream_t stream);
 int mrg_cast_bf16(const float* src, void* dst_bf16, long n, hipStream_t stream);
+/* dst_bf16[r, :] = src[r, :] * row_scale[r] for an [M, D] fp32 matrix (D % 4 == 0): the gradient entering a stochastic-depth
+ * branch (backward of drop_path, mirage/utils.py:103-118). */
+int mrg_row_scale_bf16(const float* src, const float* row_scale, void* dst_bf16, long M, int D, hipStream_t stream);
 
 #ifdef __cplusplus
 }

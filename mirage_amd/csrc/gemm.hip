@@ -38,6 +38,7 @@ struct GemmArgs {
     bf16_t* aux_out; const bf16_t* aux_in; int ldaux;
     const int* row_map;
     const float* add_tab; const int* add_row; int ldt;
+    const float* row_scale;
     int splitk; float* ws;
     int tiles_m, tiles_n;
     int ablate;   // MRG_GEMM_ABLATE (256x128 kernel only, for roofline analysis): 1 = no DMA, 2 = DMA only, 3 = DMA + LDS reads, no MFMA
@@ -157,6 +158,11 @@ __device__ __forceinline__ void epi_row(const GemmArgs& g, const float4 a4, cons
             } else { for (int e = 0; e < nv; ++e) x[e] = bf2f(ai[e]); }
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] *= gelu_grad_f(x[e]);
+        }
+        if (g.row_scale) {
+            const float rs = g.row_scale[row];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] *= rs;
         }
         if (g.add_tab) {
             const float* t = g.add_tab + (long)g.add_row[row] * g.ldt + col;
@@ -909,7 +915,7 @@ extern "C" int mrg_gemm(const mrg_gemm_desc* d, hipStream_t stream) {
     const int splitk = d->splitk > 1 ? d->splitk : 1;
     if (splitk > 1) {
         MRG_REQUIRE(d->ws, MRG_ERR_ARG, "mrg_gemm: split-K needs a workspace");
-        MRG_REQUIRE(d->act == MRG_ACT_NONE && !d->resid && !d->add_tab && !d->row_map && !d->m_dev, MRG_ERR_UNSUPPORTED,
+        MRG_REQUIRE(d->act == MRG_ACT_NONE && !d->resid && !d->add_tab && !d->row_map && !d->m_dev && !d->row_scale, MRG_ERR_UNSUPPORTED,
                     "mrg_gemm: split-K supports only bias/accumulate epilogues");
     }
     GemmArgs g;
@@ -922,7 +928,7 @@ extern "C" int mrg_gemm(const mrg_gemm_desc* d, hipStream_t stream) {
     g.C2 = (bf16_t*)d->C2; g.ldc2 = d->ldc2;
     g.bias = d->bias; g.resid = d->resid; g.ldr = d->ldr; g.accumulate = d->accumulate; g.act = d->act;
     g.aux_out = (bf16_t*)d->aux_out; g.aux_in = (const bf16_t*)d->aux_in; g.ldaux = d->ldaux;
-    g.row_map = d->row_map; g.add_tab = d->add_tab; g.add_row = d->add_row; g.ldt = d->ldt;
+    g.row_map = d->row_map; g.add_tab = d->add_tab; g.add_row = d->add_row; g.ldt = d->ldt; g.row_scale = d->row_scale;
     g.splitk = splitk; g.ws = d->ws;
     MRG_REQUIRE(d->variant >= 0 && d->variant <= MRG_GEMM_PIPE256SQ, MRG_ERR_ARG, "mrg_gemm: bad variant");
     g.tiles_m = cdiv(d->M, BM); g.tiles_n = cdiv(d->N, BN);

@@ -103,6 +103,18 @@ __global__ __launch_bounds__(256) void cast_bf16_kernel(const float* __restrict_
     if (blockIdx.x == 0 && threadIdx.x < (n & 3)) dst[(n4 << 2) + threadIdx.x] = f2bf(src[(n4 << 2) + threadIdx.x]);
 }
 
+// one wave per row segment: dst[r, :] = src[r, :] * scale[r]
+__global__ __launch_bounds__(256) void row_scale_bf16_kernel(const float* __restrict__ src, const float* __restrict__ scale,
+                                                             bf16_t* __restrict__ dst, long M, int D) {
+    const int d4 = D >> 2;
+    const long n4 = M * d4;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+        const float s = scale[i / d4];
+        const float4 v = reinterpret_cast<const float4*>(src)[i];
+        reinterpret_cast<uint2*>(dst)[i] = make_uint2(pack_bf2(v.x * s, v.y * s), pack_bf2(v.z * s, v.w * s));
+    }
+}
+
 }  // namespace
 
 extern "C" int mrg_sumsq_nblocks(long n) {
@@ -154,4 +166,14 @@ extern "C" int mrg_cast_bf16(const float* src, void* dst_bf16, long n, hipStream
     if (nb < 1) nb = 1;
     hipLaunchKernelGGL(cast_bf16_kernel, dim3((unsigned)nb), dim3(256), 0, stream, src, (bf16_t*)dst_bf16, n);
     return mrg_check_launch("mrg_cast_bf16");
+}
+
+extern "C" int mrg_row_scale_bf16(const float* src, const float* row_scale, void* dst_bf16, long M, int D, hipStream_t stream) {
+    MRG_REQUIRE(src && row_scale && dst_bf16 && M > 0 && D > 0, MRG_ERR_ARG, "mrg_row_scale_bf16: bad argument");
+    MRG_REQUIRE(D % 4 == 0, MRG_ERR_SHAPE, "mrg_row_scale_bf16: D must be a multiple of 4");
+    MRG_REQUIRE((((uintptr_t)src & 15) | ((uintptr_t)dst_bf16 & 7)) == 0, MRG_ERR_ARG, "mrg_row_scale_bf16: misaligned");
+    long nb = (M * (D / 4) + 255) / 256;
+    if (nb > 4096) nb = 4096;
+    hipLaunchKernelGGL(row_scale_bf16_kernel, dim3((unsigned)nb), dim3(256), 0, stream, src, row_scale, (bf16_t*)dst_bf16, M, D);
+    return mrg_check_launch("mrg_row_scale_bf16");
 }

@@ -62,7 +62,7 @@ def join_side_stream():
 
 # ------------------------------------------------------------------------------------------- linear helpers
 def lin_fwd(x16: torch.Tensor, lin, *, out_dtype=BF16, resid: Optional[torch.Tensor] = None, want_bf16_copy: bool = False,
-            gelu: bool = False, save_pre: bool = False):
+            gelu: bool = False, save_pre: bool = False, row_scale: Optional[torch.Tensor] = None):
     """y = x W^T + b with fused epilogue.  x16: bf16 [..., K].  Returns y (and bf16 copy / pre-activation if asked)."""
     W = shadow(lin.weight)
     N = W.shape[0]
@@ -73,7 +73,7 @@ def lin_fwd(x16: torch.Tensor, lin, *, out_dtype=BF16, resid: Optional[torch.Ten
     out2 = torch.empty(oshape, dtype=BF16, device=x16.device) if want_bf16_copy else None
     pre = torch.empty(oshape, dtype=BF16, device=x16.device) if (gelu and save_pre) else None
     K.gemm(x16, W, M, N, Kin, lda=Kin, ldb=Kin, out=out, ldc=N, out2=out2, bias=lin.bias,
-           resid=resid, act=L.MRG_ACT_GELU if gelu else L.MRG_ACT_NONE, aux_out=pre)
+           resid=resid, act=L.MRG_ACT_GELU if gelu else L.MRG_ACT_NONE, aux_out=pre, row_scale=row_scale)
     return out, out2, pre
 
 
@@ -117,8 +117,10 @@ def to_bf16(x32: torch.Tensor) -> torch.Tensor:
 
 
 # ------------------------------------------------------------------------------------------- transformer block
-def block_fwd(blk, x32: torch.Tensor, save: bool, want_bf16_out: bool = False):
-    """Block.forward (mirage/utils.py:259-262): x + attn(norm1(x)); x + mlp(norm2(x)).  x32: fp32 [B, N, D]."""
+def block_fwd(blk, x32: torch.Tensor, save: bool, want_bf16_out: bool = False, dp=None):
+    """Block.forward (mirage/utils.py:259-262): x + drop_path(attn(norm1(x))); x + drop_path(mlp(norm2(x))).  x32: fp32 [B, N, D].
+    dp = (rows_attn, rows_mlp): per-row stochastic-depth factors floor(keep + u) / keep (mirage/utils.py:103-118), fused into the
+    proj / fc2 epilogues; None when the block's drop_path is Identity (every BASELINE config)."""
     B, N, D = x32.shape
     H = blk.attn.num_heads
     hd = D // H
@@ -127,35 +129,45 @@ def block_fwd(blk, x32: torch.Tensor, save: bool, want_bf16_out: bool = False):
     qkv, _, _ = lin_fwd(ln1, blk.attn.qkv)
     st = (N * 3 * D, 3 * D)
     o, lse = K.attn_fwd(qkv[..., :D], qkv[..., D:2 * D], qkv[..., 2 * D:], B, H, N, N, hd, blk.attn.scale, st, st, st, need_lse=save)
-    x_mid, _, _ = lin_fwd(o, blk.attn.proj, out_dtype=F32, resid=x32)
+    x_mid, _, _ = lin_fwd(o, blk.attn.proj, out_dtype=F32, resid=x32, row_scale=dp[0] if dp else None)
     ln2, mean2, rstd2 = K.ln_fwd(x_mid, blk.norm2.weight, blk.norm2.bias, blk.norm2.eps)
     h_act, _, h_pre = lin_fwd(ln2, blk.mlp.fc1, gelu=True, save_pre=save)
-    x_out, x_out16, _ = lin_fwd(h_act, blk.mlp.fc2, out_dtype=F32, resid=x_mid, want_bf16_copy=want_bf16_out)
-    saved = (x32, ln1, mean1, rstd1, qkv, o, lse, x_mid, ln2, mean2, rstd2, h_pre, h_act) if save else None
+    x_out, x_out16, _ = lin_fwd(h_act, blk.mlp.fc2, out_dtype=F32, resid=x_mid, want_bf16_copy=want_bf16_out,
+                                row_scale=dp[1] if dp else None)
+    saved = (x32, ln1, mean1, rstd1, qkv, o, lse, x_mid, ln2, mean2, rstd2, h_pre, h_act, dp) if save else None
     return x_out, x_out16, saved
 
 
 def block_bwd(blk, saved, dx32: torch.Tensor, dx16: Optional[torch.Tensor]):
     """Returns (dx_in fp32, dx_in bf16).  fc2 / proj bias gradients come out of the LayerNorm backward kernels
     (column sums of the residual-stream gradient)."""
-    x_in, ln1, mean1, rstd1, qkv, o, lse, x_mid, ln2, mean2, rstd2, h_pre, h_act = saved
+    x_in, ln1, mean1, rstd1, qkv, o, lse, x_mid, ln2, mean2, rstd2, h_pre, h_act, dp = saved
     B, N, D = x_in.shape
     H = blk.attn.num_heads
     hd = D // H
-    if dx16 is None:
-        dx16 = to_bf16(dx32)
-    d_pre, _ = lin_bwd(dx16, h_act, blk.mlp.fc2, gelu_pre=h_pre, bias_grad=False)
+    if dp is not None:
+        # stochastic depth: the branch sees row_scale * dy, the residual path the unscaled dy; the branch bias gradients are
+        # then column sums of the scaled gradient, not of the residual-stream gradient the LayerNorm kernels sum
+        dxs16 = K.row_scale_bf16(dx32, dp[1])
+        d_pre, _ = lin_bwd(dxs16, h_act, blk.mlp.fc2, gelu_pre=h_pre, bias_grad=True)
+    else:
+        if dx16 is None:
+            dx16 = to_bf16(dx32)
+        d_pre, _ = lin_bwd(dx16, h_act, blk.mlp.fc2, gelu_pre=h_pre, bias_grad=False)
     d_ln2, _ = lin_bwd(d_pre, ln2, blk.mlp.fc1)
     dx_mid32, dx_mid16 = K.ln_bwd(d_ln2, x_mid, mean2, rstd2, blk.norm2.weight, dx32, grad_buffer(blk.norm2.weight),
-                                  grad_buffer(blk.norm2.bias), grad_buffer(blk.mlp.fc2.bias))
-    d_o, _ = lin_bwd(dx_mid16, o, blk.attn.proj, bias_grad=False)
+                                  grad_buffer(blk.norm2.bias), None if dp is not None else grad_buffer(blk.mlp.fc2.bias))
+    if dp is not None:
+        d_o, _ = lin_bwd(K.row_scale_bf16(dx_mid32, dp[0]), o, blk.attn.proj, bias_grad=True)
+    else:
+        d_o, _ = lin_bwd(dx_mid16, o, blk.attn.proj, bias_grad=False)
     d_qkv = torch.empty_like(qkv)
     st = (N * 3 * D, 3 * D)
     K.attn_bwd(qkv[..., :D], qkv[..., D:2 * D], qkv[..., 2 * D:], o, lse, d_o, d_qkv[..., :D], d_qkv[..., D:2 * D], d_qkv[..., 2 * D:],
                B, H, N, N, hd, blk.attn.scale, st, st, st, st, st, st)
     d_ln1, _ = lin_bwd(d_qkv, ln1, blk.attn.qkv)
     dx_in32, dx_in16 = K.ln_bwd(d_ln1, x_in, mean1, rstd1, blk.norm1.weight, dx_mid32, grad_buffer(blk.norm1.weight),
-                                grad_buffer(blk.norm1.bias), grad_buffer(blk.attn.proj.bias))
+                                grad_buffer(blk.norm1.bias), None if dp is not None else grad_buffer(blk.attn.proj.bias))
     return dx_in32, dx_in16
 
 
@@ -163,9 +175,9 @@ class BlockFn(torch.autograd.Function):
     """Stand-alone Block (mirage/utils.py:226-262) for callers that use the module directly."""
 
     @staticmethod
-    def forward(ctx, x, blk, save, *params):
+    def forward(ctx, x, blk, save, dp, *params):
         x32 = x.contiguous().float()
-        out, _, saved = block_fwd(blk, x32, save)
+        out, _, saved = block_fwd(blk, x32, save, dp=dp)
         ctx.blk, ctx.saved = blk, saved
         return out
 
@@ -174,7 +186,7 @@ class BlockFn(torch.autograd.Function):
         dx32, _ = block_bwd(ctx.blk, ctx.saved, dout.contiguous().float(), None)
         ctx.saved = None
         _Side.join()
-        return (dx32, None, None) + (None,) * 12
+        return (dx32, None, None, None) + (None,) * 12
 
 
 class EncoderFn(torch.autograd.Function):
@@ -182,14 +194,14 @@ class EncoderFn(torch.autograd.Function):
     between blocks without touching autograd."""
 
     @staticmethod
-    def forward(ctx, x, blocks, save, want_bf16, defer_join, *params):
+    def forward(ctx, x, blocks, save, want_bf16, defer_join, dps, *params):
         ctx.defer_join = defer_join
         x32 = x
         saved_all = []
         x16 = None
         n = len(blocks)
         for i, blk in enumerate(blocks):
-            x32, x16, sv = block_fwd(blk, x32, save, want_bf16_out=(want_bf16 and i == n - 1))
+            x32, x16, sv = block_fwd(blk, x32, save, want_bf16_out=(want_bf16 and i == n - 1), dp=dps[i] if dps else None)
             saved_all.append(sv)
         ctx.blocks, ctx.saved = blocks, saved_all
         if want_bf16:

@@ -114,7 +114,7 @@ def gemm(A: torch.Tensor, B: torch.Tensor, M: int, N: int, K: int, *, a_mode=L.M
          lda: Optional[int] = None, ldb: Optional[int] = None, out: Optional[torch.Tensor] = None, out_dtype=BF16,
          ldc: Optional[int] = None, out2: Optional[torch.Tensor] = None, bias=None, resid=None, accumulate=False,
          act=L.MRG_ACT_NONE, aux_out=None, aux_in=None, row_map=None, add_tab=None, add_row=None, a_map=None, b_map=None,
-         m_dev=None, k_dev=None, splitk: int = 1, tune_split: bool = False) -> torch.Tensor:
+         m_dev=None, k_dev=None, splitk: int = 1, tune_split: bool = False, row_scale=None) -> torch.Tensor:
     _need_cuda(A, "GEMM operand")
     if out is None:
         out = torch.empty((M, N), dtype=out_dtype, device=A.device)
@@ -142,6 +142,7 @@ def gemm(A: torch.Tensor, B: torch.Tensor, M: int, N: int, K: int, *, a_mode=L.M
     d.row_map = _p(row_map)
     if add_tab is not None:
         d.add_tab, d.add_row, d.ldt = add_tab.data_ptr(), add_row.data_ptr(), add_tab.stride(0)
+    d.row_scale = _p(row_scale)
     variant = L.MRG_GEMM_AUTO
     tunable = TUNE["enabled"] and a_map is None and b_map is None and m_dev is None and k_dev is None and not accumulate and M * N >= (1 << 16)
     if tunable:
@@ -400,4 +401,13 @@ def step_inc(step: torch.Tensor):
 
 def cast_bf16(src: torch.Tensor, dst: torch.Tensor):
     check(lib.mrg_cast_bf16(src.data_ptr(), dst.data_ptr(), src.numel(), _s()), "mrg_cast_bf16")
+    return dst
+
+
+def row_scale_bf16(src: torch.Tensor, row_scale: torch.Tensor) -> torch.Tensor:
+    """bf16(src[r, :] * row_scale[r]) for fp32 src [..., D] flattened to rows."""
+    D = src.shape[-1]
+    M = src.numel() // D
+    dst = torch.empty(src.shape, dtype=BF16, device=src.device)
+    check(lib.mrg_row_scale_bf16(src.data_ptr(), row_scale.data_ptr(), dst.data_ptr(), M, D, _s()), "mrg_row_scale_bf16")
     return dst

@@ -217,9 +217,10 @@ class MIRAGEModel(nn.Module):
     # ------------------------------------------------------------------------------------ forward
     def forward(self, x: Union[Dict[str, Tensor], Tensor], mask_inputs: bool = True, task_masks: Optional[Dict[str, Tensor]] = None,
                 num_encoded_tokens: int = 128, alphas: Union[float, List[float]] = 1.0, sample_tasks_uniformly: bool = False,
-                return_all_layers: bool = False, reshape: bool = False, mask_noise=None):
-        """Same contract as mirage/model.py:305-431.  Extra keyword `mask_noise=(p, u, g)` feeds explicit noise to the
-        mask generator (bit-exact parity tests)."""
+                return_all_layers: bool = False, reshape: bool = False, mask_noise=None, drop_path_noise=None):
+        """Same contract as mirage/model.py:305-431.  Extra keywords: `mask_noise=(p, u, g)` feeds explicit noise to the
+        mask generator (bit-exact parity tests); `drop_path_noise` [blocks with drop_path > 0, 2, B] feeds the uniform
+        draws of stochastic depth (default: torch.rand on the device)."""
         x = {"bscan": x} if isinstance(x, Tensor) else x
         x = {d: t for d, t in x.items() if d in self.input_adapters}
         doms = [d for d in self.input_adapters.keys() if d in x]
@@ -273,7 +274,16 @@ class MIRAGEModel(nn.Module):
             return features
 
         want16 = self.output_adapters is not None
-        enc32, enc16 = E.EncoderFn.apply(x0, blocks, save, want16, True, *self._encoder_params())
+        dps = None
+        if self.training and any(getattr(b, "drop_path_prob", 0.0) > 0.0 for b in blocks):
+            # one uniform draw per (block with drop_path > 0, branch, sample), in the reference's call order
+            # (mirage/utils.py:259-262: attention branch, then MLP branch, block by block)
+            act = [i for i, b in enumerate(blocks) if b.drop_path_prob > 0.0]
+            u = drop_path_noise if drop_path_noise is not None else torch.rand((len(act), 2, B), dtype=torch.float32, device=device)
+            dps = [None] * len(blocks)
+            for j, i in enumerate(act):
+                dps[i] = blocks[i].drop_path_rows(B, x0.shape[1], device, u[j])
+        enc32, enc16 = E.EncoderFn.apply(x0, blocks, save, want16, True, dps, *self._encoder_params())
         if self.output_adapters is None:
             if reshape:
                 gs = self.args.grid_sizes["bscan"]

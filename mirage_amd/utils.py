@@ -5,7 +5,7 @@ on the HIP kernels (no torch math), so inputs and parameters must be on the GPU.
 """
 import math
 import warnings
-from typing import Callable
+from typing import Callable, Optional
 
 import torch
 import torch.nn as nn
@@ -60,9 +60,16 @@ def trunc_normal_(tensor, mean=0.0, std=1.0, a=-2.0, b=2.0):
     return tensor
 
 
+def drop_path_factor(u: torch.Tensor, drop_prob: float) -> torch.Tensor:
+    """Per-sample factor of drop_path (mirage/utils.py:103-118): floor(keep_prob + u) / keep_prob for uniform noise u."""
+    keep = 1.0 - drop_prob
+    return torch.floor(keep + u.float()) / keep
+
+
 class DropPath(nn.Module):
     """Stochastic depth (mirage/utils.py:124-134).  Every configuration on the pretraining path uses p = 0
-    (run_pretraining.py:150), where the reference installs nn.Identity; p > 0 is not implemented on the HIP path."""
+    (run_pretraining.py:150), where the reference installs nn.Identity.  Inside a Block the per-sample factor is fused into
+    the proj / fc2 GEMM epilogues (engine.block_fwd); called stand-alone it is the same elementwise rule as the reference."""
 
     def __init__(self, drop_prob=0.0):
         super().__init__()
@@ -71,7 +78,8 @@ class DropPath(nn.Module):
     def forward(self, x):
         if self.drop_prob == 0.0 or not self.training:
             return x
-        raise NotImplementedError("mirage_amd: DropPath with p > 0 is not implemented (no BASELINE config uses it)")
+        shape = (x.shape[0],) + (1,) * (x.ndim - 1)
+        return x * drop_path_factor(torch.rand(shape, dtype=torch.float32, device=x.device), self.drop_prob).to(x.dtype)
 
     def extra_repr(self):
         return "p={}".format(self.drop_prob)
@@ -303,12 +311,22 @@ class Block(nn.Module):
         self.mlp = Mlp(in_features=dim, hidden_features=int(dim * mlp_ratio), act_layer=act_layer, drop=drop)
         if not (qkv_bias and isinstance(self.norm1, nn.LayerNorm)):
             raise NotImplementedError("mirage_amd.Block: needs qkv_bias=True and a LayerNorm norm_layer (the reference's defaults)")
-        if drop_path > 0.0:
-            raise NotImplementedError("mirage_amd.Block: drop_path > 0 is not implemented (pretraining uses 0.0)")
+        self.drop_path_prob = float(drop_path)
 
     def _params(self):
         return (self.norm1.weight, self.norm1.bias, self.attn.qkv.weight, self.attn.qkv.bias, self.attn.proj.weight, self.attn.proj.bias,
                 self.norm2.weight, self.norm2.bias, self.mlp.fc1.weight, self.mlp.fc1.bias, self.mlp.fc2.weight, self.mlp.fc2.bias)
 
-    def forward(self, x):
-        return E.BlockFn.apply(x, self, torch.is_grad_enabled(), *self._params())
+    def drop_path_rows(self, B: int, N: int, device, noise: Optional[torch.Tensor] = None):
+        """Per-row factors (attention branch, MLP branch) for one forward, or None when drop_path is inactive.  `noise`:
+        uniform [2, B] (tests feed the reference's draws); default = torch.rand on `device`, one draw per branch per sample in
+        the reference's order (attention first, mirage/utils.py:260-261)."""
+        if self.drop_path_prob == 0.0 or not self.training:
+            return None
+        u = noise if noise is not None else torch.rand((2, B), dtype=torch.float32, device=device)
+        f = drop_path_factor(u.to(device), self.drop_path_prob)
+        return (f[0].repeat_interleave(N).contiguous(), f[1].repeat_interleave(N).contiguous())
+
+    def forward(self, x, drop_path_noise: Optional[torch.Tensor] = None):
+        dp = self.drop_path_rows(x.shape[0], x.shape[1], x.device, drop_path_noise)
+        return E.BlockFn.apply(x, self, torch.is_grad_enabled(), dp, *self._params())

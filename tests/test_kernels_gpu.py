@@ -421,3 +421,20 @@ def test_adamw_gradnorm_cast(K):
     dst = torch.empty(1001, dtype=BF16, device=dev())
     K.cast_bf16(p[:1001].contiguous(), dst)
     assert torch.equal(dst, p[:1001].to(BF16))
+
+
+def test_gemm_row_scale_epilogue_and_row_scale_bf16(K):
+    """out = resid + row_scale[row] * (x W^T + b): the stochastic-depth epilogue (mirage/utils.py:103-118,259-262)."""
+    torch.manual_seed(5)
+    M, N, Kd = 300, 256, 192
+    x = torch.randn(M, Kd, device="cuda:0").bfloat16(); W = (torch.randn(N, Kd, device="cuda:0") * 0.05).bfloat16()
+    b = torch.randn(N, device="cuda:0"); r = torch.randn(M, N, device="cuda:0")
+    s = (torch.floor(0.7 + torch.rand(M, device="cuda:0")) / 0.7).contiguous()
+    out = torch.empty(M, N, device="cuda:0")
+    K.gemm(x, W, M, N, Kd, bias=b, resid=r, out=out, row_scale=s)
+    ref = r + s[:, None] * (x.float() @ W.float().t() + b)
+    assert (out - ref).abs().max() <= 2e-3 * ref.abs().max()
+    assert torch.equal(out[s == 0], r[s == 0])                      # dropped rows are exactly the residual
+    g = torch.randn(M, N, device="cuda:0")
+    gs = K.row_scale_bf16(g, s)
+    assert torch.equal(gs, (g * s[:, None]).bfloat16())

@@ -30,7 +30,8 @@ def _build(cfg, with_decoders=True):
     args = builder.make_args(cfg["in_domains"], cfg["out_domains"], input_size=dom[img]["image"] if img else 512,
                              patch_size=dom[img]["patch"] if img else 32, layermap_size=dom[lm]["image"] if lm else 128,
                              layermap_patch=dom[lm]["patch"] if lm else 8, decoder_dim=cfg["decoder_dim"],
-                             decoder_depth=cfg["decoder_depth"], decoder_num_heads=cfg["decoder_heads"])
+                             decoder_depth=cfg["decoder_depth"], decoder_num_heads=cfg["decoder_heads"],
+                             drop_path=cfg.get("drop_path_rate", 0.0))
     model = builder.get_model(args, with_decoders=with_decoders and bool(cfg["out_domains"]), dim_tokens=cfg["dim"], depth=cfg["depth"],
                               num_heads=cfg["heads"])
     sd = O.procedural_state_dict(cfg)
@@ -167,3 +168,44 @@ def test_encoder_only_pooled_features():
             out = torch.nn.functional.layer_norm(out, (D,), nw, nb, 1e-6)
             pooled = out[:, :-1].mean(1)
         assert rel_rms(pooled.cpu(), torch.from_numpy(fx["pooled"])) <= 1e-2
+
+
+def test_drop_path_training_parity():
+    """A16: stochastic depth fused into the proj / fc2 epilogues (forward) and the scaled-gradient path (backward), fed the
+    reference's own uniform draws (tests/golden/tiny3_droppath.npz; mirage/utils.py:103-134,259-262)."""
+    from mirage_amd import builder
+    fx, meta = load_golden("tiny3_droppath")
+    cfg, B, Kk = meta["cfg"], meta["B"], meta["K"]
+    model, args, sd = _build(cfg)
+    model.train()
+    assert [float(b.drop_path_prob) for b in model.encoder][0] == 0.0 and model.encoder[-1].drop_path_prob == pytest.approx(0.4)
+    from oracle import mirage_oracle as O
+    x = {d: t.to(DEV) for d, t in O.synthetic_batch(cfg, B, seed=meta["data_seed"]).items()}
+    doms = cfg["in_domains"]
+    noise = (torch.from_numpy(fx["p"]).to(DEV), torch.cat([torch.from_numpy(fx[f"u.{d}"]) for d in doms], 1).to(DEV),
+             torch.from_numpy(fx["g"]).to(DEV))
+    dpn = torch.from_numpy(fx["dp_noise"]).to(DEV)
+    oa = model.output_adapters
+    model.output_adapters = None
+    with torch.no_grad():
+        enc, _ = model({d: x[d] for d in doms}, num_encoded_tokens=Kk, mask_noise=noise, drop_path_noise=dpn)
+    model.output_adapters = oa
+    ref = torch.from_numpy(fx["enc_tokens"])
+    assert rel_rms(enc.float().cpu(), ref) <= 1e-2
+    loss_fns = builder.get_losses(args)
+    preds, masks = model({d: x[d] for d in doms}, num_encoded_tokens=Kk, mask_noise=noise, drop_path_noise=dpn)
+    total = sum(loss_fns[d](preds[d], x[d], mask=masks.get(d)) for d in preds)
+    assert abs(float(total) - float(fx["loss"])) <= 3e-3 * abs(float(fx["loss"])), (float(total), float(fx["loss"]))
+    total.backward()
+    params = dict(model.named_parameters())
+    tot = float(fx["grad_total_norm"])
+    for n, gn in zip(fx["grad_names"], fx["grad_norms"]):
+        mine = float(params[str(n)].grad.double().norm())
+        assert abs(mine - gn) <= 4e-2 * max(gn, 1e-3 * tot), (str(n), mine, gn)
+    # eval mode ignores the noise entirely (DropPath is the identity when not training)
+    model.eval()
+    with torch.no_grad():
+        p_eval, _ = model({d: x[d] for d in doms}, num_encoded_tokens=Kk, mask_noise=noise)
+        p_eval2, _ = model({d: x[d] for d in doms}, num_encoded_tokens=Kk, mask_noise=noise, drop_path_noise=dpn)
+    for d in p_eval:
+        assert torch.equal(p_eval[d], p_eval2[d])

@@ -152,3 +152,27 @@ def test_cls_pooled_features():
         with torch.no_grad():
             pooled = O.cls_global_features(cfg, sd, x, nw, nb)
         np.testing.assert_allclose(pooled.numpy(), fx["pooled"], rtol=1e-4, atol=2e-5)
+
+
+def test_drop_path_training_mode_matches_reference():
+    """Stochastic depth (A16; mirage/utils.py:103-134,249,259-262): tiny 4-block model, drop_path_rate 0.4, the reference's own
+    uniform draws replayed from the fixture.  Samples really are dropped in this case (the fixture generator prints the count)."""
+    fx, meta = load_golden("tiny3_droppath")
+    cfg, B, K = meta["cfg"], meta["B"], meta["K"]
+    assert O.drop_path_rates(cfg)[0] == 0.0 and O.drop_path_rates(cfg)[-1] == pytest.approx(0.4)
+    sd = {k: v.clone().requires_grad_(O.param_shapes(cfg)[k][1]) for k, v in O.procedural_state_dict(cfg).items()}
+    x = O.synthetic_batch(cfg, B, seed=meta["data_seed"])
+    dp = _t(fx["dp_noise"])
+    assert int((torch.floor(0.6 + dp[-1]) == 0).sum()) > 0
+    loss, ls, enc, _ = O.forward_loss(cfg, sd, x, _t(fx["ids_keep"]), _t(fx["ids_restore"]), dp_noise=dp)
+    np.testing.assert_allclose(enc.detach().numpy(), fx["enc_tokens"], rtol=2e-5, atol=5e-5)
+    assert abs(float(loss) - float(fx["loss"])) <= 1e-5 * abs(float(fx["loss"]))
+    loss.backward()
+    for n, gn in zip(fx["grad_names"], fx["grad_norms"]):
+        g = sd[str(n)].grad
+        assert g is not None, n
+        assert abs(float(g.double().norm()) - gn) <= 2e-4 * max(gn, 1e-3 * float(fx["grad_total_norm"])), (str(n), float(g.double().norm()), gn)
+    # without the noise the same weights give a different answer: the check above is not vacuous
+    with torch.no_grad():
+        l0, _, _, _ = O.forward_loss(cfg, sd, x, _t(fx["ids_keep"]), _t(fx["ids_restore"]))
+    assert abs(float(l0) - float(fx["loss"])) > 1e-3

@@ -41,7 +41,7 @@ with contextlib.redirect_stdout(io.StringIO()):
 OUT = os.path.join(ROOT, "tests", "golden")
 
 
-def build_reference(cfg):
+def build_reference(cfg, drop_path_rate=0.0):
     """Adapters exactly as run_pretraining.py:380-403 builds them, model as mirage/model.py:43."""
     args = types.SimpleNamespace()
     args.input_size = {d: (c["image"], c["image"]) for d, c in cfg["domains"].items()}
@@ -64,7 +64,7 @@ def build_reference(cfg):
                                      image_size=(c["image"], c["image"]))
     model = MIRAGEModel(args, input_adapters=ia, output_adapters=oa if cfg["out_domains"] else None,
                         num_global_tokens=cfg["num_global_tokens"], dim_tokens=cfg["dim"], depth=cfg["depth"],
-                        num_heads=cfg["heads"])
+                        num_heads=cfg["heads"], drop_path_rate=drop_path_rate)
     return model
 
 
@@ -176,6 +176,65 @@ def run_case(name, cfg, B, K, data_seed, mask_seed, keep_intermediate=False, ful
     np.savez_compressed(os.path.join(OUT, f"{name}.npz"), **fx)
     print(f"   loss={fx['loss']:.6f}  enc_norm={fx['enc_tokens_norm']:.4f}")
     return model, x, (fx["ids_keep"], fx["ids_restore"])
+
+
+def run_droppath_case(name, cfg, B, K, data_seed, mask_seed):
+    """Stochastic depth (mirage/utils.py:103-134,249,259-262) in training mode: the reference draws torch.rand((B,1,1)) per
+    active DropPath call, after the mask noise and in block order (attention branch, then MLP branch).  The draws are
+    replayed from the same seed and committed, so that the oracle and the HIP engine can be fed the identical noise."""
+    print(f"== {name}: B={B} K={K} drop_path_rate={cfg['drop_path_rate']}")
+    with contextlib.redirect_stdout(io.StringIO()):
+        model = build_reference(cfg, drop_path_rate=cfg["drop_path_rate"])
+    model.load_state_dict(O.procedural_state_dict(cfg), strict=True)
+    model.train()
+    x = O.synthetic_batch(cfg, B, seed=data_seed)
+    x_in = {d: x[d] for d in cfg["in_domains"]}
+    p, u, g = replay_mask_noise(cfg, B, mask_seed)                    # leaves the generator where the encoder starts drawing
+    rates = O.drop_path_rates(cfg)
+    nact = sum(1 for r in rates if r > 0.0)
+    dp = torch.stack([torch.stack([torch.rand((B, 1, 1)).reshape(B), torch.rand((B, 1, 1)).reshape(B)]) for _ in range(nact)])
+    fx = {"p": p, "g": g, "dp_noise": dp.numpy()}
+    for d, ud in zip(cfg["in_domains"], u):
+        fx[f"u.{d}"] = ud
+    captured = {}
+    first = cfg["out_domains"][0]
+    orig = model.output_adapters[first].forward
+
+    def spy(encoder_tokens, input_info, ids_keep, ids_restore):
+        captured["enc"] = encoder_tokens
+        captured["ids_keep"], captured["ids_restore"] = ids_keep, ids_restore
+        return orig(encoder_tokens=encoder_tokens, input_info=input_info, ids_keep=ids_keep, ids_restore=ids_restore)
+    model.output_adapters[first].forward = spy
+    torch.manual_seed(mask_seed)
+    with contextlib.redirect_stdout(io.StringIO()):
+        preds, task_masks = model(x_in, num_encoded_tokens=K, alphas=1.0, sample_tasks_uniformly=False)
+    fx["ids_keep"], fx["ids_restore"] = captured["ids_keep"].numpy(), captured["ids_restore"].numpy()
+    fx["enc_tokens"] = captured["enc"].detach().numpy()
+    loss_fns = reference_losses(cfg)
+    task_losses = {d: loss_fns[d](preds[d].float(), x[d], mask=task_masks.get(d)) for d in preds}
+    loss = sum(task_losses.values())
+    for d in preds:
+        fx[f"loss.{d}"] = np.float64(task_losses[d].item())
+    fx["loss"] = np.float64(loss.item())
+    loss.backward()
+    names, norms = [], []
+    for n_, p_ in model.named_parameters():
+        if p_.grad is not None:
+            names.append(n_); norms.append(p_.grad.double().norm().item())
+    fx["grad_names"] = np.array(names)
+    fx["grad_norms"] = np.array(norms, dtype=np.float64)
+    fx["grad_total_norm"] = np.float64(get_grad_norm_(model.parameters()).item())
+    # the oracle must reproduce the reference from the replayed noise (this is what pins the replay order)
+    ik, ir = torch.from_numpy(fx["ids_keep"]), torch.from_numpy(fx["ids_restore"])
+    sd = {k: v.clone().requires_grad_(False) for k, v in O.procedural_state_dict(cfg).items()}
+    with torch.no_grad():
+        ol, _, oenc, _ = O.forward_loss(cfg, sd, x, ik, ir, dp_noise=dp)
+    err = (oenc - captured["enc"].detach()).abs().max().item()
+    print(f"   oracle vs reference: enc max abs err {err:.3e}, loss {float(ol):.6f} vs {loss.item():.6f}; dropped samples per draw:",
+          [(torch.floor(1 - r + dp[j]) == 0).sum().item() for j, r in enumerate([r for r in rates if r > 0.0])])
+    assert err < 1e-4 and abs(float(ol) - loss.item()) < 1e-5 * abs(loss.item())
+    fx["meta"] = np.array(json.dumps(dict(cfg=cfg, B=B, K=K, data_seed=data_seed, mask_seed=mask_seed)))
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **fx)
 
 
 def run_train_curve(name, cfg, B, K, steps=5):
@@ -342,6 +401,9 @@ def main():
         "tiny2": lambda: run_case("tiny2", tiny_cfg(("bscan", "slo")), B=2, K=32, data_seed=12, mask_seed=22, keep_intermediate=True),
         "tiny3_curve": lambda: run_train_curve("tiny3_curve", tiny_cfg(three), B=4, K=24, steps=5),
         "harness": lambda: run_harness_fixtures(tiny_cfg(three)),
+        "tiny3_droppath": lambda: run_droppath_case("tiny3_droppath", dict(O.make_config(model="tiny", in_domains=three, input_size=64, patch_size=8,
+                                                    layermap_size=16, layermap_patch=2, decoder_dim=64, decoder_depth=2, decoder_heads=2,
+                                                    dim=128, depth=4, heads=2, drop_path_rate=0.4)), B=6, K=24, data_seed=13, mask_seed=23),
         "tiny_cls": lambda: run_cls_case("tiny_cls", tiny_cfg(("bscan",)), B=3),
         # BASELINE.json config 1: Base, 128/8, bscan only, B=2 (the reference's own CPU-runnable case), K=98 (run_pretraining.py:97)
         "c1_base": lambda: run_case("c1_base", O.make_config("base", ("bscan",), input_size=128, patch_size=8), B=2, K=98,
