@@ -219,6 +219,16 @@ int mrg_cast_bf16(const float* src, void* dst_bf16, long n, hipStream_t stream);
  * branch (backward of drop_path, mirage/utils.py:103-118). */
 int mrg_row_scale_bf16(const float* src, const float* row_scale, void* dst_bf16, long M, int D, hipStream_t stream);
 
+/* ---- F2: GPU-side pretraining augmentation (mutils/datasets_pretrain.py:18-83, DataAugmentationForMIRAGE.__call__) --------------
+ * One fused pass over a batch of uint8 samples [B, H, W]: horizontal flip (:41-42), intensity shift + clip to [0,1] (:43-48;
+ * image tasks), torchvision TF.affine(BILINEAR, fill=0) (:57-64; label maps take the same bilinear path and are rounded to
+ * integers, as the reference does).  params[b] = {t00, t01, t02, t10, t11, t12, shift, flip}: t = the inverse affine matrix of
+ * torchvision's _get_inverse_affine_matrix in centred pixel coordinates with row 0 divided by 0.5*W and row 1 by 0.5*H
+ * (what _gen_affine_grid feeds its bmm); shift = signed intensity shift (0 = none); flip != 0 mirrors the source along W.
+ * do_affine = 0 skips the resampling (args.affine false, :56).  Image output: fp32 [B, H, W] in [0,1]; label output: int64. */
+int mrg_augment_image(const uint8_t* src_u8, float* dst, const float* params, int B, int H, int W, int do_affine, hipStream_t stream);
+int mrg_augment_label(const uint8_t* src_u8, long* dst, const float* params, int B, int H, int W, int do_affine, hipStream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -93,6 +93,8 @@ SIGNATURES = {
     "mrg_step_inc": (ci, [vp, vp]),
     "mrg_cast_bf16": (ci, [vp, vp, cl, vp]),
     "mrg_row_scale_bf16": (ci, [vp, vp, vp, cl, ci, vp]),
+    "mrg_augment_image": (ci, [vp, vp, vp, ci, ci, ci, ci, vp]),
+    "mrg_augment_label": (ci, [vp, vp, vp, ci, ci, ci, ci, vp]),
 }
 
 if not os.path.exists(LIB_PATH):

@@ -1,0 +1,123 @@
+"""Pretraining data path: uint8 .npy samples go to the GPU as bytes (4x less PCIe than fp32) and the
+whole of DataAugmentationForMIRAGE.__call__ (reference mutils/datasets_pretrain.py:18-83) -- horizontal flip, intensity
+shift + clip, the shared random affine (full for bscan / bscanlayermap, x-translation + scale for the other tasks), bilinear
+resampling with zero fill, label rounding -- runs as one fused HIP pass per task (csrc/augment.hip).
+
+The random parameters are drawn on the host per sample in the reference's order of decisions (flip, then per image task the
+shift magnitude and its sign, then the affine parameters) from one numpy Generator per rank; the reference's own streams
+(`random`, `np.random`, torch, one per DataLoader worker) are not reproducible across worker layouts, so only the
+distributions and the parameter -> pixels map are part of the contract."""
+import math
+from typing import Dict, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+
+from . import kernels as K
+
+LABEL_TASKS = ("layermaps", "bscanlayermap")          # datasets_pretrain.py:43,65
+FULL_AFFINE_TASKS = ("bscan", "bscanlayermap")        # datasets_pretrain.py:51
+
+
+def inverse_affine_matrix(angle: float, translate: Sequence[float], scale: float, shear: Sequence[float]) -> Tuple[float, ...]:
+    """Output->input matrix of TF.affine for tensors with center=None (datasets_pretrain.py:57-64): torchvision 0.20.1
+    transforms.functional._get_inverse_affine_matrix in centre-relative pixel coordinates."""
+    rot = math.radians(angle)
+    sx, sy = math.radians(shear[0]), math.radians(shear[1])
+    tx, ty = float(translate[0]), float(translate[1])
+    a = math.cos(rot - sy) / math.cos(sy)
+    b = -math.cos(rot - sy) * math.tan(sx) / math.cos(sy) - math.sin(rot)
+    c = math.sin(rot - sy) / math.cos(sy)
+    d = -math.sin(rot - sy) * math.tan(sx) / math.cos(sy) + math.cos(rot)
+    m = [d / scale, -b / scale, 0.0, -c / scale, a / scale, 0.0]
+    m[2] += m[0] * (-tx) + m[1] * (-ty)
+    m[5] += m[3] * (-tx) + m[4] * (-ty)
+    return tuple(m)
+
+
+class RandomAffineParams:
+    """transforms.RandomAffine(degrees=10, translate=(0.1, 0.1), scale=(0.9, 1.1), shear=5).get_params(..., [512, 512])
+    (datasets_pretrain.py:24-31,37-40): angle U(-10,10) deg; tx, ty = round(U(-51.2, 51.2)) pixels -- always relative to
+    512, also for the 128x128 layer map; scale U(0.9,1.1); x-shear U(-5,5) deg, y-shear 0."""
+
+    def __init__(self, degrees=10.0, translate=(0.1, 0.1), scale=(0.9, 1.1), shear=5.0, img_size=(512, 512)):
+        self.degrees, self.translate, self.scale, self.shear, self.img_size = degrees, translate, scale, shear, img_size
+
+    def sample(self, rng: np.random.Generator):
+        angle = float(rng.uniform(-self.degrees, self.degrees))
+        max_dx, max_dy = float(self.translate[0] * self.img_size[0]), float(self.translate[1] * self.img_size[1])
+        tx = int(round(float(rng.uniform(-max_dx, max_dx))))
+        ty = int(round(float(rng.uniform(-max_dy, max_dy))))
+        sc = float(rng.uniform(self.scale[0], self.scale[1]))
+        return angle, (tx, ty), sc, (float(rng.uniform(-self.shear, self.shear)), 0.0)
+
+
+def task_affine_params(task: str, params):
+    """datasets_pretrain.py:51-56."""
+    angle, translate, sc, shear = params
+    if task in FULL_AFFINE_TASKS:
+        return angle, translate, sc, shear
+    return 0.0, (translate[0], 0), sc, (0.0, 0.0)
+
+
+def kernel_params(task: str, H: int, W: int, flip: bool, shift: float, affine_params) -> np.ndarray:
+    """The 8 floats mrg_augment_* takes per sample: theta / (0.5 W, 0.5 H) in fp32 as _gen_affine_grid computes it
+    (fp32 matrix, fp32 division), shift, flip."""
+    m = np.asarray(inverse_affine_matrix(*task_affine_params(task, affine_params)), dtype=np.float32)
+    half = np.asarray([0.5 * W, 0.5 * H], dtype=np.float32)
+    out = np.empty(8, dtype=np.float32)
+    out[0:3] = m[0:3] / half[0]
+    out[3:6] = m[3:6] / half[1]
+    out[6] = 0.0 if task in LABEL_TASKS else shift
+    out[7] = 1.0 if flip else 0.0
+    return out
+
+
+class DataAugmentationForMIRAGE:
+    """Batch-level GPU counterpart of the reference class of the same name (datasets_pretrain.py:18-83).  args fields used:
+    hflip (probability), intensity_shift (sigma), affine (bool), input_size (per-task target size; samples must already have
+    it -- the TF.resize branch of the reference is for differently sized raw data and is not implemented here)."""
+
+    def __init__(self, args, seed: int = 0):
+        self.args = args
+        self.hflip = float(getattr(args, "hflip", 0.5))
+        self.intensity_shift = float(getattr(args, "intensity_shift", 0.1))
+        self.do_affine = bool(getattr(args, "affine", True))
+        self.affine = RandomAffineParams()
+        self.rng = np.random.default_rng(seed)
+
+    def draw(self, tasks: Sequence[str], B: int):
+        """Per-sample decisions in the reference's order (:34-48): flip, affine parameters, then per image task the shift
+        magnitude |N(0, sigma)| and its sign."""
+        flips, affs, shifts = [], [], {t: np.zeros(B, dtype=np.float32) for t in tasks}
+        for b in range(B):
+            flips.append(bool(self.rng.random() < self.hflip))
+            affs.append(self.affine.sample(self.rng))
+            for t in tasks:
+                if self.intensity_shift > 0 and t not in LABEL_TASKS:
+                    s = np.float32(self.rng.normal(0.0, self.intensity_shift))
+                    if self.rng.random() < 0.5:
+                        s = -s
+                    shifts[t][b] = s
+        return flips, affs, shifts
+
+    def apply(self, batch_u8: Dict[str, torch.Tensor], flips, affs, shifts) -> Dict[str, torch.Tensor]:
+        out = {}
+        for t, src in batch_u8.items():
+            if src.dtype != torch.uint8 or src.dim() != 3:
+                raise ValueError(f"mirage_amd.data: task {t!r} must be a uint8 [B, H, W] tensor, got {src.dtype} {tuple(src.shape)}")
+            B, H, W = src.shape
+            want = getattr(self.args, "input_size", {}).get(t) if isinstance(getattr(self.args, "input_size", None), dict) else None
+            if want is not None and tuple(want) != (H, W):
+                raise NotImplementedError(f"mirage_amd.data: task {t!r} is {H}x{W}, expected {tuple(want)} (resize is not implemented)")
+            prm = np.stack([kernel_params(t, H, W, flips[b], float(shifts[t][b]), affs[b]) for b in range(B)])
+            prm = torch.from_numpy(prm).to(src.device, non_blocking=True)
+            if t in LABEL_TASKS:
+                out[t] = K.augment_label(src, prm, self.do_affine)
+            else:
+                out[t] = K.augment_image(src, prm, self.do_affine).unsqueeze(1)
+        return out
+
+    def __call__(self, batch_u8: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
+        B = next(iter(batch_u8.values())).shape[0]
+        return self.apply(batch_u8, *self.draw(list(batch_u8.keys()), B))

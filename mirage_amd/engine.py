@@ -347,6 +347,11 @@ def decoder_fwd(ad, enc32: torch.Tensor, enc16: torch.Tensor, ids_keep, ids_rest
     task_embs = [ad.task_embeddings[n] if (ad.task_embeddings is not None and n in ad.task_embeddings) else None for n in dom_names]
     pos = _pos_tokens(ad)
     Tq = pos.shape[0]
+    # generate_context_embeddings interpolates pos_emb to THIS adapter's grid and asserts every context task has that many
+    # tokens (mirage/output_adapters.py:176-179): mixed token grids are an error in the reference too
+    for i, n in enumerate(dom_names):
+        nt = dom_start[i + 1] - dom_start[i]
+        assert nt == Tq, f"# tokens ({nt}) != # pos. embeddings ({Tq})"
     q_te = None
     if qdom < 0 and ad.task_embeddings is not None and ad.task in ad.task_embeddings:
         q_te = ad.task_embeddings[ad.task]

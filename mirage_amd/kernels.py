@@ -411,3 +411,27 @@ def row_scale_bf16(src: torch.Tensor, row_scale: torch.Tensor) -> torch.Tensor:
     dst = torch.empty(src.shape, dtype=BF16, device=src.device)
     check(lib.mrg_row_scale_bf16(src.data_ptr(), row_scale.data_ptr(), dst.data_ptr(), M, D, _s()), "mrg_row_scale_bf16")
     return dst
+
+
+# ------------------------------------------------------------------------------------------- data path (F2)
+def _augment(src: torch.Tensor, params: torch.Tensor, do_affine: bool, label: bool) -> torch.Tensor:
+    _need_cuda(src, "augmentation input")
+    assert src.dtype == torch.uint8 and src.is_contiguous() and params.dtype == F32 and params.is_contiguous()
+    B, H, W = src.shape
+    assert params.shape == (B, 8)
+    dst = torch.empty((B, H, W), dtype=torch.int64 if label else F32, device=src.device)
+    fn = lib.mrg_augment_label if label else lib.mrg_augment_image
+    check(fn(src.data_ptr(), dst.data_ptr(), params.data_ptr(), B, H, W, int(bool(do_affine)), _s()),
+          "mrg_augment_label" if label else "mrg_augment_image")
+    return dst
+
+
+def augment_image(src_u8: torch.Tensor, params: torch.Tensor, do_affine: bool = True) -> torch.Tensor:
+    """uint8 [B, H, W] -> fp32 [B, H, W] in [0, 1]: flip, intensity shift + clip, bilinear affine with zero fill."""
+    return _augment(src_u8, params, do_affine, False)
+
+
+def augment_label(src_u8: torch.Tensor, params: torch.Tensor, do_affine: bool = True) -> torch.Tensor:
+    """uint8 [B, H, W] class ids -> int64 [B, H, W]: flip, bilinear affine + round (the reference's label path)."""
+    return _augment(src_u8, params, do_affine, True)
+

@@ -72,6 +72,12 @@ def get_args(argv=None):
     p.add_argument("--no_auto_resume", action="store_false", dest="auto_resume")
     p.add_argument("--start_epoch", default=0, type=int)
     p.add_argument("--weights", default="", type=str, help="optional initial weights (.pth with a 'model' entry)")
+    p.add_argument("--hflip", type=float, default=0.5, help="probability of a horizontal flip (run_pretraining.py:224)")
+    p.add_argument("--intensity_shift", type=float, default=0.1, help="sigma of the random intensity shift (run_pretraining.py:228)")
+    p.add_argument("--affine", action="store_true", help="random affine transformations (run_pretraining.py:240-244)")
+    p.add_argument("--no_affine", action="store_false", dest="affine")
+    p.set_defaults(affine=True)
+    p.add_argument("--no_augment", action="store_true", help="feed the .npy samples unchanged (no flip / shift / affine)")
     p.add_argument("--data_path", required=True, type=str, help="'synthetic' or a folder with <domain>/*.npy")
     p.add_argument("--steps_per_epoch", default=None, type=int, help="synthetic data only")
     p.add_argument("--no_graph", action="store_true", help="run the step eagerly instead of replaying a hipGraph")
@@ -121,10 +127,13 @@ class SyntheticData:
 
 
 class NpyFolderData:
-    """<root>/<domain>/*.npy, uint8 images scaled to [0,1] / integer layer maps (mutils/datasets_pretrain.py:86-207 without the
-    CPU augmentation pipeline, which is outside this round's scope).  Samples are matched by sorted file order."""
+    """<root>/<domain>/*.npy, uint8 images / integer layer maps (mutils/datasets_pretrain.py:86-207, dataset_folder.py:32-51).
+    Samples are matched by sorted file order, shipped to the GPU as bytes and augmented there by
+    mirage_amd.data.DataAugmentationForMIRAGE (the reference's CPU transform of the same name, datasets_pretrain.py:18-83)."""
 
     def __init__(self, args, device, rank, world, seed):
+        from .data import DataAugmentationForMIRAGE
+        self.augment = None if getattr(args, "no_augment", False) else DataAugmentationForMIRAGE(args, seed=seed * 1000 + rank)
         self.files = {d: sorted(glob.glob(os.path.join(args.data_path, d, "*.npy"))) for d in args.all_domains}
         n = min(len(v) for v in self.files.values())
         assert n > 0, f"no .npy files under {args.data_path}/<domain>/"
@@ -143,12 +152,14 @@ class NpyFolderData:
             ids = perm[(s * self.world + self.rank) * B:(s * self.world + self.rank + 1) * B]
             b = {}
             for d in self.args.all_domains:
-                arrs = [np.load(self.files[d][i]) for i in ids]
-                if d == "bscanlayermap":
-                    b[d] = torch.from_numpy(np.stack(arrs).astype(np.int64)).to(self.device)
+                arrs = np.stack([np.load(self.files[d][i]) for i in ids])
+                if self.augment is not None:
+                    b[d] = torch.from_numpy(np.ascontiguousarray(arrs.astype(np.uint8))).to(self.device)
+                elif d == "bscanlayermap":
+                    b[d] = torch.from_numpy(arrs.astype(np.int64)).to(self.device)
                 else:
-                    b[d] = (torch.from_numpy(np.stack(arrs).astype(np.float32)) / 255.0).unsqueeze(1).to(self.device)
-            yield b
+                    b[d] = (torch.from_numpy(arrs.astype(np.float32)) / 255.0).unsqueeze(1).to(self.device)
+            yield self.augment(b) if self.augment is not None else b
 
 
 def save_model(args, epoch, model, optimizer):

@@ -209,3 +209,16 @@ def test_drop_path_training_parity():
         p_eval2, _ = model({d: x[d] for d in doms}, num_encoded_tokens=Kk, mask_noise=noise, drop_path_noise=dpn)
     for d in p_eval:
         assert torch.equal(p_eval[d], p_eval2[d])
+
+
+def test_mixed_token_grids_raise_like_the_reference():
+    """The reference asserts that every context task has as many tokens as the decoding adapter's grid
+    (mirage/output_adapters.py:176-179); the HIP path must fail the same way, not read out of bounds."""
+    from mirage_amd import builder
+    args = builder.make_args(("bscan", "bscanlayermap"), input_size=64, patch_size=8, layermap_size=128, layermap_patch=8,
+                             decoder_dim=64, decoder_depth=1, decoder_num_heads=2)
+    model = builder.get_model(args, dim_tokens=128, depth=1, num_heads=2).to(DEV)
+    x = {"bscan": torch.rand(2, 1, 64, 64, device=DEV), "bscanlayermap": torch.randint(0, 13, (2, 128, 128), device=DEV)}
+    with pytest.raises(AssertionError, match="# tokens"):
+        model(x, num_encoded_tokens=32)
+    torch.cuda.synchronize()
