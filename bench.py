@@ -112,6 +112,9 @@ def cpu_baseline(model_name, doms, K, train, budget_s=25.0):
 
 
 def main():
+    if os.environ.get("MRG_SIDE_BLOCKS"):          # experiment knob: transformer blocks per side-stream fork
+        from mirage_amd import engine as _E
+        _E._Side.blocks_per_flush = int(os.environ["MRG_SIDE_BLOCKS"])
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)

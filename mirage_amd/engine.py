@@ -31,25 +31,53 @@ class _Side:
     stream = None
     keep = []          # tensors read by side-stream kernels stay referenced until the join
     pending = False
+    queue = []         # deferred jobs: one fork (event + cross-stream edge) per flush instead of one per Linear -- inside a
+                       # hipGraph every cross-stream edge costs ~16 us of dependent-launch latency on this runtime
+    blocks_per_flush = 4
+    _blocks = 0
+    origin = None      # stream the queued jobs were produced on (the decoders' lanes queue from their own streams)
 
     @classmethod
     def run(cls, fn, *tensors):
+        """Queue fn for the side stream; it is issued at the next flush() (end of a transformer block's backward, end of a
+        decoder's backward, or join())."""
         if not cls.enabled:
             fn()
             return
-        main = torch.cuda.current_stream()
+        cur = torch.cuda.current_stream()
+        if cls.queue and cls.origin != cur:
+            cls.flush()                      # jobs queued from another stream must fork from THAT stream
+        cls.origin = cur
+        cls.queue.append(fn)
+        cls.keep.extend(tensors)
+
+    @classmethod
+    def flush(cls):
+        if not cls.queue:
+            return
+        main = cls.origin
         if cls.stream is None or cls.stream.device != main.device:
             cls.stream = torch.cuda.Stream(device=main.device)
         ev = torch.cuda.Event()
         ev.record(main)
+        jobs, cls.queue = cls.queue, []
         with torch.cuda.stream(cls.stream):
             cls.stream.wait_event(ev)
-            fn()
-        cls.keep.extend(tensors)
+            for fn in jobs:
+                fn()
         cls.pending = True
 
     @classmethod
+    def block_done(cls):
+        cls._blocks += 1
+        if cls._blocks >= cls.blocks_per_flush:
+            cls._blocks = 0
+            cls.flush()
+
+    @classmethod
     def join(cls):
+        cls.flush()
+        cls._blocks = 0
         if cls.pending:
             torch.cuda.current_stream().wait_stream(cls.stream)
             cls.keep.clear()
@@ -168,6 +196,7 @@ def block_bwd(blk, saved, dx32: torch.Tensor, dx16: Optional[torch.Tensor]):
     d_ln1, _ = lin_bwd(d_qkv, ln1, blk.attn.qkv)
     dx_in32, dx_in16 = K.ln_bwd(d_ln1, x_in, mean1, rstd1, blk.norm1.weight, dx_mid32, grad_buffer(blk.norm1.weight),
                                 grad_buffer(blk.norm1.bias), None if dp is not None else grad_buffer(blk.attn.proj.bias))
+    _Side.block_done()
     return dx_in32, dx_in16
 
 
