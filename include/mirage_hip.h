@@ -82,6 +82,8 @@ typedef struct mrg_gemm_desc {
     const float* row_scale;          /* optional [M]: (acc + bias -> act) is multiplied by row_scale[row] before add_tab / resid are
                                         added -- stochastic depth, x + drop_path(f(x)) (mirage/utils.py:103-118,259-262);
                                         not combinable with splitk > 1 */
+    int defer_reduce;                /* splitk > 1 only: leave the split-K slabs ws[splitk][M*N] unreduced -- the caller sums them
+                                        later with mrg_reduce_batch (C must be contiguous fp32, no bias / accumulate / C2) */
 } mrg_gemm_desc;
 enum { MRG_GEMM_AUTO = 0, MRG_GEMM_GLDS3 = 1, MRG_GEMM_GLDS4 = 2, MRG_GEMM_PIPE128 = 3, MRG_GEMM_PIPE256 = 4, MRG_GEMM_PIPE256X3 = 5, MRG_GEMM_PIPE256SQ = 6 };
 
@@ -98,6 +100,13 @@ int mrg_gemm(const mrg_gemm_desc* d, hipStream_t stream);
 int mrg_ln_fwd(const float* x, const float* gamma, const float* beta, void* y_bf16, float* y_f32, float* mean, float* rstd,
                int M, int D, float eps, hipStream_t stream);
 int mrg_ln_bwd_nblocks(int M);
+int mrg_ln_bwd_partial_rows(int M, int D);   /* rows of `partials` mrg_ln_bwd actually writes (<= mrg_ln_bwd_nblocks(M)) */
+/* Batched slice reduction: for every task dst[i] = sum_{s < nslices} src[s * stride + i], i < n (fp32; n and stride multiples
+ * of 4, 16-byte aligned).  One or two launches for the whole table: it finishes the split-K slabs of deferred weight-gradient
+ * GEMMs (mrg_gemm defer_reduce) and the partial column sums mrg_ln_bwd / mrg_colsum leave behind when called with null
+ * outputs (partials [nb][3][D] resp. [nb][N]).  `tasks` is host memory and is copied into the kernel arguments. */
+typedef struct mrg_reduce_task { const float* src; float* dst; long n; long stride; int nslices; int reserved; } mrg_reduce_task;
+int mrg_reduce_batch(const mrg_reduce_task* tasks, int ntasks, hipStream_t stream);
 int mrg_ln_bwd(const void* dy_bf16, const float* dy_f32, const float* x, const float* mean, const float* rstd,
                const float* gamma, const float* dres, float* dx_f32, void* dx_bf16, float* partials, float* dgamma,
                float* dbeta, float* dres_colsum, int M, int D, hipStream_t stream);

@@ -28,7 +28,7 @@ class GemmDesc(C.Structure):
                 ("C", vp), ("ldc", ci), ("c_dtype", ci), ("C2", vp), ("ldc2", ci), ("bias", vp),
                 ("resid", vp), ("ldr", ci), ("accumulate", ci), ("act", ci),
                 ("aux_out", vp), ("aux_in", vp), ("ldaux", ci), ("row_map", vp),
-                ("add_tab", vp), ("add_row", vp), ("ldt", ci), ("splitk", ci), ("ws", vp), ("variant", ci), ("ev_start", vp), ("ev_stop", vp), ("row_scale", vp)]
+                ("add_tab", vp), ("add_row", vp), ("ldt", ci), ("splitk", ci), ("ws", vp), ("variant", ci), ("ev_start", vp), ("ev_stop", vp), ("row_scale", vp), ("defer_reduce", ci)]
 
 
 class AttnDesc(C.Structure):
@@ -93,6 +93,8 @@ SIGNATURES = {
     "mrg_step_inc": (ci, [vp, vp]),
     "mrg_cast_bf16": (ci, [vp, vp, cl, vp]),
     "mrg_row_scale_bf16": (ci, [vp, vp, vp, cl, ci, vp]),
+    "mrg_ln_bwd_partial_rows": (ci, [ci, ci]),
+    "mrg_reduce_batch": (ci, [vp, ci, vp]),
     "mrg_augment_image": (ci, [vp, vp, vp, ci, ci, ci, ci, vp]),
     "mrg_augment_label": (ci, [vp, vp, vp, ci, ci, ci, ci, vp]),
 }

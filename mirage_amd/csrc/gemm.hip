@@ -991,7 +991,11 @@ extern "C" int mrg_gemm(const mrg_gemm_desc* d, hipStream_t stream) {
     if (d->ev_stop) (void)hipEventRecord((hipEvent_t)d->ev_stop, stream);
     int rc = mrg_check_launch("mrg_gemm");
     if (rc) return rc;
-    if (splitk > 1) {
+    if (splitk > 1 && d->defer_reduce) {
+        // the caller sums the split-K slabs ws[splitk][M*N] itself (mrg_reduce_batch): plain fp32 overwrite only
+        MRG_REQUIRE(g.c_f32 && !d->accumulate && !d->bias && !d->C2 && d->ldc == d->N, MRG_ERR_UNSUPPORTED,
+                    "mrg_gemm: defer_reduce needs a contiguous fp32 C without bias / accumulate / C2");
+    } else if (splitk > 1) {
         const long mn = (long)d->M * d->N;
         const int nb = (int)((mn + 255) / 256 < 2048 ? (mn + 255) / 256 : 2048);
         hipLaunchKernelGGL(splitk_reduce_kernel, dim3(nb), dim3(256), 0, stream, d->ws, splitk, mn, d->N, (float*)d->C, d->ldc,

@@ -245,6 +245,65 @@ __global__ __launch_bounds__(256) void colsum_kernel(const bf16_t* __restrict__ 
     if (wave == 0 && c < N) partials[(long)blockIdx.y * N + c] = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
 }
 
+// ---- batched slice reductions: dst[i] = sum_s src[s * stride + i] for a table of independent tasks in ONE launch ----------
+// (split-K partials of the weight gradients, LayerNorm / bias column-sum partials: ~165 tiny launches per training step
+// otherwise).  Tasks travel by value in the kernel arguments, so a hipGraph node carries them without a staging copy.
+constexpr int RB_TASKS = 64;
+struct RbTask { const float* src; float* dst; long n4; long stride4; int ns; int first_block; };
+struct RbArgs { RbTask t[RB_TASKS]; int ntasks; };
+
+__device__ __forceinline__ int rb_find(const RbArgs& a, int bid) {
+    int lo = 0, hi = a.ntasks - 1;
+    while (lo < hi) {                       // last task whose first_block <= bid
+        const int mid = (lo + hi + 1) >> 1;
+        if (a.t[mid].first_block <= bid) lo = mid; else hi = mid - 1;
+    }
+    return lo;
+}
+
+// few slices, many outputs (split-K): one float4 column per thread, slices summed in order
+__global__ __launch_bounds__(256) void reduce_batch_wide_kernel(const RbArgs a) {
+    const int ti = rb_find(a, blockIdx.x);
+    const RbTask t = a.t[ti];
+    const long i = (long)(blockIdx.x - t.first_block) * 256 + threadIdx.x;
+    if (i >= t.n4) return;
+    const float4* s = reinterpret_cast<const float4*>(t.src) + i;
+    float4 acc = s[0];
+    for (int z = 1; z < t.ns; ++z) {
+        const float4 v = s[(long)z * t.stride4];
+        acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+    }
+    reinterpret_cast<float4*>(t.dst)[i] = acc;
+}
+
+// many slices, few outputs (column-sum partials): 64 float4 columns per workgroup, 16 waves split the slices
+__global__ __launch_bounds__(1024) void reduce_batch_tall_kernel(const RbArgs a) {
+    __shared__ float4 red[16][64];
+    const int ti = rb_find(a, blockIdx.x);
+    const RbTask t = a.t[ti];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const long i = (long)(blockIdx.x - t.first_block) * 64 + lane;
+    float4 s0 = make_float4(0.f, 0.f, 0.f, 0.f), s1 = s0;
+    if (i < t.n4) {
+        const float4* s = reinterpret_cast<const float4*>(t.src) + i;
+        int z = wave;
+        for (; z + 16 < t.ns; z += 32) {
+            const float4 u = s[(long)z * t.stride4], v = s[(long)(z + 16) * t.stride4];
+            s0.x += u.x; s0.y += u.y; s0.z += u.z; s0.w += u.w;
+            s1.x += v.x; s1.y += v.y; s1.z += v.z; s1.w += v.w;
+        }
+        for (; z < t.ns; z += 16) { const float4 u = s[(long)z * t.stride4]; s0.x += u.x; s0.y += u.y; s0.z += u.z; s0.w += u.w; }
+    }
+    red[wave][lane] = make_float4(s0.x + s1.x, s0.y + s1.y, s0.z + s1.z, s0.w + s1.w);
+    __syncthreads();
+    if (wave == 0 && i < t.n4) {
+        float4 r = red[0][lane];
+#pragma unroll
+        for (int w = 1; w < 16; ++w) { const float4 v = red[w][lane]; r.x += v.x; r.y += v.y; r.z += v.z; r.w += v.w; }
+        reinterpret_cast<float4*>(t.dst)[i] = r;
+    }
+}
+
 }  // namespace
 
 extern "C" int mrg_ln_fwd(const float* x, const float* gamma, const float* beta, void* y_bf16, float* y_f32, float* mean,
@@ -265,6 +324,12 @@ extern "C" int mrg_ln_bwd_nblocks(int M) {
     return nb;
 }
 
+extern "C" int mrg_ln_bwd_partial_rows(int M, int D) {
+    int nb = mrg_ln_bwd_nblocks(M);
+    if ((D + 255) / 256 >= 4 && nb > 512) nb = 512;   // 4-chunk rows need > 168 VGPRs: 2 workgroups per CU
+    return nb;
+}
+
 extern "C" int mrg_ln_bwd(const void* dy_bf16, const float* dy_f32, const float* x, const float* mean, const float* rstd,
                           const float* gamma, const float* dres, float* dx_f32, void* dx_bf16, float* partials, float* dgamma,
                           float* dbeta, float* dres_colsum, int M, int D, hipStream_t stream) {
@@ -272,10 +337,9 @@ extern "C" int mrg_ln_bwd(const void* dy_bf16, const float* dy_f32, const float*
                 "mrg_ln_bwd: null pointer");
     MRG_REQUIRE(M > 0 && D > 0 && D % 4 == 0 && D <= 1024, MRG_ERR_SHAPE, "mrg_ln_bwd: need D %% 4 == 0 and D <= 1024 (D=%d)", D);
     MRG_REQUIRE(!dres_colsum || dres, MRG_ERR_ARG, "mrg_ln_bwd: dres_colsum without dres");
-    int nb = mrg_ln_bwd_nblocks(M);
+    const int nb = mrg_ln_bwd_partial_rows(M, D);
     const void* dyp = dy_bf16 ? dy_bf16 : (const void*)dy_f32;
     const int NVr = (D + 255) / 256;
-    if (NVr >= 4 && nb > 512) nb = 512;   // 4-chunk rows need > 168 VGPRs: 2 workgroups per CU
 #define MRG_LNB(NV_, D16, RES) hipLaunchKernelGGL((ln_bwd_kernel<NV_, D16, RES>), dim3(nb), dim3(256), 0, stream, dyp, x, mean, rstd, \
                                                    gamma, dres, dx_f32, (bf16_t*)dx_bf16, partials, M, D)
 #define MRG_LNB2(NV_) do { if (dy_bf16) { if (dres) MRG_LNB(NV_, true, true); else MRG_LNB(NV_, true, false); } \
@@ -285,6 +349,7 @@ extern "C" int mrg_ln_bwd(const void* dy_bf16, const float* dy_f32, const float*
 #undef MRG_LNB
     int rc = mrg_check_launch("mrg_ln_bwd");
     if (rc) return rc;
+    if (!dgamma && !dbeta && !dres_colsum) return MRG_OK;   // partials [nb][3][D] left to the caller (mrg_reduce_batch)
     hipLaunchKernelGGL(colsum_partials_kernel, dim3(cdiv(D, 64), 3), dim3(1024), 0, stream, partials, nb, 3, D, dgamma, dbeta,
                        dres_colsum);
     return mrg_check_launch("mrg_ln_bwd/colsum_partials");
@@ -299,7 +364,7 @@ extern "C" int mrg_colsum_nblocks(int M) {
 
 extern "C" int mrg_colsum(const void* x, int x_dtype, int M, int N, int ld, const int* row_map, const int* m_dev, float* partials,
                           float* out, hipStream_t stream) {
-    MRG_REQUIRE(x && partials && out, MRG_ERR_ARG, "mrg_colsum: null pointer");
+    MRG_REQUIRE(x && partials, MRG_ERR_ARG, "mrg_colsum: null pointer");
     MRG_REQUIRE(M > 0 && N > 0, MRG_ERR_SHAPE, "mrg_colsum: bad shape");
     const int nb = mrg_colsum_nblocks(M);
     const bool is16 = x_dtype == MRG_DT_BF16;
@@ -316,7 +381,42 @@ extern "C" int mrg_colsum(const void* x, int x_dtype, int M, int N, int ld, cons
     }
     int rc = mrg_check_launch("mrg_colsum");
     if (rc) return rc;
+    if (!out) return MRG_OK;                                 // partials [nb][N] left to the caller (mrg_reduce_batch)
     hipLaunchKernelGGL(colsum_partials_kernel, dim3(cdiv(N, 64), 1), dim3(1024), 0, stream, partials, nb, 1, N, out, (float*)nullptr,
                        (float*)nullptr);
     return mrg_check_launch("mrg_colsum/colsum_partials");
+}
+
+extern "C" int mrg_reduce_batch(const mrg_reduce_task* tasks, int ntasks, hipStream_t stream) {
+    MRG_REQUIRE(tasks && ntasks > 0, MRG_ERR_ARG, "mrg_reduce_batch: no tasks");
+    for (int pass = 0; pass < 2; ++pass) {                 // pass 0: wide (few slices), pass 1: tall
+        RbArgs a;
+        a.ntasks = 0;
+        long nblocks = 0;
+        auto flush = [&]() -> int {
+            if (a.ntasks == 0) return MRG_OK;
+            if (pass == 0) hipLaunchKernelGGL(reduce_batch_wide_kernel, dim3((unsigned)nblocks), dim3(256), 0, stream, a);
+            else hipLaunchKernelGGL(reduce_batch_tall_kernel, dim3((unsigned)nblocks), dim3(1024), 0, stream, a);
+            a.ntasks = 0;
+            nblocks = 0;
+            return mrg_check_launch("mrg_reduce_batch");
+        };
+        for (int i = 0; i < ntasks; ++i) {
+            const mrg_reduce_task& t = tasks[i];
+            MRG_REQUIRE(t.src && t.dst && t.n > 0 && t.nslices > 0, MRG_ERR_ARG, "mrg_reduce_batch: bad task %d", i);
+            MRG_REQUIRE(t.n % 4 == 0 && t.stride % 4 == 0 && ((((uintptr_t)t.src) | ((uintptr_t)t.dst)) & 15) == 0, MRG_ERR_SHAPE,
+                        "mrg_reduce_batch: task %d is not 16-byte aligned / a multiple of 4 floats", i);
+            const bool tall = t.nslices >= 32;
+            if (tall != (pass == 1)) continue;
+            const long n4 = t.n / 4;
+            const long nb = tall ? (n4 + 63) / 64 : (n4 + 255) / 256;
+            if (a.ntasks == RB_TASKS || nblocks + nb > 0x7fffffffl) { int rc = flush(); if (rc) return rc; }
+            a.t[a.ntasks] = RbTask{t.src, t.dst, n4, t.stride / 4, t.nslices, (int)nblocks};
+            a.ntasks += 1;
+            nblocks += nb;
+        }
+        int rc = flush();
+        if (rc) return rc;
+    }
+    return MRG_OK;
 }

@@ -75,13 +75,32 @@ class _Side:
             cls.flush()
 
     @classmethod
+    def begin_backward(cls):
+        """Entry of a hand-written backward pass: from here until join() the slice reductions behind weight / bias / LayerNorm
+        gradients are collected and issued as one batched launch (kernels.Deferred)."""
+        if cls.enabled:
+            K.Deferred.active = True
+
+    @classmethod
     def join(cls):
         cls.flush()
         cls._blocks = 0
+        if K.Deferred.tasks:
+            main = torch.cuda.current_stream()
+            if cls.pending:
+                ev = torch.cuda.Event()
+                ev.record(main)                  # LayerNorm / column-sum partials were produced on the calling stream
+                with torch.cuda.stream(cls.stream):
+                    cls.stream.wait_event(ev)
+                    K.Deferred.flush()
+            else:
+                K.Deferred.flush()
+        K.Deferred.active = False
         if cls.pending:
             torch.cuda.current_stream().wait_stream(cls.stream)
             cls.keep.clear()
             cls.pending = False
+        K.Deferred.release()
 
 
 def join_side_stream():
@@ -212,6 +231,7 @@ class BlockFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dout):
+        _Side.begin_backward()
         dx32, _ = block_bwd(ctx.blk, ctx.saved, dout.contiguous().float(), None)
         ctx.saved = None
         _Side.join()
@@ -240,6 +260,7 @@ class EncoderFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dout, _unused):
+        _Side.begin_backward()
         dx32 = dout.contiguous()
         dx16 = None
         for blk, sv in zip(reversed(ctx.blocks), reversed(ctx.saved)):
@@ -353,6 +374,7 @@ class EmbedFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dx):
+        _Side.begin_backward()
         dx = dx.contiguous()
         embed_bwd(ctx.model, ctx.saved, dx, _twin_of(dx))
         ctx.saved = None
@@ -521,6 +543,7 @@ class DecodersFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, *d_imgs):
+        _Side.begin_backward()
         dev = next(d for d in d_imgs if d is not None).device
         d_enc = torch.empty(ctx.shape, dtype=F32, device=dev)
         todo = [(ad, sv, d_img) for ad, sv, d_img in zip(ctx.adapters, ctx.saved, d_imgs) if d_img is not None]

@@ -65,14 +65,60 @@ def save_tune_cache(path: str = _TUNE_FILE) -> None:
         json.dump({json.dumps([int(x) if not isinstance(x, bool) else x for x in k]): list(v) for k, v in sorted(_tune_cache.items())}, f, indent=0)
 
 
+class ReduceTask(C.Structure):
+    _fields_ = [("src", C.c_void_p), ("dst", C.c_void_p), ("n", C.c_long), ("stride", C.c_long), ("nslices", C.c_int), ("reserved", C.c_int)]
+
+
+class Deferred:
+    """Slice reductions postponed to one batched launch (mrg_reduce_batch): the split-K slabs of weight-gradient GEMMs and the
+    partial column sums of LayerNorm / bias gradients.  Nothing reads those results before the optimizer, so ~165 tiny
+    kernels per training step collapse into one or two.  `active` is switched on by the backward orchestration
+    (engine._Side) for the duration of a backward pass; stand-alone kernel calls reduce immediately."""
+    active = False
+    tasks = []        # (src tensor, byte offset, dst tensor, n, stride, nslices)
+    keep = []
+
+    @classmethod
+    def add(cls, src: torch.Tensor, src_off_elems: int, dst: torch.Tensor, n: int, stride: int, nslices: int):
+        cls.tasks.append((src.data_ptr() + 4 * src_off_elems, dst.data_ptr(), n, stride, nslices))
+        cls.keep.append(src); cls.keep.append(dst)
+
+    @classmethod
+    def ok(cls, dst: torch.Tensor, n: int, stride: int) -> bool:
+        return cls.active and dst is not None and dst.dtype == F32 and dst.is_contiguous() and n % 4 == 0 and stride % 4 == 0 \
+            and dst.data_ptr() % 16 == 0
+
+    @classmethod
+    def flush(cls):
+        if not cls.tasks:
+            return
+        arr = (ReduceTask * len(cls.tasks))()
+        for i, (src, dst, n, stride, ns) in enumerate(cls.tasks):
+            arr[i].src, arr[i].dst, arr[i].n, arr[i].stride, arr[i].nslices = src, dst, n, stride, ns
+        check(lib.mrg_reduce_batch(C.cast(arr, C.c_void_p), len(cls.tasks), _s()), "mrg_reduce_batch")
+        cls.tasks = []
+
+    @classmethod
+    def release(cls):
+        cls.keep = []
+
+
 TIMING = {"on": False, "records": []}     # bench.py: (kernel variant, mode, flops, start event, stop event) per GEMM launch
 
 
-def _gemm_launch(d, splitk, variant, dev):
+def _gemm_launch(d, splitk, variant, dev, defer_out=None):
     d.splitk = splitk
     d.variant = variant
+    d.defer_reduce = 0
     if splitk > 1:
-        d.ws = _workspace(splitk * d.M * d.N * 4, dev).data_ptr()
+        if defer_out is not None:
+            # own slab (kept alive until the batched reduction) instead of the shared workspace
+            ws = torch.empty(splitk * d.M * d.N, dtype=F32, device=dev)
+            d.ws = ws.data_ptr()
+            d.defer_reduce = 1
+            Deferred.add(ws, 0, defer_out, d.M * d.N, d.M * d.N, splitk)
+        else:
+            d.ws = _workspace(splitk * d.M * d.N * 4, dev).data_ptr()
     check(lib.mrg_gemm(C.byref(d), _s()), "mrg_gemm")
 
 
@@ -157,7 +203,10 @@ def gemm(A: torch.Tensor, B: torch.Tensor, M: int, N: int, K: int, *, a_mode=L.M
         st.record(); en.record()                                   # creates the underlying hipEvent_t handles
         d.ev_start, d.ev_stop = st.cuda_event, en.cuda_event
         TIMING["records"].append((variant, (a_mode, b_mode), 2.0 * M * N * K, st, en, (M, N, K, splitk)))
-    _gemm_launch(d, splitk, variant, A.device)
+    defer = None
+    if splitk > 1 and bias is None and not accumulate and out2 is None and d.ldc == N and (M * N) % 4 == 0 and Deferred.ok(out, M * N, M * N):
+        defer = out
+    _gemm_launch(d, splitk, variant, A.device, defer)
     return out
 
 
@@ -194,11 +243,18 @@ def ln_bwd(dy: torch.Tensor, x, mean, rstd, gamma, dres, dgamma, dbeta, dres_col
     M = x.numel() // D
     dx32 = torch.empty(x.shape, dtype=F32, device=x.device) if want_f32 else None
     dx16 = torch.empty(x.shape, dtype=BF16, device=x.device) if want_bf16 else None
-    nb = lib.mrg_ln_bwd_nblocks(M)
+    nb = lib.mrg_ln_bwd_partial_rows(M, D)
     partials = torch.empty(nb * 3 * D, dtype=F32, device=x.device)
+    outs = (dgamma, dbeta, dres_colsum)
+    defer = Deferred.active and D % 4 == 0 and all(o is None or Deferred.ok(o, D, 3 * D) for o in outs) and any(o is not None for o in outs)
     check(lib.mrg_ln_bwd(dy.data_ptr() if dy.dtype == BF16 else None, dy.data_ptr() if dy.dtype == F32 else None, x.data_ptr(),
                          mean.data_ptr(), rstd.data_ptr(), gamma.data_ptr(), _p(dres), _p(dx32), _p(dx16), partials.data_ptr(),
-                         _p(dgamma), _p(dbeta), _p(dres_colsum), M, D, _s()), "mrg_ln_bwd")
+                         None if defer else _p(dgamma), None if defer else _p(dbeta), None if defer else _p(dres_colsum), M, D, _s()),
+          "mrg_ln_bwd")
+    if defer:
+        for q, o in enumerate(outs):
+            if o is not None:
+                Deferred.add(partials, q * D, o, D, 3 * D, nb)
     return dx32, dx16
 
 
@@ -207,8 +263,11 @@ def colsum(x: torch.Tensor, out: torch.Tensor, M: Optional[int] = None, row_map=
     M = M if M is not None else x.numel() // N
     nb = lib.mrg_colsum_nblocks(M)
     partials = torch.empty(nb * N, dtype=F32, device=x.device)
+    defer = Deferred.ok(out, N, N)
     check(lib.mrg_colsum(x.data_ptr(), L.MRG_DT_BF16 if x.dtype == BF16 else L.MRG_DT_F32, M, N, x.stride(-2), _p(row_map),
-                         _p(m_dev), partials.data_ptr(), out.data_ptr(), _s()), "mrg_colsum")
+                         _p(m_dev), partials.data_ptr(), None if defer else out.data_ptr(), _s()), "mrg_colsum")
+    if defer:
+        Deferred.add(partials, 0, out, N, N, nb)
     return out
 
 
