@@ -743,6 +743,155 @@ __global__ __launch_bounds__(512, 2) void gemm_pipe256_kernel(const GemmArgs g) 
     }
 }
 
+// Warp-specialised 256 x 128 kernel: 8 compute waves (4 x 2, 64 x 64 each) + 4 loader waves.  Issuing a global_load_lds
+// costs the issuing wave ~60-180 cycles during which it cannot issue MFMAs (in-order issue); the loaders take all 48 of them
+// per k-tile off the compute waves and keep a 3-stage ring (144 KiB) two tiles ahead.  One s_barrier per k-tile for all 12 waves.
+template <int AMODE, int BMODE, bool VEC>
+__global__ __launch_bounds__(768) void gemm_ws256_kernel(const GemmArgs g) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int STAGE = 3 * TILE_BYTES, STAGES = 3;
+    const int tiles_m = (g.M + 255) / 256;
+    const int nwg = tiles_m * g.tiles_n;
+    int bid = blockIdx.x;
+    {
+        const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    constexpr int GROUP_M = 4;
+    int tm, tn;
+    {
+        const int per_group = GROUP_M * g.tiles_n;
+        const int grp = bid / per_group, in_grp = bid - grp * per_group;
+        const int first = grp * GROUP_M;
+        const int rows = min(GROUP_M, tiles_m - first);
+        tm = first + in_grp % rows;
+        tn = in_grp / rows;
+    }
+    const int m0 = tm * 256, n0 = tn * BN;
+    const int Meff = g.m_dev ? min(g.M, *g.m_dev) : g.M;
+    const int Keff = g.k_dev ? min(g.K, *g.k_dev) : g.K;
+    if (m0 >= Meff) return;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int ntiles = (Keff + BK - 1) / BK;
+    int t0 = 0, t1 = ntiles;
+    if (g.splitk > 1) {
+        const int per = (ntiles + g.splitk - 1) / g.splitk;
+        t0 = blockIdx.y * per;
+        t1 = min(ntiles, t0 + per);
+    }
+    const uint32_t sbase = __builtin_amdgcn_readfirstlane(lds_addr(smem));
+    if (wave >= 8) {
+        // ------------------------------------------------------------------ loader waves
+        const int L = wave - 8;
+        const bf16_t* pa[8]; const bf16_t* pb[4];
+        long ia[8], ib[4];
+        int ka[8], kb[4];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) glds_setup<AMODE>(g.A, g.lda, m0 + (L >> 1) * 128, Meff, t0 * BK, (L & 1) * 8 + j, lane, pa[j], ia[j], ka[j]);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) glds_setup<BMODE>(g.B, g.ldb, n0, g.N, t0 * BK, L * 4 + j, lane, pb[j], ib[j], kb[j]);
+        const bf16_t* zero = reinterpret_cast<const bf16_t*>(g_zero_page);
+        auto issue = [&](int t, int buf) {
+            const uint32_t la = sbase + buf * STAGE + (L >> 1) * TILE_BYTES + (L & 1) * 8192;
+            const uint32_t lb = sbase + buf * STAGE + 2 * TILE_BYTES + L * 4096;
+            const int krem = Keff - t * BK;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) glds16_asm((krem >= BK || ka[j] < krem) ? pa[j] : zero, la + j * 1024);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) glds16_asm((krem >= BK || kb[j] < krem) ? pb[j] : zero, lb + j * 1024);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) pa[j] += ia[j];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) pb[j] += ib[j];
+        };
+        if (t0 < t1) issue(t0, 0);
+        if (t0 + 1 < t1) issue(t0 + 1, 1);
+        int cur = 0;
+        for (int t = t0; t < t1; ++t) {
+            if (t + 1 < t1) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");   // tile t landed, tile t+1 may still fly
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            if (t + 2 < t1) issue(t + 2, (cur + 2) % STAGES);    // stage of tile t-1: every compute wave is past it
+            cur = (cur + 1 == STAGES) ? 0 : cur + 1;
+        }
+        // take part in the epilogue barriers
+        __syncthreads(); __syncthreads(); __syncthreads(); __syncthreads();
+        return;
+    }
+    // ---------------------------------------------------------------------- compute waves
+    const int half = wave >> 2, wl = wave & 3;
+    const int wm = wl >> 1, wn = wl & 1;
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    int cur = 0;
+    for (int t = t0; t < t1; ++t) {
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        const char* ldsA = smem + cur * STAGE + half * TILE_BYTES;
+        const char* ldsB = smem + cur * STAGE + 2 * TILE_BYTES;
+        const uint32_t la_u = sbase + cur * STAGE + half * TILE_BYTES, lb_u = sbase + cur * STAGE + 2 * TILE_BYTES;
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            bf16x8 fa[2], fb[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) fa[i] = read_frag<AMODE>(ldsA, la_u, wm * 64 + i * 32, kk, lane);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) fb[j] = read_frag<BMODE>(ldsB, lb_u, wn * 64 + j * 32, kk, lane);
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+        }
+        cur = (cur + 1 == STAGES) ? 0 : cur + 1;
+    }
+    float* ct = reinterpret_cast<float*>(smem);
+    const int cl = (tid & 31) << 2;
+    const int col = n0 + cl;
+    const int nv = min(4, g.N - col);
+    float* ws = g.splitk > 1 ? g.ws + (long)blockIdx.y * g.M * g.N : nullptr;
+    float bv[4] = {0.f, 0.f, 0.f, 0.f};
+    if (g.bias && !ws && col < g.N) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) if (e < nv) bv[e] = g.bias[col + e];
+    }
+#pragma unroll 1
+    for (int h = 0; h < 2; ++h) {
+        __syncthreads();
+        if (half == h) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const int c2 = wn * 64 + j * 32 + (lane & 31);
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int rl = wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                        ct[rl * BN + c2] = acc[i][j][r];
+                    }
+                }
+        }
+        __syncthreads();
+        if (col < g.N) {
+#pragma unroll 1
+            for (int it = 0; it < 8; ++it) {
+                const int rl = (tid >> 5) + (it << 4);
+                const int row = m0 + h * 128 + rl;
+                if (row < Meff) {
+                    const float4 a4 = *reinterpret_cast<const float4*>(ct + rl * BN + cl);
+                    epi_row<VEC>(g, a4, bv, ws, row, col, nv);
+                }
+            }
+        }
+    }
+}
+
 // 256 x 256 output tile (128 flop per operand byte): 8 waves as 2 (M) x 4 (N), each 128 x 64 (8 accumulator tiles), operands as
 // 2 + 2 standard [128][64] sub-tiles per stage, two stages = 128 KiB.  Only pays when there are enough 256 x 256 tiles to fill
 // 256 CUs (large M: the encoder-only configuration, Large-model MLP shapes).
@@ -930,7 +1079,7 @@ extern "C" int mrg_gemm(const mrg_gemm_desc* d, hipStream_t stream) {
     g.aux_out = (bf16_t*)d->aux_out; g.aux_in = (const bf16_t*)d->aux_in; g.ldaux = d->ldaux;
     g.row_map = d->row_map; g.add_tab = d->add_tab; g.add_row = d->add_row; g.ldt = d->ldt; g.row_scale = d->row_scale;
     g.splitk = splitk; g.ws = d->ws;
-    MRG_REQUIRE(d->variant >= 0 && d->variant <= MRG_GEMM_PIPE256SQ, MRG_ERR_ARG, "mrg_gemm: bad variant");
+    MRG_REQUIRE(d->variant >= 0 && d->variant <= MRG_GEMM_WS256, MRG_ERR_ARG, "mrg_gemm: bad variant");
     g.tiles_m = cdiv(d->M, BM); g.tiles_n = cdiv(d->N, BN);
     { static const int abl = [] { const char* e = getenv("MRG_GEMM_ABLATE"); return e ? atoi(e) : 0; }(); g.ablate = abl; }
     dim3 grid(g.tiles_m * g.tiles_n, splitk), block(256);
@@ -962,6 +1111,7 @@ extern "C" int mrg_gemm(const mrg_gemm_desc* d, hipStream_t stream) {
     else if (d->variant == MRG_GEMM_PIPE128) { use_pipe = true; }
     else if (d->variant == MRG_GEMM_PIPE256 || d->variant == MRG_GEMM_PIPE256X3) { use_big = fast && d->M > 128; use_pipe = true; }
     const bool use_sq = fast && d->variant == MRG_GEMM_PIPE256SQ && d->M > 128 && d->N > 128;
+    const bool use_ws = fast && d->variant == MRG_GEMM_WS256 && d->M > 128;
     const bool big3 = d->variant == MRG_GEMM_PIPE256X3;
 #define MRG_BIG(AM, BM_, V) do { if (big3) { const void* fn = (const void*)gemm_pipe256_kernel<AM, BM_, V, 3>; \
         (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 9 * TILE_BYTES); \
@@ -972,7 +1122,10 @@ extern "C" int mrg_gemm(const mrg_gemm_desc* d, hipStream_t stream) {
 #define MRG_SQ(AM, BM_, V) do { const void* fn = (const void*)gemm_pipe256sq_kernel<AM, BM_, V>; \
         (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 8 * TILE_BYTES); \
         hipLaunchKernelGGL((gemm_pipe256sq_kernel<AM, BM_, V>), dim3(cdiv(d->M, 256) * cdiv(d->N, 256), splitk), dim3(512), (size_t)(8 * TILE_BYTES), stream, g); } while (0)
-#define MRG_FAST(AM, BM_, V) do { if (use_sq) MRG_SQ(AM, BM_, V); else if (use_big) MRG_BIG(AM, BM_, V); else if (use_pipe) hipLaunchKernelGGL((gemm_pipe_kernel<AM, BM_, V>), grid, block, (size_t)(4 * TILE_BYTES), stream, g); \
+#define MRG_WS(AM, BM_, V) do { const void* fn = (const void*)gemm_ws256_kernel<AM, BM_, V>; \
+        (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 9 * TILE_BYTES); \
+        hipLaunchKernelGGL((gemm_ws256_kernel<AM, BM_, V>), dim3(cdiv(d->M, 256) * g.tiles_n, splitk), dim3(768), (size_t)(9 * TILE_BYTES), stream, g); } while (0)
+#define MRG_FAST(AM, BM_, V) do { if (use_ws) MRG_WS(AM, BM_, V); else if (use_sq) MRG_SQ(AM, BM_, V); else if (use_big) MRG_BIG(AM, BM_, V); else if (use_pipe) hipLaunchKernelGGL((gemm_pipe_kernel<AM, BM_, V>), grid, block, (size_t)(4 * TILE_BYTES), stream, g); \
                                   else if (occ4) hipLaunchKernelGGL((gemm_glds_kernel<AM, BM_, V, 4>), grid, block, (size_t)(2 * TILE_BYTES), stream, g); \
                                   else hipLaunchKernelGGL((gemm_glds_kernel<AM, BM_, V, 3>), grid, block, (size_t)(2 * TILE_BYTES), stream, g); } while (0)
 #define MRG_LAUNCH2(AM, BM_, AL) do { \
@@ -988,6 +1141,7 @@ extern "C" int mrg_gemm(const mrg_gemm_desc* d, hipStream_t stream) {
 #undef MRG_FAST
 #undef MRG_BIG
 #undef MRG_SQ
+#undef MRG_WS
     if (d->ev_stop) (void)hipEventRecord((hipEvent_t)d->ev_stop, stream);
     int rc = mrg_check_launch("mrg_gemm");
     if (rc) return rc;

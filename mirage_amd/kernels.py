@@ -130,8 +130,8 @@ def _autotune(d, key, splitk, allow_split, dev):
     if allow_split:
         kt = (d.K + 63) // 64
         splits = sorted({s for s in (1, 2, 4, 8, 16, 32) if s == 1 or kt // s >= 4})
-    for v in (L.MRG_GEMM_GLDS3, L.MRG_GEMM_GLDS4, L.MRG_GEMM_PIPE128, L.MRG_GEMM_PIPE256, L.MRG_GEMM_PIPE256SQ):
-        if v in (L.MRG_GEMM_PIPE256, L.MRG_GEMM_PIPE256SQ) and d.M <= 128:
+    for v in (L.MRG_GEMM_GLDS3, L.MRG_GEMM_GLDS4, L.MRG_GEMM_PIPE128, L.MRG_GEMM_PIPE256, L.MRG_GEMM_PIPE256SQ, L.MRG_GEMM_WS256):
+        if v in (L.MRG_GEMM_PIPE256, L.MRG_GEMM_PIPE256SQ, L.MRG_GEMM_WS256) and d.M <= 128:
             continue
         if v == L.MRG_GEMM_PIPE256SQ and (d.N <= 128 or ((d.M + 255) // 256) * ((d.N + 255) // 256) < 64):
             continue

@@ -11,7 +11,7 @@ if _os.environ.get("MRG_FORCE_VARIANT"):
     K.TUNE["enabled"] = False
     _v = int(_os.environ["MRG_FORCE_VARIANT"])
     _orig = K._gemm_launch
-    K._gemm_launch = lambda d, splitk, variant, dev_: _orig(d, splitk, _v, dev_)
+    K._gemm_launch = lambda d, splitk, variant, dev_, *a_: _orig(d, splitk, _v, dev_, *a_)
 elif _os.environ.get("MRG_NO_TUNE"):
     K.TUNE["enabled"] = False
 def bench(fn, iters=20):
