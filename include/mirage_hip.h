@@ -155,8 +155,9 @@ int mrg_im2col_image(const float* img, const int* srcb, const int* toks, const i
                      int P, void* out_bf16, hipStream_t stream);
 int mrg_im2col_layermap(const long* labels, const float* class_emb, const int* srcb, const int* toks, const int* count_dev,
                         int cap, int ncls, int E, int Hs, int Ws, int P, void* out_bf16, hipStream_t stream);
+int mrg_class_emb_grad_slices(void);   /* rows of the `partials` workspace: fp32 [slices][ncls][E] */
 int mrg_class_emb_grad(const void* dA_bf16, const long* labels, const int* srcb, const int* toks, const int* count_dev,
-                       int ncls, int E, int Hs, int Ws, int P, float* out, hipStream_t stream);
+                       int ncls, int E, int Hs, int Ws, int P, float* partials, float* out, hipStream_t stream);
 int mrg_fill_global(float* x, const float* global_tokens, int B, int N, int K, int ng, int D, hipStream_t stream);
 
 /* ---------------------------------------------------------------------------------------------------

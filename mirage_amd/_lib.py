@@ -77,7 +77,8 @@ SIGNATURES = {
     "mrg_embed_plan": (ci, [vp, ci, ci, ci, ci, C.POINTER(ci), vp, vp, vp, vp, vp]),
     "mrg_im2col_image": (ci, [vp, vp, vp, vp, ci, ci, ci, ci, ci, vp, vp]),
     "mrg_im2col_layermap": (ci, [vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, vp, vp]),
-    "mrg_class_emb_grad": (ci, [vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, vp, vp]),
+    "mrg_class_emb_grad_slices": (ci, []),
+    "mrg_class_emb_grad": (ci, [vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, vp, vp, vp]),
     "mrg_fill_global": (ci, [vp, vp, ci, ci, ci, ci, ci, vp]),
     "mrg_dec_assemble_fwd": (ci, [C.POINTER(DecAssembleDesc), vp]),
     "mrg_dec_assemble_bwd_nblocks": (ci, [ci, ci, ci]),

@@ -130,23 +130,28 @@ __global__ __launch_bounds__(256) void im2col_layermap_kernel(const long* __rest
 }
 
 // d class_emb[c][ch] = sum over rows i < count, pixels px with label == c of dA[i][ch*PP + px].
-// grid = E blocks (one per embedding channel); deterministic tree reduction.
+// grid = (E, nslices): one block per (embedding channel, slice of the kept rows); deterministic tree reduction per block into
+// partials[slice][c][ch], summed over slices by class_emb_grad_finish_kernel.
 __global__ __launch_bounds__(256) void class_emb_grad_kernel(const bf16_t* __restrict__ dA, const long* __restrict__ labels,
                                                              const int* __restrict__ srcb, const int* __restrict__ toks,
                                                              const int* __restrict__ count, int ncls, int E, int Hs, int Ws,
-                                                             int P, int G, float* __restrict__ out) {
+                                                             int P, int G, float* __restrict__ out_all) {
     __shared__ float red[256];
     const int ch = blockIdx.x;
     const int PP = P * P;
     const int groups = 256 / PP > 0 ? 256 / PP : 1;
     const int px = threadIdx.x % PP, grp = threadIdx.x / PP;
-    const int n = *count;
+    const int ntot = *count;
+    const int per = (ntot + gridDim.y - 1) / gridDim.y;
+    const int lo = blockIdx.y * per;
+    const int n = min(ntot, lo + per);
+    float* out = out_all + (long)blockIdx.y * ncls * E;
     float acc[16];
 #pragma unroll
     for (int c = 0; c < 16; ++c) acc[c] = 0.f;
     if (grp < groups && PP <= 256) {
         const int ph = px / P, pw = px - ph * P;
-        for (int i = grp; i < n; i += groups) {
+        for (int i = lo + grp; i < n; i += groups) {
             const int b = srcb[i], t = toks[i];
             const int ty = t / G, tx = t - ty * G;
             const int lb = (int)labels[((long)b * Hs + ty * P + ph) * Ws + tx * P + pw];
@@ -168,6 +173,14 @@ __global__ __launch_bounds__(256) void class_emb_grad_kernel(const bf16_t* __res
         if (threadIdx.x == 0) out[c * E + ch] = red[0];
         __syncthreads();
     }
+}
+
+__global__ void class_emb_grad_finish_kernel(const float* __restrict__ partials, int nslices, int n, float* __restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float s = 0.f;
+    for (int z = 0; z < nslices; ++z) s += partials[(long)z * n + i];
+    out[i] = s;
 }
 
 // x[b*N + K + g][:] = global_tokens[g][:]
@@ -218,14 +231,20 @@ extern "C" int mrg_im2col_layermap(const long* labels, const float* class_emb, c
     return mrg_check_launch("mrg_im2col_layermap");
 }
 
+extern "C" int mrg_class_emb_grad_slices(void) { return 16; }
+
 extern "C" int mrg_class_emb_grad(const void* dA_bf16, const long* labels, const int* srcb, const int* toks, const int* count_dev,
-                                  int ncls, int E, int Hs, int Ws, int P, float* out, hipStream_t stream) {
-    MRG_REQUIRE(dA_bf16 && labels && srcb && toks && count_dev && out, MRG_ERR_ARG, "mrg_class_emb_grad: null pointer");
+                                  int ncls, int E, int Hs, int Ws, int P, float* partials, float* out, hipStream_t stream) {
+    MRG_REQUIRE(dA_bf16 && labels && srcb && toks && count_dev && partials && out, MRG_ERR_ARG, "mrg_class_emb_grad: null pointer");
     MRG_REQUIRE(ncls <= 16 && P * P <= 256 && 256 % (P * P) == 0, MRG_ERR_UNSUPPORTED,
                 "mrg_class_emb_grad: need <= 16 classes and P*P dividing 256");
-    hipLaunchKernelGGL(class_emb_grad_kernel, dim3(E), dim3(256), 0, stream, (const bf16_t*)dA_bf16, labels, srcb, toks, count_dev, ncls,
-                       E, Hs, Ws, P, Ws / P, out);
-    return mrg_check_launch("mrg_class_emb_grad");
+    const int ns = mrg_class_emb_grad_slices();
+    hipLaunchKernelGGL(class_emb_grad_kernel, dim3(E, ns), dim3(256), 0, stream, (const bf16_t*)dA_bf16, labels, srcb, toks, count_dev,
+                       ncls, E, Hs, Ws, P, Ws / P, partials);
+    int rc = mrg_check_launch("mrg_class_emb_grad");
+    if (rc) return rc;
+    hipLaunchKernelGGL(class_emb_grad_finish_kernel, dim3(cdiv(ncls * E, 256)), dim3(256), 0, stream, partials, ns, ncls * E, out);
+    return mrg_check_launch("mrg_class_emb_grad/finish");
 }
 
 extern "C" int mrg_fill_global(float* x, const float* global_tokens, int B, int N, int K, int ng, int D, hipStream_t stream) {

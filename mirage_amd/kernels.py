@@ -340,8 +340,9 @@ def im2col_layermap(labels: torch.Tensor, class_emb: torch.Tensor, srcb, toks, c
 
 def class_emb_grad(dA: torch.Tensor, labels, srcb, toks, count, ncls: int, E: int, P: int, out: torch.Tensor):
     B, Hs, Ws = labels.shape
+    partials = torch.empty(lib.mrg_class_emb_grad_slices() * ncls * E, dtype=F32, device=dA.device)
     check(lib.mrg_class_emb_grad(dA.data_ptr(), labels.data_ptr(), srcb.data_ptr(), toks.data_ptr(), count.data_ptr(), ncls, E, Hs, Ws, P,
-                                 out.data_ptr(), _s()), "mrg_class_emb_grad")
+                                 partials.data_ptr(), out.data_ptr(), _s()), "mrg_class_emb_grad")
     return out
 
 
