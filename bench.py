@@ -224,6 +224,12 @@ def main():
         # park the GPU behind a long spin kernel so that the whole eager step is already queued when it starts executing:
         # the per-launch events then measure kernel durations, not the python launch gaps
         torch.cuda._sleep(int(0.12 * 2.4e9))
+        # weight-gradient GEMMs stay on the launch stream for this one step: in the graph-replayed steps the kernels run (almost)
+        # exclusively (profiles/r01_c2_timeline.md), whereas a fully pre-queued eager step would overlap the two streams
+        # maximally and inflate every per-launch duration
+        from mirage_amd import engine as _E
+        side_was = _E._Side.enabled
+        _E._Side.enabled = False
         try:
             if train:
                 ts._eager()
@@ -231,6 +237,7 @@ def main():
                 fwd()
         finally:
             K.TIMING["on"] = False
+            _E._Side.enabled = side_was
         torch.cuda.synchronize()
         vname = {0: "auto", 1: "gemm_glds_kernel<*,*,*,3>", 2: "gemm_glds_kernel<*,*,*,4>", 3: "gemm_pipe_kernel", 4: "gemm_pipe256_kernel",
                  5: "gemm_pipe256_kernel", 6: "gemm_pipe256sq_kernel", 7: "gemm_ws256_kernel"}

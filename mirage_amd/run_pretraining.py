@@ -53,6 +53,7 @@ def get_args(argv=None):
     p.add_argument("--decoder_num_heads", default=8, type=int)
     p.add_argument("--drop_path", type=float, default=0.0)
     p.add_argument("--loss_on_unmasked", default=False, action="store_true")
+    p.add_argument("--no_loss_on_unmasked", action="store_false", dest="loss_on_unmasked")
     p.add_argument("--opt", default="adamw", type=str)
     p.add_argument("--opt_eps", default=1e-8, type=float)
     p.add_argument("--opt_betas", default=[0.9, 0.95], type=float, nargs="+")
@@ -252,7 +253,8 @@ def main(args):
         for it, batch in enumerate(data):
             if step is None:
                 step = TrainStep(model, loss_fns, optimizer, batch, args.num_encoded_tokens, alphas=args.alphas,
-                                 sample_tasks_uniformly=args.sample_tasks_uniformly, use_graph=not args.no_graph, reducer=reducer)
+                                 sample_tasks_uniformly=args.sample_tasks_uniformly, use_graph=not args.no_graph, reducer=reducer,
+                                 loss_on_unmasked=args.loss_on_unmasked)
                 step.load(batch)
                 step.warmup_and_capture(warm_iters=1)
                 optimizer.step_dev.fill_(epoch * steps_per_epoch)

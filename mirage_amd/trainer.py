@@ -16,11 +16,12 @@ from .dp import GradReducer
 class TrainStep:
     def __init__(self, model, loss_fns: Dict[str, torch.nn.Module], optimizer, batch_example: Dict[str, torch.Tensor],
                  num_encoded_tokens: int, alphas: float = 1.0, sample_tasks_uniformly: bool = False, use_graph: bool = True,
-                 reducer: Optional[GradReducer] = None):
+                 reducer: Optional[GradReducer] = None, loss_on_unmasked: bool = False):
         self.model, self.loss_fns, self.opt = model, loss_fns, optimizer
         self.K, self.alphas, self.uniform = num_encoded_tokens, alphas, sample_tasks_uniformly
         self.static_x = {k: torch.empty_like(v) for k, v in batch_example.items()}
         self.in_domains = list(model.input_adapters.keys())
+        self.loss_on_unmasked = loss_on_unmasked      # run_pretraining.py:718-721: loss over every token instead of the masked ones
         self.loss = None
         self.task_losses = {}
         self.reducer = reducer
@@ -32,7 +33,7 @@ class TrainStep:
         x = self.static_x
         preds, masks = self.model({d: x[d] for d in self.in_domains}, num_encoded_tokens=self.K, alphas=self.alphas,
                                   sample_tasks_uniformly=self.uniform)
-        self.task_losses = {t: self.loss_fns[t](preds[t], x[t], mask=masks.get(t)) for t in preds}
+        self.task_losses = {t: self.loss_fns[t](preds[t], x[t], mask=None if self.loss_on_unmasked else masks.get(t)) for t in preds}
         self.loss = sum(self.task_losses.values())
         self.opt.zero_grad()
         self.loss.backward()

@@ -222,3 +222,30 @@ def test_mixed_token_grids_raise_like_the_reference():
     with pytest.raises(AssertionError, match="# tokens"):
         model(x, num_encoded_tokens=32)
     torch.cuda.synchronize()
+
+
+def test_loss_on_unmasked_matches_oracle():
+    """run_pretraining.py:718-721 with --loss_on_unmasked: the criteria are called without a mask (criterion.py:49,115:
+    plain mean over every pixel)."""
+    from mirage_amd import builder
+    from oracle import mirage_oracle as O
+    fx, meta = load_golden("tiny3")
+    cfg, B, Kk = meta["cfg"], meta["B"], meta["K"]
+    model, args, sd = _build(cfg)
+    model.train()
+    x = O.synthetic_batch(cfg, B, seed=meta["data_seed"])
+    xg = {d: t.to(DEV) for d, t in x.items()}
+    doms = cfg["in_domains"]
+    noise = (torch.from_numpy(fx["p"]).to(DEV), torch.cat([torch.from_numpy(fx[f"u.{d}"]) for d in doms], 1).to(DEV),
+             torch.from_numpy(fx["g"]).to(DEV))
+    loss_fns = builder.get_losses(args)
+    preds, _ = model({d: xg[d] for d in doms}, num_encoded_tokens=Kk, mask_noise=noise)
+    mine = {d: loss_fns[d](preds[d], xg[d]) for d in preds}
+    ik, ir = torch.from_numpy(fx["ids_keep"]), torch.from_numpy(fx["ids_restore"])
+    with torch.no_grad():
+        _, opreds = O.forward(cfg, sd, x, ik, ir)
+        ref = O.losses(cfg, opreds, x, {})
+    for d in preds:
+        assert abs(float(mine[d]) - float(ref[d])) <= 3e-3 * max(1.0, abs(float(ref[d]))), (d, float(mine[d]), float(ref[d]))
+    sum(mine.values()).backward()
+    assert all(torch.isfinite(p.grad).all() for p in model.parameters() if p.grad is not None)
