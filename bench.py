@@ -112,6 +112,35 @@ def cpu_baseline(model_name, doms, K, train, budget_s=25.0):
 
 
 def main():
+    # stdout carries exactly one JSON line: native libraries write there too (RCCL prints a version banner through C stdio
+    # when its first communicator comes up), so fd 1 points at stderr until the result is ready
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
+    try:
+        _run(real_stdout)
+    finally:
+        sys.stdout.flush()
+        try:
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
+        os.dup2(real_stdout, 1)
+        os.close(real_stdout)
+
+
+def _emit(real_stdout: int, line: str):
+    sys.stdout.flush()
+    try:
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+    except Exception:
+        pass
+    os.write(real_stdout, (line + "\n").encode())
+
+
+def _run(real_stdout: int):
     if os.environ.get("MRG_SIDE_BLOCKS"):          # experiment knob: transformer blocks per side-stream fork
         from mirage_amd import engine as _E
         _E._Side.blocks_per_flush = int(os.environ["MRG_SIDE_BLOCKS"])
@@ -133,7 +162,11 @@ def main():
         local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    force_dp = os.environ.get("MRG_FORCE_DP") == "1"      # single-GPU smoke test of the multi-rank code path (world size 1)
+    if force_dp and world == 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29541")
+        os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
+    if world > 1 or force_dp:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         backend = os.environ.get("MRG_DIST_BACKEND", "nccl")
         if backend == "nccl":
@@ -163,7 +196,7 @@ def main():
         opt = optim.FusedAdamW(model, lrs, wds, betas=(0.9, 0.95), eps=1e-8)
         broadcast_params(opt.arena.flat_p)
         opt.arena.refresh_shadow(force=True)
-        reducer = GradReducer(opt.arena.flat_g) if world > 1 else None
+        reducer = GradReducer(opt.arena.flat_g, force=force_dp) if (world > 1 or force_dp) else None
         loss_fns = builder.get_losses(args)
         ts = TrainStep(model, loss_fns, opt, pool[0], Kk, use_graph=not a.no_graph, reducer=reducer)
         ts.load(pool[0])
@@ -196,19 +229,20 @@ def main():
             else:
                 fwd()
 
+    multi = world > 1 or force_dp
     for i in range(a.warmup):
         run_step(i)
-    if world > 1:
+    if multi:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for i in range(a.steps):
         run_step(a.warmup + i)
     torch.cuda.synchronize()
-    if world > 1:
+    if multi:
         dist.barrier()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if multi:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -295,8 +329,8 @@ def main():
                 am, bm, M_, N_, K_ = key[:5]
                 print(f"tune mode=({am},{bm}) {M_}x{N_}x{K_} act={key[5]} -> {names.get(v, v)} splitk={sk} {us:.1f} us {2.0 * M_ * N_ * K_ / us / 1e6:.0f} TF/s",
                       file=sys.stderr)
-        print(json.dumps(result), flush=True)
-    if world > 1:
+        _emit(real_stdout, json.dumps(result))
+    if world > 1 or force_dp:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -29,20 +29,31 @@ def bucket_ranges(n: int, bucket_elems: int, align: int = 64) -> List[Tuple[int,
 class GradReducer:
     """Averages a flat fp32 gradient buffer across ranks."""
 
-    def __init__(self, flat_grad: torch.Tensor, bucket_bytes: int = 64 << 20, process_group=None):
+    def __init__(self, flat_grad: torch.Tensor, bucket_bytes: int = 64 << 20, process_group=None, force: bool = False):
         self.flat = flat_grad
         self.group = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        self.force = force and dist.is_initialized()      # issue the collectives even with one rank (single-GPU smoke test of the path)
         self.ranges = bucket_ranges(flat_grad.numel(), bucket_bytes // 4)
         self.backend = dist.get_backend(process_group) if dist.is_initialized() else None
         self.side = torch.cuda.Stream(device=flat_grad.device) if flat_grad.is_cuda else None
         self._done = None
+        # ncclAvg needs NCCL/RCCL >= 2.10; probe once (this also brings the communicator up before the first timed step) and
+        # fall back to SUM followed by a scale when the backend refuses it
+        self.use_avg = False
+        if (self.world > 1 or self.force) and self.backend == "nccl":
+            try:
+                probe = torch.ones(8, dtype=torch.float32, device=flat_grad.device)
+                dist.all_reduce(probe, op=dist.ReduceOp.AVG, group=process_group)
+                self.use_avg = bool(torch.allclose(probe, torch.ones_like(probe)))
+            except Exception:
+                self.use_avg = False
 
     def reduce_async(self):
         """Launch the bucket all-reduces (side stream on GPU).  Call wait() before reading the gradients."""
-        if self.world == 1:
+        if self.world == 1 and not self.force:
             return
-        use_avg = self.backend == "nccl"
+        use_avg = self.use_avg
         op = dist.ReduceOp.AVG if use_avg else dist.ReduceOp.SUM
         if self.side is not None:
             ready = torch.cuda.Event()

@@ -60,15 +60,17 @@ class TrainStep:
         torch.cuda.synchronize()
         if self.reducer is None:
             self.g_fb = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.g_fb):
+            with torch.cuda.graph(self.g_fb, capture_error_mode="thread_local"):
                 self._fwd_bwd()
                 self._opt()
         else:
             self.g_fb = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.g_fb):
+            # thread_local: the RCCL watchdog thread of torch.distributed polls events while we capture; in the default
+            # "global" mode any such call from another thread invalidates the capture
+            with torch.cuda.graph(self.g_fb, capture_error_mode="thread_local"):
                 self._fwd_bwd()
             self.g_opt = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.g_opt, pool=self.g_fb.pool()):
+            with torch.cuda.graph(self.g_opt, pool=self.g_fb.pool(), capture_error_mode="thread_local"):
                 self._opt()
         self.opt.arena.mark_fresh()
 
