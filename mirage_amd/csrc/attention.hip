@@ -119,8 +119,12 @@ template <int HD, int CB>
 __global__ __launch_bounds__(512, 2) void attn_fwd_kernel(const AttnArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int KS = HD / 16, DJ = HD / 32, ROWS = CB * 32;
+    // a.chunk_rows = rows of K and of V resident in LDS: all keys (padded to 32) when they fit, so that longer rows stage K/V
+    // once and the chunk loop below only walks LDS; otherwise ROWS and every chunk is re-staged
+    const int lds_rows = a.chunk_rows;
+    const bool resident = lds_rows >= a.Nk;
     char* ldsK = smem;
-    char* ldsV = smem + ROWS * HD * 2;
+    char* ldsV = smem + lds_rows * HD * 2;
     const uint32_t ldsV_u = lds_addr(ldsV);
     const int h = blockIdx.x, b = blockIdx.y;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -132,8 +136,8 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_kernel(const AttnArgs a) {
     const int nchunks = (a.Nk + ROWS - 1) / ROWS;
     const float sc = a.scale * LOG2E;
 
-    if (nchunks == 1) {
-        load_rows2<HD, SWZ_ROW, SWZ_TR>(ldsK, kp, a.k_rs, ldsV, vp, a.v_rs, ROWS, a.Nk, tid, nthr);
+    if (resident) {
+        load_rows2<HD, SWZ_ROW, SWZ_TR>(ldsK, kp, a.k_rs, ldsV, vp, a.v_rs, lds_rows, a.Nk, tid, nthr);
         __syncthreads();
     }
     // uniform rounds so that every wave takes part in the staging barriers of the multi-chunk path
@@ -162,12 +166,13 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_kernel(const AttnArgs a) {
         for (int ch = 0; ch < nchunks; ++ch) {
             const int kbase = ch * ROWS;
             const int kvalid = min(ROWS, a.Nk - kbase);
-            if (nchunks > 1) {
+            if (!resident) {
                 __syncthreads();
                 load_rows2<HD, SWZ_ROW, SWZ_TR>(ldsK, kp + (long)kbase * a.k_rs, a.k_rs, ldsV, vp + (long)kbase * a.v_rs, a.v_rs, ROWS, kvalid, tid, nthr);
                 __syncthreads();
             }
             if (!active) continue;
+            const int lbase = resident ? kbase : 0;      // first LDS row of this chunk
             f32x16 s[CB];
             float mx = -INFINITY;
 #pragma unroll
@@ -177,7 +182,7 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_kernel(const AttnArgs a) {
                 if (kb * 32 < kvalid) {
 #pragma unroll
                     for (int kk = 0; kk < KS; ++kk)
-                        s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows<HD, SWZ_ROW>(ldsK, kb * 32, kk, lane), qf[kk], s[kb], 0, 0, 0);
+                        s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows<HD, SWZ_ROW>(ldsK, lbase + kb * 32, kk, lane), qf[kk], s[kb], 0, 0, 0);
                 }
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
@@ -218,7 +223,7 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_kernel(const AttnArgs a) {
                         const bf16x8 pa = pack8(s[kb], mf);
 #pragma unroll
                         for (int dj = 0; dj < DJ; ++dj)
-                            o[dj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa, frag_cols_tr<HD, SWZ_TR>(ldsV_u, kb * 32, mf, dj, lane), o[dj], 0, 0, 0);
+                            o[dj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa, frag_cols_tr<HD, SWZ_TR>(ldsV_u, lbase + kb * 32, mf, dj, lane), o[dj], 0, 0, 0);
                     }
                 }
             }
@@ -269,7 +274,7 @@ __global__ void attn_bwd_prep_kernel(const AttnArgs a) {
 
 // query-owner pass: dQ.  LDS: K chunk (row + tr reads), V chunk (row reads).
 template <int HD>
-__global__ __launch_bounds__(512, 2) void attn_bwd_dq_kernel(const AttnArgs a) {
+__global__ __launch_bounds__(512, 4) void attn_bwd_dq_kernel(const AttnArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int KS = HD / 16, DJ = HD / 32;
     const int ROWS = a.chunk_rows;
@@ -483,17 +488,23 @@ static int waves_for(int ntiles) {
 }
 
 template <int HD>
-int launch_fwd(const AttnArgs& a, hipStream_t stream) {
+int launch_fwd(const AttnArgs& a0, hipStream_t stream) {
+    AttnArgs a = a0;
     const int nkb = (a.Nk + 31) / 32;
     dim3 grid(a.H, a.B), block(64 * waves_for((a.Nq + 31) / 32));
-#define MRG_FWD(CB_) do { const size_t sh = (size_t)(2 * CB_ * 32 * HD * 2); \
-        if (sh > 65536) { static bool once = false; if (!once) { (void)hipFuncSetAttribute((const void*)attn_fwd_kernel<HD, CB_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh); once = true; } } \
+    // K and V of the whole row stay in LDS when that leaves room for two workgroups per CU (<= 80 KiB)
+#define MRG_FWD(CB_) do { const bool fits = (size_t)2 * nkb * 32 * HD * 2 <= 80 * 1024; \
+        a.chunk_rows = fits ? nkb * 32 : CB_ * 32; \
+        if (a.chunk_rows < CB_ * 32) a.chunk_rows = CB_ * 32; \
+        const size_t sh = (size_t)2 * a.chunk_rows * HD * 2; \
+        if (sh > 65536) (void)hipFuncSetAttribute((const void*)attn_fwd_kernel<HD, CB_>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
         hipLaunchKernelGGL((attn_fwd_kernel<HD, CB_>), grid, block, sh, stream, a); } while (0)
-    // all scores of a chunk of CB key blocks stay in registers; longer rows run several chunks with an online-softmax rescale
-    if (nkb <= 4) MRG_FWD(4);
-    else if (nkb == 5 || nkb == 9 || nkb == 10) MRG_FWD(5);
-    else if (HD == 32 && nkb <= 8) MRG_FWD(8);
-    else MRG_FWD(4);
+    // Scores are kept in registers one chunk of CB key blocks at a time with an online-softmax rescale between chunks.  Small
+    // chunks win on these short rows: CB = 1 needs 128 VGPRs (4 waves per SIMD) against 256 for CB = 5, and the kernel is bound
+    // by latency chains, not MFMA throughput (C2 30.7 -> 23.2 us, C5 400 -> 297 us; tools/bench_attn_fwd.py)
+    (void)nkb;
+    if (HD == 64) MRG_FWD(1);
+    else MRG_FWD(2);
 #undef MRG_FWD
     return mrg_check_launch("mrg_attn_fwd");
 }
