@@ -30,7 +30,10 @@ typedef struct ihipStream_t* hipStream_t;
 
 enum { MRG_DT_BF16 = 0, MRG_DT_F32 = 1 };
 enum { MRG_OP_KCONTIG = 0, MRG_OP_KSTRIDED = 1 };
-enum { MRG_ACT_NONE = 0, MRG_ACT_GELU = 1, MRG_ACT_GELU_BWD = 2 };
+enum { MRG_ACT_NONE = 0, MRG_ACT_GELU = 1, MRG_ACT_GELU_BWD = 2,
+       MRG_ACT_GELU_SAVE_GRAD = 3,   /* out = gelu(v); aux_out (IEEE fp16, not bf16) = gelu'(v): the derivative is in [-0.13, 1.13],
+                                        so fp16 keeps 11 significant bits and the backward GEMM needs no transcendental math */
+       MRG_ACT_MUL_AUX_F16 = 4 };    /* v *= aux_in (IEEE fp16): backward of MRG_ACT_GELU_SAVE_GRAD */
 enum { MRG_LOSS_MSE = 0, MRG_LOSS_CE = 1 };
 #define MRG_MAX_DOMAINS 4
 

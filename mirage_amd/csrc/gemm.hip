@@ -148,6 +148,31 @@ __device__ __forceinline__ void epi_row(const GemmArgs& g, const float4 a4, cons
             }
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] = gelu_f(v[e]);
+        } else if (g.act == MRG_ACT_GELU_SAVE_GRAD) {
+            float gd[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float c, p;
+                gelu_parts(v[e], c, p);
+                gd[e] = c + v[e] * p;
+                v[e] = v[e] * c;
+            }
+            if (g.aux_out) {
+                _Float16* ao = reinterpret_cast<_Float16*>(g.aux_out) + (long)row * g.ldaux + col;
+                if (VEC) {
+                    typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+                    const h2 lo = {(_Float16)gd[0], (_Float16)gd[1]}, hi = {(_Float16)gd[2], (_Float16)gd[3]};
+                    *reinterpret_cast<uint2*>(ao) = make_uint2(*reinterpret_cast<const uint32_t*>(&lo), *reinterpret_cast<const uint32_t*>(&hi));
+                } else { for (int e = 0; e < nv; ++e) ao[e] = (_Float16)gd[e]; }
+            }
+        } else if (g.act == MRG_ACT_MUL_AUX_F16) {
+            const _Float16* ai = reinterpret_cast<const _Float16*>(g.aux_in) + (long)row * g.ldaux + col;
+            if (VEC) {
+                typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+                const h4 x4 = *reinterpret_cast<const h4*>(ai);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] *= (float)x4[e];
+            } else { for (int e = 0; e < nv; ++e) v[e] *= (float)ai[e]; }
         } else if (g.act == MRG_ACT_GELU_BWD) {
             const bf16_t* ai = g.aux_in + (long)row * g.ldaux + col;
             float x[4] = {0.f, 0.f, 0.f, 0.f};
@@ -1057,8 +1082,8 @@ extern "C" int mrg_gemm(const mrg_gemm_desc* d, hipStream_t stream) {
     MRG_REQUIRE(d->b_mode == MRG_OP_KCONTIG || d->b_mode == MRG_OP_KSTRIDED, MRG_ERR_ARG, "mrg_gemm: bad b_mode");
     MRG_REQUIRE(!(d->a_mode == MRG_OP_KSTRIDED && d->b_mode == MRG_OP_KCONTIG), MRG_ERR_UNSUPPORTED,
                 "mrg_gemm: (A k-strided, B k-contiguous) is not instantiated");
-    MRG_REQUIRE(d->act == MRG_ACT_NONE || d->act == MRG_ACT_GELU || d->act == MRG_ACT_GELU_BWD, MRG_ERR_ARG, "mrg_gemm: bad act");
-    MRG_REQUIRE(d->act != MRG_ACT_GELU_BWD || d->aux_in, MRG_ERR_ARG, "mrg_gemm: gelu_bwd needs aux_in");
+    MRG_REQUIRE(d->act >= MRG_ACT_NONE && d->act <= MRG_ACT_MUL_AUX_F16, MRG_ERR_ARG, "mrg_gemm: bad act");
+    MRG_REQUIRE((d->act != MRG_ACT_GELU_BWD && d->act != MRG_ACT_MUL_AUX_F16) || d->aux_in, MRG_ERR_ARG, "mrg_gemm: this act needs aux_in");
     MRG_REQUIRE(!d->add_tab || d->add_row, MRG_ERR_ARG, "mrg_gemm: add_tab needs add_row");
     MRG_REQUIRE(!d->accumulate || d->c_dtype == MRG_DT_F32, MRG_ERR_ARG, "mrg_gemm: accumulate needs fp32 C");
     const int splitk = d->splitk > 1 ? d->splitk : 1;

@@ -438,3 +438,25 @@ def test_gemm_row_scale_epilogue_and_row_scale_bf16(K):
     g = torch.randn(M, N, device="cuda:0")
     gs = K.row_scale_bf16(g, s)
     assert torch.equal(gs, (g * s[:, None]).bfloat16())
+
+
+def test_gemm_gelu_save_grad_and_mul_aux(K):
+    """act 3 / 4: forward stores gelu'(pre-activation) as fp16, backward multiplies by it (nn.GELU() erf form and its derivative,
+    mirage/utils.py:142,156)."""
+    from mirage_amd import _lib as L
+    torch.manual_seed(7)
+    M, N, Kd = 300, 384, 192
+    x = torch.randn(M, Kd, device=dev()).bfloat16(); W = (torch.randn(N, Kd, device=dev()) * 0.08).bfloat16()
+    b = torch.randn(N, device=dev())
+    out = torch.empty(M, N, dtype=torch.bfloat16, device=dev()); gd = torch.empty(M, N, dtype=torch.float16, device=dev())
+    K.gemm(x, W, M, N, Kd, bias=b, out=out, act=L.MRG_ACT_GELU_SAVE_GRAD, aux_out=gd)
+    pre = (x.float() @ W.float().t() + b).requires_grad_(True)
+    ref = torch.nn.functional.gelu(pre)
+    ref.sum().backward()
+    assert (out.float() - ref).abs().max() <= 2e-2 * ref.abs().max()
+    assert (gd.float() - pre.grad).abs().max() <= 2e-3                       # fp16 of a value in [-0.13, 1.13]
+    dy = torch.randn(M, Kd, device=dev()).bfloat16(); W2 = (torch.randn(Kd, N, device=dev()) * 0.08).bfloat16()
+    dx = torch.empty(M, N, device=dev())
+    K.gemm(dy, W2, M, N, Kd, b_mode=L.MRG_OP_KSTRIDED, out=dx, act=L.MRG_ACT_MUL_AUX_F16, aux_in=gd)
+    want = (dy.float() @ W2.float()) * gd.float()
+    assert (dx - want).abs().max() <= 2e-3 * want.abs().max()
