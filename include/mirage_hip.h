@@ -26,7 +26,7 @@ extern "C" {
 typedef struct ihipStream_t* hipStream_t;
 #endif
 
-#define MRG_ABI_VERSION 1
+#define MRG_ABI_VERSION 2   /* 2: mrg_gemm_desc grew row_scale / defer_reduce; act codes 3, 4; reduce_batch, augment, row_scale entry points */
 
 enum { MRG_DT_BF16 = 0, MRG_DT_F32 = 1 };
 enum { MRG_OP_KCONTIG = 0, MRG_OP_KSTRIDED = 1 };
