@@ -74,3 +74,27 @@ def test_bucket_ranges_cover_exactly():
     for n, b in ((1000, 256), (64, 64), (98_000_000, 16 << 20), (5, 64)):
         r = bucket_ranges(n, b)
         assert r[0][0] == 0 and r[-1][1] == n and all(a[1] == c[0] for a, c in zip(r, r[1:]))
+
+
+def test_hf_directory_layout_roundtrip(tmp_path):
+    """F4: save_pretrained / from_pretrained write and read the PyTorchModelHubMixin layout the reference uses
+    (hf/helper_hf.py:9-58): config.json + model.safetensors with `model.`-prefixed keys."""
+    import json, os
+    import torch
+    from safetensors.torch import load_file
+    from mirage_amd.hf import MIRAGEhf
+    torch.manual_seed(0)
+    m = MIRAGEhf(input_size=64, patch_size=8, modalities="bscan-slo", size="tiny", dim_tokens=64, depth=2, num_heads=2)
+    d = m.save_pretrained(str(tmp_path / "MIRAGE-tiny"))
+    cfg = json.load(open(os.path.join(d, "config.json")))
+    assert cfg == {"input_size": 64, "patch_size": 8, "modalities": "bscan-slo", "size": "tiny"}
+    sd = load_file(os.path.join(d, "model.safetensors"))
+    assert set(sd) == set(m.state_dict()) and all(k.startswith("model.") for k in sd)
+    assert "model.global_tokens" in sd and "model.input_adapters.slo.proj.weight" in sd and "model.encoder.1.mlp.fc2.bias" in sd
+    m2 = MIRAGEhf.from_pretrained(d, device="cpu", dim_tokens=64, depth=2, num_heads=2)
+    for k, v in m.state_dict().items():
+        assert torch.equal(v, m2.state_dict()[k]), k
+    # a bare (un-prefixed) model state_dict loads too, as in hf/helper_hf.py:50-54
+    m3 = MIRAGEhf(input_size=64, patch_size=8, modalities="bscan-slo", size="tiny", dim_tokens=64, depth=2, num_heads=2)
+    msg = m3.load_state_dict(m.model.state_dict(), strict=False)
+    assert len(msg.missing_keys) == 0

@@ -200,3 +200,25 @@ def test_full_size_20_step_curve_vs_cpu_oracle():
     err = np.abs(curve - ref_curve) / np.maximum(1.0, np.abs(ref_curve))
     assert err.mean() <= 2e-3 and err.max() <= 5e-3, (err.mean(), err.max(), curve.tolist(), ref_curve.tolist())
     np.testing.assert_allclose(norms, ref_norms, rtol=5e-2)
+
+
+def test_hf_feature_extractor_matches_oracle(tmp_path):
+    """F4 (hf/mirage_hf.py:540-565): the HF-packaged encoder returns the unmasked encoder tokens (global token last)."""
+    from mirage_amd.hf import MIRAGEhf
+    from oracle import mirage_oracle as O
+    cfg = O.make_config(model="tiny", in_domains=("bscan", "slo"), out_domains=(), input_size=64, patch_size=8, dim=128, depth=2, heads=2)
+    sd = O.procedural_state_dict(cfg)
+    m = MIRAGEhf(input_size=64, patch_size=8, modalities="bscan-slo", size="tiny", dim_tokens=128, depth=2, num_heads=2)
+    msg = m.load_state_dict(sd, strict=True)
+    d = m.save_pretrained(str(tmp_path / "hf"))
+    m = MIRAGEhf.from_pretrained(d, device=DEV, dim_tokens=128, depth=2, num_heads=2).eval()
+    x = O.synthetic_batch(cfg, 3, seed=5)
+    with torch.no_grad():
+        got = m({k: v.to(DEV) for k, v in x.items()}).float().cpu()
+        toks = O.input_tokens(cfg, sd, x)
+        T = toks.shape[1]
+        ids = torch.arange(T).unsqueeze(0).expand(3, -1)
+        ref = O.encoder(cfg, sd, O.select_and_append_global(cfg, sd, toks, ids))
+    assert got.shape == ref.shape == (3, T + 1, 128)
+    err = float((got - ref).norm() / ref.norm())
+    assert err <= 1e-2, err
