@@ -222,3 +222,22 @@ def test_hf_feature_extractor_matches_oracle(tmp_path):
     assert got.shape == ref.shape == (3, T + 1, 128)
     err = float((got - ref).norm() / ref.norm())
     assert err <= 1e-2, err
+
+
+def test_bench_multi_rank_code_path_single_gpu():
+    """bench.py with MRG_FORCE_DP=1 runs the several-rank structure (RCCL process group, weight broadcast, two hipGraphs with the
+    bucketed all-reduce between them, barrier + max-over-ranks timing) at world size 1, in a child process.  stdout must be
+    exactly one JSON line even though RCCL prints a banner through C stdio."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MRG_FORCE_DP="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29577", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--config", "c2", "--steps", "3", "--warmup", "1", "--batch", "8",
+                        "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [l for l in p.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, p.stdout[-2000:]
+    r = json.loads(lines[0])
+    assert r["n_gpus"] == 1 and r["value"] > 0 and r["scaling"] == "weak" and np.isfinite(r["final_loss"])
+    assert r["config"]["hipgraph"] is True
