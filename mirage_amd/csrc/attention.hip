@@ -247,32 +247,7 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_kernel(const AttnArgs a) {
 }
 
 // ================================================ backward ==============================================
-// dsum[b,h,q] = sum_d dO * O
-template <int HD>
-__global__ void attn_bwd_prep_kernel(const AttnArgs a) {
-    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    const long total = (long)a.B * a.H * a.Nq;
-    if (idx >= total) return;
-    const int q = (int)(idx % a.Nq);
-    const int h = (int)((idx / a.Nq) % a.H);
-    const int b = (int)(idx / ((long)a.Nq * a.H));
-    const bf16_t* op = a.o + (long)b * a.o_bs + (long)q * a.o_rs + h * HD;
-    const bf16_t* dp = a.d_o + (long)b * a.do_bs + (long)q * a.do_rs + h * HD;
-    float s = 0.f;
-#pragma unroll
-    for (int c = 0; c < HD / 8; ++c) {
-        const uint4 x = *reinterpret_cast<const uint4*>(op + c * 8);
-        const uint4 y = *reinterpret_cast<const uint4*>(dp + c * 8);
-        const uint32_t xs[4] = {x.x, x.y, x.z, x.w}, ys[4] = {y.x, y.y, y.z, y.w};
-#pragma unroll
-        for (int e = 0; e < 4; ++e)
-            s += __uint_as_float(xs[e] << 16) * __uint_as_float(ys[e] << 16) +
-                 __uint_as_float(xs[e] & 0xffff0000u) * __uint_as_float(ys[e] & 0xffff0000u);
-    }
-    a.dsum[idx] = s;
-}
-
-// query-owner pass: dQ.  LDS: K chunk (row + tr reads), V chunk (row reads).
+// query-owner pass: dQ (and dsum[b,h,q] = sum_d dO * O for the key-owner pass).  LDS: K chunk (row + tr reads), V chunk (row reads).
 template <int HD>
 __global__ __launch_bounds__(512, 4) void attn_bwd_dq_kernel(const AttnArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -315,7 +290,25 @@ __global__ __launch_bounds__(512, 4) void attn_bwd_dq_kernel(const AttnArgs a) {
         }
         const long sidx = ((long)b * a.H + h) * a.Nq + qr;
         const float lse2 = qok ? a.lse[sidx] * LOG2E : INFINITY;   // invalid query -> p = exp2(-inf) = 0
-        const float dsm = qok ? a.dsum[sidx] : 0.f;
+        // dsum[q] = sum_d dO[q,d] * O[q,d] (the softmax-backward row term): this lane holds half of the row's dO already, so the
+        // dot product is formed here (and published for the key-owner kernel) instead of in a separate pass over O and dO
+        float dsm = 0.f;
+        if (qok) {
+            const bf16_t* op = a.o + (long)b * a.o_bs + (long)qr * a.o_rs + h * HD + 8 * (lane >> 5);
+#pragma unroll
+            for (int kk = 0; kk < KS; ++kk) {
+                const uint4 ov = *reinterpret_cast<const uint4*>(op + kk * 16);
+                const uint32_t os[4] = {ov.x, ov.y, ov.z, ov.w};
+                const uint32_t* ds = reinterpret_cast<const uint32_t*>(&dof[kk]);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    dsm += __uint_as_float(os[e] << 16) * __uint_as_float(ds[e] << 16);
+                    dsm += __uint_as_float(os[e] & 0xffff0000u) * __uint_as_float(ds[e] & 0xffff0000u);
+                }
+            }
+        }
+        dsm += __shfl_xor(dsm, 32, 64);
+        if (qok && lane < 32) a.dsum[sidx] = dsm;
         f32x16 dq[DJ];
 #pragma unroll
         for (int dj = 0; dj < DJ; ++dj)
@@ -549,14 +542,6 @@ extern "C" int mrg_attn_bwd(const mrg_attn_desc* d, hipStream_t stream) {
     AttnArgs a;
     fill(a, d);
     const int HD = d->head_dim;
-    {
-        const long total = (long)a.B * a.H * a.Nq;
-        dim3 grid((unsigned)((total + 255) / 256)), block(256);
-        if (HD == 64) hipLaunchKernelGGL(attn_bwd_prep_kernel<64>, grid, block, 0, stream, a);
-        else hipLaunchKernelGGL(attn_bwd_prep_kernel<32>, grid, block, 0, stream, a);
-        rc = mrg_check_launch("mrg_attn_bwd/prep");
-        if (rc) return rc;
-    }
     dim3 grid(a.H, a.B);
     {   // dQ: K,V chunk in LDS
         dim3 block(64 * waves_for((a.Nq + 31) / 32));
