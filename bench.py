@@ -141,6 +141,12 @@ def _emit(real_stdout: int, line: str):
 
 
 def _run(real_stdout: int):
+    if os.environ.get("MRG_LANES") == "0" or os.environ.get("MRG_SIDE") == "0":     # experiment knobs: stream structure
+        from mirage_amd import engine as _E2
+        if os.environ.get("MRG_LANES") == "0":
+            _E2._Lanes.enabled = False
+        if os.environ.get("MRG_SIDE") == "0":
+            _E2._Side.enabled = False
     if os.environ.get("MRG_SIDE_BLOCKS"):          # experiment knob: transformer blocks per side-stream fork
         from mirage_amd import engine as _E
         _E._Side.blocks_per_flush = int(os.environ["MRG_SIDE_BLOCKS"])

@@ -497,6 +497,7 @@ class _Lanes:
     """Independent output adapters run on their own HIP streams (fork from / join into the calling stream): each adapter is a
     chain of ~25 short launches on [B*256, 256]-sized problems that cannot fill 256 CUs on its own."""
     streams = []
+    enabled = True
 
     @classmethod
     def get(cls, i, device):
@@ -510,8 +511,8 @@ class _Lanes:
     def run_all(cls, jobs, device):
         """jobs: list of zero-arg callables; job 0 runs on the current stream, the others on lane streams."""
         main = torch.cuda.current_stream(device)
-        if len(jobs) == 1:
-            return [jobs[0]()]
+        if len(jobs) == 1 or not cls.enabled:
+            return [job() for job in jobs]
         ev = torch.cuda.Event()
         ev.record(main)
         out = [None] * len(jobs)
