@@ -34,6 +34,8 @@ class _Side:
     queue = []         # deferred jobs: one fork (event + cross-stream edge) per flush instead of one per Linear -- inside a
                        # hipGraph every cross-stream edge costs ~16 us of dependent-launch latency on this runtime
     blocks_per_flush = 4
+    taper = True
+    reduce_early = True
     _blocks = 0
     origin = None      # stream the queued jobs were produced on (the decoders' lanes queue from their own streams)
 
@@ -65,12 +67,20 @@ class _Side:
             cls.stream.wait_event(ev)
             for fn in jobs:
                 fn()
+            if cls.reduce_early:
+                # finish the split-K slabs / column-sum partials produced so far (the event above covers the LayerNorm partials of
+                # the calling stream): only the last group's reductions are then left for the tail of the step
+                K.Deferred.flush()
         cls.pending = True
 
     @classmethod
-    def block_done(cls):
+    def block_done(cls, remaining=None):
+        """End of one transformer block's backward.  `remaining` = blocks of the same stack still to come: the side work
+        queued by the LAST blocks has nothing left to overlap with, so the forks get finer towards the end
+        (12 blocks -> flush after 4, 8, 10, 11, 12) instead of leaving a third of the weight-gradient GEMMs exposed."""
         cls._blocks += 1
-        if cls._blocks >= cls.blocks_per_flush:
+        need = cls.blocks_per_flush if remaining is None else min(cls.blocks_per_flush, max(1, remaining))
+        if cls._blocks >= need:
             cls._blocks = 0
             cls.flush()
 
@@ -189,7 +199,7 @@ def block_fwd(blk, x32: torch.Tensor, save: bool, want_bf16_out: bool = False, d
     return x_out, x_out16, saved
 
 
-def block_bwd(blk, saved, dx32: torch.Tensor, dx16: Optional[torch.Tensor]):
+def block_bwd(blk, saved, dx32: torch.Tensor, dx16: Optional[torch.Tensor], remaining: Optional[int] = None):
     """Returns (dx_in fp32, dx_in bf16).  fc2 / proj bias gradients come out of the LayerNorm backward kernels
     (column sums of the residual-stream gradient)."""
     x_in, ln1, mean1, rstd1, qkv, o, lse, x_mid, ln2, mean2, rstd2, h_pre, h_act, dp = saved
@@ -219,7 +229,7 @@ def block_bwd(blk, saved, dx32: torch.Tensor, dx16: Optional[torch.Tensor]):
     d_ln1, _ = lin_bwd(d_qkv, ln1, blk.attn.qkv)
     dx_in32, dx_in16 = K.ln_bwd(d_ln1, x_in, mean1, rstd1, blk.norm1.weight, dx_mid32, grad_buffer(blk.norm1.weight),
                                 grad_buffer(blk.norm1.bias), None if dp is not None else grad_buffer(blk.attn.proj.bias))
-    _Side.block_done()
+    _Side.block_done(remaining)
     return dx_in32, dx_in16
 
 
@@ -267,8 +277,9 @@ class EncoderFn(torch.autograd.Function):
         _Side.begin_backward()
         dx32 = dout.contiguous()
         dx16 = None
-        for blk, sv in zip(reversed(ctx.blocks), reversed(ctx.saved)):
-            dx32, dx16 = block_bwd(blk, sv, dx32, dx16)
+        n = len(ctx.blocks)
+        for i, (blk, sv) in enumerate(zip(reversed(ctx.blocks), reversed(ctx.saved))):
+            dx32, dx16 = block_bwd(blk, sv, dx32, dx16, remaining=(n - 1 - i) if _Side.taper else None)
         ctx.saved = None
         # hand the bf16 twin of the returned gradient to the embedding backward: keyed by the tensor OBJECT (identity
         # is checked on lookup, so a recycled address can never alias); at most one entry is alive
