@@ -45,7 +45,7 @@ def _workspace(nbytes: int, device) -> torch.Tensor:
 
 _tune_cache = {}
 _TUNE_REPS = 6
-TUNE = {"enabled": True, "log": []}
+TUNE = {"enabled": True, "log": [], "hits": None}     # hits: optional set collecting the table keys a run actually uses
 _TUNE_FILE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "gemm_tune_gfx950.json")
 
 
@@ -194,6 +194,8 @@ def gemm(A: torch.Tensor, B: torch.Tensor, M: int, N: int, K: int, *, a_mode=L.M
     if tunable:
         key = (a_mode, b_mode, M, N, K, act, resid is not None, out.dtype == F32, tune_split)
         hit = _tune_cache.get(key)
+        if TUNE["hits"] is not None:
+            TUNE["hits"].add(key)
         if hit is None and not torch.cuda.is_current_stream_capturing():
             hit = _autotune(d, key, splitk, tune_split, A.device)
         if hit is not None:
