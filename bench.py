@@ -208,7 +208,8 @@ def _run(real_stdout: int):
         opt.arena.refresh_shadow(force=True)
         reducer = GradReducer(opt.arena.flat_g, force=force_dp) if (world > 1 or force_dp) else None
         loss_fns = builder.get_losses(args)
-        ts = TrainStep(model, loss_fns, opt, pool[0], Kk, use_graph=not a.no_graph, reducer=reducer)
+        ts = TrainStep(model, loss_fns, opt, pool[0], Kk, use_graph=not a.no_graph, reducer=reducer,
+                       overlap=os.environ.get("MRG_DP_OVERLAP", "1") != "0")
         ts.load(pool[0])
         ts.warmup_and_capture()
 

@@ -34,7 +34,8 @@ class GradReducer:
         self.group = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
         self.force = force and dist.is_initialized()      # issue the collectives even with one rank (single-GPU smoke test of the path)
-        self.ranges = bucket_ranges(flat_grad.numel(), bucket_bytes // 4)
+        self.bucket_elems = bucket_bytes // 4
+        self.ranges = bucket_ranges(flat_grad.numel(), self.bucket_elems)
         self.backend = dist.get_backend(process_group) if dist.is_initialized() else None
         self.side = torch.cuda.Stream(device=flat_grad.device) if flat_grad.is_cuda else None
         self._done = None
@@ -49,8 +50,30 @@ class GradReducer:
             except Exception:
                 self.use_avg = False
 
-    def reduce_async(self):
-        """Launch the bucket all-reduces (side stream on GPU).  Call wait() before reading the gradients."""
+    def split_ranges(self, arena, first_names) -> tuple:
+        """Partition [0, numel) into the element ranges of the parameters whose names satisfy `first_names(name)` (reduced
+        first, while the rest of backward still runs) and the complement.  Parameters are contiguous in the arena, so a
+        handful of merged ranges result."""
+        marks = []
+        for name, p in arena.order:
+            h = p._mrg
+            if h.grad is None:
+                continue
+            size = (h.numel + 63) // 64 * 64
+            marks.append((h.offset, min(h.offset + size, self.flat.numel()), bool(first_names(name))))
+        marks.sort()
+        first, rest = [], []
+        for s, e, m in marks:
+            tgt = first if m else rest
+            if tgt and tgt[-1][1] == s:
+                tgt[-1] = (tgt[-1][0], e)
+            else:
+                tgt.append((s, e))
+        return first, rest
+
+    def reduce_async(self, ranges=None):
+        """Launch the bucket all-reduces (side stream on GPU).  Call wait() before reading the gradients.  `ranges`: element
+        ranges to reduce (default: the whole buffer); each is cut into buckets."""
         if self.world == 1 and not self.force:
             return
         use_avg = self.use_avg
@@ -60,21 +83,31 @@ class GradReducer:
             ready.record(torch.cuda.current_stream(self.flat.device))
             with torch.cuda.stream(self.side):
                 self.side.wait_event(ready)
-                for s, e in reversed(self.ranges):   # arena tail (decoders / last blocks) finishes first in backward
+                for s, e in self._buckets(ranges):
                     dist.all_reduce(self.flat[s:e], op=op, group=self.group)
                 self._done = torch.cuda.Event()
                 self._done.record(self.side)
         else:
-            for s, e in self.ranges:
+            for s, e in self._buckets(ranges):
                 dist.all_reduce(self.flat[s:e], op=op, group=self.group)
         if not use_avg:
             if self.side is not None:
                 with torch.cuda.stream(self.side):
-                    self.flat.div_(self.world)
+                    for s, e in (ranges if ranges is not None else [(0, self.flat.numel())]):
+                        self.flat[s:e].div_(self.world)
                     self._done = torch.cuda.Event()
                     self._done.record(self.side)
             else:
-                self.flat.div_(self.world)
+                for s, e in (ranges if ranges is not None else [(0, self.flat.numel())]):
+                    self.flat[s:e].div_(self.world)
+
+    def _buckets(self, ranges):
+        if ranges is None:
+            return list(reversed(self.ranges))       # arena tail (decoders / last blocks) finishes first in backward
+        out = []
+        for s, e in ranges:
+            out.extend((s + a, s + b) for a, b in bucket_ranges(e - s, self.bucket_elems))
+        return out
 
     def wait(self):
         if self._done is not None:

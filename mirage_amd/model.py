@@ -283,7 +283,16 @@ class MIRAGEModel(nn.Module):
             dps = [None] * len(blocks)
             for j, i in enumerate(act):
                 dps[i] = blocks[i].drop_path_rows(B, x0.shape[1], device, u[j])
-        enc32, enc16 = E.EncoderFn.apply(x0, blocks, save, want16, True, dps, *self._encoder_params())
+        split = getattr(self, "_mrg_split_at", None)
+        if split and save and 0 < split < len(blocks):
+            # data-parallel overlap (trainer.TrainStep): the encoder is two autograd nodes so that the backward pass can be run up
+            # to the activation between them, the gradients of everything above it all-reduced, and the rest run meanwhile
+            h_mid, _ = E.EncoderFn.apply(x0, blocks[:split], save, False, True, dps[:split] if dps else None, *self._encoder_params())
+            self._mrg_h_mid = h_mid
+            enc32, enc16 = E.EncoderFn.apply(h_mid, blocks[split:], save, want16, True, dps[split:] if dps else None,
+                                             *self._encoder_params())
+        else:
+            enc32, enc16 = E.EncoderFn.apply(x0, blocks, save, want16, True, dps, *self._encoder_params())
         if self.output_adapters is None:
             if reshape:
                 gs = self.args.grid_sizes["bscan"]

@@ -16,7 +16,7 @@ from .dp import GradReducer
 class TrainStep:
     def __init__(self, model, loss_fns: Dict[str, torch.nn.Module], optimizer, batch_example: Dict[str, torch.Tensor],
                  num_encoded_tokens: int, alphas: float = 1.0, sample_tasks_uniformly: bool = False, use_graph: bool = True,
-                 reducer: Optional[GradReducer] = None, loss_on_unmasked: bool = False):
+                 reducer: Optional[GradReducer] = None, loss_on_unmasked: bool = False, overlap: bool = True):
         self.model, self.loss_fns, self.opt = model, loss_fns, optimizer
         self.K, self.alphas, self.uniform = num_encoded_tokens, alphas, sample_tasks_uniformly
         self.static_x = {k: torch.empty_like(v) for k, v in batch_example.items()}
@@ -26,7 +26,22 @@ class TrainStep:
         self.task_losses = {}
         self.reducer = reducer
         self.use_graph = use_graph
-        self.g_fb = self.g_opt = None
+        self.g_fb = self.g_opt = self.g_b = None
+        # with several ranks the backward pass is cut at the middle of the encoder: everything above the cut (decoders, upper
+        # encoder blocks) is all-reduced on the side stream while the lower half is still being differentiated
+        self.split = None
+        self.r_first = self.r_rest = None
+        if reducer is not None and overlap and len(model.encoder) >= 2:
+            self.split = len(model.encoder) // 2
+            model._mrg_split_at = self.split
+            s_ = self.split
+            def upper(name):
+                if name.startswith("output_adapters."):
+                    return True
+                if name.startswith("encoder."):
+                    return int(name.split(".")[1]) >= s_
+                return False
+            self.r_first, self.r_rest = reducer.split_ranges(optimizer.arena, upper)
 
     # -- pieces ----------------------------------------------------------------------------------------
     def _fwd_bwd(self):
@@ -38,13 +53,38 @@ class TrainStep:
         self.opt.zero_grad()
         self.loss.backward()
 
+    def _fwd_bwd_upper(self):
+        """forward + losses + backward down to the activation at the encoder cut; the gradients above the cut are final on return."""
+        from . import engine as E
+        x = self.static_x
+        preds, masks = self.model({d: x[d] for d in self.in_domains}, num_encoded_tokens=self.K, alphas=self.alphas,
+                                  sample_tasks_uniformly=self.uniform)
+        self.task_losses = {t: self.loss_fns[t](preds[t], x[t], mask=None if self.loss_on_unmasked else masks.get(t)) for t in preds}
+        self.loss = sum(self.task_losses.values())
+        self.opt.zero_grad()
+        self.h_mid = self.model._mrg_h_mid
+        self.g_mid = torch.autograd.grad(self.loss, self.h_mid, retain_graph=True)[0]
+        E.join_side_stream()
+
+    def _bwd_lower(self):
+        self.h_mid.backward(self.g_mid)
+        self.h_mid = self.g_mid = None
+        self.model._mrg_h_mid = None
+
     def _opt(self):
         self.opt.step()
 
     def _eager(self):
-        self._fwd_bwd()
-        if self.reducer is not None:
-            self.reducer.reduce()
+        if self.split:
+            self._fwd_bwd_upper()
+            self.reducer.reduce_async(self.r_first)
+            self._bwd_lower()
+            self.reducer.reduce_async(self.r_rest)
+            self.reducer.wait()
+        else:
+            self._fwd_bwd()
+            if self.reducer is not None:
+                self.reducer.reduce()
         self._opt()
 
     def warmup_and_capture(self, warm_iters: int = 2):
@@ -67,8 +107,15 @@ class TrainStep:
             self.g_fb = torch.cuda.CUDAGraph()
             # thread_local: the RCCL watchdog thread of torch.distributed polls events while we capture; in the default
             # "global" mode any such call from another thread invalidates the capture
-            with torch.cuda.graph(self.g_fb, capture_error_mode="thread_local"):
-                self._fwd_bwd()
+            if self.split:
+                with torch.cuda.graph(self.g_fb, capture_error_mode="thread_local"):
+                    self._fwd_bwd_upper()
+                self.g_b = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(self.g_b, pool=self.g_fb.pool(), capture_error_mode="thread_local"):
+                    self._bwd_lower()
+            else:
+                with torch.cuda.graph(self.g_fb, capture_error_mode="thread_local"):
+                    self._fwd_bwd()
             self.g_opt = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self.g_opt, pool=self.g_fb.pool(), capture_error_mode="thread_local"):
                 self._opt()
@@ -85,6 +132,13 @@ class TrainStep:
             self._eager()
         elif self.g_opt is None:
             self.g_fb.replay()
+        elif self.g_b is not None:
+            self.g_fb.replay()
+            self.reducer.reduce_async(self.r_first)      # overlaps the lower half of the backward pass
+            self.g_b.replay()
+            self.reducer.reduce_async(self.r_rest)
+            self.reducer.wait()
+            self.g_opt.replay()
         else:
             self.g_fb.replay()
             self.reducer.reduce()

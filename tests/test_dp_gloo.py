@@ -34,6 +34,14 @@ def _worker(rank, world, port, out):
     GradReducer(flat, bucket_bytes=4096).reduce()
     want = torch.arange(n, dtype=torch.float32) * (sum(range(1, world + 1)) / world)
     ok1 = torch.allclose(flat, want)
+    # 1b) the same average as two partial reductions over disjoint range lists (the overlapped schedule of trainer.TrainStep)
+    flat2 = torch.arange(n, dtype=torch.float32) * (rank + 1)
+    r = GradReducer(flat2, bucket_bytes=4096)
+    first, rest = [(2048, 4096), (8192, n)], [(0, 2048), (4096, 8192)]
+    r.reduce_async(first)
+    mid_ok = torch.allclose(flat2[2048:4096], want[2048:4096]) and torch.equal(flat2[:2048], torch.arange(2048, dtype=torch.float32) * (rank + 1))
+    r.reduce_async(rest); r.wait()
+    ok1 = ok1 and mid_ok and torch.allclose(flat2, want)
     # 2) broadcast
     p = torch.full((100,), float(rank))
     broadcast_params(p, src=0)

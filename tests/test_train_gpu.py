@@ -241,3 +241,19 @@ def test_bench_multi_rank_code_path_single_gpu():
     r = json.loads(lines[0])
     assert r["n_gpus"] == 1 and r["value"] > 0 and r["scaling"] == "weak" and np.isfinite(r["final_loss"])
     assert r["config"]["hipgraph"] is True
+
+
+def test_overlapped_dp_schedule_is_bit_identical_to_single_graph():
+    """trainer.TrainStep with a reducer cuts the backward pass at the middle of the encoder (autograd.grad to the cut, ranged
+    all-reduce of everything above it on the side stream, then the lower half): at world size 1 over RCCL, eager and as three
+    hipGraphs, losses and weights must equal the single-graph step bit for bit (tools/debug/dp_split_check.py)."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    for extra, port, tag in ((["--eager"], "29561", "SPLIT-OK eager"), ([], "29562", "SPLIT-OK graph")):
+        env["MASTER_PORT"] = port
+        p = subprocess.run([sys.executable, os.path.join(root, "tools", "debug", "dp_split_check.py")] + extra, env=env,
+                           capture_output=True, text=True, timeout=600)
+        assert p.returncode == 0 and tag in p.stdout, (p.stdout[-1500:], p.stderr[-1500:])
