@@ -25,6 +25,15 @@ def main():
              "| kernel | calls | total ms | avg us | min us | max us | % |", "|---|---|---|---|---|---|---|"]
     for name, n, tot, mn, mx in rows:
         lines.append(f"| {short(name)} | {n} | {tot / 1e6:.3f} | {tot / n / 1e3:.2f} | {mn / 1e3:.2f} | {mx / 1e3:.2f} | {100.0 * tot / total:.2f} |")
+    # kernel families (template instantiations merged): what bench.py's `roofline.avg_launch_us` is to be compared with
+    fam = {}
+    for name, n, tot, mn, mx in rows:
+        base = re.sub(r"<.*", "", short(name)).split("(")[0]
+        f = fam.setdefault(base, [0, 0])
+        f[0] += n; f[1] += tot
+    lines += ["", "## by kernel family (all template instantiations)", "", "| family | calls | total ms | avg us |", "|---|---|---|---|"]
+    for base, (n, tot) in sorted(fam.items(), key=lambda kv: -kv[1][1])[:12]:
+        lines.append(f"| {base} | {n} | {tot / 1e6:.3f} | {tot / n / 1e3:.2f} |")
     out = "\n".join(lines) + "\n"
     if len(sys.argv) > 2:
         open(sys.argv[2], "w").write(out)
