@@ -284,7 +284,7 @@ def _run(real_stdout: int):
             K.TIMING["on"] = False
             _E._Side.enabled = side_was
         torch.cuda.synchronize()
-        vname = {0: "auto", 1: "gemm_glds_kernel<*,*,*,3>", 2: "gemm_glds_kernel<*,*,*,4>", 3: "gemm_pipe_kernel", 4: "gemm_pipe256_kernel",
+        vname = {0: "auto", 1: "gemm_glds_kernel", 2: "gemm_glds_kernel", 3: "gemm_pipe_kernel", 4: "gemm_pipe256_kernel",
                  5: "gemm_pipe256_kernel", 6: "gemm_pipe256sq_kernel", 7: "gemm_ws256_kernel"}
         mname = {(0, 0): "forward x*W^T", (0, 1): "dgrad dy*W", (1, 1): "wgrad dy^T*x"}
         groups = {}
