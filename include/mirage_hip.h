@@ -136,6 +136,10 @@ typedef struct mrg_attn_desc {
     float* dsum;
     void* dq; void* dk; void* dv;
     long dq_bs, dq_rs, dk_bs, dk_rs, dv_bs, dv_rs;
+    /* optional (backward): per-batch column sums of dQ / dK / dV, fp32 [B][..] with row stride colsum_bs floats, entry
+     * [b * colsum_bs + h * head_dim + c] -- summed over b they are the bias gradients of the q / k / v projections
+     * (colsum_k and colsum_v are used together) */
+    float* colsum_q; float* colsum_k; float* colsum_v; long colsum_bs;
 } mrg_attn_desc;
 int mrg_attn_fwd(const mrg_attn_desc* d, hipStream_t stream);
 int mrg_attn_bwd(const mrg_attn_desc* d, hipStream_t stream);

@@ -37,7 +37,8 @@ class AttnDesc(C.Structure):
                 ("B", ci), ("H", ci), ("Nq", ci), ("Nk", ci), ("head_dim", ci), ("scale", cf),
                 ("d_o", vp), ("do_bs", cl), ("do_rs", cl), ("dsum", vp),
                 ("dq", vp), ("dk", vp), ("dv", vp),
-                ("dq_bs", cl), ("dq_rs", cl), ("dk_bs", cl), ("dk_rs", cl), ("dv_bs", cl), ("dv_rs", cl)]
+                ("dq_bs", cl), ("dq_rs", cl), ("dk_bs", cl), ("dk_rs", cl), ("dv_bs", cl), ("dv_rs", cl),
+                ("colsum_q", vp), ("colsum_k", vp), ("colsum_v", vp), ("colsum_bs", cl)]
 
 
 class DecAssembleDesc(C.Structure):

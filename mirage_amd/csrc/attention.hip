@@ -112,6 +112,7 @@ struct AttnArgs {
     bf16_t* dq; bf16_t* dk; bf16_t* dv;
     long dq_bs, dq_rs, dk_bs, dk_rs, dv_bs, dv_rs;
     int chunk_rows;
+    float* cs_q; float* cs_k; float* cs_v; long cs_bs;   // optional per-(batch, head) column sums of dQ / dK / dV (bias gradients)
 };
 
 // ================================================ forward ===============================================
@@ -271,6 +272,9 @@ __global__ __launch_bounds__(512, 4) void attn_bwd_dq_kernel(const AttnArgs a) {
         load_rows2<HD, SWZ_ROW, SWZ_ROW>(ldsK, kp, a.k_rs, ldsV, vp, a.v_rs, ROWS, a.Nk, tid, nthr);
         __syncthreads();
     }
+    float csq[DJ];
+#pragma unroll
+    for (int dj = 0; dj < DJ; ++dj) csq[dj] = 0.f;
     for (int rd = 0; rd < rounds; ++rd) {
         const int qt = rd * nwav + wave;
         const bool active = qt < nqt;
@@ -355,8 +359,26 @@ __global__ __launch_bounds__(512, 4) void attn_bwd_dq_kernel(const AttnArgs a) {
             const int row = q0 + acc_row(r, lane);
             if (row < a.Nq) {
 #pragma unroll
-                for (int dj = 0; dj < DJ; ++dj) dqp[(long)row * a.dq_rs + dj * 32 + (lane & 31)] = f2bf(dq[dj][r]);
+                for (int dj = 0; dj < DJ; ++dj) {
+                    dqp[(long)row * a.dq_rs + dj * 32 + (lane & 31)] = f2bf(dq[dj][r]);
+                    csq[dj] += dq[dj][r];
+                }
             }
+        }
+    }
+    if (a.cs_q) {   // column sums of this (batch, head)'s dQ: the q-bias gradient before the reduction over the batch
+        __syncthreads();
+        float* red = reinterpret_cast<float*>(smem);
+#pragma unroll
+        for (int dj = 0; dj < DJ; ++dj) {
+            const float v = csq[dj] + __shfl_xor(csq[dj], 32, 64);
+            if (lane < 32) red[wave * HD + dj * 32 + lane] = v;
+        }
+        __syncthreads();
+        for (int c = tid; c < HD; c += nthr) {
+            float t = 0.f;
+            for (int w = 0; w < nwav; ++w) t += red[w * HD + c];
+            a.cs_q[(long)b * a.cs_bs + h * HD + c] = t;
         }
     }
 }
@@ -383,6 +405,9 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dkv_kernel(const AttnArgs a) 
     const int nchunks = (a.Nq + ROWS - 1) / ROWS;
     const int rounds = (nkt + nwav - 1) / nwav;
     const float sc = a.scale * LOG2E;
+    float csk[DJ], csv[DJ];
+#pragma unroll
+    for (int dj = 0; dj < DJ; ++dj) { csk[dj] = 0.f; csv[dj] = 0.f; }
     for (int rd = 0; rd < rounds; ++rd) {
         const int kt = rd * nwav + wave;
         const bool active = kt < nkt;
@@ -467,8 +492,27 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dkv_kernel(const AttnArgs a) 
                 for (int dj = 0; dj < DJ; ++dj) {
                     dkp[(long)row * a.dk_rs + dj * 32 + (lane & 31)] = f2bf(dk[dj][r]);
                     dvp[(long)row * a.dv_rs + dj * 32 + (lane & 31)] = f2bf(dv[dj][r]);
+                    csk[dj] += dk[dj][r];
+                    csv[dj] += dv[dj][r];
                 }
             }
+        }
+    }
+    if (a.cs_k) {   // column sums of this (batch, head)'s dK and dV (valid key rows only): k / v bias gradients before the batch sum
+        __syncthreads();
+        float* red = reinterpret_cast<float*>(smem);
+#pragma unroll
+        for (int dj = 0; dj < DJ; ++dj) {
+            const float vk = csk[dj] + __shfl_xor(csk[dj], 32, 64);
+            const float vv = csv[dj] + __shfl_xor(csv[dj], 32, 64);
+            if (lane < 32) { red[wave * 2 * HD + dj * 32 + lane] = vk; red[wave * 2 * HD + HD + dj * 32 + lane] = vv; }
+        }
+        __syncthreads();
+        for (int c = tid; c < 2 * HD; c += nthr) {
+            float t = 0.f;
+            for (int w = 0; w < nwav; ++w) t += red[w * 2 * HD + c];
+            float* dst = c < HD ? a.cs_k : a.cs_v;
+            dst[(long)b * a.cs_bs + h * HD + (c < HD ? c : c - HD)] = t;
         }
     }
 }
@@ -518,6 +562,7 @@ void fill(AttnArgs& a, const mrg_attn_desc* d) {
     a.q_bs = d->q_bs; a.q_rs = d->q_rs; a.k_bs = d->k_bs; a.k_rs = d->k_rs; a.v_bs = d->v_bs; a.v_rs = d->v_rs;
     a.o_bs = d->o_bs; a.o_rs = d->o_rs;
     a.B = d->B; a.H = d->H; a.Nq = d->Nq; a.Nk = d->Nk; a.scale = d->scale;
+    a.cs_q = d->colsum_q; a.cs_k = d->colsum_k; a.cs_v = d->colsum_v; a.cs_bs = d->colsum_bs;
     a.d_o = (const bf16_t*)d->d_o; a.do_bs = d->do_bs; a.do_rs = d->do_rs; a.dsum = d->dsum;
     a.dq = (bf16_t*)d->dq; a.dk = (bf16_t*)d->dk; a.dv = (bf16_t*)d->dv;
     a.dq_bs = d->dq_bs; a.dq_rs = d->dq_rs; a.dk_bs = d->dk_bs; a.dk_rs = d->dk_rs; a.dv_bs = d->dv_bs; a.dv_rs = d->dv_rs;

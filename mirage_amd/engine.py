@@ -19,6 +19,7 @@ from .arena import grad_buffer, shadow
 
 BF16, F32 = torch.bfloat16, torch.float32
 KS = L.MRG_OP_KSTRIDED
+FUSE_ATTN_BIAS = True     # q / k / v bias gradients from inside the attention-backward kernels (else: a column-sum pass over d_qkv)
 
 
 # ------------------------------------------------------------------------------------------- side stream for wgrad
@@ -224,9 +225,11 @@ def block_bwd(blk, saved, dx32: torch.Tensor, dx16: Optional[torch.Tensor], rema
         d_o, _ = lin_bwd(dx_mid16, o, blk.attn.proj, bias_grad=False)
     d_qkv = torch.empty_like(qkv)
     st = (N * 3 * D, 3 * D)
+    gb = grad_buffer(blk.attn.qkv.bias) if (blk.attn.qkv.bias is not None and FUSE_ATTN_BIAS) else None
     K.attn_bwd(qkv[..., :D], qkv[..., D:2 * D], qkv[..., 2 * D:], o, lse, d_o, d_qkv[..., :D], d_qkv[..., D:2 * D], d_qkv[..., 2 * D:],
-               B, H, N, N, hd, blk.attn.scale, st, st, st, st, st, st)
-    d_ln1, _ = lin_bwd(d_qkv, ln1, blk.attn.qkv)
+               B, H, N, N, hd, blk.attn.scale, st, st, st, st, st, st,
+               bias_grads=(gb[:D], gb[D:2 * D], gb[2 * D:]) if gb is not None else None)   # qkv bias gradient from inside the kernels
+    d_ln1, _ = lin_bwd(d_qkv, ln1, blk.attn.qkv, bias_grad=gb is None)
     dx_in32, dx_in16 = K.ln_bwd(d_ln1, x_in, mean1, rstd1, blk.norm1.weight, dx_mid32, grad_buffer(blk.norm1.weight),
                                 grad_buffer(blk.norm1.bias), None if dp is not None else grad_buffer(blk.attn.proj.bias))
     _Side.block_done(remaining)
@@ -474,10 +477,12 @@ def decoder_bwd(ad, saved, d_img: torch.Tensor):
     dq = torch.empty_like(qp)
     dkv = torch.empty_like(kv)
     sq, skv = (Tq * Dd, Dd), (N * 2 * Dd, 2 * Dd)
+    gq, gkv = grad_buffer(ad.decoder.q.bias), grad_buffer(ad.decoder.kv.bias)
+    fused = gq is not None and gkv is not None and FUSE_ATTN_BIAS
     K.attn_bwd(qp, kv[..., :Dd], kv[..., Dd:], o, lse, d_o, dq, dkv[..., :Dd], dkv[..., Dd:], B, H, Tq, N, hd, ad.decoder.scale,
-               sq, skv, skv, sq, skv, skv)
-    d_qn, _ = lin_bwd(dq, qn, ad.decoder.q)
-    d_cn, _ = lin_bwd(dkv, cn, ad.decoder.kv)
+               sq, skv, skv, sq, skv, skv, bias_grads=(gq, gkv[:Dd], gkv[Dd:]) if fused else None)
+    d_qn, _ = lin_bwd(dq, qn, ad.decoder.q, bias_grad=not fused)
+    d_cn, _ = lin_bwd(dkv, cn, ad.decoder.kv, bias_grad=not fused)
     d_queries, _ = K.ln_bwd(d_qn, queries, mq, rq, ad.query_norm.weight, None, grad_buffer(ad.query_norm.weight),
                             grad_buffer(ad.query_norm.bias), None, want_bf16=False)
     d_context, _ = K.ln_bwd(d_cn, context, mc, rc, ad.context_norm.weight, None, grad_buffer(ad.context_norm.weight),

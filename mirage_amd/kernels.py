@@ -292,15 +292,39 @@ def attn_fwd(q, k, v, B, H, Nq, Nk, hd, scale, q_strides, k_strides, v_strides, 
     return o, lse
 
 
+def reduce_slices(src: torch.Tensor, src_off: int, dst: torch.Tensor, n: int, stride: int, nslices: int):
+    """dst[i] = sum_s src[src_off + s * stride + i]: queued for the batched reduction while a backward pass is collecting
+    (Deferred.active), otherwise one mrg_reduce_batch launch now."""
+    if Deferred.ok(dst, n, stride):
+        Deferred.add(src, src_off, dst, n, stride, nslices)
+        return
+    t = (ReduceTask * 1)()
+    t[0].src, t[0].dst, t[0].n, t[0].stride, t[0].nslices = src.data_ptr() + 4 * src_off, dst.data_ptr(), n, stride, nslices
+    check(lib.mrg_reduce_batch(C.cast(t, C.c_void_p), 1, _s()), "mrg_reduce_batch")
+
+
 def attn_bwd(q, k, v, o, lse, d_o, dq, dk, dv, B, H, Nq, Nk, hd, scale, q_strides, k_strides, v_strides, dq_strides, dk_strides,
-             dv_strides):
+             dv_strides, bias_grads=None):
+    """bias_grads = (gq, gk, gv): fp32 [H*hd] destinations for the column sums of dQ / dK / dV over all rows (the bias
+    gradients of the projections that produced q / k / v); formed inside the kernels per (batch, head) and summed over the batch."""
     d = _attn_desc(q, k, v, o, lse, B, H, Nq, Nk, hd, scale, (q_strides, k_strides, v_strides, (Nq * H * hd, H * hd)))
+    part = None
+    if bias_grads is not None:
+        Dm = H * hd
+        part = torch.empty((B, 3 * Dm), dtype=F32, device=q.device)
+        d.colsum_q, d.colsum_k, d.colsum_v = part.data_ptr(), part.data_ptr() + 4 * Dm, part.data_ptr() + 8 * Dm
+        d.colsum_bs = 3 * Dm
     dsum = torch.empty((B, H, Nq), dtype=F32, device=q.device)
     d.d_o, d.do_bs, d.do_rs = d_o.data_ptr(), d_o.stride(0), d_o.stride(1)
     d.dsum = dsum.data_ptr()
     d.dq, d.dk, d.dv = dq.data_ptr(), dk.data_ptr(), dv.data_ptr()
     (d.dq_bs, d.dq_rs), (d.dk_bs, d.dk_rs), (d.dv_bs, d.dv_rs) = dq_strides, dk_strides, dv_strides
     check(lib.mrg_attn_bwd(C.byref(d), _s()), "mrg_attn_bwd")
+    if part is not None:
+        Dm = H * hd
+        for i, g in enumerate(bias_grads):
+            if g is not None:
+                reduce_slices(part, i * Dm, g, Dm, 3 * Dm, B)
 
 
 # ------------------------------------------------------------------------------------------- embedding

@@ -182,10 +182,16 @@ def test_self_attention_fwd_bwd(K, B, H, N, hd):
     d_o = rnd(B, N, D, dtype=BF16, seed=31)
     ref.backward(d_o.float().reshape(B, N, H, hd).permute(0, 2, 1, 3))
     dqkv = torch.zeros_like(qkv)
-    K.attn_bwd(q, k, v, o, lse, d_o, dqkv[..., :D], dqkv[..., D:2 * D], dqkv[..., 2 * D:], B, H, N, N, hd, scale, st, st, st, st, st, st)
+    gb = torch.full((3 * D,), float("nan"), device=dev())
+    K.attn_bwd(q, k, v, o, lse, d_o, dqkv[..., :D], dqkv[..., D:2 * D], dqkv[..., 2 * D:], B, H, N, N, hd, scale, st, st, st, st, st, st,
+               bias_grads=(gb[:D], gb[D:2 * D], gb[2 * D:]))
     for name, got, want in (("dq", dqkv[..., :D], qf.grad), ("dk", dqkv[..., D:2 * D], kf.grad), ("dv", dqkv[..., 2 * D:], vf.grad)):
         want_m = want.permute(0, 2, 1, 3).reshape(B, N, D)
         assert rel_rms(got.float(), want_m) < 1.5e-2, (name, rel_rms(got.float(), want_m))
+    # fused bias gradient of the qkv projection = column sums of d_qkv over every row (formed in fp32 before the bf16 store)
+    want_b = torch.cat([g.permute(0, 2, 1, 3).reshape(B * N, D).sum(0) for g in (qf.grad, kf.grad, vf.grad)])
+    assert rel_rms(gb, want_b) < 1.5e-2, rel_rms(gb, want_b)
+    assert (gb - dqkv.float().reshape(B * N, 3 * D).sum(0)).abs().max() <= 2e-2 * dqkv.float().abs().sum(dim=(0, 1)).max()
 
 
 @pytest.mark.parametrize("B,H,Nq,Nk,hd", [(2, 8, 256, 99, 32), (2, 8, 256, 129, 32), (2, 2, 64, 25, 32), (1, 2, 64, 33, 64)])
