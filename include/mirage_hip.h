@@ -26,7 +26,7 @@ extern "C" {
 typedef struct ihipStream_t* hipStream_t;
 #endif
 
-#define MRG_ABI_VERSION 2   /* 2: mrg_gemm_desc grew row_scale / defer_reduce; act codes 3, 4; reduce_batch, augment, row_scale entry points */
+#define MRG_ABI_VERSION 3   /* 2: mrg_gemm_desc grew row_scale / defer_reduce, act codes 3, 4, reduce_batch / augment / row_scale entry points; 3: colsum_out, attention colsum_* */
 
 enum { MRG_DT_BF16 = 0, MRG_DT_F32 = 1 };
 enum { MRG_OP_KCONTIG = 0, MRG_OP_KSTRIDED = 1 };
@@ -85,6 +85,9 @@ typedef struct mrg_gemm_desc {
     const float* row_scale;          /* optional [M]: (acc + bias -> act) is multiplied by row_scale[row] before add_tab / resid are
                                         added -- stochastic depth, x + drop_path(f(x)) (mirage/utils.py:103-118,259-262);
                                         not combinable with splitk > 1 */
+    float* colsum_out;               /* optional fp32 [ceil(M/128)][N]: per 128-row tile, the column sums of the values written to C (after
+                                        every epilogue step): summed over the tiles (mrg_reduce_batch) they are e.g. the bias gradient
+                                        of the layer whose output gradient this GEMM produces; forces the single-stage 128x128 kernel */
     int defer_reduce;                /* splitk > 1 only: leave the split-K slabs ws[splitk][M*N] unreduced -- the caller sums them
                                         later with mrg_reduce_batch (C must be contiguous fp32, no bias / accumulate / C2) */
 } mrg_gemm_desc;

@@ -39,6 +39,7 @@ struct GemmArgs {
     const int* row_map;
     const float* add_tab; const int* add_row; int ldt;
     const float* row_scale;
+    float* colsum;             // [tiles_m][N]: column sums of the final C values per 128-row tile (single-stage kernel only)
     int splitk; float* ws;
     int tiles_m, tiles_n;
     int ablate;   // MRG_GEMM_ABLATE (256x128 kernel only, for roofline analysis): 1 = no DMA, 2 = DMA only, 3 = DMA + LDS reads, no MFMA
@@ -129,8 +130,9 @@ __device__ __forceinline__ bf16x8 read_frag(const char* lds, uint32_t lds_base, 
 }
 
 // one output row segment (4 consecutive columns) of the fused epilogue
-template <bool VEC>
-__device__ __forceinline__ void epi_row(const GemmArgs& g, const float4 a4, const float (&bv)[4], float* ws, int row, int col, int nv) {
+template <bool VEC, bool CS = false>
+__device__ __forceinline__ void epi_row(const GemmArgs& g, const float4 a4, const float (&bv)[4], float* ws, int row, int col, int nv,
+                                        float* cs = nullptr) {
         float v[4] = {a4.x, a4.y, a4.z, a4.w};
         if (ws) {
             float* w = ws + (long)row * g.N + col;
@@ -198,6 +200,10 @@ __device__ __forceinline__ void epi_row(const GemmArgs& g, const float4 a4, cons
             const float* t = g.resid + (long)row * g.ldr + col;
             if (VEC) { const float4 t4 = *reinterpret_cast<const float4*>(t); v[0] += t4.x; v[1] += t4.y; v[2] += t4.z; v[3] += t4.w; }
             else { for (int e = 0; e < nv; ++e) v[e] += t[e]; }
+        }
+        if (CS) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) cs[e] += e < nv ? v[e] : 0.f;
         }
         const long orow = g.row_map ? g.row_map[row] : row;
         if (g.c_f32) {
@@ -458,6 +464,7 @@ __global__ __launch_bounds__(256, OCC) void gemm_glds_kernel(const GemmArgs g) {
     }
     // ---- epilogue in two passes of 64 rows x 128 cols fp32 (32 KiB)
     float* ct = reinterpret_cast<float*>(smem);
+    float cs[4] = {0.f, 0.f, 0.f, 0.f};
     const int cl = (tid & 31) << 2;
     const int col = n0 + cl;
     const int nv = min(4, g.N - col);
@@ -487,9 +494,22 @@ __global__ __launch_bounds__(256, OCC) void gemm_glds_kernel(const GemmArgs g) {
                 const int row = m0 + (rl >> 5) * 64 + pss * 32 + (rl & 31);
                 if (row < Meff) {
                     const float4 a4 = *reinterpret_cast<const float4*>(ct + rl * BN + cl);
-                    epi_row<VEC>(g, a4, bv, ws, row, col, nv);
+                    if (g.colsum) epi_row<VEC, true>(g, a4, bv, ws, row, col, nv, cs);
+                    else epi_row<VEC>(g, a4, bv, ws, row, col, nv);
                 }
             }
+        }
+    }
+    if (g.colsum) {   // column sums of this tile's final values (e.g. the bias gradient of the layer whose output gradient C is)
+        __syncthreads();
+#pragma unroll
+        for (int e = 0; e < 4; ++e) ct[(tid >> 5) * BN + cl + e] = cs[e];
+        __syncthreads();
+        if (tid < BN && n0 + tid < g.N) {
+            float t = 0.f;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) t += ct[k * BN + tid];
+            g.colsum[(long)tm * g.N + n0 + tid] = t;
         }
     }
 }
@@ -1102,7 +1122,7 @@ extern "C" int mrg_gemm(const mrg_gemm_desc* d, hipStream_t stream) {
     g.C2 = (bf16_t*)d->C2; g.ldc2 = d->ldc2;
     g.bias = d->bias; g.resid = d->resid; g.ldr = d->ldr; g.accumulate = d->accumulate; g.act = d->act;
     g.aux_out = (bf16_t*)d->aux_out; g.aux_in = (const bf16_t*)d->aux_in; g.ldaux = d->ldaux;
-    g.row_map = d->row_map; g.add_tab = d->add_tab; g.add_row = d->add_row; g.ldt = d->ldt; g.row_scale = d->row_scale;
+    g.row_map = d->row_map; g.add_tab = d->add_tab; g.add_row = d->add_row; g.ldt = d->ldt; g.row_scale = d->row_scale; g.colsum = d->colsum_out;
     g.splitk = splitk; g.ws = d->ws;
     MRG_REQUIRE(d->variant >= 0 && d->variant <= MRG_GEMM_WS256, MRG_ERR_ARG, "mrg_gemm: bad variant");
     g.tiles_m = cdiv(d->M, BM); g.tiles_n = cdiv(d->N, BN);
@@ -1135,8 +1155,12 @@ extern "C" int mrg_gemm(const mrg_gemm_desc* d, hipStream_t stream) {
     else if (d->variant == MRG_GEMM_GLDS4) { use_pipe = false; occ4 = true; }
     else if (d->variant == MRG_GEMM_PIPE128) { use_pipe = true; }
     else if (d->variant == MRG_GEMM_PIPE256 || d->variant == MRG_GEMM_PIPE256X3) { use_big = fast && d->M > 128; use_pipe = true; }
-    const bool use_sq = fast && d->variant == MRG_GEMM_PIPE256SQ && d->M > 128 && d->N > 128;
-    const bool use_ws = fast && d->variant == MRG_GEMM_WS256 && d->M > 128;
+    if (d->colsum_out) {      // only the single-stage 128 x 128 kernel carries the column-sum epilogue
+        MRG_REQUIRE(fast && splitk == 1 && !d->row_map, MRG_ERR_UNSUPPORTED, "mrg_gemm: colsum_out needs aligned unmapped operands and no split-K");
+        use_pipe = false; use_big = false;
+    }
+    const bool use_sq = !d->colsum_out && fast && d->variant == MRG_GEMM_PIPE256SQ && d->M > 128 && d->N > 128;
+    const bool use_ws = !d->colsum_out && fast && d->variant == MRG_GEMM_WS256 && d->M > 128;
     const bool big3 = d->variant == MRG_GEMM_PIPE256X3;
 #define MRG_BIG(AM, BM_, V) do { if (big3) { const void* fn = (const void*)gemm_pipe256_kernel<AM, BM_, V, 3>; \
         (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 9 * TILE_BYTES); \

@@ -19,6 +19,7 @@ from .arena import grad_buffer, shadow
 
 BF16, F32 = torch.bfloat16, torch.float32
 KS = L.MRG_OP_KSTRIDED
+FUSE_EPI_COLSUM = True    # bias gradient of the producing layer from the dgrad GEMM's epilogue (column sums of dx per tile)
 FUSE_ATTN_BIAS = True     # q / k / v bias gradients from inside the attention-backward kernels (else: a column-sum pass over d_qkv)
 
 
@@ -140,9 +141,10 @@ def lin_fwd(x16: torch.Tensor, lin, *, out_dtype=BF16, resid: Optional[torch.Ten
 
 def lin_bwd(dy16: torch.Tensor, x16: torch.Tensor, lin, *, need_dx: bool = True, gelu_pre: Optional[torch.Tensor] = None,
             dx_dtype=BF16, dx_bf16_copy: bool = False, bias_grad: bool = True, a_map=None, k_dev=None, m_rows: Optional[int] = None,
-            dx_accumulate_into: Optional[torch.Tensor] = None):
+            dx_accumulate_into: Optional[torch.Tensor] = None, dx_colsum: Optional[torch.Tensor] = None):
     """Backward of y = x W^T + b given dy (bf16 [M, N]) and x (bf16 [M, K]).
-    Writes dW (and db) in place; returns dx (bf16 or fp32, optionally both) or None."""
+    Writes dW (and db) in place; returns dx (bf16 or fp32, optionally both) or None.  dx_colsum: fp32 [K] destination for the
+    column sums of dx (the bias gradient of the layer that produced x's pre-activation), formed in the dgrad epilogue."""
     Wp = lin.weight
     W = shadow(Wp)
     N = W.shape[0]
@@ -168,7 +170,9 @@ def lin_bwd(dy16: torch.Tensor, x16: torch.Tensor, lin, *, need_dx: bool = True,
     dx2 = torch.empty(dshape, dtype=BF16, device=dy16.device) if dx_bf16_copy else None
     K.gemm(dy16, W, M, Kin, N, b_mode=KS, lda=N, ldb=Kin, out=dx, ldc=Kin, out2=dx2, accumulate=acc,
            act=L.MRG_ACT_NONE if gelu_pre is None else (L.MRG_ACT_MUL_AUX_F16 if gelu_pre.dtype == torch.float16 else L.MRG_ACT_GELU_BWD),
-           aux_in=gelu_pre)
+           aux_in=gelu_pre, colsum=dx_colsum if FUSE_EPI_COLSUM else None)
+    if dx_colsum is not None and not FUSE_EPI_COLSUM:
+        K.colsum(dx.view(-1, Kin), dx_colsum, M=M)
     return dx, dx2
 
 
@@ -211,12 +215,12 @@ def block_bwd(blk, saved, dx32: torch.Tensor, dx16: Optional[torch.Tensor], rema
         # stochastic depth: the branch sees row_scale * dy, the residual path the unscaled dy; the branch bias gradients are
         # then column sums of the scaled gradient, not of the residual-stream gradient the LayerNorm kernels sum
         dxs16 = K.row_scale_bf16(dx32, dp[1])
-        d_pre, _ = lin_bwd(dxs16, h_act, blk.mlp.fc2, gelu_pre=h_pre, bias_grad=True)
+        d_pre, _ = lin_bwd(dxs16, h_act, blk.mlp.fc2, gelu_pre=h_pre, bias_grad=True, dx_colsum=grad_buffer(blk.mlp.fc1.bias))
     else:
         if dx16 is None:
             dx16 = to_bf16(dx32)
-        d_pre, _ = lin_bwd(dx16, h_act, blk.mlp.fc2, gelu_pre=h_pre, bias_grad=False)
-    d_ln2, _ = lin_bwd(d_pre, ln2, blk.mlp.fc1)
+        d_pre, _ = lin_bwd(dx16, h_act, blk.mlp.fc2, gelu_pre=h_pre, bias_grad=False, dx_colsum=grad_buffer(blk.mlp.fc1.bias))
+    d_ln2, _ = lin_bwd(d_pre, ln2, blk.mlp.fc1, bias_grad=False)      # fc1 bias gradient = column sums of d_pre, formed above
     dx_mid32, dx_mid16 = K.ln_bwd(d_ln2, x_mid, mean2, rstd2, blk.norm2.weight, dx32, grad_buffer(blk.norm2.weight),
                                   grad_buffer(blk.norm2.bias), None if dp is not None else grad_buffer(blk.mlp.fc2.bias))
     if dp is not None:
@@ -468,8 +472,8 @@ def decoder_bwd(ad, saved, d_img: torch.Tensor):
     dx16 = dx16.view(B, Tq, Dd)
     for blk, sv in zip(reversed(blocks), reversed(blk_saved)):
         dx32, dx16 = block_bwd(blk, sv, dx32, dx16)
-    d_pre, _ = lin_bwd(dx16, h_act, ad.mlp.fc2, gelu_pre=h_pre, bias_grad=False)
-    d_on, _ = lin_bwd(d_pre, on, ad.mlp.fc1)
+    d_pre, _ = lin_bwd(dx16, h_act, ad.mlp.fc2, gelu_pre=h_pre, bias_grad=False, dx_colsum=grad_buffer(ad.mlp.fc1.bias))
+    d_on, _ = lin_bwd(d_pre, on, ad.mlp.fc1, bias_grad=False)
     dx1_32, dx1_16 = K.ln_bwd(d_on, x1, mo, ro, ad.out_norm.weight, dx32, grad_buffer(ad.out_norm.weight),
                               grad_buffer(ad.out_norm.bias), grad_buffer(ad.mlp.fc2.bias))
     d_o, _ = lin_bwd(dx1_16, o, ad.decoder.proj, bias_grad=False)

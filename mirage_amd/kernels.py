@@ -160,7 +160,9 @@ def gemm(A: torch.Tensor, B: torch.Tensor, M: int, N: int, K: int, *, a_mode=L.M
          lda: Optional[int] = None, ldb: Optional[int] = None, out: Optional[torch.Tensor] = None, out_dtype=BF16,
          ldc: Optional[int] = None, out2: Optional[torch.Tensor] = None, bias=None, resid=None, accumulate=False,
          act=L.MRG_ACT_NONE, aux_out=None, aux_in=None, row_map=None, add_tab=None, add_row=None, a_map=None, b_map=None,
-         m_dev=None, k_dev=None, splitk: int = 1, tune_split: bool = False, row_scale=None) -> torch.Tensor:
+         m_dev=None, k_dev=None, splitk: int = 1, tune_split: bool = False, row_scale=None, colsum=None) -> torch.Tensor:
+    """colsum: optional fp32 [N] destination for the column sums of the values written to `out` (per-tile partial sums in the
+    epilogue + batched reduction): the bias gradient of the layer whose output gradient this GEMM produces."""
     _need_cuda(A, "GEMM operand")
     if out is None:
         out = torch.empty((M, N), dtype=out_dtype, device=A.device)
@@ -189,6 +191,10 @@ def gemm(A: torch.Tensor, B: torch.Tensor, M: int, N: int, K: int, *, a_mode=L.M
     if add_tab is not None:
         d.add_tab, d.add_row, d.ldt = add_tab.data_ptr(), add_row.data_ptr(), add_tab.stride(0)
     d.row_scale = _p(row_scale)
+    cs_part = None
+    if colsum is not None:
+        cs_part = torch.empty(((M + 127) // 128, N), dtype=F32, device=A.device)
+        d.colsum_out = cs_part.data_ptr()
     variant = L.MRG_GEMM_AUTO
     tunable = TUNE["enabled"] and a_map is None and b_map is None and m_dev is None and k_dev is None and not accumulate and M * N >= (1 << 16)
     if tunable:
@@ -208,7 +214,11 @@ def gemm(A: torch.Tensor, B: torch.Tensor, M: int, N: int, K: int, *, a_mode=L.M
     defer = None
     if splitk > 1 and bias is None and not accumulate and out2 is None and d.ldc == N and (M * N) % 4 == 0 and Deferred.ok(out, M * N, M * N):
         defer = out
+    if cs_part is not None and variant not in (L.MRG_GEMM_GLDS3, L.MRG_GEMM_GLDS4):
+        variant = L.MRG_GEMM_GLDS4 if (a_mode == L.MRG_OP_KCONTIG and M * N >= 1400 * 16384) else L.MRG_GEMM_GLDS3
     _gemm_launch(d, splitk, variant, A.device, defer)
+    if cs_part is not None:
+        reduce_slices(cs_part, 0, colsum, N, N, cs_part.shape[0])
     return out
 
 

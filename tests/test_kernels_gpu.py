@@ -466,3 +466,17 @@ def test_gemm_gelu_save_grad_and_mul_aux(K):
     K.gemm(dy, W2, M, N, Kd, b_mode=L.MRG_OP_KSTRIDED, out=dx, act=L.MRG_ACT_MUL_AUX_F16, aux_in=gd)
     want = (dy.float() @ W2.float()) * gd.float()
     assert (dx - want).abs().max() <= 2e-3 * want.abs().max()
+
+
+def test_gemm_colsum_epilogue(K):
+    """colsum: column sums of the final C values from the GEMM epilogue (bias gradient of the producing layer)."""
+    from mirage_amd import _lib as L
+    torch.manual_seed(9)
+    M, N, Kd = 1000, 384, 256                        # 8 row tiles, the last one partial
+    dy = torch.randn(M, Kd, device=dev()).bfloat16(); W = (torch.randn(Kd, N, device=dev()) * 0.05).bfloat16()
+    gd = torch.rand(M, N, device=dev()).half()
+    dx = torch.empty(M, N, dtype=torch.bfloat16, device=dev()); cs = torch.full((N,), float("nan"), device=dev())
+    K.gemm(dy, W, M, N, Kd, b_mode=L.MRG_OP_KSTRIDED, out=dx, act=L.MRG_ACT_MUL_AUX_F16, aux_in=gd, colsum=cs)
+    want = ((dy.float() @ W.float()) * gd.float())
+    assert rel_rms(dx.float(), want) < 1e-2
+    assert rel_rms(cs, want.sum(0)) < 2e-3, rel_rms(cs, want.sum(0))
