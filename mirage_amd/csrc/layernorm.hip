@@ -135,7 +135,9 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const void* __restrict__ dy
         }
     }
     float* outp = partials + (long)blockIdx.x * 3 * D;
-#pragma unroll 1
+    // fully unrolled: selecting among the three accumulator arrays with a run-time index would demote them to scratch memory
+    // (they then cost a read-modify-write of 48 * NV bytes per lane per row)
+#pragma unroll
     for (int qn = 0; qn < 3; ++qn) {
 #pragma unroll
         for (int j = 0; j < NV; ++j) {
