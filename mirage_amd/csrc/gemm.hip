@@ -373,7 +373,7 @@ __device__ __forceinline__ void glds_setup(const bf16_t* P, int ld, int row0, in
     }
 }
 
-template <int AMODE, int BMODE, bool VEC, int OCC>
+template <int AMODE, int BMODE, bool VEC, int OCC, bool CSUM = false>
 __global__ __launch_bounds__(256, OCC) void gemm_glds_kernel(const GemmArgs g) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int nwg = g.tiles_m * g.tiles_n;
@@ -494,13 +494,13 @@ __global__ __launch_bounds__(256, OCC) void gemm_glds_kernel(const GemmArgs g) {
                 const int row = m0 + (rl >> 5) * 64 + pss * 32 + (rl & 31);
                 if (row < Meff) {
                     const float4 a4 = *reinterpret_cast<const float4*>(ct + rl * BN + cl);
-                    if (g.colsum) epi_row<VEC, true>(g, a4, bv, ws, row, col, nv, cs);
+                    if (CSUM) epi_row<VEC, true>(g, a4, bv, ws, row, col, nv, cs);
                     else epi_row<VEC>(g, a4, bv, ws, row, col, nv);
                 }
             }
         }
     }
-    if (g.colsum) {   // column sums of this tile's final values (e.g. the bias gradient of the layer whose output gradient C is)
+    if (CSUM) {   // column sums of this tile's final values (e.g. the bias gradient of the layer whose output gradient C is)
         __syncthreads();
 #pragma unroll
         for (int e = 0; e < 4; ++e) ct[(tid >> 5) * BN + cl + e] = cs[e];
@@ -1155,9 +1155,15 @@ extern "C" int mrg_gemm(const mrg_gemm_desc* d, hipStream_t stream) {
     else if (d->variant == MRG_GEMM_GLDS4) { use_pipe = false; occ4 = true; }
     else if (d->variant == MRG_GEMM_PIPE128) { use_pipe = true; }
     else if (d->variant == MRG_GEMM_PIPE256 || d->variant == MRG_GEMM_PIPE256X3) { use_big = fast && d->M > 128; use_pipe = true; }
-    if (d->colsum_out) {      // only the single-stage 128 x 128 kernel carries the column-sum epilogue
-        MRG_REQUIRE(fast && splitk == 1 && !d->row_map, MRG_ERR_UNSUPPORTED, "mrg_gemm: colsum_out needs aligned unmapped operands and no split-K");
-        use_pipe = false; use_big = false;
+    if (d->colsum_out) {      // only the single-stage 128 x 128 kernel (dgrad layout) is instantiated with the column-sum epilogue
+        MRG_REQUIRE(fast && splitk == 1 && !d->row_map && d->a_mode == MRG_OP_KCONTIG && d->b_mode == MRG_OP_KSTRIDED, MRG_ERR_UNSUPPORTED,
+                    "mrg_gemm: colsum_out needs the dgrad layout (A k-contiguous, B k-strided), aligned unmapped operands and no split-K");
+        if (vec) { if (occ4) hipLaunchKernelGGL((gemm_glds_kernel<0, 1, true, 4, true>), grid, block, (size_t)(2 * TILE_BYTES), stream, g);
+                   else hipLaunchKernelGGL((gemm_glds_kernel<0, 1, true, 3, true>), grid, block, (size_t)(2 * TILE_BYTES), stream, g); }
+        else { if (occ4) hipLaunchKernelGGL((gemm_glds_kernel<0, 1, false, 4, true>), grid, block, (size_t)(2 * TILE_BYTES), stream, g);
+               else hipLaunchKernelGGL((gemm_glds_kernel<0, 1, false, 3, true>), grid, block, (size_t)(2 * TILE_BYTES), stream, g); }
+        if (d->ev_stop) (void)hipEventRecord((hipEvent_t)d->ev_stop, stream);
+        return mrg_check_launch("mrg_gemm");
     }
     const bool use_sq = !d->colsum_out && fast && d->variant == MRG_GEMM_PIPE256SQ && d->M > 128 && d->N > 128;
     const bool use_ws = !d->colsum_out && fast && d->variant == MRG_GEMM_WS256 && d->M > 128;
