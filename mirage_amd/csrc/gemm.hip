@@ -1071,6 +1071,107 @@ __global__ __launch_bounds__(512, 2) void gemm_pipe256sq_kernel(const GemmArgs g
     }
 }
 
+// 64 x 128 tile, single stage (24 KiB operands; 32 KiB for the epilogue): twice as many, half as tall workgroups for the short,
+// latency-bound problems of the output adapters (K = 256 ... 1024 on 16384 rows) and the N = 768 encoder shapes, where a
+// 128-row tile leaves 1-1.5 workgroups per CU.  A must be k-contiguous (forward / dgrad layouts).
+template <int BMODE, bool VEC>
+__global__ __launch_bounds__(256, 4) void gemm_glds64_kernel(const GemmArgs g) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tiles_m = (g.M + 63) / 64;
+    const int nwg = tiles_m * g.tiles_n;
+    int bid = blockIdx.x;
+    {
+        const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    constexpr int GROUP_M = 16;
+    int tm, tn;
+    {
+        const int per_group = GROUP_M * g.tiles_n;
+        const int grp = bid / per_group, in_grp = bid - grp * per_group;
+        const int first = grp * GROUP_M;
+        const int rows = min(GROUP_M, tiles_m - first);
+        tm = first + in_grp % rows;
+        tn = in_grp / rows;
+    }
+    const int m0 = tm * 64, n0 = tn * BN;
+    const int Meff = g.m_dev ? min(g.M, *g.m_dev) : g.M;
+    const int Keff = g.k_dev ? min(g.K, *g.k_dev) : g.K;
+    if (m0 >= Meff) return;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int ntiles = (Keff + BK - 1) / BK;
+    f32x16 acc[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+    char* ldsA = smem;
+    char* ldsB = smem + TILE_BYTES / 2;
+    const uint32_t la_u = lds_addr(ldsA), lb_u = lds_addr(ldsB);
+    const bf16_t* pa[2]; const bf16_t* pb[4];
+    long ia[2], ib[4];
+    int ka[2], kb[4];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) glds_setup<MRG_OP_KCONTIG>(g.A, g.lda, m0, Meff, 0, wave * 2 + j, lane, pa[j], ia[j], ka[j]);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) glds_setup<BMODE>(g.B, g.ldb, n0, g.N, 0, wave * 4 + j, lane, pb[j], ib[j], kb[j]);
+    const bf16_t* zero = reinterpret_cast<const bf16_t*>(g_zero_page);
+    for (int t = 0; t < ntiles; ++t) {
+        const int krem = Keff - t * BK;
+        if (t > 0) __syncthreads();
+#pragma unroll
+        for (int j = 0; j < 2; ++j) glds16((krem >= BK || ka[j] < krem) ? pa[j] : zero, ldsA + (wave * 2 + j) * 1024);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) glds16((krem >= BK || kb[j] < krem) ? pb[j] : zero, ldsB + (wave * 4 + j) * 1024);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) pa[j] += ia[j];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) pb[j] += ib[j];
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            const bf16x8 fa = read_frag<MRG_OP_KCONTIG>(ldsA, la_u, wm * 32, kk, lane);
+            bf16x8 fb[2];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) fb[j] = read_frag<BMODE>(ldsB, lb_u, wn * 64 + j * 32, kk, lane);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb[j], acc[j], 0, 0, 0);
+        }
+    }
+    __syncthreads();
+    float* ct = reinterpret_cast<float*>(smem);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int c2 = wn * 64 + j * 32 + (lane & 31);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int rl = wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            ct[rl * BN + c2] = acc[j][r];
+        }
+    }
+    __syncthreads();
+    const int cl = (tid & 31) << 2;
+    const int col = n0 + cl;
+    if (col >= g.N) return;
+    const int nv = min(4, g.N - col);
+    float bv[4] = {0.f, 0.f, 0.f, 0.f};
+    if (g.bias) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) if (e < nv) bv[e] = g.bias[col + e];
+    }
+#pragma unroll 1
+    for (int it = 0; it < 8; ++it) {
+        const int rl = (tid >> 5) + (it << 3);
+        const int row = m0 + rl;
+        if (row >= Meff) break;
+        const float4 a4 = *reinterpret_cast<const float4*>(ct + rl * BN + cl);
+        epi_row<VEC>(g, a4, bv, nullptr, row, col, nv);
+    }
+}
+
 // split-K finish: C (+)= sum_z ws[z]  (+ bias) ; fp32 out, optional bf16 copy
 __global__ void splitk_reduce_kernel(const float* __restrict__ ws, int splitk, long mn, int N, float* __restrict__ C, int ldc,
                                      int accumulate, const float* __restrict__ bias, bf16_t* __restrict__ C2, int ldc2,
@@ -1124,7 +1225,7 @@ extern "C" int mrg_gemm(const mrg_gemm_desc* d, hipStream_t stream) {
     g.aux_out = (bf16_t*)d->aux_out; g.aux_in = (const bf16_t*)d->aux_in; g.ldaux = d->ldaux;
     g.row_map = d->row_map; g.add_tab = d->add_tab; g.add_row = d->add_row; g.ldt = d->ldt; g.row_scale = d->row_scale; g.colsum = d->colsum_out;
     g.splitk = splitk; g.ws = d->ws;
-    MRG_REQUIRE(d->variant >= 0 && d->variant <= MRG_GEMM_WS256, MRG_ERR_ARG, "mrg_gemm: bad variant");
+    MRG_REQUIRE(d->variant >= 0 && d->variant <= MRG_GEMM_GLDS64, MRG_ERR_ARG, "mrg_gemm: bad variant");
     g.tiles_m = cdiv(d->M, BM); g.tiles_n = cdiv(d->N, BN);
     { static const int abl = [] { const char* e = getenv("MRG_GEMM_ABLATE"); return e ? atoi(e) : 0; }(); g.ablate = abl; }
     dim3 grid(g.tiles_m * g.tiles_n, splitk), block(256);
@@ -1167,6 +1268,15 @@ extern "C" int mrg_gemm(const mrg_gemm_desc* d, hipStream_t stream) {
     }
     const bool use_sq = !d->colsum_out && fast && d->variant == MRG_GEMM_PIPE256SQ && d->M > 128 && d->N > 128;
     const bool use_ws = !d->colsum_out && fast && d->variant == MRG_GEMM_WS256 && d->M > 128;
+    if (fast && d->variant == MRG_GEMM_GLDS64 && d->a_mode == MRG_OP_KCONTIG && splitk == 1 && !d->colsum_out) {
+        const dim3 g64(cdiv(d->M, 64) * g.tiles_n);
+        if (d->b_mode == MRG_OP_KCONTIG) { if (vec) hipLaunchKernelGGL((gemm_glds64_kernel<0, true>), g64, block, (size_t)(2 * TILE_BYTES), stream, g);
+                                           else hipLaunchKernelGGL((gemm_glds64_kernel<0, false>), g64, block, (size_t)(2 * TILE_BYTES), stream, g); }
+        else { if (vec) hipLaunchKernelGGL((gemm_glds64_kernel<1, true>), g64, block, (size_t)(2 * TILE_BYTES), stream, g);
+               else hipLaunchKernelGGL((gemm_glds64_kernel<1, false>), g64, block, (size_t)(2 * TILE_BYTES), stream, g); }
+        if (d->ev_stop) (void)hipEventRecord((hipEvent_t)d->ev_stop, stream);
+        return mrg_check_launch("mrg_gemm");
+    }
     const bool big3 = d->variant == MRG_GEMM_PIPE256X3;
 #define MRG_BIG(AM, BM_, V) do { if (big3) { const void* fn = (const void*)gemm_pipe256_kernel<AM, BM_, V, 3>; \
         (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 9 * TILE_BYTES); \

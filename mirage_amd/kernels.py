@@ -137,6 +137,8 @@ def _autotune(d, key, splitk, allow_split, dev):
             continue
         for s_ in splits:
             cands.append((v, s_))
+    if d.a_mode == L.MRG_OP_KCONTIG and not d.colsum_out:          # half-height tiles: only pays when 128-row tiles underfill the chip
+        cands.append((L.MRG_GEMM_GLDS64, 1))
     best, best_t = (L.MRG_GEMM_AUTO, splitk), float("inf")
     for v, s_ in cands:
         _gemm_launch(d, s_, v, dev)
@@ -206,6 +208,8 @@ def gemm(A: torch.Tensor, B: torch.Tensor, M: int, N: int, K: int, *, a_mode=L.M
             hit = _autotune(d, key, splitk, tune_split, A.device)
         if hit is not None:
             variant, splitk = hit
+    if TUNE.get("force") is not None:                              # tests / tools: pin one kernel variant
+        variant = TUNE["force"]
     if TIMING["on"]:
         st, en = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         st.record(); en.record()                                   # creates the underlying hipEvent_t handles

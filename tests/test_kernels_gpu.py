@@ -74,6 +74,34 @@ def test_gemm_wgrad_kstrided_both(K, Mtok, Nout, Kin, splitk):
     torch.testing.assert_close(out, ref, rtol=3e-3, atol=3e-3 * float(ref.abs().max()))
 
 
+@pytest.mark.parametrize("variant", [1, 2, 3, 4, 6, 7, 8])
+def test_gemm_every_variant_same_result(K, variant):
+    """Each kernel variant the tuner may pick computes the same forward / dgrad product (ragged M, N and K tails, bias + GELU'
+    side output, device row count)."""
+    from mirage_amd import _lib as L
+    M, N, Kd = 1000, 328, 200
+    A = rnd(M, Kd, dtype=BF16, seed=31); W = rnd(N, Kd, scale=0.05, dtype=BF16, seed=32); b = rnd(N, seed=33)
+    Wt = rnd(Kd, N, scale=0.05, dtype=BF16, seed=34)
+    cnt = torch.tensor([901], dtype=torch.int32, device=dev())
+    K.TUNE["force"] = variant
+    try:
+        out = K.gemm(A, W, M, N, Kd, bias=b, out_dtype=F32)
+        aux = torch.empty(M, N, dtype=torch.float16, device=dev())
+        act = K.gemm(A, W, M, N, Kd, bias=b, act=L.MRG_ACT_GELU_SAVE_GRAD, aux_out=aux)
+        dg = K.gemm(A, Wt, M, N, Kd, b_mode=L.MRG_OP_KSTRIDED, out_dtype=F32)
+        part = torch.full((M, N), 3.0, device=dev())
+        K.gemm(A, W, M, N, Kd, out=part, m_dev=cnt)
+    finally:
+        K.TUNE["force"] = None
+    lin = A.float() @ W.float().t() + b
+    torch.testing.assert_close(out, lin, rtol=2e-3, atol=2e-3 * float(lin.abs().max()))
+    assert rel_rms(act.float(), torch.nn.functional.gelu(lin)) < 5e-3
+    ref = dg_ref = A.float() @ Wt.float()
+    torch.testing.assert_close(dg, dg_ref, rtol=2e-3, atol=2e-3 * float(ref.abs().max()))
+    torch.testing.assert_close(part[:901], (lin - b)[:901], rtol=2e-3, atol=2e-3 * float(lin.abs().max()))
+    assert float((part[901:] - 3.0).abs().max()) == 0.0
+
+
 def test_gemm_epilogues(K):
     from mirage_amd import _lib as L
     M, N, Kd = 517, 384, 256
