@@ -42,6 +42,8 @@ struct GemmArgs {
     float* colsum;             // [tiles_m][N]: column sums of the final C values per 128-row tile (single-stage kernel only)
     int splitk; float* ws;
     int tiles_m, tiles_n;
+    int xcd_split; // MRG_GEMM_XCD_SPLIT (default 1): split-K index slowest in the XCD band order
+    int nt;       // MRG_GEMM_NT: 0 plain stores, 1 streaming (nontemporal) stores for C / C2 / aux_out, 2 (default) for aux_out only
     int ablate;   // MRG_GEMM_ABLATE (256x128 kernel only, for roofline analysis): 1 = no DMA, 2 = DMA only, 3 = DMA + LDS reads, no MFMA
 };
 
@@ -129,6 +131,34 @@ __device__ __forceinline__ bf16x8 read_frag(const char* lds, uint32_t lds_base, 
     }
 }
 
+// XCD-aware workgroup order.  Workgroups are dispatched round-robin over the 8 XCDs (each with its own L2) in linear order
+// (x fastest, then y); XCD x is given one contiguous band of the logical (split, tile) space with the split-K index slowest, so the
+// workgroups sharing an L2 work on the same k-range and on neighbouring tiles (with the split index taken from blockIdx.y instead,
+// every XCD streams every k-range: 2.4x the operand bytes from HBM on the fc1/fc2 wgrad shapes, profiles/r01_c2_pmc_traffic.md).
+__device__ __forceinline__ void wg_remap(int nwg, int xcd_split, int& bid, int& ksplit) {
+    if (xcd_split) {
+        const int L = blockIdx.x + blockIdx.y * gridDim.x, total = nwg * gridDim.y;
+        const int q = total >> 3, r = total & 7, xcd = L & 7, idx = L >> 3;
+        const int lin = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+        ksplit = lin / nwg;
+        bid = lin - ksplit * nwg;
+    } else {
+        const int b = blockIdx.x;
+        const int q = nwg >> 3, r = nwg & 7, xcd = b & 7, idx = b >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+        ksplit = blockIdx.y;
+    }
+}
+
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void st_out(u32x2* p, const u32x2 v, int nt) {
+    if (nt) asm volatile("global_store_dwordx2 %0, %1, off nt" :: "v"(p), "v"(v) : "memory"); else *p = v;
+}
+__device__ __forceinline__ void st_out(f32x4v* p, const f32x4v v, int nt) {
+    if (nt) asm volatile("global_store_dwordx4 %0, %1, off nt" :: "v"(p), "v"(v) : "memory"); else *p = v;
+}
+
 // one output row segment (4 consecutive columns) of the fused epilogue
 template <bool VEC, bool CS = false>
 __device__ __forceinline__ void epi_row(const GemmArgs& g, const float4 a4, const float (&bv)[4], float* ws, int row, int col, int nv,
@@ -145,7 +175,7 @@ __device__ __forceinline__ void epi_row(const GemmArgs& g, const float4 a4, cons
         if (g.act == MRG_ACT_GELU) {
             if (g.aux_out) {
                 bf16_t* ao = g.aux_out + (long)row * g.ldaux + col;
-                if (VEC) *reinterpret_cast<uint2*>(ao) = make_uint2(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]));
+                if (VEC) st_out(reinterpret_cast<u32x2*>(ao), u32x2{pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3])}, g.nt);
                 else { for (int e = 0; e < nv; ++e) ao[e] = f2bf(v[e]); }
             }
 #pragma unroll
@@ -164,7 +194,7 @@ __device__ __forceinline__ void epi_row(const GemmArgs& g, const float4 a4, cons
                 if (VEC) {
                     typedef _Float16 h2 __attribute__((ext_vector_type(2)));
                     const h2 lo = {(_Float16)gd[0], (_Float16)gd[1]}, hi = {(_Float16)gd[2], (_Float16)gd[3]};
-                    *reinterpret_cast<uint2*>(ao) = make_uint2(*reinterpret_cast<const uint32_t*>(&lo), *reinterpret_cast<const uint32_t*>(&hi));
+                    st_out(reinterpret_cast<u32x2*>(ao), u32x2{*reinterpret_cast<const uint32_t*>(&lo), *reinterpret_cast<const uint32_t*>(&hi)}, g.nt);
                 } else { for (int e = 0; e < nv; ++e) ao[e] = (_Float16)gd[e]; }
             }
         } else if (g.act == MRG_ACT_MUL_AUX_F16) {
@@ -210,18 +240,18 @@ __device__ __forceinline__ void epi_row(const GemmArgs& g, const float4 a4, cons
             float* c = reinterpret_cast<float*>(g.C) + orow * g.ldc + col;
             if (VEC) {
                 if (g.accumulate) { const float4 o = *reinterpret_cast<const float4*>(c); v[0] += o.x; v[1] += o.y; v[2] += o.z; v[3] += o.w; }
-                *reinterpret_cast<float4*>(c) = make_float4(v[0], v[1], v[2], v[3]);
+                st_out(reinterpret_cast<f32x4v*>(c), f32x4v{v[0], v[1], v[2], v[3]}, g.nt == 1);
             } else {
                 for (int e = 0; e < nv; ++e) { if (g.accumulate) v[e] += c[e]; c[e] = v[e]; }
             }
         } else {
             bf16_t* c = reinterpret_cast<bf16_t*>(g.C) + orow * g.ldc + col;
-            if (VEC) *reinterpret_cast<uint2*>(c) = make_uint2(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]));
+            if (VEC) st_out(reinterpret_cast<u32x2*>(c), u32x2{pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3])}, g.nt == 1);
             else { for (int e = 0; e < nv; ++e) c[e] = f2bf(v[e]); }
         }
         if (g.C2) {
             bf16_t* c = g.C2 + orow * g.ldc2 + col;
-            if (VEC) *reinterpret_cast<uint2*>(c) = make_uint2(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]));
+            if (VEC) st_out(reinterpret_cast<u32x2*>(c), u32x2{pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3])}, g.nt == 1);
             else { for (int e = 0; e < nv; ++e) c[e] = f2bf(v[e]); }
         }
 }
@@ -231,11 +261,8 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs g) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     // XCD-aware tile order: block b runs on XCD b%8; give each XCD a contiguous band of logical tiles
     const int nwg = g.tiles_m * g.tiles_n;
-    int bid = blockIdx.x;
-    {
-        const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
-        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-    }
+    int bid, ksplit;
+    wg_remap(nwg, g.xcd_split, bid, ksplit);
     const int tm = bid / g.tiles_n, tn = bid % g.tiles_n;
     const int m0 = tm * BM, n0 = tn * BN;
     const int Meff = g.m_dev ? min(g.M, *g.m_dev) : g.M;
@@ -249,7 +276,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs g) {
     int t0 = 0, t1 = ntiles;
     if (g.splitk > 1) {
         const int per = (ntiles + g.splitk - 1) / g.splitk;
-        t0 = blockIdx.y * per;
+        t0 = ksplit * per;
         t1 = min(ntiles, t0 + per);
     }
 
@@ -322,7 +349,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs g) {
     const int col = n0 + cl;
     if (col >= g.N) return;
     const int nv = min(4, g.N - col);
-    float* ws = g.splitk > 1 ? g.ws + (long)blockIdx.y * g.M * g.N : nullptr;
+    float* ws = g.splitk > 1 ? g.ws + (long)ksplit * g.M * g.N : nullptr;
     float bv[4] = {0.f, 0.f, 0.f, 0.f};
     if (g.bias && !ws) {
 #pragma unroll
@@ -377,11 +404,8 @@ template <int AMODE, int BMODE, bool VEC, int OCC, bool CSUM = false>
 __global__ __launch_bounds__(256, OCC) void gemm_glds_kernel(const GemmArgs g) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int nwg = g.tiles_m * g.tiles_n;
-    int bid = blockIdx.x;
-    {
-        const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
-        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-    }
+    int bid, ksplit;
+    wg_remap(nwg, g.xcd_split, bid, ksplit);
     // grouped rasterisation inside the XCD's band: GROUP_M row panels x all column tiles, column-major within the group,
     // so a B (weight) tile is reused by GROUP_M consecutive workgroups while their A panels stay L2-resident
     constexpr int GROUP_M = 8;
@@ -405,7 +429,7 @@ __global__ __launch_bounds__(256, OCC) void gemm_glds_kernel(const GemmArgs g) {
     int t0 = 0, t1 = ntiles;
     if (g.splitk > 1) {
         const int per = (ntiles + g.splitk - 1) / g.splitk;
-        t0 = blockIdx.y * per;
+        t0 = ksplit * per;
         t1 = min(ntiles, t0 + per);
     }
     f32x16 acc[2][2];
@@ -468,7 +492,7 @@ __global__ __launch_bounds__(256, OCC) void gemm_glds_kernel(const GemmArgs g) {
     const int cl = (tid & 31) << 2;
     const int col = n0 + cl;
     const int nv = min(4, g.N - col);
-    float* ws = g.splitk > 1 ? g.ws + (long)blockIdx.y * g.M * g.N : nullptr;
+    float* ws = g.splitk > 1 ? g.ws + (long)ksplit * g.M * g.N : nullptr;
     float bv[4] = {0.f, 0.f, 0.f, 0.f};
     if (g.bias && !ws && col < g.N) {
 #pragma unroll
@@ -528,11 +552,8 @@ template <int AMODE, int BMODE, bool VEC>
 __global__ __launch_bounds__(256, 2) void gemm_pipe_kernel(const GemmArgs g) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int nwg = g.tiles_m * g.tiles_n;
-    int bid = blockIdx.x;
-    {
-        const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
-        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-    }
+    int bid, ksplit;
+    wg_remap(nwg, g.xcd_split, bid, ksplit);
     constexpr int GROUP_M = 8;
     int tm, tn;
     {
@@ -554,7 +575,7 @@ __global__ __launch_bounds__(256, 2) void gemm_pipe_kernel(const GemmArgs g) {
     int t0 = 0, t1 = ntiles;
     if (g.splitk > 1) {
         const int per = (ntiles + g.splitk - 1) / g.splitk;
-        t0 = blockIdx.y * per;
+        t0 = ksplit * per;
         t1 = min(ntiles, t0 + per);
     }
     f32x16 acc[2][2];
@@ -629,7 +650,7 @@ __global__ __launch_bounds__(256, 2) void gemm_pipe_kernel(const GemmArgs g) {
     const int col = n0 + cl;
     if (col >= g.N) return;
     const int nv = min(4, g.N - col);
-    float* ws = g.splitk > 1 ? g.ws + (long)blockIdx.y * g.M * g.N : nullptr;
+    float* ws = g.splitk > 1 ? g.ws + (long)ksplit * g.M * g.N : nullptr;
     float bv[4] = {0.f, 0.f, 0.f, 0.f};
     if (g.bias && !ws) {
 #pragma unroll
@@ -653,11 +674,8 @@ __global__ __launch_bounds__(512, 2) void gemm_pipe256_kernel(const GemmArgs g) 
     constexpr int STAGE = 3 * TILE_BYTES;
     const int tiles_m = (g.M + 255) / 256;
     const int nwg = tiles_m * g.tiles_n;
-    int bid = blockIdx.x;
-    {
-        const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
-        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-    }
+    int bid, ksplit;
+    wg_remap(nwg, g.xcd_split, bid, ksplit);
     constexpr int GROUP_M = 4;
     int tm, tn;
     {
@@ -680,7 +698,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pipe256_kernel(const GemmArgs g) 
     int t0 = 0, t1 = ntiles;
     if (g.splitk > 1) {
         const int per = (ntiles + g.splitk - 1) / g.splitk;
-        t0 = blockIdx.y * per;
+        t0 = ksplit * per;
         t1 = min(ntiles, t0 + per);
     }
     f32x16 acc[2][2];
@@ -751,7 +769,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pipe256_kernel(const GemmArgs g) 
     const int cl = (tid & 31) << 2;
     const int col = n0 + cl;
     const int nv = min(4, g.N - col);
-    float* ws = g.splitk > 1 ? g.ws + (long)blockIdx.y * g.M * g.N : nullptr;
+    float* ws = g.splitk > 1 ? g.ws + (long)ksplit * g.M * g.N : nullptr;
     float bv[4] = {0.f, 0.f, 0.f, 0.f};
     if (g.bias && !ws && col < g.N) {
 #pragma unroll
@@ -797,11 +815,8 @@ __global__ __launch_bounds__(768) void gemm_ws256_kernel(const GemmArgs g) {
     constexpr int STAGE = 3 * TILE_BYTES, STAGES = 3;
     const int tiles_m = (g.M + 255) / 256;
     const int nwg = tiles_m * g.tiles_n;
-    int bid = blockIdx.x;
-    {
-        const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
-        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-    }
+    int bid, ksplit;
+    wg_remap(nwg, g.xcd_split, bid, ksplit);
     constexpr int GROUP_M = 4;
     int tm, tn;
     {
@@ -822,7 +837,7 @@ __global__ __launch_bounds__(768) void gemm_ws256_kernel(const GemmArgs g) {
     int t0 = 0, t1 = ntiles;
     if (g.splitk > 1) {
         const int per = (ntiles + g.splitk - 1) / g.splitk;
-        t0 = blockIdx.y * per;
+        t0 = ksplit * per;
         t1 = min(ntiles, t0 + per);
     }
     const uint32_t sbase = __builtin_amdgcn_readfirstlane(lds_addr(smem));
@@ -900,7 +915,7 @@ __global__ __launch_bounds__(768) void gemm_ws256_kernel(const GemmArgs g) {
     const int cl = (tid & 31) << 2;
     const int col = n0 + cl;
     const int nv = min(4, g.N - col);
-    float* ws = g.splitk > 1 ? g.ws + (long)blockIdx.y * g.M * g.N : nullptr;
+    float* ws = g.splitk > 1 ? g.ws + (long)ksplit * g.M * g.N : nullptr;
     float bv[4] = {0.f, 0.f, 0.f, 0.f};
     if (g.bias && !ws && col < g.N) {
 #pragma unroll
@@ -946,11 +961,8 @@ __global__ __launch_bounds__(512, 2) void gemm_pipe256sq_kernel(const GemmArgs g
     constexpr int STAGE = 4 * TILE_BYTES;
     const int tiles_m = (g.M + 255) / 256, tiles_n = (g.N + 255) / 256;
     const int nwg = tiles_m * tiles_n;
-    int bid = blockIdx.x;
-    {
-        const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
-        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-    }
+    int bid, ksplit;
+    wg_remap(nwg, g.xcd_split, bid, ksplit);
     constexpr int GROUP_M = 4;
     int tm, tn;
     {
@@ -973,7 +985,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pipe256sq_kernel(const GemmArgs g
     int t0 = 0, t1 = ntiles;
     if (g.splitk > 1) {
         const int per = (ntiles + g.splitk - 1) / g.splitk;
-        t0 = blockIdx.y * per;
+        t0 = ksplit * per;
         t1 = min(ntiles, t0 + per);
     }
     f32x16 acc[4][2];
@@ -1034,7 +1046,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pipe256sq_kernel(const GemmArgs g
     const int cl = (tid & 63) << 2;
     const int col = n0 + cl;
     const int nv = min(4, g.N - col);
-    float* ws = g.splitk > 1 ? g.ws + (long)blockIdx.y * g.M * g.N : nullptr;
+    float* ws = g.splitk > 1 ? g.ws + (long)ksplit * g.M * g.N : nullptr;
     float bv[4] = {0.f, 0.f, 0.f, 0.f};
     if (g.bias && !ws && col < g.N) {
 #pragma unroll
@@ -1079,11 +1091,8 @@ __global__ __launch_bounds__(256, 4) void gemm_glds64_kernel(const GemmArgs g) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tiles_m = (g.M + 63) / 64;
     const int nwg = tiles_m * g.tiles_n;
-    int bid = blockIdx.x;
-    {
-        const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
-        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-    }
+    int bid, ksplit;
+    wg_remap(nwg, g.xcd_split, bid, ksplit);
     constexpr int GROUP_M = 16;
     int tm, tn;
     {
@@ -1228,6 +1237,8 @@ extern "C" int mrg_gemm(const mrg_gemm_desc* d, hipStream_t stream) {
     MRG_REQUIRE(d->variant >= 0 && d->variant <= MRG_GEMM_GLDS64, MRG_ERR_ARG, "mrg_gemm: bad variant");
     g.tiles_m = cdiv(d->M, BM); g.tiles_n = cdiv(d->N, BN);
     { static const int abl = [] { const char* e = getenv("MRG_GEMM_ABLATE"); return e ? atoi(e) : 0; }(); g.ablate = abl; }
+    { static const int nt = [] { const char* e = getenv("MRG_GEMM_NT"); return e ? atoi(e) : 2; }(); g.nt = nt; }
+    { static const int xs = [] { const char* e = getenv("MRG_GEMM_XCD_SPLIT"); return e ? atoi(e) : 1; }(); g.xcd_split = xs; }
     dim3 grid(g.tiles_m * g.tiles_n, splitk), block(256);
     const size_t shmem = 4 * TILE_BYTES;
     // vector (16 B) loads need 16-B aligned bases, ld % 8 == 0 and whole chunks inside the matrix
