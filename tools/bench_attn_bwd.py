@@ -1,6 +1,6 @@
 """Attention backward in isolation (run under `rocprofv3 --kernel-trace --stats` for the per-kernel split)."""
 import os, sys
-sys.path.insert(0, os.getcwd())
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from mirage_amd import kernels as K
 dev = "cuda:0"; BF16 = torch.bfloat16
@@ -25,3 +25,5 @@ which = sys.argv[1] if len(sys.argv) > 1 else "all"
 if which in ("all", "c2"): run(64, 12, 129, 64, "C2")
 if which in ("all", "c4"): run(64, 16, 99, 64, "C4")
 if which in ("all", "dec"): run(64, 8, 256, 32, "dec")
+if which == "sweep":                      # items per CU: 1, 2, 3 (one workgroup per (batch, head))
+    for H in (4, 8, 12): run(64, H, 129, 64, f"sweep H={H}", iters=10)

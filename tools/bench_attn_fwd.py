@@ -1,5 +1,5 @@
 import os, sys
-sys.path.insert(0, os.getcwd())
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from mirage_amd import kernels as K
 dev = "cuda:0"; BF16 = torch.bfloat16
