@@ -42,6 +42,8 @@ struct GemmArgs {
     float* colsum;             // [tiles_m][N]: column sums of the final C values per 128-row tile (single-stage kernel only)
     int splitk; float* ws;
     int tiles_m, tiles_n;
+    int epi_kind;  // 0 generic epilogue; lean paths: 1 (+bias) -> bf16 C; 2 (+bias)(*row_scale) + fp32 residual -> fp32 C (+ bf16 twin);
+                   // 3 bias + GELU with fp16 GELU' side output; 4 multiply by the fp16 side input -> bf16 C (1 and 4 also with column sums)
     int xcd_split; // MRG_GEMM_XCD_SPLIT (default 1): split-K index slowest in the XCD band order
     int nt;       // MRG_GEMM_NT: 0 plain stores, 1 streaming (nontemporal) stores for C / C2 / aux_out, 2 (default) for aux_out only
     int ablate;   // MRG_GEMM_ABLATE (256x128 kernel only, for roofline analysis): 1 = no DMA, 2 = DMA only, 3 = DMA + LDS reads, no MFMA
@@ -256,6 +258,95 @@ __device__ __forceinline__ void epi_row(const GemmArgs& g, const float4 a4, cons
         }
 }
 
+// Lean epilogues for the two commonest cases: the generic epi_row spends ~40 scalar instructions per 4 outputs on branches that are
+// uniform over the whole launch (at K = 768 the epilogue + prologue of a 128 x 128 tile issue more instructions than its main loop).
+template <bool VEC, bool CS = false>
+__device__ __forceinline__ void epi_row_bf16(const GemmArgs& g, const float4 a4, const float (&bv)[4], int row, int col, int nv, float* cs = nullptr) {
+    const float v[4] = {a4.x + bv[0], a4.y + bv[1], a4.z + bv[2], a4.w + bv[3]};
+    bf16_t* c = reinterpret_cast<bf16_t*>(g.C) + (long)row * g.ldc + col;
+    if (VEC) *reinterpret_cast<u32x2*>(c) = u32x2{pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3])};
+    else { for (int e = 0; e < nv; ++e) c[e] = f2bf(v[e]); }
+    if (CS) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) cs[e] += e < nv ? v[e] : 0.f;
+    }
+}
+// fc1 forward: bias -> GELU; stores gelu(x) as bf16 and gelu'(x) as fp16 (MRG_ACT_GELU_SAVE_GRAD)
+template <bool VEC>
+__device__ __forceinline__ void epi_row_gelu_save(const GemmArgs& g, const float4 a4, const float (&bv)[4], int row, int col, int nv) {
+    float v[4] = {a4.x + bv[0], a4.y + bv[1], a4.z + bv[2], a4.w + bv[3]}, gd[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        float c, p;
+        gelu_parts(v[e], c, p);
+        gd[e] = c + v[e] * p;
+        v[e] = v[e] * c;
+    }
+    _Float16* ao = reinterpret_cast<_Float16*>(g.aux_out) + (long)row * g.ldaux + col;
+    bf16_t* c = reinterpret_cast<bf16_t*>(g.C) + (long)row * g.ldc + col;
+    if (VEC) {
+        typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+        const h2 lo = {(_Float16)gd[0], (_Float16)gd[1]}, hi = {(_Float16)gd[2], (_Float16)gd[3]};
+        st_out(reinterpret_cast<u32x2*>(ao), u32x2{*reinterpret_cast<const uint32_t*>(&lo), *reinterpret_cast<const uint32_t*>(&hi)}, g.nt);
+        *reinterpret_cast<u32x2*>(c) = u32x2{pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3])};
+    } else {
+        for (int e = 0; e < nv; ++e) { ao[e] = (_Float16)gd[e]; c[e] = f2bf(v[e]); }
+    }
+}
+// fc2 dgrad: multiply by the saved fp16 GELU' (MRG_ACT_MUL_AUX_F16), optional column sums (the fc1 bias gradient)
+template <bool VEC, bool CS = false>
+__device__ __forceinline__ void epi_row_mulaux(const GemmArgs& g, const float4 a4, const float (&bv)[4], int row, int col, int nv, float* cs = nullptr) {
+    float v[4] = {a4.x + bv[0], a4.y + bv[1], a4.z + bv[2], a4.w + bv[3]};
+    const _Float16* ai = reinterpret_cast<const _Float16*>(g.aux_in) + (long)row * g.ldaux + col;
+    bf16_t* c = reinterpret_cast<bf16_t*>(g.C) + (long)row * g.ldc + col;
+    if (VEC) {
+        typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+        const h4 x4 = *reinterpret_cast<const h4*>(ai);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] *= (float)x4[e];
+        *reinterpret_cast<u32x2*>(c) = u32x2{pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3])};
+    } else {
+        for (int e = 0; e < nv; ++e) { v[e] *= (float)ai[e]; c[e] = f2bf(v[e]); }
+    }
+    if (CS) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) cs[e] += e < nv ? v[e] : 0.f;
+    }
+}
+template <bool VEC>
+__device__ __forceinline__ void epi_row_resid(const GemmArgs& g, const float4 a4, const float (&bv)[4], int row, int col, int nv) {
+    float v[4] = {a4.x + bv[0], a4.y + bv[1], a4.z + bv[2], a4.w + bv[3]};
+    if (g.row_scale) {
+        const float rs = g.row_scale[row];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] *= rs;
+    }
+    const float* t = g.resid + (long)row * g.ldr + col;
+    float* c = reinterpret_cast<float*>(g.C) + (long)row * g.ldc + col;
+    if (VEC) {
+        const float4 t4 = *reinterpret_cast<const float4*>(t);
+        v[0] += t4.x; v[1] += t4.y; v[2] += t4.z; v[3] += t4.w;
+        *reinterpret_cast<float4*>(c) = make_float4(v[0], v[1], v[2], v[3]);
+        if (g.C2) *reinterpret_cast<u32x2*>(g.C2 + (long)row * g.ldc2 + col) = u32x2{pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3])};
+    } else {
+        for (int e = 0; e < nv; ++e) { v[e] += t[e]; c[e] = v[e]; if (g.C2) g.C2[(long)row * g.ldc2 + col + e] = f2bf(v[e]); }
+    }
+}
+template <bool VEC>
+__device__ __forceinline__ void epi_any(const GemmArgs& g, const float4 a4, const float (&bv)[4], float* ws, int row, int col, int nv) {
+    if (g.epi_kind == 1) epi_row_bf16<VEC>(g, a4, bv, row, col, nv);
+    else if (g.epi_kind == 2) epi_row_resid<VEC>(g, a4, bv, row, col, nv);
+    else if (g.epi_kind == 3) epi_row_gelu_save<VEC>(g, a4, bv, row, col, nv);
+    else if (g.epi_kind == 4) epi_row_mulaux<VEC>(g, a4, bv, row, col, nv);
+    else epi_row<VEC>(g, a4, bv, ws, row, col, nv);
+}
+template <bool VEC>
+__device__ __forceinline__ void epi_any_cs(const GemmArgs& g, const float4 a4, const float (&bv)[4], float* ws, int row, int col, int nv, float* cs) {
+    if (g.epi_kind == 1) epi_row_bf16<VEC, true>(g, a4, bv, row, col, nv, cs);
+    else if (g.epi_kind == 4) epi_row_mulaux<VEC, true>(g, a4, bv, row, col, nv, cs);
+    else epi_row<VEC, true>(g, a4, bv, ws, row, col, nv, cs);
+}
+
 template <int AMODE, int BMODE, bool ALIGNED, bool VEC>
 __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs g) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -361,7 +452,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs g) {
         const int row = m0 + rl;
         if (row >= Meff) break;
         const float4 a4 = *reinterpret_cast<const float4*>(ct + rl * BN + cl);
-        epi_row<VEC>(g, a4, bv, ws, row, col, nv);
+        epi_any<VEC>(g, a4, bv, ws, row, col, nv);
     }
 }
 
@@ -518,8 +609,8 @@ __global__ __launch_bounds__(256, OCC) void gemm_glds_kernel(const GemmArgs g) {
                 const int row = m0 + (rl >> 5) * 64 + pss * 32 + (rl & 31);
                 if (row < Meff) {
                     const float4 a4 = *reinterpret_cast<const float4*>(ct + rl * BN + cl);
-                    if (CSUM) epi_row<VEC, true>(g, a4, bv, ws, row, col, nv, cs);
-                    else epi_row<VEC>(g, a4, bv, ws, row, col, nv);
+                    if (CSUM) epi_any_cs<VEC>(g, a4, bv, ws, row, col, nv, cs);
+                    else epi_any<VEC>(g, a4, bv, ws, row, col, nv);
                 }
             }
         }
@@ -662,7 +753,7 @@ __global__ __launch_bounds__(256, 2) void gemm_pipe_kernel(const GemmArgs g) {
         const int row = m0 + rl;
         if (row >= Meff) break;
         const float4 a4 = *reinterpret_cast<const float4*>(ct + rl * BN + cl);
-        epi_row<VEC>(g, a4, bv, ws, row, col, nv);
+        epi_any<VEC>(g, a4, bv, ws, row, col, nv);
     }
 }
 
@@ -799,7 +890,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pipe256_kernel(const GemmArgs g) 
                 const int row = m0 + h * 128 + rl;
                 if (row < Meff) {
                     const float4 a4 = *reinterpret_cast<const float4*>(ct + rl * BN + cl);
-                    epi_row<VEC>(g, a4, bv, ws, row, col, nv);
+                    epi_any<VEC>(g, a4, bv, ws, row, col, nv);
                 }
             }
         }
@@ -945,7 +1036,7 @@ __global__ __launch_bounds__(768) void gemm_ws256_kernel(const GemmArgs g) {
                 const int row = m0 + h * 128 + rl;
                 if (row < Meff) {
                     const float4 a4 = *reinterpret_cast<const float4*>(ct + rl * BN + cl);
-                    epi_row<VEC>(g, a4, bv, ws, row, col, nv);
+                    epi_any<VEC>(g, a4, bv, ws, row, col, nv);
                 }
             }
         }
@@ -1076,12 +1167,150 @@ __global__ __launch_bounds__(512, 2) void gemm_pipe256sq_kernel(const GemmArgs g
                 const int row = m0 + sl * 64 + rl;
                 if (row < Meff) {
                     const float4 a4 = *reinterpret_cast<const float4*>(ct + rl * 256 + cl);
-                    epi_row<VEC>(g, a4, bv, ws, row, col, nv);
+                    epi_any<VEC>(g, a4, bv, ws, row, col, nv);
                 }
             }
         }
     }
 }
+
+// Persistent version of the 256 x 256 kernel: one workgroup per CU walks its output tiles; the first k-tile of the next output
+// tile is requested before the epilogue of the current one (the epilogue stages through the LDS stage that was consumed last),
+// so tile-to-tile there is no relaunch, no exposed first-load latency and no chip-wide store burst in front of idle MFMAs.
+template <int AMODE, int BMODE, bool VEC>
+__global__ __launch_bounds__(512, 2) void gemm_sqp_kernel(const GemmArgs g) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int STAGE = 4 * TILE_BYTES;
+    const int tiles_m = (g.M + 255) / 256, tiles_n = (g.N + 255) / 256;
+    const int nwg = tiles_m * tiles_n;
+    const int Meff = g.m_dev ? min(g.M, *g.m_dev) : g.M;
+    const int Keff = g.k_dev ? min(g.K, *g.k_dev) : g.K;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 2, wn = wave & 3;             // rows wm*128.., cols wn*64..
+    const int hsub = wave >> 2, wl = wave & 3;           // DMA assignment: sub-tile index, 4-block group inside it
+    const int ntiles = (Keff + BK - 1) / BK;
+    constexpr int GROUP_M = 4;
+    f32x16 acc[4][2];
+    const uint32_t sbase = __builtin_amdgcn_readfirstlane(lds_addr(smem));
+    const bf16_t* pa[4]; const bf16_t* pb[4];
+    long ia[4], ib[4];
+    int ka[4], kb[4];
+    int m0 = 0, n0 = 0;
+    // logical tile of persistent step `tile` (same XCD band order as the one-tile-per-workgroup kernels: gridDim.x is a multiple of 8)
+    auto setup = [&](int tile) {
+        int bid;
+        {
+            const int q = nwg >> 3, r = nwg & 7, xcd = tile & 7, idx = tile >> 3;
+            bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+        }
+        const int per_group = GROUP_M * tiles_n;
+        const int grp = bid / per_group, in_grp = bid - grp * per_group;
+        const int first = grp * GROUP_M;
+        const int rows = min(GROUP_M, tiles_m - first);
+        m0 = (first + in_grp % rows) * 256;
+        n0 = (in_grp / rows) * 256;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            glds_setup<AMODE>(g.A, g.lda, m0 + hsub * 128, Meff, 0, wl * 4 + j, lane, pa[j], ia[j], ka[j]);
+            glds_setup<BMODE>(g.B, g.ldb, n0 + hsub * 128, g.N, 0, wl * 4 + j, lane, pb[j], ib[j], kb[j]);
+        }
+    };
+    const bf16_t* zero = reinterpret_cast<const bf16_t*>(g_zero_page);
+    auto issue = [&](int t, int buf) {
+        const uint32_t la = sbase + buf * STAGE + hsub * TILE_BYTES + wl * 4096;
+        const uint32_t lb = la + 2 * TILE_BYTES;
+        const int krem = Keff - t * BK;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            glds16_asm((krem >= BK || ka[j] < krem) ? pa[j] : zero, la + j * 1024);
+            glds16_asm((krem >= BK || kb[j] < krem) ? pb[j] : zero, lb + j * 1024);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { pa[j] += ia[j]; pb[j] += ib[j]; }
+    };
+    int buf = 0;                                  // LDS stage that holds (or is receiving) k-tile 0 of the current output tile
+    setup(blockIdx.x);
+    issue(0, buf);
+    for (int tile = blockIdx.x; tile < nwg; tile += gridDim.x) {
+    const int tm0 = m0, tn0 = n0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    for (int t = 0; t < ntiles; ++t) {
+        const int cur = buf;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        if (t + 1 < ntiles) issue(t + 1, cur ^ 1);
+        const char* ldsA = smem + cur * STAGE + wm * TILE_BYTES;
+        const char* ldsB = smem + cur * STAGE + (2 + (wn >> 1)) * TILE_BYTES;
+        const uint32_t la_u = sbase + cur * STAGE + wm * TILE_BYTES, lb_u = sbase + cur * STAGE + (2 + (wn >> 1)) * TILE_BYTES;
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            bf16x8 fa[4], fb[2];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) fa[i] = read_frag<AMODE>(ldsA, la_u, i * 32, kk, lane);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) fb[j] = read_frag<BMODE>(ldsB, lb_u, (wn & 1) * 64 + j * 32, kk, lane);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+        }
+        buf ^= 1;
+    }
+    // `buf` is now the free stage (its k-tile was consumed one step ago); the other one becomes the epilogue's staging tile.
+    // The next output tile's first k-tile starts flying before the epilogue so that neither its latency nor the store drain
+    // of this tile is exposed.
+    if (tile + (int)gridDim.x < nwg) { setup(tile + gridDim.x); issue(0, buf); }
+    // ---- epilogue: four 64-row x 256-col slabs through a 64 KiB fp32 staging tile
+    float* ct = reinterpret_cast<float*>(smem + (buf ^ 1) * STAGE);
+    const int cl = (tid & 63) << 2;
+    const int col = tn0 + cl;
+    const int nv = min(4, g.N - col);
+    float* ws = nullptr;
+    float bv[4] = {0.f, 0.f, 0.f, 0.f};
+    if (g.bias && !ws && col < g.N) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) if (e < nv) bv[e] = g.bias[col + e];
+    }
+#pragma unroll
+    for (int sl = 0; sl < 4; ++sl) {
+        __syncthreads();
+        if (wm == (sl >> 1)) {
+#pragma unroll
+            for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const int c2 = wn * 64 + j * 32 + (lane & 31);
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int rl = ii * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                        ct[rl * 256 + c2] = acc[2 * (sl & 1) + ii][j][r];
+                    }
+                }
+        }
+        __syncthreads();
+        if (col < g.N) {
+#pragma unroll 1
+            for (int it = 0; it < 8; ++it) {
+                const int rl = (tid >> 6) + (it << 3);                  // 0..63
+                const int row = tm0 + sl * 64 + rl;
+                if (row < Meff) {
+                    const float4 a4 = *reinterpret_cast<const float4*>(ct + rl * 256 + cl);
+                    epi_any<VEC>(g, a4, bv, ws, row, col, nv);
+                }
+            }
+        }
+    }
+    }
+}
+
 
 // 64 x 128 tile, single stage (24 KiB operands; 32 KiB for the epilogue): twice as many, half as tall workgroups for the short,
 // latency-bound problems of the output adapters (K = 256 ... 1024 on 16384 rows) and the N = 768 encoder shapes, where a
@@ -1177,7 +1406,7 @@ __global__ __launch_bounds__(256, 4) void gemm_glds64_kernel(const GemmArgs g) {
         const int row = m0 + rl;
         if (row >= Meff) break;
         const float4 a4 = *reinterpret_cast<const float4*>(ct + rl * BN + cl);
-        epi_row<VEC>(g, a4, bv, nullptr, row, col, nv);
+        epi_any<VEC>(g, a4, bv, nullptr, row, col, nv);
     }
 }
 
@@ -1234,11 +1463,22 @@ extern "C" int mrg_gemm(const mrg_gemm_desc* d, hipStream_t stream) {
     g.aux_out = (bf16_t*)d->aux_out; g.aux_in = (const bf16_t*)d->aux_in; g.ldaux = d->ldaux;
     g.row_map = d->row_map; g.add_tab = d->add_tab; g.add_row = d->add_row; g.ldt = d->ldt; g.row_scale = d->row_scale; g.colsum = d->colsum_out;
     g.splitk = splitk; g.ws = d->ws;
-    MRG_REQUIRE(d->variant >= 0 && d->variant <= MRG_GEMM_GLDS64, MRG_ERR_ARG, "mrg_gemm: bad variant");
+    MRG_REQUIRE(d->variant >= 0 && d->variant <= MRG_GEMM_SQP, MRG_ERR_ARG, "mrg_gemm: bad variant");
     g.tiles_m = cdiv(d->M, BM); g.tiles_n = cdiv(d->N, BN);
     { static const int abl = [] { const char* e = getenv("MRG_GEMM_ABLATE"); return e ? atoi(e) : 0; }(); g.ablate = abl; }
     { static const int nt = [] { const char* e = getenv("MRG_GEMM_NT"); return e ? atoi(e) : 2; }(); g.nt = nt; }
     { static const int xs = [] { const char* e = getenv("MRG_GEMM_XCD_SPLIT"); return e ? atoi(e) : 1; }(); g.xcd_split = xs; }
+    {   // lean epilogue selection (uniform over the launch)
+        static const int lean = [] { const char* e = getenv("MRG_GEMM_LEAN"); return e ? atoi(e) : 1; }();
+        const bool base = splitk == 1 && !d->add_tab && !d->row_map && !d->accumulate && !d->resid && !d->row_scale && !d->C2 && !g.c_f32;
+        g.epi_kind = 0;
+        if (lean) {
+            if (base && d->act == MRG_ACT_NONE) g.epi_kind = 1;
+            else if (base && d->act == MRG_ACT_GELU_SAVE_GRAD && d->aux_out && !d->colsum_out) g.epi_kind = 3;
+            else if (base && d->act == MRG_ACT_MUL_AUX_F16 && d->aux_in) g.epi_kind = 4;
+            else if (splitk == 1 && d->act == MRG_ACT_NONE && !d->add_tab && !d->row_map && !d->accumulate && !d->colsum_out && d->resid && g.c_f32) g.epi_kind = 2;
+        }
+    }
     dim3 grid(g.tiles_m * g.tiles_n, splitk), block(256);
     const size_t shmem = 4 * TILE_BYTES;
     // vector (16 B) loads need 16-B aligned bases, ld % 8 == 0 and whole chunks inside the matrix
@@ -1279,6 +1519,19 @@ extern "C" int mrg_gemm(const mrg_gemm_desc* d, hipStream_t stream) {
     }
     const bool use_sq = !d->colsum_out && fast && d->variant == MRG_GEMM_PIPE256SQ && d->M > 128 && d->N > 128;
     const bool use_ws = !d->colsum_out && fast && d->variant == MRG_GEMM_WS256 && d->M > 128;
+    if (fast && d->variant == MRG_GEMM_SQP && splitk == 1 && !d->colsum_out && d->M > 128 && d->N > 128) {
+        const int nt = cdiv(d->M, 256) * cdiv(d->N, 256);
+        const dim3 gp(nt < 256 ? nt : 256), bp(512);
+#define MRG_SQP(AM, BM_, V) do { const void* fn = (const void*)gemm_sqp_kernel<AM, BM_, V>; \
+        (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 8 * TILE_BYTES); \
+        hipLaunchKernelGGL((gemm_sqp_kernel<AM, BM_, V>), gp, bp, (size_t)(8 * TILE_BYTES), stream, g); } while (0)
+        if (d->a_mode == MRG_OP_KCONTIG && d->b_mode == MRG_OP_KCONTIG) { if (vec) MRG_SQP(0, 0, true); else MRG_SQP(0, 0, false); }
+        else if (d->a_mode == MRG_OP_KCONTIG && d->b_mode == MRG_OP_KSTRIDED) { if (vec) MRG_SQP(0, 1, true); else MRG_SQP(0, 1, false); }
+        else { if (vec) MRG_SQP(1, 1, true); else MRG_SQP(1, 1, false); }
+#undef MRG_SQP
+        if (d->ev_stop) (void)hipEventRecord((hipEvent_t)d->ev_stop, stream);
+        return mrg_check_launch("mrg_gemm");
+    }
     if (fast && d->variant == MRG_GEMM_GLDS64 && d->a_mode == MRG_OP_KCONTIG && splitk == 1 && !d->colsum_out) {
         const dim3 g64(cdiv(d->M, 64) * g.tiles_n);
         if (d->b_mode == MRG_OP_KCONTIG) { if (vec) hipLaunchKernelGGL((gemm_glds64_kernel<0, true>), g64, block, (size_t)(2 * TILE_BYTES), stream, g);
