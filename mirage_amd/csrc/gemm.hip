@@ -469,6 +469,36 @@ __device__ __forceinline__ void glds16(const bf16_t* src, char* lds_wave_base) {
                                      (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
 
+// K-multiple-of-64 fast loader: per operand one wave-uniform 64-bit base (advanced by scalar adds per k-tile) plus a constant 32-bit
+// per-lane byte offset per 1 KiB LDS block, so a DMA is s_mov m0 + global_load_lds with an SGPR base: no per-lane 64-bit pointers
+// (48 VGPRs in the general loader), no pointer increments and no zero-page selects in the k loop.  Rows past the operand's edge are
+// clamped to a valid row instead of zero-filled (their products land in output rows / columns that are never stored).
+template <int MODE>
+__device__ __forceinline__ uint32_t glds_lane_off(int ld, int row0, int nrows, int b, int lane) {
+    if (MODE == MRG_OP_KCONTIG) {
+        const int r = b * 8 + (lane >> 3);
+        const int c = (lane & 7) ^ ((r >> 1) & 7);
+        const int rr = min(row0 + r, nrows - 1) - row0;
+        return (uint32_t)(rr * ld * 2 + (c << 4));
+    } else {
+        const int kr = b * 4 + (lane >> 4);
+        const int c = (lane & 15) ^ ((kr & 3) << 2);
+        const int col = (row0 + (c << 3) < nrows) ? (c << 3) : 0;
+        return (uint32_t)(kr * ld * 2 + col * 2);
+    }
+}
+// LDS-DMA with a scalar base: global address = sbase + voff, LDS destination = lds_wave_base + 16 * lane
+__device__ __forceinline__ void glds16_s(const char* sbase, uint32_t voff, uint32_t lds_wave_base) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(lds_wave_base) : "memory");
+}
+__device__ __forceinline__ const char* uniform_ptr(const char* p) {
+    const uint64_t v = (uint64_t)p;
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v), hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
+    return (const char*)(((uint64_t)hi << 32) | lo);
+}
+
 // per-thread source pointer + per-tile increment for LDS block b (1 KiB) of an operand tile
 template <int MODE>
 __device__ __forceinline__ void glds_setup(const bf16_t* P, int ld, int row0, int nrows, int k_first, int b, int lane,
@@ -491,7 +521,7 @@ __device__ __forceinline__ void glds_setup(const bf16_t* P, int ld, int row0, in
     }
 }
 
-template <int AMODE, int BMODE, bool VEC, int OCC, bool CSUM = false>
+template <int AMODE, int BMODE, bool VEC, int OCC, bool CSUM = false, bool KF = false>
 __global__ __launch_bounds__(256, OCC) void gemm_glds_kernel(const GemmArgs g) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int nwg = g.tiles_m * g.tiles_n;
@@ -537,15 +567,37 @@ __global__ __launch_bounds__(256, OCC) void gemm_glds_kernel(const GemmArgs g) {
     const bf16_t* pa[4]; const bf16_t* pb[4];
     long ia[4], ib[4];
     int ka[4], kb[4];
+    uint32_t oa[4], ob[4];
+    const char* sa = nullptr; const char* sb = nullptr;
+    const uint32_t la_s = __builtin_amdgcn_readfirstlane(la_u), lb_s = __builtin_amdgcn_readfirstlane(lb_u);
+    if constexpr (KF) {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        glds_setup<AMODE>(g.A, g.lda, m0, Meff, t0 * BK, wave * 4 + j, lane, pa[j], ia[j], ka[j]);
-        glds_setup<BMODE>(g.B, g.ldb, n0, g.N, t0 * BK, wave * 4 + j, lane, pb[j], ib[j], kb[j]);
+        for (int j = 0; j < 4; ++j) {
+            oa[j] = glds_lane_off<AMODE>(g.lda, m0, Meff, wave * 4 + j, lane);
+            ob[j] = glds_lane_off<BMODE>(g.ldb, n0, g.N, wave * 4 + j, lane);
+        }
+        sa = uniform_ptr(reinterpret_cast<const char*>(g.A) + (AMODE == MRG_OP_KCONTIG ? ((long)m0 * g.lda + (long)t0 * BK) * 2 : ((long)t0 * BK * g.lda + m0) * 2));
+        sb = uniform_ptr(reinterpret_cast<const char*>(g.B) + (BMODE == MRG_OP_KCONTIG ? ((long)n0 * g.ldb + (long)t0 * BK) * 2 : ((long)t0 * BK * g.ldb + n0) * 2));
+    } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            glds_setup<AMODE>(g.A, g.lda, m0, Meff, t0 * BK, wave * 4 + j, lane, pa[j], ia[j], ka[j]);
+            glds_setup<BMODE>(g.B, g.ldb, n0, g.N, t0 * BK, wave * 4 + j, lane, pb[j], ib[j], kb[j]);
+        }
     }
+    const long step_a = AMODE == MRG_OP_KCONTIG ? BK * 2 : (long)BK * g.lda * 2, step_b = BMODE == MRG_OP_KCONTIG ? BK * 2 : (long)BK * g.ldb * 2;
     const bf16_t* zero = reinterpret_cast<const bf16_t*>(g_zero_page);
     for (int t = t0; t < t1; ++t) {
         const int krem = Keff - t * BK;           // valid k in this tile (>= BK except for the last, partial tile)
         if (t > t0) __syncthreads();              // everyone finished reading the previous tile
+        if constexpr (KF) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                glds16_s(sa, oa[j], la_s + (wave * 4 + j) * 1024);
+                glds16_s(sb, ob[j], lb_s + (wave * 4 + j) * 1024);
+            }
+            sa = uniform_ptr(sa + step_a); sb = uniform_ptr(sb + step_b);
+        } else {
         if (krem >= BK) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
@@ -561,6 +613,7 @@ __global__ __launch_bounds__(256, OCC) void gemm_glds_kernel(const GemmArgs g) {
         }
 #pragma unroll
         for (int j = 0; j < 4; ++j) { pa[j] += ia[j]; pb[j] += ib[j]; }
+        }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
 #pragma unroll
@@ -1468,6 +1521,8 @@ extern "C" int mrg_gemm(const mrg_gemm_desc* d, hipStream_t stream) {
     { static const int abl = [] { const char* e = getenv("MRG_GEMM_ABLATE"); return e ? atoi(e) : 0; }(); g.ablate = abl; }
     { static const int nt = [] { const char* e = getenv("MRG_GEMM_NT"); return e ? atoi(e) : 2; }(); g.nt = nt; }
     { static const int xs = [] { const char* e = getenv("MRG_GEMM_XCD_SPLIT"); return e ? atoi(e) : 1; }(); g.xcd_split = xs; }
+    static const int kfast = [] { const char* e = getenv("MRG_GEMM_KFAST"); return e ? atoi(e) : 1; }();
+    const bool kf = kfast && (d->K % BK == 0) && !d->k_dev;      // scalar-base loader of the single-stage kernel
     {   // lean epilogue selection (uniform over the launch)
         static const int lean = [] { const char* e = getenv("MRG_GEMM_LEAN"); return e ? atoi(e) : 1; }();
         const bool base = splitk == 1 && !d->add_tab && !d->row_map && !d->accumulate && !d->resid && !d->row_scale && !d->C2 && !g.c_f32;
@@ -1510,7 +1565,9 @@ extern "C" int mrg_gemm(const mrg_gemm_desc* d, hipStream_t stream) {
     if (d->colsum_out) {      // only the single-stage 128 x 128 kernel (dgrad layout) is instantiated with the column-sum epilogue
         MRG_REQUIRE(fast && splitk == 1 && !d->row_map && d->a_mode == MRG_OP_KCONTIG && d->b_mode == MRG_OP_KSTRIDED, MRG_ERR_UNSUPPORTED,
                     "mrg_gemm: colsum_out needs the dgrad layout (A k-contiguous, B k-strided), aligned unmapped operands and no split-K");
-        if (vec) { if (occ4) hipLaunchKernelGGL((gemm_glds_kernel<0, 1, true, 4, true>), grid, block, (size_t)(2 * TILE_BYTES), stream, g);
+        if (vec && kf) { if (occ4) hipLaunchKernelGGL((gemm_glds_kernel<0, 1, true, 4, true, true>), grid, block, (size_t)(2 * TILE_BYTES), stream, g);
+                         else hipLaunchKernelGGL((gemm_glds_kernel<0, 1, true, 3, true, true>), grid, block, (size_t)(2 * TILE_BYTES), stream, g); }
+        else if (vec) { if (occ4) hipLaunchKernelGGL((gemm_glds_kernel<0, 1, true, 4, true>), grid, block, (size_t)(2 * TILE_BYTES), stream, g);
                    else hipLaunchKernelGGL((gemm_glds_kernel<0, 1, true, 3, true>), grid, block, (size_t)(2 * TILE_BYTES), stream, g); }
         else { if (occ4) hipLaunchKernelGGL((gemm_glds_kernel<0, 1, false, 4, true>), grid, block, (size_t)(2 * TILE_BYTES), stream, g);
                else hipLaunchKernelGGL((gemm_glds_kernel<0, 1, false, 3, true>), grid, block, (size_t)(2 * TILE_BYTES), stream, g); }
@@ -1555,6 +1612,8 @@ extern "C" int mrg_gemm(const mrg_gemm_desc* d, hipStream_t stream) {
         (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 9 * TILE_BYTES); \
         hipLaunchKernelGGL((gemm_ws256_kernel<AM, BM_, V>), dim3(cdiv(d->M, 256) * g.tiles_n, splitk), dim3(768), (size_t)(9 * TILE_BYTES), stream, g); } while (0)
 #define MRG_FAST(AM, BM_, V) do { if (use_ws) MRG_WS(AM, BM_, V); else if (use_sq) MRG_SQ(AM, BM_, V); else if (use_big) MRG_BIG(AM, BM_, V); else if (use_pipe) hipLaunchKernelGGL((gemm_pipe_kernel<AM, BM_, V>), grid, block, (size_t)(4 * TILE_BYTES), stream, g); \
+                                  else if (occ4 && kf && V) hipLaunchKernelGGL((gemm_glds_kernel<AM, BM_, true, 4, false, true>), grid, block, (size_t)(2 * TILE_BYTES), stream, g); \
+                                  else if (kf && V) hipLaunchKernelGGL((gemm_glds_kernel<AM, BM_, true, 3, false, true>), grid, block, (size_t)(2 * TILE_BYTES), stream, g); \
                                   else if (occ4) hipLaunchKernelGGL((gemm_glds_kernel<AM, BM_, V, 4>), grid, block, (size_t)(2 * TILE_BYTES), stream, g); \
                                   else hipLaunchKernelGGL((gemm_glds_kernel<AM, BM_, V, 3>), grid, block, (size_t)(2 * TILE_BYTES), stream, g); } while (0)
 #define MRG_LAUNCH2(AM, BM_, AL) do { \
