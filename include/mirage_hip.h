@@ -60,7 +60,7 @@ const char* mrg_last_error_string(void);
  *           (positional-embedding add of the input adapters, mirage/input_adapters.py:104-108)
  *   splitk  >1: partial sums to ws [splitk][M][N] fp32, then reduced (bias/accumulate epilogue only)
  *   variant kernel variant for aligned, map-free problems: single-stage LDS-DMA kernel at 3 or 4 workgroups/CU,
- *           two-stage pipelined 128x128 kernel, two- / three-stage pipelined 256x128 kernel (8 waves), two-stage 256x256 kernel, warp-specialised 256x128 kernel (8 compute + 4 loader waves, 3-stage ring), single-stage 64x128 kernel (A k-contiguous only), persistent 256x256 kernel (one workgroup per CU, no split-K);
+ *           two-stage pipelined 128x128 kernel, two- / three-stage pipelined 256x128 kernel (8 waves), two-stage 256x256 kernel, warp-specialised 256x128 kernel (8 compute + 4 loader waves, 3-stage ring), single-stage 64x128 kernel (A k-contiguous only), persistent 256x256 kernel (one workgroup per CU, no split-K), single-stage 256x128 kernel with 4 waves x (128x64) (K a multiple of 64);
  *           0 picks by shape
  */
 typedef struct mrg_gemm_desc {
@@ -79,7 +79,7 @@ typedef struct mrg_gemm_desc {
     const int* row_map;
     const float* add_tab; const int* add_row; int ldt;
     int splitk; float* ws;
-    int variant;   /* 0 = heuristic choice; 1..9 force a kernel variant (see MRG_GEMM_* below); used by the host-side autotuner */
+    int variant;   /* 0 = heuristic choice; 1..10 force a kernel variant (see MRG_GEMM_* below); used by the host-side autotuner */
     void* ev_start; void* ev_stop;   /* optional hipEvent_t pair recorded on `stream` around the main GEMM kernel only (not the
                                         split-K finishing kernel): lets a benchmark time exactly what rocprofv3 reports per kernel */
     const float* row_scale;          /* optional [M]: (acc + bias -> act) is multiplied by row_scale[row] before add_tab / resid are
@@ -91,7 +91,7 @@ typedef struct mrg_gemm_desc {
     int defer_reduce;                /* splitk > 1 only: leave the split-K slabs ws[splitk][M*N] unreduced -- the caller sums them
                                         later with mrg_reduce_batch (C must be contiguous fp32, no bias / accumulate / C2) */
 } mrg_gemm_desc;
-enum { MRG_GEMM_AUTO = 0, MRG_GEMM_GLDS3 = 1, MRG_GEMM_GLDS4 = 2, MRG_GEMM_PIPE128 = 3, MRG_GEMM_PIPE256 = 4, MRG_GEMM_PIPE256X3 = 5, MRG_GEMM_PIPE256SQ = 6, MRG_GEMM_WS256 = 7, MRG_GEMM_GLDS64 = 8, MRG_GEMM_SQP = 9 };
+enum { MRG_GEMM_AUTO = 0, MRG_GEMM_GLDS3 = 1, MRG_GEMM_GLDS4 = 2, MRG_GEMM_PIPE128 = 3, MRG_GEMM_PIPE256 = 4, MRG_GEMM_PIPE256X3 = 5, MRG_GEMM_PIPE256SQ = 6, MRG_GEMM_WS256 = 7, MRG_GEMM_GLDS64 = 8, MRG_GEMM_SQP = 9, MRG_GEMM_G256 = 10 };
 
 int mrg_gemm(const mrg_gemm_desc* d, hipStream_t stream);
 

@@ -43,7 +43,8 @@ struct GemmArgs {
     int splitk; float* ws;
     int tiles_m, tiles_n;
     int epi_kind;  // 0 generic epilogue; lean paths: 1 (+bias) -> bf16 C; 2 (+bias)(*row_scale) + fp32 residual -> fp32 C (+ bf16 twin);
-                   // 3 bias + GELU with fp16 GELU' side output; 4 multiply by the fp16 side input -> bf16 C (1 and 4 also with column sums)
+                   // 3 bias + GELU with fp16 GELU' side output; 4 multiply by the fp16 side input -> bf16 C (1 and 4 also with column sums);
+                   // 5 bias + GELU -> bf16 C
     int xcd_split; // MRG_GEMM_XCD_SPLIT (default 1): split-K index slowest in the XCD band order
     int nt;       // MRG_GEMM_NT: 0 plain stores, 1 streaming (nontemporal) stores for C / C2 / aux_out, 2 (default) for aux_out only
     int ablate;   // MRG_GEMM_ABLATE (256x128 kernel only, for roofline analysis): 1 = no DMA, 2 = DMA only, 3 = DMA + LDS reads, no MFMA
@@ -293,6 +294,14 @@ __device__ __forceinline__ void epi_row_gelu_save(const GemmArgs& g, const float
         for (int e = 0; e < nv; ++e) { ao[e] = (_Float16)gd[e]; c[e] = f2bf(v[e]); }
     }
 }
+// inference fc1: bias -> GELU -> bf16 (MRG_ACT_GELU without a saved pre-activation)
+template <bool VEC>
+__device__ __forceinline__ void epi_row_gelu(const GemmArgs& g, const float4 a4, const float (&bv)[4], int row, int col, int nv) {
+    const float v[4] = {gelu_f(a4.x + bv[0]), gelu_f(a4.y + bv[1]), gelu_f(a4.z + bv[2]), gelu_f(a4.w + bv[3])};
+    bf16_t* c = reinterpret_cast<bf16_t*>(g.C) + (long)row * g.ldc + col;
+    if (VEC) *reinterpret_cast<u32x2*>(c) = u32x2{pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3])};
+    else { for (int e = 0; e < nv; ++e) c[e] = f2bf(v[e]); }
+}
 // fc2 dgrad: multiply by the saved fp16 GELU' (MRG_ACT_MUL_AUX_F16), optional column sums (the fc1 bias gradient)
 template <bool VEC, bool CS = false>
 __device__ __forceinline__ void epi_row_mulaux(const GemmArgs& g, const float4 a4, const float (&bv)[4], int row, int col, int nv, float* cs = nullptr) {
@@ -338,6 +347,7 @@ __device__ __forceinline__ void epi_any(const GemmArgs& g, const float4 a4, cons
     else if (g.epi_kind == 2) epi_row_resid<VEC>(g, a4, bv, row, col, nv);
     else if (g.epi_kind == 3) epi_row_gelu_save<VEC>(g, a4, bv, row, col, nv);
     else if (g.epi_kind == 4) epi_row_mulaux<VEC>(g, a4, bv, row, col, nv);
+    else if (g.epi_kind == 5) epi_row_gelu<VEC>(g, a4, bv, row, col, nv);
     else epi_row<VEC>(g, a4, bv, ws, row, col, nv);
 }
 template <bool VEC>
@@ -692,7 +702,7 @@ __device__ __forceinline__ void glds16_asm(const bf16_t* src, uint32_t lds_wave_
 
 // Two-stage ring, 64 KiB LDS, 2 workgroups per CU: the DMA of tile t+1 flies while tile t is on the MFMA pipe;
 // one raw s_barrier per k-tile.
-template <int AMODE, int BMODE, bool VEC>
+template <int AMODE, int BMODE, bool VEC, bool KF = false>
 __global__ __launch_bounds__(256, 2) void gemm_pipe_kernel(const GemmArgs g) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int nwg = g.tiles_m * g.tiles_n;
@@ -733,15 +743,36 @@ __global__ __launch_bounds__(256, 2) void gemm_pipe_kernel(const GemmArgs g) {
     const bf16_t* pa[4]; const bf16_t* pb[4];
     long ia[4], ib[4];
     int ka[4], kb[4];
+    uint32_t oa[4], ob[4];
+    const char* sa = nullptr; const char* sb = nullptr;
+    if constexpr (KF) {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        glds_setup<AMODE>(g.A, g.lda, m0, Meff, t0 * BK, wave * 4 + j, lane, pa[j], ia[j], ka[j]);
-        glds_setup<BMODE>(g.B, g.ldb, n0, g.N, t0 * BK, wave * 4 + j, lane, pb[j], ib[j], kb[j]);
+        for (int j = 0; j < 4; ++j) {
+            oa[j] = glds_lane_off<AMODE>(g.lda, m0, Meff, wave * 4 + j, lane);
+            ob[j] = glds_lane_off<BMODE>(g.ldb, n0, g.N, wave * 4 + j, lane);
+        }
+        sa = uniform_ptr(reinterpret_cast<const char*>(g.A) + (AMODE == MRG_OP_KCONTIG ? ((long)m0 * g.lda + (long)t0 * BK) * 2 : ((long)t0 * BK * g.lda + m0) * 2));
+        sb = uniform_ptr(reinterpret_cast<const char*>(g.B) + (BMODE == MRG_OP_KCONTIG ? ((long)n0 * g.ldb + (long)t0 * BK) * 2 : ((long)t0 * BK * g.ldb + n0) * 2));
+    } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            glds_setup<AMODE>(g.A, g.lda, m0, Meff, t0 * BK, wave * 4 + j, lane, pa[j], ia[j], ka[j]);
+            glds_setup<BMODE>(g.B, g.ldb, n0, g.N, t0 * BK, wave * 4 + j, lane, pb[j], ib[j], kb[j]);
+        }
     }
+    const long step_a = AMODE == MRG_OP_KCONTIG ? BK * 2 : (long)BK * g.lda * 2, step_b = BMODE == MRG_OP_KCONTIG ? BK * 2 : (long)BK * g.ldb * 2;
     const bf16_t* zero = reinterpret_cast<const bf16_t*>(g_zero_page);
     auto issue = [&](int t, int buf) {
         const uint32_t la = sbase + buf * (2 * TILE_BYTES) + wave * 4096;
         const uint32_t lb = la + TILE_BYTES;
+        if constexpr (KF) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                glds16_s(sa, oa[j], la + j * 1024);
+                glds16_s(sb, ob[j], lb + j * 1024);
+            }
+            sa = uniform_ptr(sa + step_a); sb = uniform_ptr(sb + step_b);
+        } else {
         const int krem = Keff - t * BK;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -750,6 +781,7 @@ __global__ __launch_bounds__(256, 2) void gemm_pipe_kernel(const GemmArgs g) {
         }
 #pragma unroll
         for (int j = 0; j < 4; ++j) { pa[j] += ia[j]; pb[j] += ib[j]; }
+        }
     };
     if (t0 < t1) issue(t0, 0);
     for (int t = t0; t < t1; ++t) {
@@ -1365,6 +1397,129 @@ __global__ __launch_bounds__(512, 2) void gemm_sqp_kernel(const GemmArgs g) {
 }
 
 
+// 256 x 128 tile, single stage, 4 waves x (128 x 64): the single-stage kernel's structure (two co-resident workgroups cover each
+// other's load -> barrier -> MFMA chain; scalar-base loader; K a multiple of 64) with twice the MFMA work per wave and barrier
+// and 85 instead of 64 flop per operand byte moved from L2 to LDS.  48 KiB LDS, accumulators 128 VGPRs, 2 waves per SIMD.
+template <int AMODE, int BMODE, bool VEC>
+__global__ __launch_bounds__(256, 2) void gemm_g256_kernel(const GemmArgs g) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tiles_m = (g.M + 255) / 256;
+    const int nwg = tiles_m * g.tiles_n;
+    int bid, ksplit;
+    wg_remap(nwg, g.xcd_split, bid, ksplit);
+    constexpr int GROUP_M = 4;
+    int tm, tn;
+    {
+        const int per_group = GROUP_M * g.tiles_n;
+        const int grp = bid / per_group, in_grp = bid - grp * per_group;
+        const int first = grp * GROUP_M;
+        const int rows = min(GROUP_M, tiles_m - first);
+        tm = first + in_grp % rows;
+        tn = in_grp / rows;
+    }
+    const int m0 = tm * 256, n0 = tn * BN;
+    const int Meff = g.m_dev ? min(g.M, *g.m_dev) : g.M;
+    if (m0 >= Meff) return;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int ntiles = g.K / BK;
+    int t0 = 0, t1 = ntiles;
+    if (g.splitk > 1) {
+        const int per = (ntiles + g.splitk - 1) / g.splitk;
+        t0 = ksplit * per;
+        t1 = min(ntiles, t0 + per);
+    }
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    char* ldsA = smem;                                   // 256 x 64 bf16 = 32 KiB (two 128-row sub-tiles)
+    char* ldsB = smem + 2 * TILE_BYTES;                  // 128 x 64 bf16 = 16 KiB
+    const uint32_t la_s = __builtin_amdgcn_readfirstlane(lds_addr(ldsA)), lb_s = __builtin_amdgcn_readfirstlane(lds_addr(ldsB));
+    // wave w loads A blocks of sub-tile (w >> 1), blocks (w & 1) * 8 .. + 8, and B blocks 4 w .. + 4
+    uint32_t oa[8], ob[4];
+    // a 128-row sub-tile that starts past the last row (M = 8256: rows 8320.. of the last tile) is loaded from the last valid rows
+    const int ra = min(m0 + (wave >> 1) * 128, (AMODE == MRG_OP_KCONTIG ? Meff - 1 : max(0, ((Meff - 1) & ~7))));
+#pragma unroll
+    for (int j = 0; j < 8; ++j) oa[j] = glds_lane_off<AMODE>(g.lda, ra, Meff, (wave & 1) * 8 + j, lane);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) ob[j] = glds_lane_off<BMODE>(g.ldb, n0, g.N, wave * 4 + j, lane);
+    const long ma = ra;
+    const char* sa = uniform_ptr(reinterpret_cast<const char*>(g.A) + (AMODE == MRG_OP_KCONTIG ? (ma * g.lda + (long)t0 * BK) * 2 : ((long)t0 * BK * g.lda + ma) * 2));
+    const char* sb = uniform_ptr(reinterpret_cast<const char*>(g.B) + (BMODE == MRG_OP_KCONTIG ? ((long)n0 * g.ldb + (long)t0 * BK) * 2 : ((long)t0 * BK * g.ldb + n0) * 2));
+    const long step_a = AMODE == MRG_OP_KCONTIG ? BK * 2 : (long)BK * g.lda * 2, step_b = BMODE == MRG_OP_KCONTIG ? BK * 2 : (long)BK * g.ldb * 2;
+    const uint32_t la_w = la_s + (wave >> 1) * TILE_BYTES + (wave & 1) * 8192, lb_w = lb_s + wave * 4096;
+    const char* fragA = ldsA + wm * TILE_BYTES;
+    const uint32_t fragA_u = la_s + wm * TILE_BYTES;
+    for (int t = t0; t < t1; ++t) {
+        if (t > t0) __syncthreads();
+#pragma unroll
+        for (int j = 0; j < 8; ++j) glds16_s(sa, oa[j], la_w + j * 1024);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) glds16_s(sb, ob[j], lb_w + j * 1024);
+        sa = uniform_ptr(sa + step_a); sb = uniform_ptr(sb + step_b);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            bf16x8 fa[4], fb[2];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) fa[i] = read_frag<AMODE>(fragA, fragA_u, i * 32, kk, lane);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) fb[j] = read_frag<BMODE>(ldsB, lb_s, wn * 64 + j * 32, kk, lane);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+        }
+    }
+    // ---- epilogue: four passes of 64 rows x 128 cols fp32 (32 KiB) through the operand stage
+    float* ct = reinterpret_cast<float*>(smem);
+    const int cl = (tid & 31) << 2;
+    const int col = n0 + cl;
+    const int nv = min(4, g.N - col);
+    float* ws = g.splitk > 1 ? g.ws + (long)ksplit * g.M * g.N : nullptr;
+    float bv[4] = {0.f, 0.f, 0.f, 0.f};
+    if (g.bias && !ws && col < g.N) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) if (e < nv) bv[e] = g.bias[col + e];
+    }
+#pragma unroll
+    for (int ps = 0; ps < 4; ++ps) {
+        __syncthreads();
+        if (wm == (ps >> 1)) {
+#pragma unroll
+            for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const int c2 = wn * 64 + j * 32 + (lane & 31);
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int rl = ii * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                        ct[rl * BN + c2] = acc[2 * (ps & 1) + ii][j][r];
+                    }
+                }
+        }
+        __syncthreads();
+        if (col < g.N) {
+#pragma unroll 1
+            for (int it = 0; it < 8; ++it) {
+                const int rl = (tid >> 5) + (it << 3);                  // 0..63
+                const int row = m0 + ps * 64 + rl;
+                if (row < Meff) {
+                    const float4 a4 = *reinterpret_cast<const float4*>(ct + rl * BN + cl);
+                    epi_any<VEC>(g, a4, bv, ws, row, col, nv);
+                }
+            }
+        }
+    }
+}
+
 // 64 x 128 tile, single stage (24 KiB operands; 32 KiB for the epilogue): twice as many, half as tall workgroups for the short,
 // latency-bound problems of the output adapters (K = 256 ... 1024 on 16384 rows) and the N = 768 encoder shapes, where a
 // 128-row tile leaves 1-1.5 workgroups per CU.  A must be k-contiguous (forward / dgrad layouts).
@@ -1516,7 +1671,7 @@ extern "C" int mrg_gemm(const mrg_gemm_desc* d, hipStream_t stream) {
     g.aux_out = (bf16_t*)d->aux_out; g.aux_in = (const bf16_t*)d->aux_in; g.ldaux = d->ldaux;
     g.row_map = d->row_map; g.add_tab = d->add_tab; g.add_row = d->add_row; g.ldt = d->ldt; g.row_scale = d->row_scale; g.colsum = d->colsum_out;
     g.splitk = splitk; g.ws = d->ws;
-    MRG_REQUIRE(d->variant >= 0 && d->variant <= MRG_GEMM_SQP, MRG_ERR_ARG, "mrg_gemm: bad variant");
+    MRG_REQUIRE(d->variant >= 0 && d->variant <= MRG_GEMM_G256, MRG_ERR_ARG, "mrg_gemm: bad variant");
     g.tiles_m = cdiv(d->M, BM); g.tiles_n = cdiv(d->N, BN);
     { static const int abl = [] { const char* e = getenv("MRG_GEMM_ABLATE"); return e ? atoi(e) : 0; }(); g.ablate = abl; }
     { static const int nt = [] { const char* e = getenv("MRG_GEMM_NT"); return e ? atoi(e) : 2; }(); g.nt = nt; }
@@ -1531,6 +1686,7 @@ extern "C" int mrg_gemm(const mrg_gemm_desc* d, hipStream_t stream) {
             if (base && d->act == MRG_ACT_NONE) g.epi_kind = 1;
             else if (base && d->act == MRG_ACT_GELU_SAVE_GRAD && d->aux_out && !d->colsum_out) g.epi_kind = 3;
             else if (base && d->act == MRG_ACT_MUL_AUX_F16 && d->aux_in) g.epi_kind = 4;
+            else if (base && d->act == MRG_ACT_GELU && !d->aux_out && !d->colsum_out) g.epi_kind = 5;
             else if (splitk == 1 && d->act == MRG_ACT_NONE && !d->add_tab && !d->row_map && !d->accumulate && !d->colsum_out && d->resid && g.c_f32) g.epi_kind = 2;
         }
     }
@@ -1589,6 +1745,16 @@ extern "C" int mrg_gemm(const mrg_gemm_desc* d, hipStream_t stream) {
         if (d->ev_stop) (void)hipEventRecord((hipEvent_t)d->ev_stop, stream);
         return mrg_check_launch("mrg_gemm");
     }
+    if (fast && d->variant == MRG_GEMM_G256 && kf && !d->colsum_out && d->M > 128) {
+        const dim3 gg(cdiv(d->M, 256) * g.tiles_n, splitk);
+#define MRG_G256(AM, BM_, V) hipLaunchKernelGGL((gemm_g256_kernel<AM, BM_, V>), gg, block, (size_t)(3 * TILE_BYTES), stream, g)
+        if (d->a_mode == MRG_OP_KCONTIG && d->b_mode == MRG_OP_KCONTIG) { if (vec) MRG_G256(0, 0, true); else MRG_G256(0, 0, false); }
+        else if (d->a_mode == MRG_OP_KCONTIG && d->b_mode == MRG_OP_KSTRIDED) { if (vec) MRG_G256(0, 1, true); else MRG_G256(0, 1, false); }
+        else { if (vec) MRG_G256(1, 1, true); else MRG_G256(1, 1, false); }
+#undef MRG_G256
+        if (d->ev_stop) (void)hipEventRecord((hipEvent_t)d->ev_stop, stream);
+        return mrg_check_launch("mrg_gemm");
+    }
     if (fast && d->variant == MRG_GEMM_GLDS64 && d->a_mode == MRG_OP_KCONTIG && splitk == 1 && !d->colsum_out) {
         const dim3 g64(cdiv(d->M, 64) * g.tiles_n);
         if (d->b_mode == MRG_OP_KCONTIG) { if (vec) hipLaunchKernelGGL((gemm_glds64_kernel<0, true>), g64, block, (size_t)(2 * TILE_BYTES), stream, g);
@@ -1611,7 +1777,8 @@ extern "C" int mrg_gemm(const mrg_gemm_desc* d, hipStream_t stream) {
 #define MRG_WS(AM, BM_, V) do { const void* fn = (const void*)gemm_ws256_kernel<AM, BM_, V>; \
         (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 9 * TILE_BYTES); \
         hipLaunchKernelGGL((gemm_ws256_kernel<AM, BM_, V>), dim3(cdiv(d->M, 256) * g.tiles_n, splitk), dim3(768), (size_t)(9 * TILE_BYTES), stream, g); } while (0)
-#define MRG_FAST(AM, BM_, V) do { if (use_ws) MRG_WS(AM, BM_, V); else if (use_sq) MRG_SQ(AM, BM_, V); else if (use_big) MRG_BIG(AM, BM_, V); else if (use_pipe) hipLaunchKernelGGL((gemm_pipe_kernel<AM, BM_, V>), grid, block, (size_t)(4 * TILE_BYTES), stream, g); \
+#define MRG_FAST(AM, BM_, V) do { if (use_ws) MRG_WS(AM, BM_, V); else if (use_sq) MRG_SQ(AM, BM_, V); else if (use_big) MRG_BIG(AM, BM_, V); else if (use_pipe && kf && V) hipLaunchKernelGGL((gemm_pipe_kernel<AM, BM_, true, true>), grid, block, (size_t)(4 * TILE_BYTES), stream, g); \
+                                  else if (use_pipe) hipLaunchKernelGGL((gemm_pipe_kernel<AM, BM_, V>), grid, block, (size_t)(4 * TILE_BYTES), stream, g); \
                                   else if (occ4 && kf && V) hipLaunchKernelGGL((gemm_glds_kernel<AM, BM_, true, 4, false, true>), grid, block, (size_t)(2 * TILE_BYTES), stream, g); \
                                   else if (kf && V) hipLaunchKernelGGL((gemm_glds_kernel<AM, BM_, true, 3, false, true>), grid, block, (size_t)(2 * TILE_BYTES), stream, g); \
                                   else if (occ4) hipLaunchKernelGGL((gemm_glds_kernel<AM, BM_, V, 4>), grid, block, (size_t)(2 * TILE_BYTES), stream, g); \

@@ -139,6 +139,9 @@ def _autotune(d, key, splitk, allow_split, dev):
             cands.append((v, s_))
     if d.a_mode == L.MRG_OP_KCONTIG and not d.colsum_out:          # half-height tiles: only pays when 128-row tiles underfill the chip
         cands.append((L.MRG_GEMM_GLDS64, 1))
+    if d.K % 64 == 0 and d.M > 128 and not d.colsum_out and not d.k_dev:   # single-stage 256x128 (wins when there are many tiles per CU)
+        for s_ in splits:
+            cands.append((L.MRG_GEMM_G256, s_))
     best, best_t = (L.MRG_GEMM_AUTO, splitk), float("inf")
     for v, s_ in cands:
         _gemm_launch(d, s_, v, dev)

@@ -74,7 +74,7 @@ def test_gemm_wgrad_kstrided_both(K, Mtok, Nout, Kin, splitk):
     torch.testing.assert_close(out, ref, rtol=3e-3, atol=3e-3 * float(ref.abs().max()))
 
 
-@pytest.mark.parametrize("variant", [1, 2, 3, 4, 6, 7, 8, 9])
+@pytest.mark.parametrize("variant", [1, 2, 3, 4, 6, 7, 8, 9, 10])
 def test_gemm_every_variant_same_result(K, variant):
     """Each kernel variant the tuner may pick computes the same forward / dgrad product (ragged M, N and K tails, bias + GELU'
     side output, device row count)."""
@@ -96,6 +96,23 @@ def test_gemm_every_variant_same_result(K, variant):
     lin = A.float() @ W.float().t() + b
     torch.testing.assert_close(out, lin, rtol=2e-3, atol=2e-3 * float(lin.abs().max()))
     assert rel_rms(act.float(), torch.nn.functional.gelu(lin)) < 5e-3
+    # K a multiple of 64 (scalar-base loaders, 256-row tiles whose lower half starts past M), bf16 + bias, dgrad and wgrad layouts
+    M2, N2, K2 = 576 + 64, 320, 256
+    A2 = rnd(M2, K2, dtype=BF16, seed=35); W2 = rnd(N2, K2, scale=0.05, dtype=BF16, seed=36); b2 = rnd(N2, seed=37)
+    W2t = rnd(K2, N2, scale=0.05, dtype=BF16, seed=38)
+    dy = rnd(M2, N2, dtype=BF16, seed=39)
+    K.TUNE["force"] = variant
+    try:
+        o2 = K.gemm(A2, W2, M2, N2, K2, bias=b2, out_dtype=BF16)
+        d2 = K.gemm(A2, W2t, M2, N2, K2, b_mode=L.MRG_OP_KSTRIDED, out_dtype=F32)
+        w2 = K.gemm(dy, A2, N2, K2, M2, a_mode=L.MRG_OP_KSTRIDED, b_mode=L.MRG_OP_KSTRIDED, out_dtype=F32, splitk=2)
+    finally:
+        K.TUNE["force"] = None
+    assert rel_rms(o2.float(), A2.float() @ W2.float().t() + b2) < 4e-3
+    r2 = A2.float() @ W2t.float()
+    torch.testing.assert_close(d2, r2, rtol=2e-3, atol=2e-3 * float(r2.abs().max()))
+    r3 = dy.float().t() @ A2.float()
+    torch.testing.assert_close(w2, r3, rtol=3e-3, atol=3e-3 * float(r3.abs().max()))
     ref = dg_ref = A.float() @ Wt.float()
     torch.testing.assert_close(dg, dg_ref, rtol=2e-3, atol=2e-3 * float(ref.abs().max()))
     torch.testing.assert_close(part[:901], (lin - b)[:901], rtol=2e-3, atol=2e-3 * float(lin.abs().max()))

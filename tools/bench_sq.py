@@ -18,7 +18,7 @@ for (M, N, Kd) in ((8192, 2048, 768), (8192, 4096, 768), (8192, 2048, 3072), (81
     x = torch.randn(M, Kd, device=dev).bfloat16(); W = (torch.randn(N, Kd, device=dev) * 0.02).bfloat16(); b = torch.zeros(N, device=dev)
     out = torch.empty(M, N, dtype=torch.bfloat16, device=dev)
     row = []
-    for v in (1, 3, 6, 7, 9):
+    for v in [int(t) for t in os.environ.get("VARS", "1,3,6,7,10").split(",")]:
         K.TUNE["force"] = v
         t = bench(lambda: K.gemm(x, W, M, N, Kd, bias=b, out=out))
         row.append(f"v{v} {t * 1e6:6.1f} us {2.0 * M * N * Kd / t / 1e12:5.0f} TF")
