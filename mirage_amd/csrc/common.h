@@ -54,7 +54,7 @@ __device__ __forceinline__ float wave_max(float v) {
 __device__ __forceinline__ void gelu_parts(float x, float& cdf, float& pdf) {
     const float ax = fabsf(x) * 0.70710678118654752f;                 // |x| / sqrt(2)
     const float e = __expf(-0.5f * x * x);                            // exp(-x^2/2)
-    const float t = __frcp_rn(fmaf(0.3275911f, ax, 1.0f));
+    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, ax, 1.0f));   // v_rcp_f32 (1 ulp): __frcp_rn expands to the 10-instruction IEEE division
     float poly = fmaf(1.061405429f, t, -1.453152027f);
     poly = fmaf(poly, t, 1.421413741f);
     poly = fmaf(poly, t, -0.284496736f);
