@@ -60,7 +60,7 @@ const char* mrg_last_error_string(void);
  *           (positional-embedding add of the input adapters, mirage/input_adapters.py:104-108)
  *   splitk  >1: partial sums to ws [splitk][M][N] fp32, then reduced (bias/accumulate epilogue only)
  *   variant kernel variant for aligned, map-free problems: single-stage LDS-DMA kernel at 3 or 4 workgroups/CU,
- *           two-stage pipelined 128x128 kernel, two- / three-stage pipelined 256x128 kernel (8 waves), two-stage 256x256 kernel, warp-specialised 256x128 kernel (8 compute + 4 loader waves, 3-stage ring), single-stage 64x128 kernel (A k-contiguous only), persistent 256x256 kernel (one workgroup per CU, no split-K), single-stage 256x128 kernel with 4 waves x (128x64) (K a multiple of 64);
+ *           two-stage pipelined 128x128 kernel, two- / three-stage pipelined 256x128 kernel (8 waves), two-stage 256x256 kernel, warp-specialised 256x128 kernel (8 compute + 4 loader waves, 3-stage ring), single-stage 64x128 kernel (A k-contiguous only), (9 reserved: a persistent 256x256 kernel that was measured and dropped), single-stage 256x128 kernel with 4 waves x (128x64) (K a multiple of 64);
  *           0 picks by shape
  */
 typedef struct mrg_gemm_desc {

@@ -985,7 +985,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pipe256_kernel(const GemmArgs g) 
 // Warp-specialised 256 x 128 kernel: 8 compute waves (4 x 2, 64 x 64 each) + 4 loader waves.  Issuing a global_load_lds
 // costs the issuing wave ~60-180 cycles during which it cannot issue MFMAs (in-order issue); the loaders take all 48 of them
 // per k-tile off the compute waves and keep a 3-stage ring (144 KiB) two tiles ahead.  One s_barrier per k-tile for all 12 waves.
-template <int AMODE, int BMODE, bool VEC>
+template <int AMODE, int BMODE, bool VEC, bool KF = false>
 __global__ __launch_bounds__(768) void gemm_ws256_kernel(const GemmArgs g) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int STAGE = 3 * TILE_BYTES, STAGES = 3;
@@ -1023,14 +1023,34 @@ __global__ __launch_bounds__(768) void gemm_ws256_kernel(const GemmArgs g) {
         const bf16_t* pa[8]; const bf16_t* pb[4];
         long ia[8], ib[4];
         int ka[8], kb[4];
+        uint32_t oa[8], ob[4];
+        const char* sa = nullptr; const char* sb = nullptr;
+        if constexpr (KF) {
+            const int ra = min(m0 + (L >> 1) * 128, (AMODE == MRG_OP_KCONTIG ? Meff - 1 : max(0, ((Meff - 1) & ~7))));
 #pragma unroll
-        for (int j = 0; j < 8; ++j) glds_setup<AMODE>(g.A, g.lda, m0 + (L >> 1) * 128, Meff, t0 * BK, (L & 1) * 8 + j, lane, pa[j], ia[j], ka[j]);
+            for (int j = 0; j < 8; ++j) oa[j] = glds_lane_off<AMODE>(g.lda, ra, Meff, (L & 1) * 8 + j, lane);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) glds_setup<BMODE>(g.B, g.ldb, n0, g.N, t0 * BK, L * 4 + j, lane, pb[j], ib[j], kb[j]);
+            for (int j = 0; j < 4; ++j) ob[j] = glds_lane_off<BMODE>(g.ldb, n0, g.N, L * 4 + j, lane);
+            sa = uniform_ptr(reinterpret_cast<const char*>(g.A) + (AMODE == MRG_OP_KCONTIG ? ((long)ra * g.lda + (long)t0 * BK) * 2 : ((long)t0 * BK * g.lda + ra) * 2));
+            sb = uniform_ptr(reinterpret_cast<const char*>(g.B) + (BMODE == MRG_OP_KCONTIG ? ((long)n0 * g.ldb + (long)t0 * BK) * 2 : ((long)t0 * BK * g.ldb + n0) * 2));
+        } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) glds_setup<AMODE>(g.A, g.lda, m0 + (L >> 1) * 128, Meff, t0 * BK, (L & 1) * 8 + j, lane, pa[j], ia[j], ka[j]);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) glds_setup<BMODE>(g.B, g.ldb, n0, g.N, t0 * BK, L * 4 + j, lane, pb[j], ib[j], kb[j]);
+        }
+        const long step_a = AMODE == MRG_OP_KCONTIG ? BK * 2 : (long)BK * g.lda * 2, step_b = BMODE == MRG_OP_KCONTIG ? BK * 2 : (long)BK * g.ldb * 2;
         const bf16_t* zero = reinterpret_cast<const bf16_t*>(g_zero_page);
         auto issue = [&](int t, int buf) {
             const uint32_t la = sbase + buf * STAGE + (L >> 1) * TILE_BYTES + (L & 1) * 8192;
             const uint32_t lb = sbase + buf * STAGE + 2 * TILE_BYTES + L * 4096;
+            if constexpr (KF) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) glds16_s(sa, oa[j], la + j * 1024);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) glds16_s(sb, ob[j], lb + j * 1024);
+                sa = uniform_ptr(sa + step_a); sb = uniform_ptr(sb + step_b);
+            } else {
             const int krem = Keff - t * BK;
 #pragma unroll
             for (int j = 0; j < 8; ++j) glds16_asm((krem >= BK || ka[j] < krem) ? pa[j] : zero, la + j * 1024);
@@ -1040,6 +1060,7 @@ __global__ __launch_bounds__(768) void gemm_ws256_kernel(const GemmArgs g) {
             for (int j = 0; j < 8; ++j) pa[j] += ia[j];
 #pragma unroll
             for (int j = 0; j < 4; ++j) pb[j] += ib[j];
+            }
         };
         if (t0 < t1) issue(t0, 0);
         if (t0 + 1 < t1) issue(t0 + 1, 1);
@@ -1258,144 +1279,6 @@ __global__ __launch_bounds__(512, 2) void gemm_pipe256sq_kernel(const GemmArgs g
         }
     }
 }
-
-// Persistent version of the 256 x 256 kernel: one workgroup per CU walks its output tiles; the first k-tile of the next output
-// tile is requested before the epilogue of the current one (the epilogue stages through the LDS stage that was consumed last),
-// so tile-to-tile there is no relaunch, no exposed first-load latency and no chip-wide store burst in front of idle MFMAs.
-template <int AMODE, int BMODE, bool VEC>
-__global__ __launch_bounds__(512, 2) void gemm_sqp_kernel(const GemmArgs g) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int STAGE = 4 * TILE_BYTES;
-    const int tiles_m = (g.M + 255) / 256, tiles_n = (g.N + 255) / 256;
-    const int nwg = tiles_m * tiles_n;
-    const int Meff = g.m_dev ? min(g.M, *g.m_dev) : g.M;
-    const int Keff = g.k_dev ? min(g.K, *g.k_dev) : g.K;
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 2, wn = wave & 3;             // rows wm*128.., cols wn*64..
-    const int hsub = wave >> 2, wl = wave & 3;           // DMA assignment: sub-tile index, 4-block group inside it
-    const int ntiles = (Keff + BK - 1) / BK;
-    constexpr int GROUP_M = 4;
-    f32x16 acc[4][2];
-    const uint32_t sbase = __builtin_amdgcn_readfirstlane(lds_addr(smem));
-    const bf16_t* pa[4]; const bf16_t* pb[4];
-    long ia[4], ib[4];
-    int ka[4], kb[4];
-    int m0 = 0, n0 = 0;
-    // logical tile of persistent step `tile` (same XCD band order as the one-tile-per-workgroup kernels: gridDim.x is a multiple of 8)
-    auto setup = [&](int tile) {
-        int bid;
-        {
-            const int q = nwg >> 3, r = nwg & 7, xcd = tile & 7, idx = tile >> 3;
-            bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-        }
-        const int per_group = GROUP_M * tiles_n;
-        const int grp = bid / per_group, in_grp = bid - grp * per_group;
-        const int first = grp * GROUP_M;
-        const int rows = min(GROUP_M, tiles_m - first);
-        m0 = (first + in_grp % rows) * 256;
-        n0 = (in_grp / rows) * 256;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            glds_setup<AMODE>(g.A, g.lda, m0 + hsub * 128, Meff, 0, wl * 4 + j, lane, pa[j], ia[j], ka[j]);
-            glds_setup<BMODE>(g.B, g.ldb, n0 + hsub * 128, g.N, 0, wl * 4 + j, lane, pb[j], ib[j], kb[j]);
-        }
-    };
-    const bf16_t* zero = reinterpret_cast<const bf16_t*>(g_zero_page);
-    auto issue = [&](int t, int buf) {
-        const uint32_t la = sbase + buf * STAGE + hsub * TILE_BYTES + wl * 4096;
-        const uint32_t lb = la + 2 * TILE_BYTES;
-        const int krem = Keff - t * BK;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            glds16_asm((krem >= BK || ka[j] < krem) ? pa[j] : zero, la + j * 1024);
-            glds16_asm((krem >= BK || kb[j] < krem) ? pb[j] : zero, lb + j * 1024);
-        }
-#pragma unroll
-        for (int j = 0; j < 4; ++j) { pa[j] += ia[j]; pb[j] += ib[j]; }
-    };
-    int buf = 0;                                  // LDS stage that holds (or is receiving) k-tile 0 of the current output tile
-    setup(blockIdx.x);
-    issue(0, buf);
-    for (int tile = blockIdx.x; tile < nwg; tile += gridDim.x) {
-    const int tm0 = m0, tn0 = n0;
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-    for (int t = 0; t < ntiles; ++t) {
-        const int cur = buf;
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        __builtin_amdgcn_sched_barrier(0);
-        if (t + 1 < ntiles) issue(t + 1, cur ^ 1);
-        const char* ldsA = smem + cur * STAGE + wm * TILE_BYTES;
-        const char* ldsB = smem + cur * STAGE + (2 + (wn >> 1)) * TILE_BYTES;
-        const uint32_t la_u = sbase + cur * STAGE + wm * TILE_BYTES, lb_u = sbase + cur * STAGE + (2 + (wn >> 1)) * TILE_BYTES;
-#pragma unroll
-        for (int kk = 0; kk < 4; ++kk) {
-            bf16x8 fa[4], fb[2];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) fa[i] = read_frag<AMODE>(ldsA, la_u, i * 32, kk, lane);
-#pragma unroll
-            for (int j = 0; j < 2; ++j) fb[j] = read_frag<BMODE>(ldsB, lb_u, (wn & 1) * 64 + j * 32, kk, lane);
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int j = 0; j < 2; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
-        }
-        buf ^= 1;
-    }
-    // `buf` is now the free stage (its k-tile was consumed one step ago); the other one becomes the epilogue's staging tile.
-    // The next output tile's first k-tile starts flying before the epilogue so that neither its latency nor the store drain
-    // of this tile is exposed.
-    if (tile + (int)gridDim.x < nwg) { setup(tile + gridDim.x); issue(0, buf); }
-    // ---- epilogue: four 64-row x 256-col slabs through a 64 KiB fp32 staging tile
-    float* ct = reinterpret_cast<float*>(smem + (buf ^ 1) * STAGE);
-    const int cl = (tid & 63) << 2;
-    const int col = tn0 + cl;
-    const int nv = min(4, g.N - col);
-    float* ws = nullptr;
-    float bv[4] = {0.f, 0.f, 0.f, 0.f};
-    if (g.bias && !ws && col < g.N) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) if (e < nv) bv[e] = g.bias[col + e];
-    }
-#pragma unroll
-    for (int sl = 0; sl < 4; ++sl) {
-        __syncthreads();
-        if (wm == (sl >> 1)) {
-#pragma unroll
-            for (int ii = 0; ii < 2; ++ii)
-#pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    const int c2 = wn * 64 + j * 32 + (lane & 31);
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int rl = ii * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                        ct[rl * 256 + c2] = acc[2 * (sl & 1) + ii][j][r];
-                    }
-                }
-        }
-        __syncthreads();
-        if (col < g.N) {
-#pragma unroll 1
-            for (int it = 0; it < 8; ++it) {
-                const int rl = (tid >> 6) + (it << 3);                  // 0..63
-                const int row = tm0 + sl * 64 + rl;
-                if (row < Meff) {
-                    const float4 a4 = *reinterpret_cast<const float4*>(ct + rl * 256 + cl);
-                    epi_any<VEC>(g, a4, bv, ws, row, col, nv);
-                }
-            }
-        }
-    }
-    }
-}
-
 
 // 256 x 128 tile, single stage, 4 waves x (128 x 64): the single-stage kernel's structure (two co-resident workgroups cover each
 // other's load -> barrier -> MFMA chain; scalar-base loader; K a multiple of 64) with twice the MFMA work per wave and barrier
@@ -1732,19 +1615,6 @@ extern "C" int mrg_gemm(const mrg_gemm_desc* d, hipStream_t stream) {
     }
     const bool use_sq = !d->colsum_out && fast && d->variant == MRG_GEMM_PIPE256SQ && d->M > 128 && d->N > 128;
     const bool use_ws = !d->colsum_out && fast && d->variant == MRG_GEMM_WS256 && d->M > 128;
-    if (fast && d->variant == MRG_GEMM_SQP && splitk == 1 && !d->colsum_out && d->M > 128 && d->N > 128) {
-        const int nt = cdiv(d->M, 256) * cdiv(d->N, 256);
-        const dim3 gp(nt < 256 ? nt : 256), bp(512);
-#define MRG_SQP(AM, BM_, V) do { const void* fn = (const void*)gemm_sqp_kernel<AM, BM_, V>; \
-        (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 8 * TILE_BYTES); \
-        hipLaunchKernelGGL((gemm_sqp_kernel<AM, BM_, V>), gp, bp, (size_t)(8 * TILE_BYTES), stream, g); } while (0)
-        if (d->a_mode == MRG_OP_KCONTIG && d->b_mode == MRG_OP_KCONTIG) { if (vec) MRG_SQP(0, 0, true); else MRG_SQP(0, 0, false); }
-        else if (d->a_mode == MRG_OP_KCONTIG && d->b_mode == MRG_OP_KSTRIDED) { if (vec) MRG_SQP(0, 1, true); else MRG_SQP(0, 1, false); }
-        else { if (vec) MRG_SQP(1, 1, true); else MRG_SQP(1, 1, false); }
-#undef MRG_SQP
-        if (d->ev_stop) (void)hipEventRecord((hipEvent_t)d->ev_stop, stream);
-        return mrg_check_launch("mrg_gemm");
-    }
     if (fast && d->variant == MRG_GEMM_G256 && kf && !d->colsum_out && d->M > 128) {
         const dim3 gg(cdiv(d->M, 256) * g.tiles_n, splitk);
 #define MRG_G256(AM, BM_, V) hipLaunchKernelGGL((gemm_g256_kernel<AM, BM_, V>), gg, block, (size_t)(3 * TILE_BYTES), stream, g)
@@ -1774,9 +1644,12 @@ extern "C" int mrg_gemm(const mrg_gemm_desc* d, hipStream_t stream) {
 #define MRG_SQ(AM, BM_, V) do { const void* fn = (const void*)gemm_pipe256sq_kernel<AM, BM_, V>; \
         (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 8 * TILE_BYTES); \
         hipLaunchKernelGGL((gemm_pipe256sq_kernel<AM, BM_, V>), dim3(cdiv(d->M, 256) * cdiv(d->N, 256), splitk), dim3(512), (size_t)(8 * TILE_BYTES), stream, g); } while (0)
-#define MRG_WS(AM, BM_, V) do { const void* fn = (const void*)gemm_ws256_kernel<AM, BM_, V>; \
+#define MRG_WS(AM, BM_, V) do { if (kf && V) { const void* fn = (const void*)gemm_ws256_kernel<AM, BM_, true, true>; \
         (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 9 * TILE_BYTES); \
-        hipLaunchKernelGGL((gemm_ws256_kernel<AM, BM_, V>), dim3(cdiv(d->M, 256) * g.tiles_n, splitk), dim3(768), (size_t)(9 * TILE_BYTES), stream, g); } while (0)
+        hipLaunchKernelGGL((gemm_ws256_kernel<AM, BM_, true, true>), dim3(cdiv(d->M, 256) * g.tiles_n, splitk), dim3(768), (size_t)(9 * TILE_BYTES), stream, g); } else { \
+        const void* fn = (const void*)gemm_ws256_kernel<AM, BM_, V>; \
+        (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 9 * TILE_BYTES); \
+        hipLaunchKernelGGL((gemm_ws256_kernel<AM, BM_, V>), dim3(cdiv(d->M, 256) * g.tiles_n, splitk), dim3(768), (size_t)(9 * TILE_BYTES), stream, g); } } while (0)
 #define MRG_FAST(AM, BM_, V) do { if (use_ws) MRG_WS(AM, BM_, V); else if (use_sq) MRG_SQ(AM, BM_, V); else if (use_big) MRG_BIG(AM, BM_, V); else if (use_pipe && kf && V) hipLaunchKernelGGL((gemm_pipe_kernel<AM, BM_, true, true>), grid, block, (size_t)(4 * TILE_BYTES), stream, g); \
                                   else if (use_pipe) hipLaunchKernelGGL((gemm_pipe_kernel<AM, BM_, V>), grid, block, (size_t)(4 * TILE_BYTES), stream, g); \
                                   else if (occ4 && kf && V) hipLaunchKernelGGL((gemm_glds_kernel<AM, BM_, true, 4, false, true>), grid, block, (size_t)(2 * TILE_BYTES), stream, g); \

@@ -74,7 +74,7 @@ def test_gemm_wgrad_kstrided_both(K, Mtok, Nout, Kin, splitk):
     torch.testing.assert_close(out, ref, rtol=3e-3, atol=3e-3 * float(ref.abs().max()))
 
 
-@pytest.mark.parametrize("variant", [1, 2, 3, 4, 6, 7, 8, 9, 10])
+@pytest.mark.parametrize("variant", [1, 2, 3, 4, 6, 7, 8, 10])
 def test_gemm_every_variant_same_result(K, variant):
     """Each kernel variant the tuner may pick computes the same forward / dgrad product (ragged M, N and K tails, bias + GELU'
     side output, device row count)."""
