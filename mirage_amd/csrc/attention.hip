@@ -185,12 +185,12 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_kernel(const AttnArgs a) {
                     for (int kk = 0; kk < KS; ++kk)
                         s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows<HD, SWZ_ROW>(ldsK, lbase + kb * 32, kk, lane), qf[kk], s[kb], 0, 0, 0);
                 }
+                if (kb * 32 + 32 > kvalid) {         // only the last, partial key block needs the key-range test
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int key = kb * 32 + acc_row(r, lane);
-                    if (key >= kvalid) s[kb][r] = -INFINITY;
-                    mx = fmaxf(mx, s[kb][r]);
+                    for (int r = 0; r < 16; ++r) if (kb * 32 + acc_row(r, lane) >= kvalid) s[kb][r] = -INFINITY;
                 }
+#pragma unroll
+                for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[kb][r]);
             }
             mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
             const float m_new = fmaxf(m_run, mx);
@@ -250,7 +250,7 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_kernel(const AttnArgs a) {
 // ================================================ backward ==============================================
 // query-owner pass: dQ (and dsum[b,h,q] = sum_d dO * O for the key-owner pass).  LDS: K chunk (row + tr reads), V chunk (row reads).
 template <int HD>
-__global__ __launch_bounds__(512, 4) void attn_bwd_dq_kernel(const AttnArgs a) {
+__global__ __launch_bounds__(512, 3) void attn_bwd_dq_kernel(const AttnArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int KS = HD / 16, DJ = HD / 32;
     const int ROWS = a.chunk_rows;
@@ -337,11 +337,16 @@ __global__ __launch_bounds__(512, 4) void attn_bwd_dq_kernel(const AttnArgs a) {
                     s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows<HD, SWZ_ROW>(ldsK, kb * 32, kk, lane), qf[kk], s, 0, 0, 0);
                     dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows<HD, SWZ_ROW>(ldsV, kb * 32, kk, lane), dof[kk], dp, 0, 0, 0);
                 }
+                if (kb * 32 + 32 <= kvalid) {        // full key block: no per-element key-range test (a third of the loop's VALU)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int key = kb * 32 + acc_row(r, lane);
-                    const float p = key < kvalid ? fast_exp2(s[r] * sc - lse2) : 0.f;
-                    s[r] = p * (dp[r] - dsm) * a.scale;
+                    for (int r = 0; r < 16; ++r) s[r] = fast_exp2(s[r] * sc - lse2) * (dp[r] - dsm) * a.scale;
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int key = kb * 32 + acc_row(r, lane);
+                        const float p = key < kvalid ? fast_exp2(s[r] * sc - lse2) : 0.f;
+                        s[r] = p * (dp[r] - dsm) * a.scale;
+                    }
                 }
 #pragma unroll
                 for (int mf = 0; mf < 2; ++mf) {
