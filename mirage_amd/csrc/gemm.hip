@@ -134,6 +134,16 @@ __device__ __forceinline__ bf16x8 read_frag(const char* lds, uint32_t lds_base, 
     }
 }
 
+// a / b for 0 <= a < 2^22, b > 0 without the ~40-instruction integer division (v_rcp_f32 is within 1 ulp, so the quotient is
+// off by at most one before the fix-up); the tile-coordinate prologue has four of them per workgroup
+__device__ __forceinline__ int fast_udiv(int a, int b) {
+    int q = (int)((float)a * __builtin_amdgcn_rcpf((float)b));
+    int r = a - q * b;
+    if (r < 0) { --q; r += b; }
+    if (r >= b) ++q;
+    return q;
+}
+
 // XCD-aware workgroup order.  Workgroups are dispatched round-robin over the 8 XCDs (each with its own L2) in linear order
 // (x fastest, then y); XCD x is given one contiguous band of the logical (split, tile) space with the split-K index slowest, so the
 // workgroups sharing an L2 work on the same k-range and on neighbouring tiles (with the split index taken from blockIdx.y instead,
@@ -143,7 +153,7 @@ __device__ __forceinline__ void wg_remap(int nwg, int xcd_split, int& bid, int& 
         const int L = blockIdx.x + blockIdx.y * gridDim.x, total = nwg * gridDim.y;
         const int q = total >> 3, r = total & 7, xcd = L & 7, idx = L >> 3;
         const int lin = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-        ksplit = lin / nwg;
+        ksplit = gridDim.y > 1 ? fast_udiv(lin, nwg) : 0;
         bid = lin - ksplit * nwg;
     } else {
         const int b = blockIdx.x;
@@ -543,11 +553,11 @@ __global__ __launch_bounds__(256, OCC) void gemm_glds_kernel(const GemmArgs g) {
     int tm, tn;
     {
         const int per_group = GROUP_M * g.tiles_n;
-        const int grp = bid / per_group, in_grp = bid - grp * per_group;
+        const int grp = fast_udiv(bid, per_group), in_grp = bid - grp * per_group;
         const int first = grp * GROUP_M;
         const int rows = min(GROUP_M, g.tiles_m - first);
-        tm = first + in_grp % rows;
-        tn = in_grp / rows;
+        tn = fast_udiv(in_grp, rows);
+        tm = first + in_grp - tn * rows;
     }
     const int m0 = tm * BM, n0 = tn * BN;
     const int Meff = g.m_dev ? min(g.M, *g.m_dev) : g.M;
@@ -712,11 +722,11 @@ __global__ __launch_bounds__(256, 2) void gemm_pipe_kernel(const GemmArgs g) {
     int tm, tn;
     {
         const int per_group = GROUP_M * g.tiles_n;
-        const int grp = bid / per_group, in_grp = bid - grp * per_group;
+        const int grp = fast_udiv(bid, per_group), in_grp = bid - grp * per_group;
         const int first = grp * GROUP_M;
         const int rows = min(GROUP_M, g.tiles_m - first);
-        tm = first + in_grp % rows;
-        tn = in_grp / rows;
+        tn = fast_udiv(in_grp, rows);
+        tm = first + in_grp - tn * rows;
     }
     const int m0 = tm * BM, n0 = tn * BN;
     const int Meff = g.m_dev ? min(g.M, *g.m_dev) : g.M;
@@ -856,11 +866,11 @@ __global__ __launch_bounds__(512, 2) void gemm_pipe256_kernel(const GemmArgs g) 
     int tm, tn;
     {
         const int per_group = GROUP_M * g.tiles_n;
-        const int grp = bid / per_group, in_grp = bid - grp * per_group;
+        const int grp = fast_udiv(bid, per_group), in_grp = bid - grp * per_group;
         const int first = grp * GROUP_M;
         const int rows = min(GROUP_M, tiles_m - first);
-        tm = first + in_grp % rows;
-        tn = in_grp / rows;
+        tn = fast_udiv(in_grp, rows);
+        tm = first + in_grp - tn * rows;
     }
     const int m0 = tm * 256, n0 = tn * BN;
     const int Meff = g.m_dev ? min(g.M, *g.m_dev) : g.M;
@@ -997,11 +1007,11 @@ __global__ __launch_bounds__(768) void gemm_ws256_kernel(const GemmArgs g) {
     int tm, tn;
     {
         const int per_group = GROUP_M * g.tiles_n;
-        const int grp = bid / per_group, in_grp = bid - grp * per_group;
+        const int grp = fast_udiv(bid, per_group), in_grp = bid - grp * per_group;
         const int first = grp * GROUP_M;
         const int rows = min(GROUP_M, tiles_m - first);
-        tm = first + in_grp % rows;
-        tn = in_grp / rows;
+        tn = fast_udiv(in_grp, rows);
+        tm = first + in_grp - tn * rows;
     }
     const int m0 = tm * 256, n0 = tn * BN;
     const int Meff = g.m_dev ? min(g.M, *g.m_dev) : g.M;
@@ -1164,11 +1174,11 @@ __global__ __launch_bounds__(512, 2) void gemm_pipe256sq_kernel(const GemmArgs g
     int tm, tn;
     {
         const int per_group = GROUP_M * tiles_n;
-        const int grp = bid / per_group, in_grp = bid - grp * per_group;
+        const int grp = fast_udiv(bid, per_group), in_grp = bid - grp * per_group;
         const int first = grp * GROUP_M;
         const int rows = min(GROUP_M, tiles_m - first);
-        tm = first + in_grp % rows;
-        tn = in_grp / rows;
+        tn = fast_udiv(in_grp, rows);
+        tm = first + in_grp - tn * rows;
     }
     const int m0 = tm * 256, n0 = tn * 256;
     const int Meff = g.m_dev ? min(g.M, *g.m_dev) : g.M;
@@ -1294,11 +1304,11 @@ __global__ __launch_bounds__(256, 2) void gemm_g256_kernel(const GemmArgs g) {
     int tm, tn;
     {
         const int per_group = GROUP_M * g.tiles_n;
-        const int grp = bid / per_group, in_grp = bid - grp * per_group;
+        const int grp = fast_udiv(bid, per_group), in_grp = bid - grp * per_group;
         const int first = grp * GROUP_M;
         const int rows = min(GROUP_M, tiles_m - first);
-        tm = first + in_grp % rows;
-        tn = in_grp / rows;
+        tn = fast_udiv(in_grp, rows);
+        tm = first + in_grp - tn * rows;
     }
     const int m0 = tm * 256, n0 = tn * BN;
     const int Meff = g.m_dev ? min(g.M, *g.m_dev) : g.M;
@@ -1417,11 +1427,11 @@ __global__ __launch_bounds__(256, 4) void gemm_glds64_kernel(const GemmArgs g) {
     int tm, tn;
     {
         const int per_group = GROUP_M * g.tiles_n;
-        const int grp = bid / per_group, in_grp = bid - grp * per_group;
+        const int grp = fast_udiv(bid, per_group), in_grp = bid - grp * per_group;
         const int first = grp * GROUP_M;
         const int rows = min(GROUP_M, tiles_m - first);
-        tm = first + in_grp % rows;
-        tn = in_grp / rows;
+        tn = fast_udiv(in_grp, rows);
+        tm = first + in_grp - tn * rows;
     }
     const int m0 = tm * 64, n0 = tn * BN;
     const int Meff = g.m_dev ? min(g.M, *g.m_dev) : g.M;
