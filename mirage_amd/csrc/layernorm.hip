@@ -87,20 +87,38 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const void* __restrict__ dy
     }
     const bf16_t* dy16 = reinterpret_cast<const bf16_t*>(dyp);
     const float* dy32 = reinterpret_cast<const float*>(dyp);
-    for (int row = blockIdx.x * LNB_WAVES + wave; row < M; row += gridDim.x * LNB_WAVES) {
-        float4 xv[NV], dyv[NV], rv[NV];
+    // the next row's operands are requested before this row's reductions and stores (a wave owns one row at a time; without the
+    // prefetch its load -> reduce -> store chain leaves the memory pipe idle for most of each row)
+    float4 xn[NV], dn[NV], rn[NV];
+    float mun = 0.f, rsn = 0.f;
+    auto fetch = [&](int row) {
 #pragma unroll
         for (int j = 0; j < NV; ++j) {
             const int c = lane + 64 * j;
-            const bool ok = c < nv;
-            const int cc = ok ? c : 0;
-            xv[j] = reinterpret_cast<const float4*>(x + (long)row * D)[cc];
-            if (DY16) dyv[j] = bf4_to_f4(reinterpret_cast<const uint2*>(dy16 + (long)row * D)[cc]);
-            else dyv[j] = reinterpret_cast<const float4*>(dy32 + (long)row * D)[cc];
-            if (HAS_RES) rv[j] = reinterpret_cast<const float4*>(dres + (long)row * D)[cc];
+            const int cc = c < nv ? c : 0;
+            xn[j] = reinterpret_cast<const float4*>(x + (long)row * D)[cc];
+            if (DY16) { const uint2 u = reinterpret_cast<const uint2*>(dy16 + (long)row * D)[cc]; dn[j].x = __uint_as_float(u.x); dn[j].y = __uint_as_float(u.y); }
+            else dn[j] = reinterpret_cast<const float4*>(dy32 + (long)row * D)[cc];
+            if (HAS_RES) rn[j] = reinterpret_cast<const float4*>(dres + (long)row * D)[cc];
+        }
+        mun = mean[row]; rsn = rstd[row];
+    };
+    const int row0 = blockIdx.x * LNB_WAVES + wave, rstep = gridDim.x * LNB_WAVES;
+    if (row0 < M) fetch(row0);
+    for (int row = row0; row < M; row += rstep) {
+        float4 xv[NV], dyv[NV], rv[NV];
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+            const bool ok = (lane + 64 * j) < nv;
+            xv[j] = xn[j];
+            if (DY16) dyv[j] = bf4_to_f4(make_uint2(__float_as_uint(dn[j].x), __float_as_uint(dn[j].y)));
+            else dyv[j] = dn[j];
+            if (HAS_RES) rv[j] = rn[j];
             if (!ok) { xv[j] = dyv[j] = make_float4(0.f, 0.f, 0.f, 0.f); if (HAS_RES) rv[j] = xv[j]; }
         }
-        const float mu = mean[row], rs = rstd[row];
+        const float mu_c = mun, rs_c = rsn;
+        if (row + rstep < M) fetch(row + rstep);
+        const float mu = mu_c, rs = rs_c;
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
         for (int j = 0; j < NV; ++j) {
