@@ -28,15 +28,20 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
     if (row >= M) return;
     const int nv = D >> 2;
     const float4* xr = reinterpret_cast<const float4*>(x + (long)row * D);
-    float4 v[LN_MAX_V];
+    float4 v[LN_MAX_V], gv[LN_MAX_V], bvv[LN_MAX_V];
     float s = 0.f;
+    const float4* g4 = reinterpret_cast<const float4*>(gamma);
+    const float4* b4 = reinterpret_cast<const float4*>(beta);
+    const float invD = 1.f / (float)D;
 #pragma unroll
     for (int j = 0; j < LN_MAX_V; ++j) {
         const int c = lane + 64 * j;
-        if (c < nv) { v[j] = xr[c]; s += (v[j].x + v[j].y) + (v[j].z + v[j].w); }
-        else v[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (c < nv) { v[j] = xr[c]; gv[j] = g4[c]; bvv[j] = b4[c]; }     // gamma / beta requested with the row, not after the reductions
+        else v[j] = gv[j] = bvv[j] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
-    const float mu = wave_sum(s) / (float)D;
+#pragma unroll
+    for (int j = 0; j < LN_MAX_V; ++j) s += (v[j].x + v[j].y) + (v[j].z + v[j].w);
+    const float mu = wave_sum(s) * invD;
     float q = 0.f;
 #pragma unroll
     for (int j = 0; j < LN_MAX_V; ++j) {
@@ -46,15 +51,13 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
             q += (a * a + b * b) + (c2 * c2 + d * d);
         }
     }
-    const float rs = rsqrtf(wave_sum(q) / (float)D + eps);
+    const float rs = rsqrtf(wave_sum(q) * invD + eps);
     if (lane == 0) { mean[row] = mu; rstd[row] = rs; }
-    const float4* g4 = reinterpret_cast<const float4*>(gamma);
-    const float4* b4 = reinterpret_cast<const float4*>(beta);
 #pragma unroll
     for (int j = 0; j < LN_MAX_V; ++j) {
         const int c = lane + 64 * j;
         if (c < nv) {
-            const float4 g = g4[c], b = b4[c];
+            const float4 g = gv[j], b = bvv[j];
             const float o0 = (v[j].x - mu) * rs * g.x + b.x, o1 = (v[j].y - mu) * rs * g.y + b.y;
             const float o2 = (v[j].z - mu) * rs * g.z + b.z, o3 = (v[j].w - mu) * rs * g.w + b.w;
             if (y) reinterpret_cast<uint2*>(y + (long)row * D)[c] = make_uint2(pack_bf2(o0, o1), pack_bf2(o2, o3));
