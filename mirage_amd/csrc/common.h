@@ -78,4 +78,11 @@ __device__ __forceinline__ s16x4 lds_read_tr16(uint32_t byte_addr) {
     return __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(uintptr_t)byte_addr);
 }
 
+// same with a compile-time byte offset (multiple of 8) that is folded into the instruction's offset field (pointer indexing
+// carries the no-wrap guarantee the integer add lacks)
+__device__ __forceinline__ s16x4 lds_read_tr16_off(uint32_t byte_addr, int byte_off) {
+    typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+    return __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(uintptr_t)byte_addr + (byte_off >> 3));
+}
+
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }

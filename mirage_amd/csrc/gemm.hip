@@ -119,14 +119,14 @@ __device__ __forceinline__ bf16x8 read_frag(const char* lds, uint32_t lds_base, 
         const int c = kk * 2 + (lane >> 5);
         return *reinterpret_cast<const bf16x8*>(lds + row * 128 + ((c ^ ((row >> 1) & 7)) << 4));
     } else {
+        // k-row of this lane = 16 kk + 8 (lane >> 5) + (i >> 2) [+ 4]: the swizzle only sees k-row & 3 = (i >> 2) & 3, so the lane
+        // part of the address is independent of kk and of the +4 row and both become immediate offsets of the LDS instruction
         const int i = lane & 15;
         const int col = row_in_tile + (lane & 16) + ((i & 3) << 2);
-        const int kr0 = kk * 16 + ((lane >> 5) << 3) + (i >> 2);
-        const int kr1 = kr0 + 4;
-        const uint32_t a0 = lds_base + kr0 * 256 + ((((col >> 3) ^ ((kr0 & 3) << 2))) << 4) + ((col & 4) << 1);
-        const uint32_t a1 = lds_base + kr1 * 256 + ((((col >> 3) ^ ((kr1 & 3) << 2))) << 4) + ((col & 4) << 1);
-        const s16x4 lo = lds_read_tr16(a0);
-        const s16x4 hi = lds_read_tr16(a1);
+        const int krl = ((lane >> 5) << 3) + (i >> 2);
+        const uint32_t a0 = lds_base + krl * 256 + ((((col >> 3) ^ ((krl & 3) << 2))) << 4) + ((col & 4) << 1);
+        const s16x4 lo = lds_read_tr16_off(a0, kk * 4096);
+        const s16x4 hi = lds_read_tr16_off(a0, kk * 4096 + 1024);
         bf16x8 f;
         f[0] = lo[0]; f[1] = lo[1]; f[2] = lo[2]; f[3] = lo[3];
         f[4] = hi[0]; f[5] = hi[1]; f[6] = hi[2]; f[7] = hi[3];
