@@ -40,6 +40,8 @@ class _Side:
     reduce_early = True
     _blocks = 0
     origin = None      # stream the queued jobs were produced on (the decoders' lanes queue from their own streams)
+    early_opt = None   # optional callable(list of finished blocks): optimizer update of blocks whose gradients are final, issued on
+    finished = []      # the side stream right after the reductions of a flush (installed per step by trainer.TrainStep)
 
     @classmethod
     def run(cls, fn, *tensors):
@@ -73,14 +75,22 @@ class _Side:
                 # finish the split-K slabs / column-sum partials produced so far (the event above covers the LayerNorm partials of
                 # the calling stream): only the last group's reductions are then left for the tail of the step
                 K.Deferred.flush()
+                if cls.early_opt is not None and cls.finished:
+                    done, cls.finished = cls.finished, []
+                    cls.early_opt(done)          # their gradients are final now: AdamW for these blocks overlaps the rest of backward
         cls.pending = True
 
     @classmethod
-    def block_done(cls, remaining=None):
+    def block_done(cls, remaining=None, blk=None):
         """End of one transformer block's backward.  `remaining` = blocks of the same stack still to come: the side work
         queued by the LAST blocks has nothing left to overlap with, so the forks get finer towards the end
         (12 blocks -> flush after 4, 8, 10, 11, 12) instead of leaving a third of the weight-gradient GEMMs exposed."""
         cls._blocks += 1
+        if cls.early_opt is not None and blk is not None:
+            if cls.enabled:
+                cls.finished.append(blk)
+            else:
+                cls.early_opt([blk])             # no side stream, no deferred reductions: the gradients are final already
         need = cls.blocks_per_flush if remaining is None else min(cls.blocks_per_flush, max(1, remaining))
         if cls._blocks >= need:
             cls._blocks = 0
@@ -107,6 +117,13 @@ class _Side:
                     K.Deferred.flush()
             else:
                 K.Deferred.flush()
+        if cls.early_opt is not None and cls.finished:       # reduce_early off: nothing was final before this point
+            done, cls.finished = cls.finished, []
+            if cls.pending:
+                with torch.cuda.stream(cls.stream):
+                    cls.early_opt(done)
+            else:
+                cls.early_opt(done)
         K.Deferred.active = False
         if cls.pending:
             torch.cuda.current_stream().wait_stream(cls.stream)
@@ -236,7 +253,7 @@ def block_bwd(blk, saved, dx32: torch.Tensor, dx16: Optional[torch.Tensor], rema
     d_ln1, _ = lin_bwd(d_qkv, ln1, blk.attn.qkv, bias_grad=gb is None)
     dx_in32, dx_in16 = K.ln_bwd(d_ln1, x_in, mean1, rstd1, blk.norm1.weight, dx_mid32, grad_buffer(blk.norm1.weight),
                                 grad_buffer(blk.norm1.bias), None if dp is not None else grad_buffer(blk.attn.proj.bias))
-    _Side.block_done(remaining)
+    _Side.block_done(remaining, blk)
     return dx_in32, dx_in16
 
 

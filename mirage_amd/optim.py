@@ -89,16 +89,38 @@ class FusedAdamW:
         """Gradients are overwritten by every backward pass, so nothing has to be cleared; the views stay attached."""
         self.arena.reattach_grads()
 
-    def step(self):
-        """global grad norm (native_scaler.py:46-61) -> AdamW (+clip / skip) -> step counter + 1."""
+    def step_ranges(self, ranges):
+        """AdamW over element ranges [s, e) of the arena (64-element aligned) with the CURRENT step counter: the element updates are
+        independent, so any partition of the arena gives bit-identical results to the single launch.  Only without clip / skip
+        (the update must not depend on the global gradient norm)."""
+        a = self.arena
+        for s, e in ranges:
+            nd = max(0, min(e, a.n_decay) - s)
+            K.adamw(a.flat_p[s:e], a.flat_g[s:e], self.exp_avg[s:e], self.exp_avg_sq[s:e], a.flat_bf16[s:e], nd, self.lr_table,
+                    self.wd_table, self.step_dev, self.betas[0], self.betas[1], self.eps)
+
+    def step(self, done_ranges=None):
+        """global grad norm (native_scaler.py:46-61) -> AdamW (+clip / skip) -> step counter + 1.  `done_ranges`: sorted, disjoint
+        element ranges already updated this step through step_ranges() (early, overlapped with backward)."""
         from .engine import join_side_stream
         join_side_stream()
         a = self.arena
         g = a.flat_g
         K.grad_norm(g, self.grad_norm)
-        K.adamw(a.flat_p[:a.n_trainable], g, self.exp_avg, self.exp_avg_sq, a.flat_bf16[:a.n_trainable], a.n_decay, self.lr_table,
-                self.wd_table, self.step_dev, self.betas[0], self.betas[1], self.eps, grad_norm_t=self.grad_norm,
-                clip_norm=self.clip_grad or 0.0, skip_norm=self.skip_grad or 0.0)
+        if done_ranges:
+            assert not self.clip_grad and not self.skip_grad
+            rest, pos = [], 0
+            for s, e in done_ranges:
+                if s > pos:
+                    rest.append((pos, s))
+                pos = max(pos, e)
+            if pos < a.n_trainable:
+                rest.append((pos, a.n_trainable))
+            self.step_ranges(rest)
+        else:
+            K.adamw(a.flat_p[:a.n_trainable], g, self.exp_avg, self.exp_avg_sq, a.flat_bf16[:a.n_trainable], a.n_decay, self.lr_table,
+                    self.wd_table, self.step_dev, self.betas[0], self.betas[1], self.eps, grad_norm_t=self.grad_norm,
+                    clip_norm=self.clip_grad or 0.0, skip_norm=self.skip_grad or 0.0)
         K.step_inc(self.step_dev)
         if not torch.cuda.is_current_stream_capturing():
             a.mark_fresh()

@@ -42,6 +42,47 @@ class TrainStep:
                     return int(name.split(".")[1]) >= s_
                 return False
             self.r_first, self.r_rest = reducer.split_ranges(optimizer.arena, upper)
+        # single GPU, no clipping: the AdamW update of an encoder block does not depend on anything but that block's gradients, so it
+        # is issued on the side stream as soon as they are final and overlaps the rest of the backward pass (HBM-bound update
+        # under MFMA-bound GEMMs) instead of running alone at the end of the step
+        self._early = None
+        import os
+        from .optim import FusedAdamW
+        if (reducer is None and os.environ.get("MRG_EARLY_OPT", "1") != "0" and isinstance(optimizer, FusedAdamW)
+                and not optimizer.clip_grad and not optimizer.skip_grad and hasattr(model, "encoder")):
+            arena = optimizer.arena
+            per_blk = {}
+            for i, blk in enumerate(model.encoder):
+                pre = f"encoder.{i}."
+                rs = []
+                for name, p in arena.order:
+                    if name.startswith(pre) and p.requires_grad:
+                        h = p._mrg
+                        s0, e0 = h.offset, min((h.offset + h.numel + 63) // 64 * 64, arena.n_trainable)
+                        if rs and rs[-1][1] == s0:
+                            rs[-1] = (rs[-1][0], e0)
+                        else:
+                            rs.append((s0, e0))
+                per_blk[id(blk)] = rs
+            if per_blk:
+                self._early = per_blk
+                self._early_all = self._merge([r for rs in per_blk.values() for r in rs])
+
+    @staticmethod
+    def _merge(ranges):
+        out = []
+        for s0, e0 in sorted(ranges):
+            if out and out[-1][1] >= s0:
+                out[-1] = (out[-1][0], max(out[-1][1], e0))
+            else:
+                out.append((s0, e0))
+        return out
+
+    def _early_cb(self, blks):
+        rs = self._merge([r for b in blks for r in self._early.get(id(b), [])])
+        if rs:
+            self.opt.step_ranges(rs)
+            self._early_seen += len([b for b in blks if id(b) in self._early])
 
     # -- pieces ----------------------------------------------------------------------------------------
     def _fwd_bwd(self):
@@ -51,7 +92,18 @@ class TrainStep:
         self.task_losses = {t: self.loss_fns[t](preds[t], x[t], mask=None if self.loss_on_unmasked else masks.get(t)) for t in preds}
         self.loss = sum(self.task_losses.values())
         self.opt.zero_grad()
-        self.loss.backward()
+        if self._early is not None:
+            from . import engine as E
+            E._Side.early_opt, E._Side.finished, self._early_seen = self._early_cb, [], 0
+            try:
+                self.loss.backward()
+                E.join_side_stream()             # issues the update of the last blocks as well
+            finally:
+                E._Side.early_opt, E._Side.finished = None, []
+            if self._early_seen != len(self._early):      # e.g. side stream disabled: fall back to the single update
+                raise RuntimeError(f"early optimizer: {self._early_seen} of {len(self._early)} encoder blocks were updated")
+        else:
+            self.loss.backward()
 
     def _fwd_bwd_upper(self):
         """forward + losses + backward down to the activation at the encoder cut; the gradients above the cut are final on return."""
@@ -72,7 +124,10 @@ class TrainStep:
         self.model._mrg_h_mid = None
 
     def _opt(self):
-        self.opt.step()
+        if self._early is not None:
+            self.opt.step(done_ranges=self._early_all)
+        else:
+            self.opt.step()
 
     def _eager(self):
         if self.split:
