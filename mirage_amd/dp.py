@@ -71,10 +71,13 @@ class GradReducer:
                 tgt.append((s, e))
         return first, rest
 
-    def reduce_async(self, ranges=None):
+    def reduce_async(self, ranges=None, then=None):
         """Launch the bucket all-reduces (side stream on GPU).  Call wait() before reading the gradients.  `ranges`: element
-        ranges to reduce (default: the whole buffer); each is cut into buckets."""
+        ranges to reduce (default: the whole buffer); each is cut into buckets.  `then`: callable issued on the same stream right
+        after them."""
         if self.world == 1 and not self.force:
+            if then is not None:
+                then()
             return
         use_avg = self.use_avg
         op = dist.ReduceOp.AVG if use_avg else dist.ReduceOp.SUM
@@ -95,11 +98,18 @@ class GradReducer:
                 with torch.cuda.stream(self.side):
                     for s, e in (ranges if ranges is not None else [(0, self.flat.numel())]):
                         self.flat[s:e].div_(self.world)
-                    self._done = torch.cuda.Event()
-                    self._done.record(self.side)
             else:
                 for s, e in (ranges if ranges is not None else [(0, self.flat.numel())]):
                     self.flat[s:e].div_(self.world)
+        if then is not None:                 # work that only needs THESE gradients (e.g. their AdamW update), behind the collectives
+            if self.side is not None:
+                with torch.cuda.stream(self.side):
+                    then()
+            else:
+                then()
+        if self.side is not None:
+            self._done = torch.cuda.Event()
+            self._done.record(self.side)
 
     def _buckets(self, ranges):
         if ranges is None:

@@ -48,6 +48,10 @@ class TrainStep:
         self._early = None
         import os
         from .optim import FusedAdamW
+        self._first_merged = None
+        if (self.split and os.environ.get("MRG_EARLY_OPT", "1") != "0" and isinstance(optimizer, FusedAdamW)
+                and not optimizer.clip_grad and not optimizer.skip_grad):
+            self._first_merged = self._merge(self.r_first)
         if (reducer is None and os.environ.get("MRG_EARLY_OPT", "1") != "0" and isinstance(optimizer, FusedAdamW)
                 and not optimizer.clip_grad and not optimizer.skip_grad and hasattr(model, "encoder")):
             arena = optimizer.arena
@@ -67,6 +71,11 @@ class TrainStep:
             if per_blk:
                 self._early = per_blk
                 self._early_all = self._merge([r for rs in per_blk.values() for r in rs])
+
+    def _dp_first_opt(self):
+        """several ranks, no clipping: AdamW of the parameters above the encoder cut runs on the communication stream right behind
+        their all-reduce, i.e. under the lower half of the backward pass; the optimizer graph then covers the rest."""
+        self.opt.step_ranges(self._first_merged)
 
     @staticmethod
     def _merge(ranges):
@@ -126,13 +135,15 @@ class TrainStep:
     def _opt(self):
         if self._early is not None:
             self.opt.step(done_ranges=self._early_all)
+        elif self._first_merged is not None:
+            self.opt.step(done_ranges=self._first_merged)
         else:
             self.opt.step()
 
     def _eager(self):
         if self.split:
             self._fwd_bwd_upper()
-            self.reducer.reduce_async(self.r_first)
+            self.reducer.reduce_async(self.r_first, then=self._dp_first_opt if self._first_merged is not None else None)
             self._bwd_lower()
             self.reducer.reduce_async(self.r_rest)
             self.reducer.wait()
@@ -189,7 +200,8 @@ class TrainStep:
             self.g_fb.replay()
         elif self.g_b is not None:
             self.g_fb.replay()
-            self.reducer.reduce_async(self.r_first)      # overlaps the lower half of the backward pass
+            # overlaps the lower half of the backward pass (and, without clipping, takes the upper half's AdamW along)
+            self.reducer.reduce_async(self.r_first, then=self._dp_first_opt if self._first_merged is not None else None)
             self.g_b.replay()
             self.reducer.reduce_async(self.r_rest)
             self.reducer.wait()
