@@ -7,7 +7,7 @@ db = sqlite3.connect(sys.argv[1])
 k = int(sys.argv[2]) if len(sys.argv) > 2 else 2
 rows = db.execute("""select s.display_name, d.start, d.end, d.queue_id from rocpd_kernel_dispatch d
                      join rocpd_info_kernel_symbol s on d.kernel_id = s.id order by d.start""").fetchall()
-ends = [r[2] for r in rows if "adamw" in r[0]]
+ends = [r[2] for r in rows if "step_inc" in r[0]]
 t0, t1 = ends[-k - 1], ends[-k]
 sel = [r for r in rows if r[1] >= t0 and r[2] <= t1 + 1]
 short = lambda n: re.sub(r"\(.*", "", re.sub(r"\(anonymous namespace\)::|void ", "", n))[:34]

@@ -14,8 +14,8 @@ def main():
     cur = db.cursor()
     rows = cur.execute("""select s.display_name, d.start, d.end, d.queue_id, d.stream_id from rocpd_kernel_dispatch d
                           join rocpd_info_kernel_symbol s on d.kernel_id = s.id order by d.start""").fetchall()
-    # steps are delimited by the adamw kernel (one per step)
-    ends = [r[2] for r in rows if "adamw" in r[0]]
+    # steps are delimited by the step-counter increment (one per step; AdamW itself is issued in several ranges)
+    ends = [r[2] for r in rows if "step_inc" in r[0]]
     skip = int(sys.argv[3]) if len(sys.argv) > 3 else 1          # trailing steps to ignore (bench.py's instrumented eager step)
     if len(ends) < nsteps + 1 + skip:
         print("not enough steps"); return
