@@ -8,7 +8,7 @@ db = sqlite3.connect(sys.argv[1])
 ms_per_step = float(sys.argv[2]); alg_tf = float(sys.argv[3])
 rows = db.execute("""select s.display_name, d.start, d.end, d.id from rocpd_kernel_dispatch d
                      join rocpd_info_kernel_symbol s on d.kernel_id = s.id order by d.start""").fetchall()
-ends = [r[2] for r in rows if "adamw" in r[0]]
+ends = [r[2] for r in rows if "step_inc" in r[0]]
 t0, t1 = ends[-3], ends[-2]                       # one graph-replayed step (the last one is bench.py's instrumented eager step)
 ids = {r[3]: r[0] for r in rows if r[1] >= t0 and r[2] <= t1 + 1}
 pm = db.execute("""select d.id, p.name, e.value from rocpd_pmc_event e join rocpd_info_pmc p on e.pmc_id = p.id
