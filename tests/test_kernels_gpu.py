@@ -106,8 +106,14 @@ def test_gemm_every_variant_same_result(K, variant):
         o2 = K.gemm(A2, W2, M2, N2, K2, bias=b2, out_dtype=BF16)
         d2 = K.gemm(A2, W2t, M2, N2, K2, b_mode=L.MRG_OP_KSTRIDED, out_dtype=F32)
         w2 = K.gemm(dy, A2, N2, K2, M2, a_mode=L.MRG_OP_KSTRIDED, b_mode=L.MRG_OP_KSTRIDED, out_dtype=F32, splitk=2)
+        cnt2 = torch.tensor([397], dtype=torch.int32, device=dev())          # device row count with the clamped-row loaders
+        part2 = torch.full((M2, N2), -5.0, device=dev())
+        K.gemm(A2, W2, M2, N2, K2, out=part2, m_dev=cnt2)
     finally:
         K.TUNE["force"] = None
+    lin2 = A2.float() @ W2.float().t()
+    torch.testing.assert_close(part2[:397], lin2[:397], rtol=2e-3, atol=2e-3 * float(lin2.abs().max()))
+    assert float((part2[397:] + 5.0).abs().max()) == 0.0
     assert rel_rms(o2.float(), A2.float() @ W2.float().t() + b2) < 4e-3
     r2 = A2.float() @ W2t.float()
     torch.testing.assert_close(d2, r2, rtol=2e-3, atol=2e-3 * float(r2.abs().max()))
