@@ -284,13 +284,26 @@ class MIRAGEModel(nn.Module):
             for j, i in enumerate(act):
                 dps[i] = blocks[i].drop_path_rows(B, x0.shape[1], device, u[j])
         split = getattr(self, "_mrg_split_at", None)
-        if split and save and 0 < split < len(blocks):
-            # data-parallel overlap (trainer.TrainStep): the encoder is two autograd nodes so that the backward pass can be run up
-            # to the activation between them, the gradients of everything above it all-reduced, and the rest run meanwhile
-            h_mid, _ = E.EncoderFn.apply(x0, blocks[:split], save, False, True, dps[:split] if dps else None, *self._encoder_params())
-            self._mrg_h_mid = h_mid
-            enc32, enc16 = E.EncoderFn.apply(h_mid, blocks[split:], save, want16, True, dps[split:] if dps else None,
+        cuts = [split] if isinstance(split, int) else list(split or [])
+        cuts = [c for c in cuts if 0 < c < len(blocks)]
+        if cuts and save:
+            # data-parallel overlap (trainer.TrainStep): the encoder is several autograd nodes so that the backward pass can be run
+            # down to the activation at a cut, the gradients of everything above it all-reduced, and the rest run meanwhile
+            bounds = [0] + sorted(cuts) + [len(blocks)]
+            h, hs = x0, []
+            enc32 = enc16 = None
+            for j in range(len(bounds) - 1):
+                a, b = bounds[j], bounds[j + 1]
+                last = j == len(bounds) - 2
+                h32, h16 = E.EncoderFn.apply(h, blocks[a:b], save, want16 if last else False, True, dps[a:b] if dps else None,
                                              *self._encoder_params())
+                if last:
+                    enc32, enc16 = h32, h16
+                else:
+                    hs.append(h32)
+                    h = h32
+            self._mrg_h_cuts = hs
+            self._mrg_h_mid = hs[-1]
         else:
             enc32, enc16 = E.EncoderFn.apply(x0, blocks, save, want16, True, dps, *self._encoder_params())
         if self.output_adapters is None:

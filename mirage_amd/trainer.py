@@ -27,31 +27,49 @@ class TrainStep:
         self.reducer = reducer
         self.use_graph = use_graph
         self.g_fb = self.g_opt = self.g_b = None
+        self.g_mids = []
         # with several ranks the backward pass is cut at the middle of the encoder: everything above the cut (decoders, upper
         # encoder blocks) is all-reduced on the side stream while the lower half is still being differentiated
         self.split = None
         self.r_first = self.r_rest = None
+        self.cuts, self.stage_ranges = [], []
         if reducer is not None and overlap and len(model.encoder) >= 2:
-            self.split = len(model.encoder) // 2
-            model._mrg_split_at = self.split
-            s_ = self.split
-            def upper(name):
-                if name.startswith("output_adapters."):
-                    return True
-                if name.startswith("encoder."):
-                    return int(name.split(".")[1]) >= s_
-                return False
-            self.r_first, self.r_rest = reducer.split_ranges(optimizer.arena, upper)
+            import os as _os
+            L_ = len(model.encoder)
+            ncut = int(_os.environ.get("MRG_DP_CUTS", "2"))
+            # cut points (block indices, ascending): backward reaches the highest first.  Two cuts = three stages: decoders + upper
+            # half | third quarter | first quarter + embeddings, so that only the last quarter's all-reduce has nothing to hide under
+            cuts = sorted({c for c in ([L_ // 2] if ncut <= 1 or L_ < 4 else [L_ // 4, L_ // 2]) if 0 < c < L_})
+            self.cuts = cuts
+            self.split = cuts[-1]
+            model._mrg_split_at = list(cuts)
+            bounds = cuts + [L_]
+
+            def stage_pred(j):                       # stage 0 = above the highest cut (and the output adapters), then downwards
+                lo, hi = bounds[len(cuts) - 1 - j], bounds[len(cuts) - j]
+                def pred(name):
+                    if j == 0 and name.startswith("output_adapters."):
+                        return True
+                    if name.startswith("encoder."):
+                        return lo <= int(name.split(".")[1]) < hi
+                    return False
+                return pred
+            preds_ = [stage_pred(j) for j in range(len(cuts))]
+            self.stage_ranges = [reducer.split_ranges(optimizer.arena, pr)[0] for pr in preds_]
+            self.r_first = self.stage_ranges[0]
+            self.r_rest = reducer.split_ranges(optimizer.arena, lambda n: any(pr(n) for pr in preds_))[1]
         # single GPU, no clipping: the AdamW update of an encoder block does not depend on anything but that block's gradients, so it
         # is issued on the side stream as soon as they are final and overlaps the rest of the backward pass (HBM-bound update
         # under MFMA-bound GEMMs) instead of running alone at the end of the step
         self._early = None
         import os
         from .optim import FusedAdamW
-        self._first_merged = None
+        self._first_merged = None            # union of the ranges updated early in data-parallel mode (None: single update)
+        self._stage_merged = []
         if (self.split and os.environ.get("MRG_EARLY_OPT", "1") != "0" and isinstance(optimizer, FusedAdamW)
                 and not optimizer.clip_grad and not optimizer.skip_grad):
-            self._first_merged = self._merge(self.r_first)
+            self._stage_merged = [self._merge(r) for r in self.stage_ranges]
+            self._first_merged = self._merge([r for rs in self.stage_ranges for r in rs])
         if (reducer is None and os.environ.get("MRG_EARLY_OPT", "1") != "0" and isinstance(optimizer, FusedAdamW)
                 and not optimizer.clip_grad and not optimizer.skip_grad and hasattr(model, "encoder")):
             arena = optimizer.arena
@@ -72,10 +90,13 @@ class TrainStep:
                 self._early = per_blk
                 self._early_all = self._merge([r for rs in per_blk.values() for r in rs])
 
-    def _dp_first_opt(self):
-        """several ranks, no clipping: AdamW of the parameters above the encoder cut runs on the communication stream right behind
-        their all-reduce, i.e. under the lower half of the backward pass; the optimizer graph then covers the rest."""
-        self.opt.step_ranges(self._first_merged)
+    def _stage_then(self, j):
+        """several ranks, no clipping: AdamW of a stage's parameters runs on the communication stream right behind their all-reduce,
+        i.e. under the following stages of the backward pass; the optimizer graph then covers the rest."""
+        if not self._stage_merged:
+            return None
+        rs = self._stage_merged[j]
+        return lambda: self.opt.step_ranges(rs)
 
     @staticmethod
     def _merge(ranges):
@@ -123,13 +144,20 @@ class TrainStep:
         self.task_losses = {t: self.loss_fns[t](preds[t], x[t], mask=None if self.loss_on_unmasked else masks.get(t)) for t in preds}
         self.loss = sum(self.task_losses.values())
         self.opt.zero_grad()
-        self.h_mid = self.model._mrg_h_mid
-        self.g_mid = torch.autograd.grad(self.loss, self.h_mid, retain_graph=True)[0]
+        self._hs = list(self.model._mrg_h_cuts)
+        self._g = torch.autograd.grad(self.loss, self._hs[-1], retain_graph=True)[0]
+        E.join_side_stream()
+
+    def _bwd_mid(self, k):
+        """backward from the cut activation k+1 down to cut activation k (parameter gradients are written by the engine)."""
+        from . import engine as E
+        self._g = torch.autograd.grad(self._hs[k + 1], self._hs[k], self._g, retain_graph=True)[0]
         E.join_side_stream()
 
     def _bwd_lower(self):
-        self.h_mid.backward(self.g_mid)
-        self.h_mid = self.g_mid = None
+        self._hs[0].backward(self._g)
+        self._hs = self._g = None
+        self.model._mrg_h_cuts = None
         self.model._mrg_h_mid = None
 
     def _opt(self):
@@ -143,7 +171,10 @@ class TrainStep:
     def _eager(self):
         if self.split:
             self._fwd_bwd_upper()
-            self.reducer.reduce_async(self.r_first, then=self._dp_first_opt if self._first_merged is not None else None)
+            self.reducer.reduce_async(self.stage_ranges[0], then=self._stage_then(0))
+            for j in range(1, len(self.cuts)):
+                self._bwd_mid(len(self.cuts) - 1 - j)
+                self.reducer.reduce_async(self.stage_ranges[j], then=self._stage_then(j))
             self._bwd_lower()
             self.reducer.reduce_async(self.r_rest)
             self.reducer.wait()
@@ -176,6 +207,12 @@ class TrainStep:
             if self.split:
                 with torch.cuda.graph(self.g_fb, capture_error_mode="thread_local"):
                     self._fwd_bwd_upper()
+                self.g_mids = []
+                for j in range(1, len(self.cuts)):
+                    gm = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(gm, pool=self.g_fb.pool(), capture_error_mode="thread_local"):
+                        self._bwd_mid(len(self.cuts) - 1 - j)
+                    self.g_mids.append(gm)
                 self.g_b = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(self.g_b, pool=self.g_fb.pool(), capture_error_mode="thread_local"):
                     self._bwd_lower()
@@ -200,8 +237,12 @@ class TrainStep:
             self.g_fb.replay()
         elif self.g_b is not None:
             self.g_fb.replay()
-            # overlaps the lower half of the backward pass (and, without clipping, takes the upper half's AdamW along)
-            self.reducer.reduce_async(self.r_first, then=self._dp_first_opt if self._first_merged is not None else None)
+            # each stage's all-reduce overlaps the following stages of the backward pass (and, without clipping, takes the stage's
+            # AdamW along)
+            self.reducer.reduce_async(self.stage_ranges[0], then=self._stage_then(0))
+            for j, gm in enumerate(self.g_mids, start=1):
+                gm.replay()
+                self.reducer.reduce_async(self.stage_ranges[j], then=self._stage_then(j))
             self.g_b.replay()
             self.reducer.reduce_async(self.r_rest)
             self.reducer.wait()

@@ -244,9 +244,9 @@ def test_bench_multi_rank_code_path_single_gpu():
 
 
 def test_overlapped_dp_schedule_is_bit_identical_to_single_graph():
-    """trainer.TrainStep with a reducer cuts the backward pass at the middle of the encoder (autograd.grad to the cut, ranged
-    all-reduce of everything above it on the side stream, then the lower half): at world size 1 over RCCL, eager and as three
-    hipGraphs, losses and weights must equal the single-graph step bit for bit (tools/debug/dp_split_check.py)."""
+    """trainer.TrainStep with a reducer cuts the backward pass at a quarter and at the middle of the encoder (autograd.grad to a cut,
+    ranged all-reduce + AdamW of everything above it on the side stream, then the next stage): at world size 1 over RCCL, eager and
+    as four hipGraphs, losses and weights must equal the single-graph step bit for bit (tools/debug/dp_split_check.py)."""
     import subprocess
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")

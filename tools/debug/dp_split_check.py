@@ -1,5 +1,5 @@
-"""World-size-1 check of the overlapped data-parallel schedule (backward cut at the middle of the encoder, ranged all-reduces on
-the side stream between the graph segments): it must produce bit-identical losses and weights to the single-graph step."""
+"""World-size-1 check of the overlapped data-parallel schedule (backward cut at a quarter and at the middle of the encoder, ranged
+all-reduces and the stages' AdamW on the side stream between the graph segments): it must produce bit-identical losses and weights to the single-graph step."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29555")
@@ -29,9 +29,9 @@ def run(split):
     batches = [{d: t.to(dev) for d, t in O.synthetic_batch(cfg, 4, seed=40 + i).items()} for i in range(3)]
     ts = TrainStep(model, builder.get_losses(args), opt, batches[0], 24, use_graph=use_graph, reducer=red)
     if split:
-        assert ts.split == 2 and ts.r_first and ts.r_rest
-        n1 = sum(e - s for s, e in ts.r_first); n2 = sum(e - s for s, e in ts.r_rest)
-        assert n1 + n2 == opt.arena.flat_g.numel(), (n1, n2, opt.arena.flat_g.numel())
+        assert ts.split == 2 and ts.cuts == [1, 2] and all(ts.stage_ranges) and ts.r_rest
+        n1 = sum(e - s for rs in ts.stage_ranges for s, e in rs); n2 = sum(e - s for s, e in ts.r_rest)
+        assert n1 + n2 == opt.arena.flat_g.numel(), (n1, n2, opt.arena.flat_g.numel())       # the stages partition the arena
     ts.load(batches[0])
     torch.manual_seed(7); torch.cuda.manual_seed(7)
     ts.warmup_and_capture(warm_iters=1)
