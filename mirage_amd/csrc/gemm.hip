@@ -522,14 +522,14 @@ __device__ __forceinline__ const char* uniform_ptr(const char* p) {
 // per-thread source pointer + per-tile increment for LDS block b (1 KiB) of an operand tile
 template <int MODE>
 __device__ __forceinline__ void glds_setup(const bf16_t* P, int ld, int row0, int nrows, int k_first, int b, int lane,
-                                           const bf16_t*& ptr, long& inc, int& koff) {
+                                           const bf16_t*& ptr, long& inc, int& koff, const int* __restrict__ map = nullptr) {
     const bf16_t* zero = reinterpret_cast<const bf16_t*>(g_zero_page);
     if (MODE == MRG_OP_KCONTIG) {
         const int r = b * 8 + (lane >> 3);
         const int c = (lane & 7) ^ ((r >> 1) & 7);
         const int row = row0 + r;
         koff = c << 3;
-        if (row < nrows) { ptr = P + (long)row * ld + k_first + koff; inc = BK; }
+        if (row < nrows) { ptr = P + (long)(map ? map[row] : row) * ld + k_first + koff; inc = BK; }   // map: gathered rows (embedding dgrad)
         else { ptr = zero; inc = 0; koff = -(1 << 30); }
     } else {
         const int kr = b * 4 + (lane >> 4);
@@ -601,7 +601,7 @@ __global__ __launch_bounds__(256, OCC) void gemm_glds_kernel(const GemmArgs g) {
     } else {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            glds_setup<AMODE>(g.A, g.lda, m0, Meff, t0 * BK, wave * 4 + j, lane, pa[j], ia[j], ka[j]);
+            glds_setup<AMODE>(g.A, g.lda, m0, Meff, t0 * BK, wave * 4 + j, lane, pa[j], ia[j], ka[j], g.a_map);
             glds_setup<BMODE>(g.B, g.ldb, n0, g.N, t0 * BK, wave * 4 + j, lane, pb[j], ib[j], kb[j]);
         }
     }
@@ -766,7 +766,7 @@ __global__ __launch_bounds__(256, 2) void gemm_pipe_kernel(const GemmArgs g) {
     } else {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            glds_setup<AMODE>(g.A, g.lda, m0, Meff, t0 * BK, wave * 4 + j, lane, pa[j], ia[j], ka[j]);
+            glds_setup<AMODE>(g.A, g.lda, m0, Meff, t0 * BK, wave * 4 + j, lane, pa[j], ia[j], ka[j], g.a_map);
             glds_setup<BMODE>(g.B, g.ldb, n0, g.N, t0 * BK, wave * 4 + j, lane, pb[j], ib[j], kb[j]);
         }
     }
@@ -1570,7 +1570,7 @@ extern "C" int mrg_gemm(const mrg_gemm_desc* d, hipStream_t stream) {
     { static const int nt = [] { const char* e = getenv("MRG_GEMM_NT"); return e ? atoi(e) : 2; }(); g.nt = nt; }
     { static const int xs = [] { const char* e = getenv("MRG_GEMM_XCD_SPLIT"); return e ? atoi(e) : 1; }(); g.xcd_split = xs; }
     static const int kfast = [] { const char* e = getenv("MRG_GEMM_KFAST"); return e ? atoi(e) : 1; }();
-    const bool kf = kfast && (d->K % BK == 0) && !d->k_dev;      // scalar-base loader of the single-stage kernel
+    const bool kf = kfast && (d->K % BK == 0) && !d->k_dev && !d->a_map;      // scalar-base loaders
     {   // lean epilogue selection (uniform over the launch)
         static const int lean = [] { const char* e = getenv("MRG_GEMM_LEAN"); return e ? atoi(e) : 1; }();
         const bool base = splitk == 1 && !d->add_tab && !d->row_map && !d->accumulate && !d->resid && !d->row_scale && !d->C2 && !g.c_f32;
@@ -1595,7 +1595,8 @@ extern "C" int mrg_gemm(const mrg_gemm_desc* d, hipStream_t stream) {
     auto al4 = [](const void* p, int ld, int bytes) { return p == nullptr || ((((uintptr_t)p) % (4 * bytes) == 0) && (ld % 4 == 0)); };
     const bool vec = (d->N % 4 == 0) && al4(d->C, d->ldc, g.c_f32 ? 4 : 2) && al4(d->C2, d->ldc2, 2) && al4(d->resid, d->ldr, 4) &&
                      al4(d->add_tab, d->ldt, 4) && al4(d->aux_out, d->ldaux, 2) && al4(d->aux_in, d->ldaux, 2) && al4(d->ws, d->N, 4);
-    const bool fast = al && !d->a_map && !d->b_map;
+    const bool fast = al && !d->b_map && (!d->a_map || d->a_mode == MRG_OP_KCONTIG);
+    const bool mapped = d->a_map != nullptr;                       // gathered A rows: single-/two-stage 128 x 128 kernels, general loader
     if (d->ev_start) (void)hipEventRecord((hipEvent_t)d->ev_start, stream);
     // 4 workgroups per CU (<= 128 VGPRs) pay off only when there are enough tiles to fill them (measured: +13..18 % at
     // >= ~1500 tiles, -3..-15 % below and for the wgrad layout)
@@ -1610,7 +1611,7 @@ extern "C" int mrg_gemm(const mrg_gemm_desc* d, hipStream_t stream) {
     if (d->variant == MRG_GEMM_GLDS3) { use_pipe = false; occ4 = false; }
     else if (d->variant == MRG_GEMM_GLDS4) { use_pipe = false; occ4 = true; }
     else if (d->variant == MRG_GEMM_PIPE128) { use_pipe = true; }
-    else if (d->variant == MRG_GEMM_PIPE256 || d->variant == MRG_GEMM_PIPE256X3) { use_big = fast && d->M > 128; use_pipe = true; }
+    else if (d->variant == MRG_GEMM_PIPE256 || d->variant == MRG_GEMM_PIPE256X3) { use_big = fast && !mapped && d->M > 128; use_pipe = true; }
     if (d->colsum_out) {      // only the single-stage 128 x 128 kernel (dgrad layout) is instantiated with the column-sum epilogue
         MRG_REQUIRE(fast && splitk == 1 && !d->row_map && d->a_mode == MRG_OP_KCONTIG && d->b_mode == MRG_OP_KSTRIDED, MRG_ERR_UNSUPPORTED,
                     "mrg_gemm: colsum_out needs the dgrad layout (A k-contiguous, B k-strided), aligned unmapped operands and no split-K");
@@ -1623,8 +1624,8 @@ extern "C" int mrg_gemm(const mrg_gemm_desc* d, hipStream_t stream) {
         if (d->ev_stop) (void)hipEventRecord((hipEvent_t)d->ev_stop, stream);
         return mrg_check_launch("mrg_gemm");
     }
-    const bool use_sq = !d->colsum_out && fast && d->variant == MRG_GEMM_PIPE256SQ && d->M > 128 && d->N > 128;
-    const bool use_ws = !d->colsum_out && fast && d->variant == MRG_GEMM_WS256 && d->M > 128;
+    const bool use_sq = !d->colsum_out && fast && !mapped && d->variant == MRG_GEMM_PIPE256SQ && d->M > 128 && d->N > 128;
+    const bool use_ws = !d->colsum_out && fast && !mapped && d->variant == MRG_GEMM_WS256 && d->M > 128;
     if (fast && d->variant == MRG_GEMM_G256 && kf && !d->colsum_out && d->M > 128) {
         const dim3 gg(cdiv(d->M, 256) * g.tiles_n, splitk);
 #define MRG_G256(AM, BM_, V) hipLaunchKernelGGL((gemm_g256_kernel<AM, BM_, V>), gg, block, (size_t)(3 * TILE_BYTES), stream, g)
@@ -1635,7 +1636,7 @@ extern "C" int mrg_gemm(const mrg_gemm_desc* d, hipStream_t stream) {
         if (d->ev_stop) (void)hipEventRecord((hipEvent_t)d->ev_stop, stream);
         return mrg_check_launch("mrg_gemm");
     }
-    if (fast && d->variant == MRG_GEMM_GLDS64 && d->a_mode == MRG_OP_KCONTIG && splitk == 1 && !d->colsum_out) {
+    if (fast && !mapped && d->variant == MRG_GEMM_GLDS64 && d->a_mode == MRG_OP_KCONTIG && splitk == 1 && !d->colsum_out) {
         const dim3 g64(cdiv(d->M, 64) * g.tiles_n);
         if (d->b_mode == MRG_OP_KCONTIG) { if (vec) hipLaunchKernelGGL((gemm_glds64_kernel<0, true>), g64, block, (size_t)(2 * TILE_BYTES), stream, g);
                                            else hipLaunchKernelGGL((gemm_glds64_kernel<0, false>), g64, block, (size_t)(2 * TILE_BYTES), stream, g); }
