@@ -44,7 +44,7 @@ struct GemmArgs {
     int tiles_m, tiles_n;
     int epi_kind;  // 0 generic epilogue; lean paths: 1 (+bias) -> bf16 C; 2 (+bias)(*row_scale) + fp32 residual -> fp32 C (+ bf16 twin);
                    // 3 bias + GELU with fp16 GELU' side output; 4 multiply by the fp16 side input -> bf16 C (1 and 4 also with column sums);
-                   // 5 bias + GELU -> bf16 C
+                   // 5 bias + GELU -> bf16 C; 6 bias + table row -> fp32 C at a mapped row (patch embedding)
     int xcd_split; // MRG_GEMM_XCD_SPLIT (default 1): split-K index slowest in the XCD band order
     int nt;       // MRG_GEMM_NT: 0 plain stores, 1 streaming (nontemporal) stores for C / C2 / aux_out, 2 (default) for aux_out only
     int ablate;   // MRG_GEMM_ABLATE (256x128 kernel only, for roofline analysis): 1 = no DMA, 2 = DMA only, 3 = DMA + LDS reads, no MFMA
@@ -304,6 +304,19 @@ __device__ __forceinline__ void epi_row_gelu_save(const GemmArgs& g, const float
         for (int e = 0; e < nv; ++e) { ao[e] = (_Float16)gd[e]; c[e] = f2bf(v[e]); }
     }
 }
+// patch embedding: bias + positional row (table lookup) -> fp32 C at a mapped row (token-select fused into the projection)
+template <bool VEC>
+__device__ __forceinline__ void epi_row_embed(const GemmArgs& g, const float4 a4, const float (&bv)[4], int row, int col, int nv) {
+    float v[4] = {a4.x + bv[0], a4.y + bv[1], a4.z + bv[2], a4.w + bv[3]};
+    const float* t = g.add_tab + (long)g.add_row[row] * g.ldt + col;
+    float* c = reinterpret_cast<float*>(g.C) + (long)g.row_map[row] * g.ldc + col;
+    if (VEC) {
+        const float4 t4 = *reinterpret_cast<const float4*>(t);
+        *reinterpret_cast<float4*>(c) = make_float4(v[0] + t4.x, v[1] + t4.y, v[2] + t4.z, v[3] + t4.w);
+    } else {
+        for (int e = 0; e < nv; ++e) c[e] = v[e] + t[e];
+    }
+}
 // inference fc1: bias -> GELU -> bf16 (MRG_ACT_GELU without a saved pre-activation)
 template <bool VEC>
 __device__ __forceinline__ void epi_row_gelu(const GemmArgs& g, const float4 a4, const float (&bv)[4], int row, int col, int nv) {
@@ -358,6 +371,7 @@ __device__ __forceinline__ void epi_any(const GemmArgs& g, const float4 a4, cons
     else if (g.epi_kind == 3) epi_row_gelu_save<VEC>(g, a4, bv, row, col, nv);
     else if (g.epi_kind == 4) epi_row_mulaux<VEC>(g, a4, bv, row, col, nv);
     else if (g.epi_kind == 5) epi_row_gelu<VEC>(g, a4, bv, row, col, nv);
+    else if (g.epi_kind == 6) epi_row_embed<VEC>(g, a4, bv, row, col, nv);
     else epi_row<VEC>(g, a4, bv, ws, row, col, nv);
 }
 template <bool VEC>
@@ -1580,6 +1594,8 @@ extern "C" int mrg_gemm(const mrg_gemm_desc* d, hipStream_t stream) {
             else if (base && d->act == MRG_ACT_GELU_SAVE_GRAD && d->aux_out && !d->colsum_out) g.epi_kind = 3;
             else if (base && d->act == MRG_ACT_MUL_AUX_F16 && d->aux_in) g.epi_kind = 4;
             else if (base && d->act == MRG_ACT_GELU && !d->aux_out && !d->colsum_out) g.epi_kind = 5;
+            else if (splitk == 1 && d->act == MRG_ACT_NONE && d->add_tab && d->add_row && d->row_map && !d->accumulate && !d->resid && !d->row_scale &&
+                     !d->C2 && g.c_f32 && !d->colsum_out) g.epi_kind = 6;
             else if (splitk == 1 && d->act == MRG_ACT_NONE && !d->add_tab && !d->row_map && !d->accumulate && !d->colsum_out && d->resid && g.c_f32) g.epi_kind = 2;
         }
     }
