@@ -257,3 +257,41 @@ def test_overlapped_dp_schedule_is_bit_identical_to_single_graph():
         p = subprocess.run([sys.executable, os.path.join(root, "tools", "debug", "dp_split_check.py")] + extra, env=env,
                            capture_output=True, text=True, timeout=600)
         assert p.returncode == 0 and tag in p.stdout, (p.stdout[-1500:], p.stderr[-1500:])
+
+
+def test_early_blockwise_adamw_is_bit_identical_to_single_update(monkeypatch):
+    """Single GPU, no clipping: trainer.TrainStep issues each encoder block's AdamW on the side stream as soon as the block's
+    gradients are final (engine._Side.early_opt, FusedAdamW.step_ranges).  The element updates are independent, so weights,
+    moments and losses must equal the single end-of-step update bit for bit, eager and as a graph; with clipping the early path
+    must switch itself off."""
+    from mirage_amd import builder, optim
+    from mirage_amd.trainer import TrainStep
+    from oracle import mirage_oracle as O
+    import test_model_gpu as T
+    fx, meta = load_golden("tiny2")
+    cfg = meta["cfg"]
+
+    def run(early, use_graph, clip=None):
+        monkeypatch.setenv("MRG_EARLY_OPT", "1" if early else "0")
+        model, args, _ = T._build(cfg)
+        model.train()
+        opt = optim.FusedAdamW(model, [1e-3] * 16, [0.05] * 16, clip_grad=clip)
+        batch = {d: t.to(DEV) for d, t in O.synthetic_batch(cfg, 4, seed=3).items()}
+        ts = TrainStep(model, builder.get_losses(args), opt, batch, 32, use_graph=use_graph)
+        assert (ts._early is not None) == (early and clip is None)
+        ts.load(batch)
+        torch.manual_seed(11); torch.cuda.manual_seed(11)
+        if use_graph:
+            ts.warmup_and_capture(warm_iters=1)
+        losses = []
+        for _ in range(3):
+            ts.step(batch); losses.append(float(ts.loss))
+        torch.cuda.synchronize()
+        return losses, opt.arena.flat_p.detach().clone(), opt.exp_avg.clone(), opt.exp_avg_sq.clone()
+
+    for use_graph in (False, True):
+        l0, p0, m0, v0 = run(False, use_graph)
+        l1, p1, m1, v1 = run(True, use_graph)
+        assert l0 == l1
+        assert torch.equal(p0, p1) and torch.equal(m0, m1) and torch.equal(v0, v1)
+    run(True, False, clip=1.0)
