@@ -594,6 +594,11 @@ class DecodersFn(torch.autograd.Function):
         for i, ((ad, _, _), d_ctx16) in enumerate(zip(todo, d_ctxs)):
             decoder_bwd_finish(ad, d_ctx16, d_enc, i == 0)
         ctx.saved = None
+        if _Side.early_opt is not None:          # every output-adapter gradient is final after the next reduction flush
+            if _Side.enabled:
+                _Side.finished.append("decoders")
+            else:
+                _Side.early_opt(["decoders"])
         if not ctx.defer_join:
             _Side.join()
         return (d_enc,) + (None,) * (len(ctx.needs_input_grad) - 1)

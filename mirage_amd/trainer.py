@@ -86,6 +86,14 @@ class TrainStep:
                         else:
                             rs.append((s0, e0))
                 per_blk[id(blk)] = rs
+            if per_blk and getattr(model, "output_adapters", None) is not None:
+                rs = []
+                for name, p in arena.order:
+                    if name.startswith("output_adapters.") and p.requires_grad:
+                        h = p._mrg
+                        rs.append((h.offset, min((h.offset + h.numel + 63) // 64 * 64, arena.n_trainable)))
+                if rs:
+                    per_blk["decoders"] = self._merge(rs)
             if per_blk:
                 self._early = per_blk
                 self._early_all = self._merge([r for rs in per_blk.values() for r in rs])
@@ -109,10 +117,11 @@ class TrainStep:
         return out
 
     def _early_cb(self, blks):
-        rs = self._merge([r for b in blks for r in self._early.get(id(b), [])])
+        key = lambda b: b if isinstance(b, str) else id(b)
+        rs = self._merge([r for b in blks for r in self._early.get(key(b), [])])
         if rs:
             self.opt.step_ranges(rs)
-            self._early_seen += len([b for b in blks if id(b) in self._early])
+            self._early_seen += len([b for b in blks if key(b) in self._early])
 
     # -- pieces ----------------------------------------------------------------------------------------
     def _fwd_bwd(self):
