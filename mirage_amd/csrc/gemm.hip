@@ -45,6 +45,7 @@ struct GemmArgs {
     int epi_kind;  // 0 generic epilogue; lean paths: 1 (+bias) -> bf16 C; 2 (+bias)(*row_scale) + fp32 residual -> fp32 C (+ bf16 twin);
                    // 3 bias + GELU with fp16 GELU' side output; 4 multiply by the fp16 side input -> bf16 C (1 and 4 also with column sums);
                    // 5 bias + GELU -> bf16 C; 6 bias + table row -> fp32 C at a mapped row (patch embedding)
+    int side_drain; // MRG_GEMM_SIDE_DRAIN (default 1): two-phase drain for the epilogues with a per-output side operand
     int xcd_split; // MRG_GEMM_XCD_SPLIT (default 1): split-K index slowest in the XCD band order
     int nt;       // MRG_GEMM_NT: 0 plain stores, 1 streaming (nontemporal) stores for C / C2 / aux_out, 2 (default) for aux_out only
     int ablate;   // MRG_GEMM_ABLATE (256x128 kernel only, for roofline analysis): 1 = no DMA, 2 = DMA only, 3 = DMA + LDS reads, no MFMA
@@ -381,6 +382,57 @@ __device__ __forceinline__ void epi_any_cs(const GemmArgs& g, const float4 a4, c
     else epi_row<VEC, true>(g, a4, bv, ws, row, col, nv, cs);
 }
 
+// Two-phase drain of one staged pass for the epilogues that read a side operand per output (fp32 residual, fp16 GELU'): the side
+// operands of all NIT row segments are requested before the first one is consumed.  The row-at-a-time loop exposes one global
+// round trip per iteration (8-16 dependent ones per thread and pass).  row_of(it, rl, row): staging row / output row of step it.
+template <int KIND, bool CS, int NIT, int CTW, typename RowOf>
+__device__ __forceinline__ void drain_side(const GemmArgs& g, const float* ct, int cl, int col, const float (&bv)[4], int Meff,
+                                           RowOf row_of, float* cs) {
+    typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+    float4 a[NIT], t[NIT];
+    h4 x[NIT];
+    float rs[NIT];
+    int rows[NIT];
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        int rl, row;
+        row_of(it, rl, row);
+        rows[it] = row;
+        const long rr = row < Meff ? row : Meff - 1;              // clamped: the load is unconditional, only the store is masked
+        a[it] = *reinterpret_cast<const float4*>(ct + rl * CTW + cl);
+        if (KIND == 2) {
+            t[it] = *reinterpret_cast<const float4*>(g.resid + rr * g.ldr + col);
+            rs[it] = g.row_scale ? g.row_scale[rr] : 1.f;
+        } else {
+            x[it] = *reinterpret_cast<const h4*>(reinterpret_cast<const _Float16*>(g.aux_in) + rr * g.ldaux + col);
+        }
+    }
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        const int row = rows[it];
+        if (row < Meff) {
+            float v[4] = {a[it].x + bv[0], a[it].y + bv[1], a[it].z + bv[2], a[it].w + bv[3]};
+            if (KIND == 2) {
+                if (g.row_scale) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] *= rs[it];
+                }
+                v[0] += t[it].x; v[1] += t[it].y; v[2] += t[it].z; v[3] += t[it].w;
+                *reinterpret_cast<float4*>(reinterpret_cast<float*>(g.C) + (long)row * g.ldc + col) = make_float4(v[0], v[1], v[2], v[3]);
+                if (g.C2) *reinterpret_cast<u32x2*>(g.C2 + (long)row * g.ldc2 + col) = u32x2{pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3])};
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] *= (float)x[it][e];
+                *reinterpret_cast<u32x2*>(reinterpret_cast<bf16_t*>(g.C) + (long)row * g.ldc + col) = u32x2{pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3])};
+                if (CS) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) cs[e] += v[e];
+                }
+            }
+        }
+    }
+}
+
 template <int AMODE, int BMODE, bool ALIGNED, bool VEC>
 __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs g) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -690,6 +742,10 @@ __global__ __launch_bounds__(256, OCC) void gemm_glds_kernel(const GemmArgs g) {
         }
         __syncthreads();
         if (col < g.N) {
+            auto row_of = [&](int it, int& rl, int& row) { rl = (tid >> 5) + (it << 3); row = m0 + (rl >> 5) * 64 + pss * 32 + (rl & 31); };
+            if (VEC && g.side_drain && g.epi_kind == 4) { drain_side<4, CSUM, 4, BN>(g, ct, cl, col, bv, Meff, [&](int it, int& rl, int& row) { row_of(it, rl, row); }, cs); drain_side<4, CSUM, 4, BN>(g, ct, cl, col, bv, Meff, [&](int it, int& rl, int& row) { row_of(it + 4, rl, row); }, cs); }
+            else if (VEC && !CSUM && g.side_drain && g.epi_kind == 2) { drain_side<2, false, 4, BN>(g, ct, cl, col, bv, Meff, [&](int it, int& rl, int& row) { row_of(it, rl, row); }, cs); drain_side<2, false, 4, BN>(g, ct, cl, col, bv, Meff, [&](int it, int& rl, int& row) { row_of(it + 4, rl, row); }, cs); }
+            else {
 #pragma unroll 1
             for (int it = 0; it < 8; ++it) {
                 const int rl = (tid >> 5) + (it << 3);                       // 0..63
@@ -699,6 +755,7 @@ __global__ __launch_bounds__(256, OCC) void gemm_glds_kernel(const GemmArgs g) {
                     if (CSUM) epi_any_cs<VEC>(g, a4, bv, ws, row, col, nv, cs);
                     else epi_any<VEC>(g, a4, bv, ws, row, col, nv);
                 }
+            }
             }
         }
     }
@@ -855,6 +912,15 @@ __global__ __launch_bounds__(256, 2) void gemm_pipe_kernel(const GemmArgs g) {
     if (g.bias && !ws) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) if (e < nv) bv[e] = g.bias[col + e];
+    }
+    if (VEC && g.side_drain && (g.epi_kind == 2 || g.epi_kind == 4)) {
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh) {
+            auto row_of = [&](int it, int& rl, int& row) { rl = (tid >> 5) + ((it + 8 * hh) << 3); row = m0 + rl; };
+            if (g.epi_kind == 2) { drain_side<2, false, 4, BN>(g, ct, cl, col, bv, Meff, [&](int it, int& rl, int& row) { row_of(it, rl, row); }, nullptr); drain_side<2, false, 4, BN>(g, ct, cl, col, bv, Meff, [&](int it, int& rl, int& row) { row_of(it + 4, rl, row); }, nullptr); }
+            else { drain_side<4, false, 4, BN>(g, ct, cl, col, bv, Meff, [&](int it, int& rl, int& row) { row_of(it, rl, row); }, nullptr); drain_side<4, false, 4, BN>(g, ct, cl, col, bv, Meff, [&](int it, int& rl, int& row) { row_of(it + 4, rl, row); }, nullptr); }
+        }
+        return;
     }
 #pragma unroll 1
     for (int it = 0; it < 16; ++it) {
@@ -1160,6 +1226,10 @@ __global__ __launch_bounds__(768) void gemm_ws256_kernel(const GemmArgs g) {
         }
         __syncthreads();
         if (col < g.N) {
+            auto row_of = [&](int it, int& rl, int& row) { rl = (tid >> 5) + (it << 4); row = m0 + h * 128 + rl; };
+            if (VEC && g.side_drain && g.epi_kind == 2) { drain_side<2, false, 4, BN>(g, ct, cl, col, bv, Meff, [&](int it, int& rl, int& row) { row_of(it, rl, row); }, nullptr); drain_side<2, false, 4, BN>(g, ct, cl, col, bv, Meff, [&](int it, int& rl, int& row) { row_of(it + 4, rl, row); }, nullptr); }
+            else if (VEC && g.side_drain && g.epi_kind == 4) { drain_side<4, false, 4, BN>(g, ct, cl, col, bv, Meff, [&](int it, int& rl, int& row) { row_of(it, rl, row); }, nullptr); drain_side<4, false, 4, BN>(g, ct, cl, col, bv, Meff, [&](int it, int& rl, int& row) { row_of(it + 4, rl, row); }, nullptr); }
+            else {
 #pragma unroll 1
             for (int it = 0; it < 8; ++it) {
                 const int rl = (tid >> 5) + (it << 4);
@@ -1168,6 +1238,7 @@ __global__ __launch_bounds__(768) void gemm_ws256_kernel(const GemmArgs g) {
                     const float4 a4 = *reinterpret_cast<const float4*>(ct + rl * BN + cl);
                     epi_any<VEC>(g, a4, bv, ws, row, col, nv);
                 }
+            }
             }
         }
     }
@@ -1414,6 +1485,10 @@ __global__ __launch_bounds__(256, 2) void gemm_g256_kernel(const GemmArgs g) {
         }
         __syncthreads();
         if (col < g.N) {
+            auto row_of = [&](int it, int& rl, int& row) { rl = (tid >> 5) + (it << 3); row = m0 + ps * 64 + rl; };
+            if (VEC && g.side_drain && g.epi_kind == 2) { drain_side<2, false, 4, BN>(g, ct, cl, col, bv, Meff, [&](int it, int& rl, int& row) { row_of(it, rl, row); }, nullptr); drain_side<2, false, 4, BN>(g, ct, cl, col, bv, Meff, [&](int it, int& rl, int& row) { row_of(it + 4, rl, row); }, nullptr); }
+            else if (VEC && g.side_drain && g.epi_kind == 4) { drain_side<4, false, 4, BN>(g, ct, cl, col, bv, Meff, [&](int it, int& rl, int& row) { row_of(it, rl, row); }, nullptr); drain_side<4, false, 4, BN>(g, ct, cl, col, bv, Meff, [&](int it, int& rl, int& row) { row_of(it + 4, rl, row); }, nullptr); }
+            else {
 #pragma unroll 1
             for (int it = 0; it < 8; ++it) {
                 const int rl = (tid >> 5) + (it << 3);                  // 0..63
@@ -1422,6 +1497,7 @@ __global__ __launch_bounds__(256, 2) void gemm_g256_kernel(const GemmArgs g) {
                     const float4 a4 = *reinterpret_cast<const float4*>(ct + rl * BN + cl);
                     epi_any<VEC>(g, a4, bv, ws, row, col, nv);
                 }
+            }
             }
         }
     }
@@ -1583,6 +1659,7 @@ extern "C" int mrg_gemm(const mrg_gemm_desc* d, hipStream_t stream) {
     { static const int abl = [] { const char* e = getenv("MRG_GEMM_ABLATE"); return e ? atoi(e) : 0; }(); g.ablate = abl; }
     { static const int nt = [] { const char* e = getenv("MRG_GEMM_NT"); return e ? atoi(e) : 2; }(); g.nt = nt; }
     { static const int xs = [] { const char* e = getenv("MRG_GEMM_XCD_SPLIT"); return e ? atoi(e) : 1; }(); g.xcd_split = xs; }
+    { static const int sd = [] { const char* e = getenv("MRG_GEMM_SIDE_DRAIN"); return e ? atoi(e) : 1; }(); g.side_drain = sd; }
     static const int kfast = [] { const char* e = getenv("MRG_GEMM_KFAST"); return e ? atoi(e) : 1; }();
     const bool kf = kfast && (d->K % BK == 0) && !d->k_dev && !d->a_map;      // scalar-base loaders
     {   // lean epilogue selection (uniform over the launch)
