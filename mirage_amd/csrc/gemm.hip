@@ -135,6 +135,11 @@ __device__ __forceinline__ bf16x8 read_frag(const char* lds, uint32_t lds_base, 
     }
 }
 
+// two batches of four row segments (see drain_side); row_of, ct, cl, col, bv, Meff are the caller's
+#define MRG_DRAIN8(KIND_, CS_, CSP_) do { \
+        drain_side<KIND_, CS_, 4, BN>(g, ct, cl, col, bv, Meff, [&](int it, int& rl, int& row) { row_of(it, rl, row); }, CSP_); \
+        drain_side<KIND_, CS_, 4, BN>(g, ct, cl, col, bv, Meff, [&](int it, int& rl, int& row) { row_of(it + 4, rl, row); }, CSP_); } while (0)
+
 // a / b for 0 <= a < 2^22, b > 0 without the ~40-instruction integer division (v_rcp_f32 is within 1 ulp, so the quotient is
 // off by at most one before the fix-up); the tile-coordinate prologue has four of them per workgroup
 __device__ __forceinline__ int fast_udiv(int a, int b) {
@@ -403,7 +408,7 @@ __device__ __forceinline__ void drain_side(const GemmArgs& g, const float* ct, i
         if (KIND == 2) {
             t[it] = *reinterpret_cast<const float4*>(g.resid + rr * g.ldr + col);
             rs[it] = g.row_scale ? g.row_scale[rr] : 1.f;
-        } else {
+        } else if (KIND == 4) {
             x[it] = *reinterpret_cast<const h4*>(reinterpret_cast<const _Float16*>(g.aux_in) + rr * g.ldaux + col);
         }
     }
@@ -411,6 +416,9 @@ __device__ __forceinline__ void drain_side(const GemmArgs& g, const float* ct, i
     for (int it = 0; it < NIT; ++it) {
         const int row = rows[it];
         if (row < Meff) {
+            if (KIND == 1) { epi_row_bf16<true, CS>(g, a[it], bv, row, col, 4, cs); continue; }
+            if (KIND == 3) { epi_row_gelu_save<true>(g, a[it], bv, row, col, 4); continue; }
+            if (KIND == 5) { epi_row_gelu<true>(g, a[it], bv, row, col, 4); continue; }
             float v[4] = {a[it].x + bv[0], a[it].y + bv[1], a[it].z + bv[2], a[it].w + bv[3]};
             if (KIND == 2) {
                 if (g.row_scale) {
@@ -743,8 +751,11 @@ __global__ __launch_bounds__(256, OCC) void gemm_glds_kernel(const GemmArgs g) {
         __syncthreads();
         if (col < g.N) {
             auto row_of = [&](int it, int& rl, int& row) { rl = (tid >> 5) + (it << 3); row = m0 + (rl >> 5) * 64 + pss * 32 + (rl & 31); };
-            if (VEC && g.side_drain && g.epi_kind == 4) { drain_side<4, CSUM, 4, BN>(g, ct, cl, col, bv, Meff, [&](int it, int& rl, int& row) { row_of(it, rl, row); }, cs); drain_side<4, CSUM, 4, BN>(g, ct, cl, col, bv, Meff, [&](int it, int& rl, int& row) { row_of(it + 4, rl, row); }, cs); }
-            else if (VEC && !CSUM && g.side_drain && g.epi_kind == 2) { drain_side<2, false, 4, BN>(g, ct, cl, col, bv, Meff, [&](int it, int& rl, int& row) { row_of(it, rl, row); }, cs); drain_side<2, false, 4, BN>(g, ct, cl, col, bv, Meff, [&](int it, int& rl, int& row) { row_of(it + 4, rl, row); }, cs); }
+            if (VEC && g.side_drain && g.epi_kind == 4) MRG_DRAIN8(4, CSUM, cs);
+            else if (VEC && !CSUM && g.side_drain && g.epi_kind == 2) MRG_DRAIN8(2, false, cs);
+            else if (VEC && g.side_drain && g.epi_kind == 1) MRG_DRAIN8(1, CSUM, cs);
+            else if (VEC && !CSUM && g.side_drain && g.epi_kind == 3) MRG_DRAIN8(3, false, cs);
+            else if (VEC && !CSUM && g.side_drain && g.epi_kind == 5) MRG_DRAIN8(5, false, cs);
             else {
 #pragma unroll 1
             for (int it = 0; it < 8; ++it) {
@@ -913,12 +924,15 @@ __global__ __launch_bounds__(256, 2) void gemm_pipe_kernel(const GemmArgs g) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) if (e < nv) bv[e] = g.bias[col + e];
     }
-    if (VEC && g.side_drain && (g.epi_kind == 2 || g.epi_kind == 4)) {
+    if (VEC && g.side_drain && g.epi_kind >= 1 && g.epi_kind <= 5) {
 #pragma unroll
         for (int hh = 0; hh < 2; ++hh) {
             auto row_of = [&](int it, int& rl, int& row) { rl = (tid >> 5) + ((it + 8 * hh) << 3); row = m0 + rl; };
-            if (g.epi_kind == 2) { drain_side<2, false, 4, BN>(g, ct, cl, col, bv, Meff, [&](int it, int& rl, int& row) { row_of(it, rl, row); }, nullptr); drain_side<2, false, 4, BN>(g, ct, cl, col, bv, Meff, [&](int it, int& rl, int& row) { row_of(it + 4, rl, row); }, nullptr); }
-            else { drain_side<4, false, 4, BN>(g, ct, cl, col, bv, Meff, [&](int it, int& rl, int& row) { row_of(it, rl, row); }, nullptr); drain_side<4, false, 4, BN>(g, ct, cl, col, bv, Meff, [&](int it, int& rl, int& row) { row_of(it + 4, rl, row); }, nullptr); }
+            if (g.epi_kind == 2) MRG_DRAIN8(2, false, nullptr);
+            else if (g.epi_kind == 4) MRG_DRAIN8(4, false, nullptr);
+            else if (g.epi_kind == 1) MRG_DRAIN8(1, false, nullptr);
+            else if (g.epi_kind == 3) MRG_DRAIN8(3, false, nullptr);
+            else MRG_DRAIN8(5, false, nullptr);
         }
         return;
     }
@@ -1227,8 +1241,11 @@ __global__ __launch_bounds__(768) void gemm_ws256_kernel(const GemmArgs g) {
         __syncthreads();
         if (col < g.N) {
             auto row_of = [&](int it, int& rl, int& row) { rl = (tid >> 5) + (it << 4); row = m0 + h * 128 + rl; };
-            if (VEC && g.side_drain && g.epi_kind == 2) { drain_side<2, false, 4, BN>(g, ct, cl, col, bv, Meff, [&](int it, int& rl, int& row) { row_of(it, rl, row); }, nullptr); drain_side<2, false, 4, BN>(g, ct, cl, col, bv, Meff, [&](int it, int& rl, int& row) { row_of(it + 4, rl, row); }, nullptr); }
-            else if (VEC && g.side_drain && g.epi_kind == 4) { drain_side<4, false, 4, BN>(g, ct, cl, col, bv, Meff, [&](int it, int& rl, int& row) { row_of(it, rl, row); }, nullptr); drain_side<4, false, 4, BN>(g, ct, cl, col, bv, Meff, [&](int it, int& rl, int& row) { row_of(it + 4, rl, row); }, nullptr); }
+            if (VEC && g.side_drain && g.epi_kind == 2) MRG_DRAIN8(2, false, nullptr);
+            else if (VEC && g.side_drain && g.epi_kind == 4) MRG_DRAIN8(4, false, nullptr);
+            else if (VEC && g.side_drain && g.epi_kind == 1) MRG_DRAIN8(1, false, nullptr);
+            else if (VEC && g.side_drain && g.epi_kind == 3) MRG_DRAIN8(3, false, nullptr);
+            else if (VEC && g.side_drain && g.epi_kind == 5) MRG_DRAIN8(5, false, nullptr);
             else {
 #pragma unroll 1
             for (int it = 0; it < 8; ++it) {
@@ -1486,8 +1503,11 @@ __global__ __launch_bounds__(256, 2) void gemm_g256_kernel(const GemmArgs g) {
         __syncthreads();
         if (col < g.N) {
             auto row_of = [&](int it, int& rl, int& row) { rl = (tid >> 5) + (it << 3); row = m0 + ps * 64 + rl; };
-            if (VEC && g.side_drain && g.epi_kind == 2) { drain_side<2, false, 4, BN>(g, ct, cl, col, bv, Meff, [&](int it, int& rl, int& row) { row_of(it, rl, row); }, nullptr); drain_side<2, false, 4, BN>(g, ct, cl, col, bv, Meff, [&](int it, int& rl, int& row) { row_of(it + 4, rl, row); }, nullptr); }
-            else if (VEC && g.side_drain && g.epi_kind == 4) { drain_side<4, false, 4, BN>(g, ct, cl, col, bv, Meff, [&](int it, int& rl, int& row) { row_of(it, rl, row); }, nullptr); drain_side<4, false, 4, BN>(g, ct, cl, col, bv, Meff, [&](int it, int& rl, int& row) { row_of(it + 4, rl, row); }, nullptr); }
+            if (VEC && g.side_drain && g.epi_kind == 2) MRG_DRAIN8(2, false, nullptr);
+            else if (VEC && g.side_drain && g.epi_kind == 4) MRG_DRAIN8(4, false, nullptr);
+            else if (VEC && g.side_drain && g.epi_kind == 1) MRG_DRAIN8(1, false, nullptr);
+            else if (VEC && g.side_drain && g.epi_kind == 3) MRG_DRAIN8(3, false, nullptr);
+            else if (VEC && g.side_drain && g.epi_kind == 5) MRG_DRAIN8(5, false, nullptr);
             else {
 #pragma unroll 1
             for (int it = 0; it < 8; ++it) {
