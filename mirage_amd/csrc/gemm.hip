@@ -45,7 +45,7 @@ struct GemmArgs {
     int epi_kind;  // 0 generic epilogue; lean paths: 1 (+bias) -> bf16 C; 2 (+bias)(*row_scale) + fp32 residual -> fp32 C (+ bf16 twin);
                    // 3 bias + GELU with fp16 GELU' side output; 4 multiply by the fp16 side input -> bf16 C (1 and 4 also with column sums);
                    // 5 bias + GELU -> bf16 C; 6 bias + table row -> fp32 C at a mapped row (patch embedding)
-    int side_drain; // MRG_GEMM_SIDE_DRAIN (default 1): two-phase drain for the epilogues with a per-output side operand
+    int side_drain; // MRG_GEMM_SIDE_DRAIN (bit 0: batched drain of the lean epilogues, bit 1: of the split-K slab stores; default 3)
     int xcd_split; // MRG_GEMM_XCD_SPLIT (default 1): split-K index slowest in the XCD band order
     int nt;       // MRG_GEMM_NT: 0 plain stores, 1 streaming (nontemporal) stores for C / C2 / aux_out, 2 (default) for aux_out only
     int ablate;   // MRG_GEMM_ABLATE (256x128 kernel only, for roofline analysis): 1 = no DMA, 2 = DMA only, 3 = DMA + LDS reads, no MFMA
@@ -416,6 +416,7 @@ __device__ __forceinline__ void drain_side(const GemmArgs& g, const float* ct, i
     for (int it = 0; it < NIT; ++it) {
         const int row = rows[it];
         if (row < Meff) {
+            if (KIND == 7) { *reinterpret_cast<float4*>(cs + (long)row * g.N + col) = a[it]; continue; }      // split-K slab (cs = slab base)
             if (KIND == 1) { epi_row_bf16<true, CS>(g, a[it], bv, row, col, 4, cs); continue; }
             if (KIND == 3) { epi_row_gelu_save<true>(g, a[it], bv, row, col, 4); continue; }
             if (KIND == 5) { epi_row_gelu<true>(g, a[it], bv, row, col, 4); continue; }
@@ -751,11 +752,12 @@ __global__ __launch_bounds__(256, OCC) void gemm_glds_kernel(const GemmArgs g) {
         __syncthreads();
         if (col < g.N) {
             auto row_of = [&](int it, int& rl, int& row) { rl = (tid >> 5) + (it << 3); row = m0 + (rl >> 5) * 64 + pss * 32 + (rl & 31); };
-            if (VEC && g.side_drain && g.epi_kind == 4) MRG_DRAIN8(4, CSUM, cs);
-            else if (VEC && !CSUM && g.side_drain && g.epi_kind == 2) MRG_DRAIN8(2, false, cs);
-            else if (VEC && g.side_drain && g.epi_kind == 1) MRG_DRAIN8(1, CSUM, cs);
-            else if (VEC && !CSUM && g.side_drain && g.epi_kind == 3) MRG_DRAIN8(3, false, cs);
-            else if (VEC && !CSUM && g.side_drain && g.epi_kind == 5) MRG_DRAIN8(5, false, cs);
+            if (VEC && !CSUM && (g.side_drain & 2) && ws) MRG_DRAIN8(7, false, ws);
+            else if (VEC && (g.side_drain & 1) && g.epi_kind == 4) MRG_DRAIN8(4, CSUM, cs);
+            else if (VEC && !CSUM && (g.side_drain & 1) && g.epi_kind == 2) MRG_DRAIN8(2, false, cs);
+            else if (VEC && (g.side_drain & 1) && g.epi_kind == 1) MRG_DRAIN8(1, CSUM, cs);
+            else if (VEC && !CSUM && (g.side_drain & 1) && g.epi_kind == 3) MRG_DRAIN8(3, false, cs);
+            else if (VEC && !CSUM && (g.side_drain & 1) && g.epi_kind == 5) MRG_DRAIN8(5, false, cs);
             else {
 #pragma unroll 1
             for (int it = 0; it < 8; ++it) {
@@ -924,11 +926,12 @@ __global__ __launch_bounds__(256, 2) void gemm_pipe_kernel(const GemmArgs g) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) if (e < nv) bv[e] = g.bias[col + e];
     }
-    if (VEC && g.side_drain && g.epi_kind >= 1 && g.epi_kind <= 5) {
+    if (VEC && ((ws && (g.side_drain & 2)) || (!ws && (g.side_drain & 1) && g.epi_kind >= 1 && g.epi_kind <= 5))) {
 #pragma unroll
         for (int hh = 0; hh < 2; ++hh) {
             auto row_of = [&](int it, int& rl, int& row) { rl = (tid >> 5) + ((it + 8 * hh) << 3); row = m0 + rl; };
-            if (g.epi_kind == 2) MRG_DRAIN8(2, false, nullptr);
+            if (ws) MRG_DRAIN8(7, false, ws);
+            else if (g.epi_kind == 2) MRG_DRAIN8(2, false, nullptr);
             else if (g.epi_kind == 4) MRG_DRAIN8(4, false, nullptr);
             else if (g.epi_kind == 1) MRG_DRAIN8(1, false, nullptr);
             else if (g.epi_kind == 3) MRG_DRAIN8(3, false, nullptr);
@@ -1241,11 +1244,12 @@ __global__ __launch_bounds__(768) void gemm_ws256_kernel(const GemmArgs g) {
         __syncthreads();
         if (col < g.N) {
             auto row_of = [&](int it, int& rl, int& row) { rl = (tid >> 5) + (it << 4); row = m0 + h * 128 + rl; };
-            if (VEC && g.side_drain && g.epi_kind == 2) MRG_DRAIN8(2, false, nullptr);
-            else if (VEC && g.side_drain && g.epi_kind == 4) MRG_DRAIN8(4, false, nullptr);
-            else if (VEC && g.side_drain && g.epi_kind == 1) MRG_DRAIN8(1, false, nullptr);
-            else if (VEC && g.side_drain && g.epi_kind == 3) MRG_DRAIN8(3, false, nullptr);
-            else if (VEC && g.side_drain && g.epi_kind == 5) MRG_DRAIN8(5, false, nullptr);
+            if (VEC && (g.side_drain & 2) && ws) MRG_DRAIN8(7, false, ws);
+            else if (VEC && (g.side_drain & 1) && g.epi_kind == 2) MRG_DRAIN8(2, false, nullptr);
+            else if (VEC && (g.side_drain & 1) && g.epi_kind == 4) MRG_DRAIN8(4, false, nullptr);
+            else if (VEC && (g.side_drain & 1) && g.epi_kind == 1) MRG_DRAIN8(1, false, nullptr);
+            else if (VEC && (g.side_drain & 1) && g.epi_kind == 3) MRG_DRAIN8(3, false, nullptr);
+            else if (VEC && (g.side_drain & 1) && g.epi_kind == 5) MRG_DRAIN8(5, false, nullptr);
             else {
 #pragma unroll 1
             for (int it = 0; it < 8; ++it) {
@@ -1503,11 +1507,12 @@ __global__ __launch_bounds__(256, 2) void gemm_g256_kernel(const GemmArgs g) {
         __syncthreads();
         if (col < g.N) {
             auto row_of = [&](int it, int& rl, int& row) { rl = (tid >> 5) + (it << 3); row = m0 + ps * 64 + rl; };
-            if (VEC && g.side_drain && g.epi_kind == 2) MRG_DRAIN8(2, false, nullptr);
-            else if (VEC && g.side_drain && g.epi_kind == 4) MRG_DRAIN8(4, false, nullptr);
-            else if (VEC && g.side_drain && g.epi_kind == 1) MRG_DRAIN8(1, false, nullptr);
-            else if (VEC && g.side_drain && g.epi_kind == 3) MRG_DRAIN8(3, false, nullptr);
-            else if (VEC && g.side_drain && g.epi_kind == 5) MRG_DRAIN8(5, false, nullptr);
+            if (VEC && (g.side_drain & 2) && ws) MRG_DRAIN8(7, false, ws);
+            else if (VEC && (g.side_drain & 1) && g.epi_kind == 2) MRG_DRAIN8(2, false, nullptr);
+            else if (VEC && (g.side_drain & 1) && g.epi_kind == 4) MRG_DRAIN8(4, false, nullptr);
+            else if (VEC && (g.side_drain & 1) && g.epi_kind == 1) MRG_DRAIN8(1, false, nullptr);
+            else if (VEC && (g.side_drain & 1) && g.epi_kind == 3) MRG_DRAIN8(3, false, nullptr);
+            else if (VEC && (g.side_drain & 1) && g.epi_kind == 5) MRG_DRAIN8(5, false, nullptr);
             else {
 #pragma unroll 1
             for (int it = 0; it < 8; ++it) {
@@ -1679,7 +1684,7 @@ extern "C" int mrg_gemm(const mrg_gemm_desc* d, hipStream_t stream) {
     { static const int abl = [] { const char* e = getenv("MRG_GEMM_ABLATE"); return e ? atoi(e) : 0; }(); g.ablate = abl; }
     { static const int nt = [] { const char* e = getenv("MRG_GEMM_NT"); return e ? atoi(e) : 2; }(); g.nt = nt; }
     { static const int xs = [] { const char* e = getenv("MRG_GEMM_XCD_SPLIT"); return e ? atoi(e) : 1; }(); g.xcd_split = xs; }
-    { static const int sd = [] { const char* e = getenv("MRG_GEMM_SIDE_DRAIN"); return e ? atoi(e) : 1; }(); g.side_drain = sd; }
+    { static const int sd = [] { const char* e = getenv("MRG_GEMM_SIDE_DRAIN"); return e ? atoi(e) : 3; }(); g.side_drain = sd; }
     static const int kfast = [] { const char* e = getenv("MRG_GEMM_KFAST"); return e ? atoi(e) : 1; }();
     const bool kf = kfast && (d->K % BK == 0) && !d->k_dev && !d->a_map;      // scalar-base loaders
     {   // lean epilogue selection (uniform over the launch)
