@@ -137,8 +137,17 @@ __global__ __launch_bounds__(1024) void dec_assemble_fin_kernel(const FinArgs f)
     for (int d = 0; d <= MAXDOM; ++d) if (d == q) o = f.out[d];
     if (!o) return;
     float s = 0.f;
-    if (c < f.Dd)
-        for (int b = wave; b < f.nblocks; b += 16) s += f.partials[((long)b * (MAXDOM + 1) + q) * f.Dd + c];
+    if (c < f.Dd) {
+        const float* p = f.partials + (long)q * f.Dd + c;
+        const long st = (long)(MAXDOM + 1) * f.Dd;
+        int b = wave;
+        float s1 = 0.f, s2 = 0.f, s3 = 0.f;
+        for (; b + 48 < f.nblocks; b += 64) {      // four independent loads in flight per lane (the rows are one round trip each)
+            s += p[b * st]; s1 += p[(b + 16) * st]; s2 += p[(b + 32) * st]; s3 += p[(b + 48) * st];
+        }
+        for (; b < f.nblocks; b += 16) s += p[b * st];
+        s += (s1 + s2) + s3;
+    }
     red[wave][lane] = s;
     __syncthreads();
     if (wave == 0 && c < f.Dd) {
@@ -180,7 +189,7 @@ extern "C" int mrg_dec_assemble_fwd(const mrg_dec_assemble_desc* d, hipStream_t 
 extern "C" int mrg_dec_assemble_bwd_nblocks(int B, int N, int Tq) {
     long rows = (long)B * (N > Tq ? N : Tq);
     int nb = (int)((rows + 15) / 16);
-    if (nb > 256) nb = 256;
+    if (nb > 1024) nb = 1024;      // each block walks its rows one dependent round trip at a time: 4 x more blocks, 4 x shorter chains
     if (nb < 1) nb = 1;
     return nb;
 }
