@@ -102,13 +102,14 @@ def cpu_baseline(model_name, doms, K, train, budget_s=25.0):
                 O.forward(cfg, sd, {d: x[d] for d in doms}, ids_keep, ids_restore, decode=False)
         dt = time.perf_counter() - t0
         it += 1
-        if it > 1:
+        if it > 2:                                    # 2 warm-up iterations
             times.append(dt)
         if len(times) >= 3 or (time.perf_counter() - t_start > budget_s and len(times) >= 1):
             break
     best = min(times)
-    return {"value": round(B / best, 3), "unit": "images/sec", "cores": n_threads, "kind": "port",
-            "sample": f"CPU oracle fp32, B={B}, {'fwd+loss+bwd' if train else 'fwd'}, 1 warm-up + {len(times)} timed iterations (best)"}
+    return {"value": round(B / best, 3), "unit": "images/sec", "cores": n_threads, "host_cores": os.cpu_count(), "kind": "port",
+            "sample": f"CPU oracle fp32, B={B}, {'fwd+loss+bwd' if train else 'fwd'}, 2 warm-up + {len(times)} timed iterations (best), "
+                      f"{n_threads} threads of {os.cpu_count()} host cores"}
 
 
 def main():
@@ -130,6 +131,38 @@ def main():
         os.close(real_stdout)
 
 
+def _self_launch(n: int, real_stdout: int) -> int:
+    """Start n ranks of this script (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in their environment), wait for all of them and
+    relay rank 0's JSON line.  Runs before anything in this process touches the GPU; the children are fresh processes."""
+    import socket
+    import subprocess
+    if os.environ.get("MRG_SHARE_GPU") != "1" and torch.cuda.device_count() < n:
+        print(f"bench.py: --gpus {n} but only {torch.cuda.device_count()} GPUs are visible", file=sys.stderr)
+        return 2
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out0 = procs[0].stdout.read().decode()
+    rcs = [p.wait() for p in procs]
+    bad = [(r, rc) for r, rc in enumerate(rcs) if rc != 0]
+    if bad:
+        print(f"bench.py: ranks failed (rank, exit code): {bad}", file=sys.stderr)
+        return 1
+    lines = [l for l in out0.splitlines() if l.startswith("{")]
+    if len(lines) != 1:
+        print(f"bench.py: rank 0 printed {len(lines)} JSON lines", file=sys.stderr)
+        return 1
+    _emit(real_stdout, lines[0])
+    return 0
+
+
 def _emit(real_stdout: int, line: str):
     sys.stdout.flush()
     try:
@@ -141,6 +174,20 @@ def _emit(real_stdout: int, line: str):
 
 
 def _run(real_stdout: int):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--config", default="c2", choices=sorted(CONFIGS))
+    ap.add_argument("--batch", type=int, default=None, help="per-GPU batch override (debug)")
+    ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    a = ap.parse_args()
+
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` without a launcher: this process has not touched the GPU yet, so it only spawns the N ranks
+        # (fresh child processes, one per GPU) and relays rank 0's JSON line
+        sys.exit(_self_launch(a.gpus, real_stdout))
     if os.environ.get("MRG_LANES") == "0" or os.environ.get("MRG_SIDE") == "0":     # experiment knobs: stream structure
         from mirage_amd import engine as _E2
         if os.environ.get("MRG_LANES") == "0":
@@ -158,22 +205,17 @@ def _run(real_stdout: int):
     if os.environ.get("MRG_SIDE_BLOCKS"):          # experiment knob: transformer blocks per side-stream fork
         from mirage_amd import engine as _E
         _E._Side.blocks_per_flush = int(os.environ["MRG_SIDE_BLOCKS"])
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--config", default="c2", choices=sorted(CONFIGS))
-    ap.add_argument("--batch", type=int, default=None, help="per-GPU batch override (debug)")
-    ap.add_argument("--no-graph", action="store_true")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    a = ap.parse_args()
-
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    assert world == a.gpus or world == 1, f"--gpus {a.gpus} but WORLD_SIZE={world}"
-    if os.environ.get("MRG_SHARE_GPU") == "1":          # test hook: several ranks on one GPU (use with MRG_DIST_BACKEND=gloo)
+    if world != a.gpus:
+        raise SystemExit(f"bench.py: --gpus {a.gpus} but WORLD_SIZE={world}: launch one rank per GPU "
+                         f"(torch.distributed.run --nproc-per-node {a.gpus}) or drop WORLD_SIZE and let bench.py spawn them")
+    share = os.environ.get("MRG_SHARE_GPU") == "1"      # test hook: several ranks on one GPU (use with MRG_DIST_BACKEND=gloo)
+    if share:
         local_rank = 0
+    elif torch.cuda.device_count() <= local_rank:        # device_count() does not initialise the GPU
+        raise SystemExit(f"bench.py: rank {rank} needs GPU {local_rank} but only {torch.cuda.device_count()} are visible")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     force_dp = os.environ.get("MRG_FORCE_DP") == "1"      # single-GPU smoke test of the multi-rank code path (world size 1)
@@ -182,11 +224,17 @@ def _run(real_stdout: int):
         os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
     if world > 1 or force_dp:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        import datetime
         backend = os.environ.get("MRG_DIST_BACKEND", "nccl")
+        # a rank that never joins makes the rendezvous fail after the timeout instead of producing a number for fewer GPUs
+        tmo = datetime.timedelta(seconds=int(os.environ.get("MRG_DIST_TIMEOUT", "600")))
         if backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev)
+            dist.init_process_group("nccl", device_id=dev, timeout=tmo)
         else:
-            dist.init_process_group(backend)
+            dist.init_process_group(backend, timeout=tmo)
+        if dist.get_world_size() != a.gpus and not force_dp:
+            raise SystemExit(f"bench.py: {dist.get_world_size()} ranks joined, --gpus {a.gpus} asked for")
+    ranks_seen = dist.get_world_size() if dist.is_initialized() else 1
 
     from mirage_amd import builder, kernels as K, optim
     from mirage_amd import _lib as L
@@ -200,6 +248,10 @@ def _run(real_stdout: int):
     torch.manual_seed(0)
     model = builder.get_model(args, model_name, with_decoders=train).to(dev)
     model.train(train)
+    # weights come from the common seed above (and are broadcast from rank 0); mask / stochastic-depth draws use a per-rank stream
+    # ("own mask RNG stream (seed+rank)")
+    torch.manual_seed(4321 + rank)
+    torch.cuda.manual_seed(4321 + rank)
     pool = synth_batches(doms, B, 4, 1234 + rank, dev)
 
     if train:
@@ -281,7 +333,17 @@ def _run(real_stdout: int):
         _E._Side.enabled = False
         try:
             if train:
-                ts._eager()
+                # forward + losses + backward only, with the reducer detached: rank 0 runs this step alone, so nothing in it
+                # may be collective (the other ranks are already waiting at the final barrier); the optimizer is skipped because
+                # the gradients of a detached step are this rank's only
+                keep = (ts.reducer, ts.split, ts._early, getattr(model, "_mrg_split_at", None))
+                ts.reducer, ts.split, ts._early = None, None, None
+                model._mrg_split_at = None
+                try:
+                    ts._fwd_bwd()
+                    _E.join_side_stream()
+                finally:
+                    ts.reducer, ts.split, ts._early, model._mrg_split_at = keep
             else:
                 fwd()
         finally:
@@ -308,22 +370,27 @@ def _run(real_stdout: int):
         dom = max(groups, key=lambda m: groups[m][1])
         fl, tsec, n, modes = groups[dom]
         all_fl = sum(g[0] for g in groups.values()); all_t = sum(g[1] for g in groups.values())
-        traffic = None
-        tfile = os.path.join(ROOT, "profiles", "r01_c2_pmc_traffic.json")
-        if a.config == "c2" and os.path.exists(tfile):
-            tj = json.load(open(tfile))
-            cand = [v for k, v in tj.items() if k.startswith(dom.split("<")[0])]
-            if cand:
-                traffic = int(sum(v["hbm_bytes_per_launch"] * v["launches"] for v in cand) / max(1, sum(v["launches"] for v in cand)))
+        # HBM bytes per launch of the dominant kernel come from a separate rocprofv3 --pmc pass (counters cannot be read from
+        # inside the process): the committed summary of that pass is quoted and its file named in `traffic_source`
+        traffic, traffic_src = None, None
+        for tname in ("r02_c2_pmc_traffic.json", "r01_c2_pmc_traffic.json"):
+            tfile = os.path.join(ROOT, "profiles", tname)
+            if a.config == "c2" and os.path.exists(tfile):
+                tj = json.load(open(tfile))
+                cand = [v for k, v in tj.items() if k.startswith(dom.split("<")[0])]
+                if cand:
+                    traffic = int(sum(v["hbm_bytes_per_launch"] * v["launches"] for v in cand) / max(1, sum(v["launches"] for v in cand)))
+                    traffic_src = "profiles/" + tname
+                    break
         roofline = {"bound": "mfma", "kernel": dom, "achieved": round(fl / tsec / 1e12, 2), "peak": MFMA_BF16_PEAK / 1e12,
-                    "unit": "TFLOP/s", "frac": round(fl / tsec / MFMA_BF16_PEAK, 4), "traffic": traffic,
+                    "unit": "TFLOP/s", "frac": round(fl / tsec / MFMA_BF16_PEAK, 4), "traffic": traffic, "traffic_source": traffic_src,
                     "launches_per_step": n, "avg_launch_us": round(1e6 * tsec / n, 2), "launch_mix": modes,
                     "all_gemm_achieved": round(all_fl / all_t / 1e12, 2),
                     "whole_step_achieved": round(value / world * fpi / 1e12, 2),
                     "whole_step_frac": round(value / world * fpi / MFMA_BF16_PEAK, 4)}
         result = {
             "metric": "pretrain images/sec (node) MIRAGE-Base 512/32 bscan+slo; MFMA % of peak" if a.config == "c2" else f"images/sec (node) {a.config}",
-            "value": round(value, 2), "unit": "images/sec", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "value": round(value, 2), "unit": "images/sec", "n_gpus": world, "ranks_seen": ranks_seen, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "bf16", "data": "synthetic",
             "config": {"workload": f"{a.config}: {model_name} 512/32 {'+'.join(doms)}, per-GPU batch {B}, {Kk} of {256 * len(doms)} tokens encoded, "

@@ -26,7 +26,7 @@ extern "C" {
 typedef struct ihipStream_t* hipStream_t;
 #endif
 
-#define MRG_ABI_VERSION 3   /* 2: mrg_gemm_desc grew row_scale / defer_reduce, act codes 3, 4, reduce_batch / augment / row_scale entry points; 3: colsum_out, attention colsum_* */
+#define MRG_ABI_VERSION 4   /* 2: mrg_gemm_desc grew row_scale / defer_reduce, act codes 3, 4, reduce_batch / augment / row_scale entry points; 3: colsum_out, attention colsum_*; 4: step = int[2], mrg_step_inc takes the skip decision */
 
 enum { MRG_DT_BF16 = 0, MRG_DT_F32 = 1 };
 enum { MRG_OP_KCONTIG = 0, MRG_OP_KSTRIDED = 1 };
@@ -220,8 +220,12 @@ int mrg_maskgen(const float* p, const float* u, const float* g, int B, int T, in
 /* ---------------------------------------------------------------------------------------------------
  * Step boundary on flat arenas: global grad L2 norm (mutils/native_scaler.py:46-61), AdamW with decoupled decay on
  * the first n_decay elements (mutils/optim_factory.py:33-92 groups; torch.optim.AdamW update), per-step lr / wd
- * read from device tables at index *step (run_pretraining.py:683-688), bf16 shadow weights refreshed in the same
- * pass.  clip_norm / skip_norm <= 0 disable clipping / skipping (native_scaler.py:19-32).
+ * read from device tables (run_pretraining.py:683-688), bf16 shadow weights refreshed in the same pass.
+ * step = int[2] on the device: step[0] = iteration counter (schedule index), step[1] = AdamW updates applied so far (torch's
+ * per-parameter state['step']: the bias-correction exponent is step[1] + 1).  clip_norm / skip_norm <= 0 disable clipping /
+ * skipping; as in native_scaler.py:19-34 clipping takes precedence (skip_norm is ignored beside it) and a skipped iteration
+ * (grad_norm >= skip_norm) changes neither weights nor moments.  mrg_step_inc ends the iteration: step[0] += 1 always,
+ * step[1] += 1 unless the iteration was skipped (same decision from the same grad_norm / clip_norm / skip_norm).
  */
 typedef struct mrg_adamw_desc {
     float* p; const float* g; float* m; float* v; void* shadow_bf16;
@@ -233,7 +237,7 @@ typedef struct mrg_adamw_desc {
 int mrg_sumsq_nblocks(long n);
 int mrg_grad_norm(const float* g, long n, float* partials, float* out, hipStream_t stream);
 int mrg_adamw(const mrg_adamw_desc* d, hipStream_t stream);
-int mrg_step_inc(int* step, hipStream_t stream);
+int mrg_step_inc(int* step, const float* grad_norm, float clip_norm, float skip_norm, hipStream_t stream);
 int mrg_cast_bf16(const float* src, void* dst_bf16, long n, hipStream_t stream);
 /* dst_bf16[r, :] = src[r, :] * row_scale[r] for an [M, D] fp32 matrix (D % 4 == 0): the gradient entering a stochastic-depth
  * branch (backward of drop_path, mirage/utils.py:103-118). */

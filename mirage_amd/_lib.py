@@ -92,7 +92,7 @@ SIGNATURES = {
     "mrg_sumsq_nblocks": (ci, [cl]),
     "mrg_grad_norm": (ci, [vp, cl, vp, vp, vp]),
     "mrg_adamw": (ci, [C.POINTER(AdamWDesc), vp]),
-    "mrg_step_inc": (ci, [vp, vp]),
+    "mrg_step_inc": (ci, [vp, vp, C.c_float, C.c_float, vp]),
     "mrg_cast_bf16": (ci, [vp, vp, cl, vp]),
     "mrg_row_scale_bf16": (ci, [vp, vp, vp, cl, ci, vp]),
     "mrg_ln_bwd_partial_rows": (ci, [ci, ci]),
@@ -113,7 +113,7 @@ for _name, (_res, _args) in SIGNATURES.items():
     _fn.argtypes = _args
 
 ABI_VERSION = lib.mrg_version()
-EXPECTED_ABI_VERSION = 3       # must match MRG_ABI_VERSION in include/mirage_hip.h: the ctypes structs above mirror that layout
+EXPECTED_ABI_VERSION = 4       # must match MRG_ABI_VERSION in include/mirage_hip.h: the ctypes structs above mirror that layout
 if ABI_VERSION != EXPECTED_ABI_VERSION:
     raise ImportError(f"{LIB_PATH} reports ABI version {ABI_VERSION}, the Python bindings expect {EXPECTED_ABI_VERSION}: rebuild it "
                       "(python -c 'import __graft_entry__ as g; g.build()')")

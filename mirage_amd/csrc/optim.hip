@@ -49,9 +49,11 @@ struct AdamArgs {
 __global__ __launch_bounds__(256) void adamw_kernel(const AdamArgs a) {
     __shared__ float hp[5];
     if (threadIdx.x == 0) {
-        int st = *a.step;
+        // step[0]: iteration counter = index into the lr / wd schedules (advances every iteration, run_pretraining.py:683-688);
+        // step[1]: updates applied so far = AdamW's per-parameter `step` (torch bias correction; does not advance on a skipped step)
+        const int st = a.step[0];
         const int ti = st < a.table_len ? st : a.table_len - 1;
-        const double t = (double)(st + 1);
+        const double t = (double)(a.step[1] + 1);
         hp[0] = a.lr_table[ti] * a.lr_scale;
         hp[1] = a.wd_table[ti];
         hp[2] = (float)(1.0 / (1.0 - pow((double)a.beta1, t)));
@@ -59,8 +61,8 @@ __global__ __launch_bounds__(256) void adamw_kernel(const AdamArgs a) {
         float gs = 1.f;
         if (a.grad_norm) {
             const float nrm = a.grad_norm[0];
-            if (a.clip_norm > 0.f) gs = fminf(1.f, a.clip_norm / (nrm + 1e-6f));   // torch clip_grad_norm_
-            if (a.skip_norm > 0.f && nrm >= a.skip_norm) gs = -1.f;               // native_scaler.py:24-29: skip the update
+            if (a.clip_norm > 0.f) gs = fminf(1.f, a.clip_norm / (nrm + 1e-6f));   // native_scaler.py:19-23: torch clip_grad_norm_
+            else if (a.skip_norm > 0.f && nrm >= a.skip_norm) gs = -1.f;          // :24-29 (`elif`: ignored beside clip_grad): no update
         }
         hp[4] = gs;
     }
@@ -92,7 +94,14 @@ __global__ __launch_bounds__(256) void adamw_kernel(const AdamArgs a) {
     }
 }
 
-__global__ void step_inc_kernel(int* step) { if (threadIdx.x == 0 && blockIdx.x == 0) step[0] += 1; }
+// end of an iteration: the schedule index always advances, the AdamW step count only when the update was applied
+__global__ void step_inc_kernel(int* step, const float* grad_norm, float clip_norm, float skip_norm) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        const bool skipped = grad_norm && !(clip_norm > 0.f) && skip_norm > 0.f && grad_norm[0] >= skip_norm;
+        step[0] += 1;
+        if (!skipped) step[1] += 1;
+    }
+}
 
 __global__ __launch_bounds__(256) void cast_bf16_kernel(const float* __restrict__ src, bf16_t* __restrict__ dst, long n) {
     const long n4 = n >> 2;
@@ -152,9 +161,9 @@ extern "C" int mrg_adamw(const mrg_adamw_desc* d, hipStream_t stream) {
     return mrg_check_launch("mrg_adamw");
 }
 
-extern "C" int mrg_step_inc(int* step, hipStream_t stream) {
+extern "C" int mrg_step_inc(int* step, const float* grad_norm, float clip_norm, float skip_norm, hipStream_t stream) {
     MRG_REQUIRE(step, MRG_ERR_ARG, "mrg_step_inc: null pointer");
-    hipLaunchKernelGGL(step_inc_kernel, dim3(1), dim3(64), 0, stream, step);
+    hipLaunchKernelGGL(step_inc_kernel, dim3(1), dim3(64), 0, stream, step, grad_norm, clip_norm, skip_norm);
     return mrg_check_launch("mrg_step_inc");
 }
 

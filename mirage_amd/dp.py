@@ -6,7 +6,17 @@ Buckets are contiguous slices of the arena (no packing copies); they are issued 
 of early buckets overlaps whatever still runs on the compute stream; the optimizer waits on the last bucket's event.
 xGMI is point-to-point (7 links per GPU), so buckets are large (default 64 MiB) -- per-call latency, not bandwidth,
 is what many small buckets would pay for.
+
+Exchange format (SURVEY.md section 5 / 8e leaves it open; no 8-GPU node was available to measure, so both knobs default to the
+conservative choice and can be A/B-ed on the first real node without code changes):
+  MRG_DP_COMM  = allreduce (default): one ncclAllReduce per bucket, RCCL picks ring / tree / direct itself;
+               = rs_ag: explicit reduce-scatter + all-gather per bucket (each rank reduces 1/world of the bucket, all 7 xGMI links
+                 carry one shard each in both phases -- the "direct" schedule of SURVEY.md section 8e's budget row).
+  MRG_DP_DTYPE = fp32 (default): gradients travel as produced (393 MB Base / 1.27 GB Large per step);
+               = bf16: buckets are cast to bf16 into a staging buffer, summed in bf16 on the wire, cast back and divided in fp32
+                 (half the xGMI bytes, two extra HBM passes over the bucket, ~3 significant digits per addend).
 """
+import os
 from typing import List, Optional, Tuple
 
 import torch
@@ -39,6 +49,16 @@ class GradReducer:
         self.backend = dist.get_backend(process_group) if dist.is_initialized() else None
         self.side = torch.cuda.Stream(device=flat_grad.device) if flat_grad.is_cuda else None
         self._done = None
+        self.comm = os.environ.get("MRG_DP_COMM", "allreduce")
+        self.wire = os.environ.get("MRG_DP_DTYPE", "fp32")
+        if self.comm not in ("allreduce", "rs_ag") or self.wire not in ("fp32", "bf16"):
+            raise ValueError(f"GradReducer: MRG_DP_COMM={self.comm!r} / MRG_DP_DTYPE={self.wire!r} (allreduce|rs_ag, fp32|bf16)")
+        active = dist.is_initialized() and (self.world > 1 or self.force)
+        self._stage16 = torch.empty(self.bucket_elems, dtype=torch.bfloat16, device=flat_grad.device) if (active and self.wire == "bf16") else None
+        self._shard = None
+        if active and self.comm == "rs_ag":
+            per = (self.bucket_elems + self.world - 1) // self.world
+            self._shard = torch.empty(per, dtype=torch.bfloat16 if self.wire == "bf16" else torch.float32, device=flat_grad.device)
         # ncclAvg needs NCCL/RCCL >= 2.10; probe once (this also brings the communicator up before the first timed step) and
         # fall back to SUM followed by a scale when the backend refuses it
         self.use_avg = False
@@ -71,6 +91,27 @@ class GradReducer:
                 tgt.append((s, e))
         return first, rest
 
+    def _exchange(self, s: int, e: int, op):
+        """Sum (or average, when `op` is AVG) of flat[s:e] over the ranks, in place, in the configured wire format."""
+        buf = self.flat[s:e]
+        n = e - s
+        if self.wire == "bf16":
+            wire = self._stage16[:n]
+            wire.copy_(buf)
+            wop = dist.ReduceOp.SUM
+        else:
+            wire, wop = buf, op
+        if self.comm == "rs_ag" and n % self.world == 0:
+            shard = self._shard[:n // self.world]
+            dist.reduce_scatter_tensor(shard, wire, op=wop, group=self.group)
+            dist.all_gather_into_tensor(wire, shard, group=self.group)
+        else:
+            dist.all_reduce(wire, op=wop, group=self.group)
+        if self.wire == "bf16":
+            buf.copy_(wire)
+            if op == dist.ReduceOp.AVG:
+                buf.mul_(1.0 / self.world)
+
     def reduce_async(self, ranges=None, then=None):
         """Launch the bucket all-reduces (side stream on GPU).  Call wait() before reading the gradients.  `ranges`: element
         ranges to reduce (default: the whole buffer); each is cut into buckets.  `then`: callable issued on the same stream right
@@ -87,12 +128,12 @@ class GradReducer:
             with torch.cuda.stream(self.side):
                 self.side.wait_event(ready)
                 for s, e in self._buckets(ranges):
-                    dist.all_reduce(self.flat[s:e], op=op, group=self.group)
+                    self._exchange(s, e, op)
                 self._done = torch.cuda.Event()
                 self._done.record(self.side)
         else:
             for s, e in self._buckets(ranges):
-                dist.all_reduce(self.flat[s:e], op=op, group=self.group)
+                self._exchange(s, e, op)
         if not use_avg:
             if self.side is not None:
                 with torch.cuda.stream(self.side):

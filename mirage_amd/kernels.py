@@ -498,8 +498,10 @@ def adamw(p, g, m, v, shadow, n_decay, lr_table, wd_table, step, beta1, beta2, e
     check(lib.mrg_adamw(C.byref(d), _s()), "mrg_adamw")
 
 
-def step_inc(step: torch.Tensor):
-    check(lib.mrg_step_inc(step.data_ptr(), _s()), "mrg_step_inc")
+def step_inc(step: torch.Tensor, grad_norm_t=None, clip_norm=0.0, skip_norm=0.0):
+    """step: int32[2] = (iteration counter, AdamW updates applied); the second only advances when the iteration was not skipped."""
+    assert step.numel() == 2 and step.dtype == torch.int32
+    check(lib.mrg_step_inc(step.data_ptr(), _p(grad_norm_t), clip_norm or 0.0, skip_norm or 0.0, _s()), "mrg_step_inc")
 
 
 def cast_bf16(src: torch.Tensor, dst: torch.Tensor):

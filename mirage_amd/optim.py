@@ -52,9 +52,13 @@ def get_parameter_groups(model, weight_decay=1e-5, skip_list=()):
 class FusedAdamW:
     """AdamW over the model's flat arenas: one gradient-norm reduction + one update launch per step; the update also
     refreshes the bf16 shadow weights.  lr / weight-decay come from device-resident per-step tables indexed by a device
-    step counter, so `step()` is hipGraph-replayable and needs no host->device traffic.
+    iteration counter, so `step()` is hipGraph-replayable and needs no host->device traffic.
 
-    param_groups keeps the reference's shape ([{'params', 'weight_decay', 'lr', 'lr_scale'}...]) for logging code.
+    step_dev = int32[2] on the device: [0] the iteration counter (schedule index), [1] the number of updates applied (torch AdamW's
+    per-parameter state['step']; a skipped iteration, native_scaler.py:24-29, advances only [0]).
+
+    param_groups keeps the reference's shape ([{'params', 'weight_decay', 'lr', 'lr_scale'}...]) for logging code;
+    state_dict() / load_state_dict() speak torch.optim.AdamW's format (what mutils/checkpoint.py:14-20,62-66 stores and loads).
     """
 
     def __init__(self, model, lr_schedule, wd_schedule, betas=(0.9, 0.95), eps=1e-8, clip_grad: Optional[float] = None,
@@ -71,12 +75,14 @@ class FusedAdamW:
         self.wd_table = torch.as_tensor(np.asarray(wd_schedule, dtype=np.float32), device=dev)
         self._lr_host = np.asarray(lr_schedule, dtype=np.float64)
         self._wd_host = np.asarray(wd_schedule, dtype=np.float64)
-        self.step_dev = torch.zeros(1, dtype=torch.int32, device=dev)
+        self.step_dev = torch.zeros(2, dtype=torch.int32, device=dev)
         self.exp_avg = torch.zeros(arena.n_trainable, dtype=torch.float32, device=dev)
         self.exp_avg_sq = torch.zeros(arena.n_trainable, dtype=torch.float32, device=dev)
         self.grad_norm = torch.zeros(1, dtype=torch.float32, device=dev)
         self.betas, self.eps = betas, eps
-        self.clip_grad, self.skip_grad = clip_grad, skip_grad
+        # native_scaler.py:19-34: clip_grad takes precedence, skip_grad is only consulted without it
+        self.clip_grad = clip_grad
+        self.skip_grad = skip_grad if clip_grad is None else None
         self._host_step = 0
         self.param_groups = [
             {"params": [arena.params[n] for n in arena.names_decay], "names": arena.names_decay, "weight_decay": float(self._wd_host[0]),
@@ -89,9 +95,14 @@ class FusedAdamW:
         """Gradients are overwritten by every backward pass, so nothing has to be cleared; the views stay attached."""
         self.arena.reattach_grads()
 
+    def set_iteration(self, it: int):
+        """Position in the lr / wd schedules (start of an epoch / resume); the AdamW step count is left alone."""
+        self.step_dev[0:1].fill_(int(it))
+        self._host_step = int(it)
+
     def step_ranges(self, ranges):
-        """AdamW over element ranges [s, e) of the arena (64-element aligned) with the CURRENT step counter: the element updates are
-        independent, so any partition of the arena gives bit-identical results to the single launch.  Only without clip / skip
+        """AdamW over element ranges [s, e) of the arena (64-element aligned) with the CURRENT step counters: the element updates
+        are independent, so any partition of the arena gives bit-identical results to the single launch.  Only without clip / skip
         (the update must not depend on the global gradient norm)."""
         a = self.arena
         for s, e in ranges:
@@ -100,7 +111,7 @@ class FusedAdamW:
                     self.wd_table, self.step_dev, self.betas[0], self.betas[1], self.eps)
 
     def step(self, done_ranges=None):
-        """global grad norm (native_scaler.py:46-61) -> AdamW (+clip / skip) -> step counter + 1.  `done_ranges`: sorted, disjoint
+        """global grad norm (native_scaler.py:46-61) -> AdamW (+clip / skip) -> counters.  `done_ranges`: sorted, disjoint
         element ranges already updated this step through step_ranges() (early, overlapped with backward)."""
         from .engine import join_side_stream
         join_side_stream()
@@ -121,7 +132,7 @@ class FusedAdamW:
             K.adamw(a.flat_p[:a.n_trainable], g, self.exp_avg, self.exp_avg_sq, a.flat_bf16[:a.n_trainable], a.n_decay, self.lr_table,
                     self.wd_table, self.step_dev, self.betas[0], self.betas[1], self.eps, grad_norm_t=self.grad_norm,
                     clip_norm=self.clip_grad or 0.0, skip_norm=self.skip_grad or 0.0)
-        K.step_inc(self.step_dev)
+        K.step_inc(self.step_dev, self.grad_norm, self.clip_grad or 0.0, self.skip_grad or 0.0)
         if not torch.cuda.is_current_stream_capturing():
             a.mark_fresh()
             i = min(self._host_step, len(self._lr_host) - 1)
@@ -130,13 +141,89 @@ class FusedAdamW:
             self._host_step += 1
         return self.grad_norm
 
+    # -- warm-up support ---------------------------------------------------------------------------
+    def snapshot(self):
+        """Everything a step modifies (weights, bf16 shadow, moments, counters), for iterations that must leave no trace
+        (allocator / tuner warm-up before hipGraph capture, trainer.TrainStep.warmup_and_capture)."""
+        a = self.arena
+        return (a.flat_p.clone(), a.flat_bf16.clone(), self.exp_avg.clone(), self.exp_avg_sq.clone(), self.step_dev.clone(), self._host_step)
+
+    def restore(self, snap):
+        a = self.arena
+        p, b, m, v, st, hs = snap
+        a.flat_p.copy_(p); a.flat_bf16.copy_(b); self.exp_avg.copy_(m); self.exp_avg_sq.copy_(v); self.step_dev.copy_(st)
+        self._host_step = hs
+        a.mark_fresh()
+
+    # -- checkpoint format: torch.optim.AdamW's -----------------------------------------------------
+    def _index_order(self):
+        """Parameter numbering of the reference's optimizer: create_optimizer -> get_parameter_groups (mutils/optim_factory.py:33-92)
+        forms the groups in order of first appearance in named_parameters() and torch numbers parameters group after group."""
+        groups = get_parameter_groups(self.model, 1.0, self.model.no_weight_decay() if hasattr(self.model, "no_weight_decay") else ())
+        return groups
+
     def state_dict(self):
-        return {"exp_avg": self.exp_avg, "exp_avg_sq": self.exp_avg_sq, "step": self.step_dev, "betas": self.betas, "eps": self.eps,
-                "names_decay": self.arena.names_decay, "names_no_decay": self.arena.names_no_decay}
+        """{'state': {i: {'step', 'exp_avg', 'exp_avg_sq'}}, 'param_groups': [...]} exactly as torch.optim.AdamW.state_dict() of the
+        reference's optimizer would hold it (checkpoint['optimizer'], mutils/checkpoint.py:14-20), so that a reference run can resume
+        from our checkpoint.  Moments are copied out of the flat arena per parameter (CPU tensors)."""
+        groups = self._index_order()
+        it = int(self.step_dev[0].item()); t_adam = int(self.step_dev[1].item())
+        i_lr = min(max(it - 1, 0), len(self._lr_host) - 1)
+        state, pgs, idx = {}, [], 0
+        for gr in groups:
+            ids = []
+            for name in gr["names"]:
+                h = self.arena.params[name]._mrg
+                if t_adam > 0:
+                    shape = self.arena.params[name].shape
+                    state[idx] = {"step": torch.tensor(float(t_adam), dtype=torch.float32),
+                                  "exp_avg": self.exp_avg[h.offset:h.offset + h.numel].view(shape).detach().cpu().clone(),
+                                  "exp_avg_sq": self.exp_avg_sq[h.offset:h.offset + h.numel].view(shape).detach().cpu().clone()}
+                ids.append(idx)
+                idx += 1
+            decay = gr["weight_decay"] > 0
+            pgs.append({"weight_decay": float(self._wd_host[i_lr]) if decay else 0.0, "lr_scale": 1.0, "lr": float(self._lr_host[i_lr]),
+                        "betas": (float(self.betas[0]), float(self.betas[1])), "eps": float(self.eps), "amsgrad": False, "maximize": False,
+                        "foreach": None, "capturable": False, "differentiable": False, "fused": None, "decoupled_weight_decay": True,
+                        "params": ids})
+        return {"state": state, "param_groups": pgs,
+                # extras (ignored by torch.optim.Optimizer.load_state_dict): parameter names per index and the iteration counter
+                "mrg_param_names": [n for gr in groups for n in gr["names"]], "mrg_iteration": it}
 
     def load_state_dict(self, sd):
-        self.exp_avg.copy_(sd["exp_avg"]); self.exp_avg_sq.copy_(sd["exp_avg_sq"]); self.step_dev.copy_(sd["step"])
-        self._host_step = int(self.step_dev.item())
+        """Accepts torch.optim.AdamW's state_dict (a reference checkpoint, or ours).  Parameter i of the file is matched to the i-th
+        parameter of the reference's group order; shapes are verified (and names, when the file carries them)."""
+        if "state" not in sd or "param_groups" not in sd:
+            raise ValueError("FusedAdamW.load_state_dict: expected a torch.optim.AdamW state_dict ({'state', 'param_groups'})")
+        groups = self._index_order()
+        names = [n for gr in groups for n in gr["names"]]
+        n_file = sum(len(g["params"]) for g in sd["param_groups"])
+        if n_file != len(names):
+            raise ValueError(f"FusedAdamW.load_state_dict: checkpoint has {n_file} parameters, the model {len(names)}")
+        if [len(g["params"]) for g in sd["param_groups"]] != [len(gr["names"]) for gr in groups]:
+            raise ValueError("FusedAdamW.load_state_dict: parameter-group sizes differ from the model's decay / no_decay split")
+        if "mrg_param_names" in sd and list(sd["mrg_param_names"]) != names:
+            raise ValueError("FusedAdamW.load_state_dict: parameter names / order differ from the model's")
+        file_ids = [i for g in sd["param_groups"] for i in g["params"]]
+        steps = set()
+        self.exp_avg.zero_(); self.exp_avg_sq.zero_()
+        for fid, name in zip(file_ids, names):
+            st = sd["state"].get(fid)
+            if st is None:
+                continue
+            p = self.arena.params[name]
+            h = p._mrg
+            if tuple(st["exp_avg"].shape) != tuple(p.shape):
+                raise ValueError(f"FusedAdamW.load_state_dict: {name}: moment shape {tuple(st['exp_avg'].shape)} vs parameter {tuple(p.shape)}")
+            self.exp_avg[h.offset:h.offset + h.numel].copy_(st["exp_avg"].reshape(-1).to(self.exp_avg.device, torch.float32))
+            self.exp_avg_sq[h.offset:h.offset + h.numel].copy_(st["exp_avg_sq"].reshape(-1).to(self.exp_avg.device, torch.float32))
+            steps.add(int(float(st["step"])))
+        if len(steps) > 1:
+            raise ValueError(f"FusedAdamW.load_state_dict: parameters carry different step counts {sorted(steps)}: one fused counter cannot hold them")
+        t_adam = steps.pop() if steps else 0
+        it = int(sd.get("mrg_iteration", t_adam))
+        self.step_dev.copy_(torch.tensor([it, t_adam], dtype=torch.int32))
+        self._host_step = it
 
 
 def create_optimizer(args, model, lr_schedule=None, wd_schedule=None):

@@ -200,7 +200,7 @@ def main(args):
     device = torch.device("cuda", local_rank)
     if world > 1:
         dist.init_process_group("nccl", device_id=device)
-    torch.manual_seed(args.seed)
+    torch.manual_seed(args.seed)                      # weight init: common to all ranks (and broadcast from rank 0 below)
     np.random.seed(args.seed)
     args.in_domains = args.in_domains.split("-")
     args.out_domains = args.out_domains.split("-")
@@ -220,6 +220,9 @@ def main(args):
             w = {k: v for k, v in w.items() if "input_adapter" not in k and "output_adapter" not in k}
         print(model.load_state_dict(w, strict=False))
     model.to(device).train()
+    # masks / stochastic depth: one RNG stream per rank, so that a global batch sees world x B mask draws
+    torch.manual_seed(args.seed + 1 + rank)
+    torch.cuda.manual_seed(args.seed + 1 + rank)
     loss_fns = builder.get_losses(args)
 
     if args.data_path == "synthetic":
@@ -239,7 +242,7 @@ def main(args):
     broadcast_params(optimizer.arena.flat_p)
     optimizer.arena.refresh_shadow(force=True)
     if args.start_epoch:
-        optimizer.step_dev.fill_(args.start_epoch * steps_per_epoch)
+        optimizer.set_iteration(args.start_epoch * steps_per_epoch)
     reducer = GradReducer(optimizer.arena.flat_g) if world > 1 else None
     n_parameters = sum(p.numel() for p in model.parameters() if p.requires_grad)
     if rank == 0:
@@ -257,7 +260,7 @@ def main(args):
                                  loss_on_unmasked=args.loss_on_unmasked)
                 step.load(batch)
                 step.warmup_and_capture(warm_iters=1)
-                optimizer.step_dev.fill_(epoch * steps_per_epoch)
+                optimizer.set_iteration(epoch * steps_per_epoch)
             step.step(batch)
             if it % args.print_freq == 0 or it == steps_per_epoch - 1:
                 vals = {"loss": all_reduce_scalar_mean(step.loss.detach().clone().reshape(1))}

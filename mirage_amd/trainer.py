@@ -16,11 +16,20 @@ from .dp import GradReducer
 class TrainStep:
     def __init__(self, model, loss_fns: Dict[str, torch.nn.Module], optimizer, batch_example: Dict[str, torch.Tensor],
                  num_encoded_tokens: int, alphas: float = 1.0, sample_tasks_uniformly: bool = False, use_graph: bool = True,
-                 reducer: Optional[GradReducer] = None, loss_on_unmasked: bool = False, overlap: bool = True):
+                 reducer: Optional[GradReducer] = None, loss_on_unmasked: bool = False, overlap: bool = True,
+                 feed_mask_noise: bool = False):
         self.model, self.loss_fns, self.opt = model, loss_fns, optimizer
         self.K, self.alphas, self.uniform = num_encoded_tokens, alphas, sample_tasks_uniformly
         self.static_x = {k: torch.empty_like(v) for k, v in batch_example.items()}
         self.in_domains = list(model.input_adapters.keys())
+        # parity runs: the three random inputs of the mask generator (Dirichlet shares p [B, n], per-task
+        # noise u [B, T], tie-break noise g [B, T]) come from static buffers filled by step(noise=...) instead of the device RNG
+        self.static_noise = None
+        if feed_mask_noise:
+            first = next(iter(batch_example.values()))
+            B, dev = first.shape[0], first.device
+            T = model._dom_start(self.in_domains)[-1]
+            self.static_noise = (torch.empty(B, len(self.in_domains), device=dev), torch.empty(B, T, device=dev), torch.empty(B, T, device=dev))
         self.loss_on_unmasked = loss_on_unmasked      # run_pretraining.py:718-721: loss over every token instead of the masked ones
         self.loss = None
         self.task_losses = {}
@@ -127,7 +136,7 @@ class TrainStep:
     def _fwd_bwd(self):
         x = self.static_x
         preds, masks = self.model({d: x[d] for d in self.in_domains}, num_encoded_tokens=self.K, alphas=self.alphas,
-                                  sample_tasks_uniformly=self.uniform)
+                                  sample_tasks_uniformly=self.uniform, mask_noise=self.static_noise)
         self.task_losses = {t: self.loss_fns[t](preds[t], x[t], mask=None if self.loss_on_unmasked else masks.get(t)) for t in preds}
         self.loss = sum(self.task_losses.values())
         self.opt.zero_grad()
@@ -149,7 +158,7 @@ class TrainStep:
         from . import engine as E
         x = self.static_x
         preds, masks = self.model({d: x[d] for d in self.in_domains}, num_encoded_tokens=self.K, alphas=self.alphas,
-                                  sample_tasks_uniformly=self.uniform)
+                                  sample_tasks_uniformly=self.uniform, mask_noise=self.static_noise)
         self.task_losses = {t: self.loss_fns[t](preds[t], x[t], mask=None if self.loss_on_unmasked else masks.get(t)) for t in preds}
         self.loss = sum(self.task_losses.values())
         self.opt.zero_grad()
@@ -194,9 +203,12 @@ class TrainStep:
         self._opt()
 
     def warmup_and_capture(self, warm_iters: int = 2):
-        """A few eager iterations on a side stream (allocator warm-up, workspace sizing), then graph capture."""
+        """A few eager iterations on a side stream (allocator warm-up, workspace sizing, GEMM autotuning), then graph capture.
+        The warm-up iterations leave no trace: weights, bf16 shadow, AdamW moments and both step counters are restored afterwards
+        (the reference takes no such extra steps), so the first replay is the first optimizer step."""
         if not self.use_graph:
             return
+        snap = self.opt.snapshot() if hasattr(self.opt, "snapshot") else None
         s = torch.cuda.Stream()
         s.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(s):
@@ -204,6 +216,9 @@ class TrainStep:
                 self._eager()
         torch.cuda.current_stream().wait_stream(s)
         torch.cuda.synchronize()
+        if snap is not None:
+            self.opt.restore(snap)
+            torch.cuda.synchronize()
         if self.reducer is None:
             self.g_fb = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self.g_fb, capture_error_mode="thread_local"):
@@ -237,9 +252,14 @@ class TrainStep:
         for k, v in batch.items():
             self.static_x[k].copy_(v, non_blocking=True)
 
-    def step(self, batch: Optional[Dict[str, torch.Tensor]] = None):
+    def step(self, batch: Optional[Dict[str, torch.Tensor]] = None, noise=None):
         if batch is not None:
             self.load(batch)
+        if noise is not None:
+            if self.static_noise is None:
+                raise RuntimeError("TrainStep.step(noise=...): construct the TrainStep with feed_mask_noise=True")
+            for dst, src in zip(self.static_noise, noise):
+                dst.copy_(src, non_blocking=True)
         if self.g_fb is None:
             self._eager()
         elif self.g_opt is None:

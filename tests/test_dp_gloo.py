@@ -42,6 +42,15 @@ def _worker(rank, world, port, out):
     mid_ok = torch.allclose(flat2[2048:4096], want[2048:4096]) and torch.equal(flat2[:2048], torch.arange(2048, dtype=torch.float32) * (rank + 1))
     r.reduce_async(rest); r.wait()
     ok1 = ok1 and mid_ok and torch.allclose(flat2, want)
+    # 1c) the alternative exchange formats (MRG_DP_COMM / MRG_DP_DTYPE): explicit reduce-scatter + all-gather, bf16 on the wire
+    for comm, wire, tol in (("rs_ag", "fp32", 0.0), ("allreduce", "bf16", 8e-3), ("rs_ag", "bf16", 8e-3)):
+        os.environ["MRG_DP_COMM"], os.environ["MRG_DP_DTYPE"] = comm, wire
+        flat3 = (torch.arange(n, dtype=torch.float32) % 97 + 1.0) * (rank + 1)
+        want3 = (torch.arange(n, dtype=torch.float32) % 97 + 1.0) * (sum(range(1, world + 1)) / world)
+        r3 = GradReducer(flat3, bucket_bytes=4096)
+        r3.reduce_async([(0, 4096), (4096, n)]); r3.wait()
+        ok1 = ok1 and bool(((flat3 - want3).abs() <= tol * want3.abs() + 1e-6).all())
+    os.environ.pop("MRG_DP_COMM"); os.environ.pop("MRG_DP_DTYPE")
     # 2) broadcast
     p = torch.full((100,), float(rank))
     broadcast_params(p, src=0)

@@ -462,7 +462,7 @@ def test_adamw_gradnorm_cast(K):
     m = torch.zeros(n, device=dev()); v = torch.zeros(n, device=dev())
     shadow = torch.empty(n, dtype=BF16, device=dev())
     lrs = torch.tensor([1e-3, 5e-4, 2e-4], device=dev()); wds = torch.tensor([0.05, 0.04, 0.03], device=dev())
-    step = torch.zeros(1, dtype=torch.int32, device=dev())
+    step = torch.zeros(2, dtype=torch.int32, device=dev())     # (iteration counter, AdamW updates applied)
     pr, mr, vr = p.cpu().clone(), torch.zeros(n), torch.zeros(n)
     norm = torch.empty(1, device=dev())
     for it in range(3):
@@ -474,7 +474,7 @@ def test_adamw_gradnorm_cast(K):
         O.adamw_step(pr[n_decay:], g.cpu()[n_decay:], mr[n_decay:], vr[n_decay:], it + 1, float(lrs[it]), 0.0)
         torch.testing.assert_close(p.cpu(), pr, rtol=1e-5, atol=1e-7)
         assert torch.equal(shadow, p.to(BF16))
-    assert int(step) == 3
+    assert step.tolist() == [3, 3]
     dst = torch.empty(1001, dtype=BF16, device=dev())
     K.cast_bf16(p[:1001].contiguous(), dst)
     assert torch.equal(dst, p[:1001].to(BF16))

@@ -18,7 +18,7 @@ def _sub(t, n):
     return f[::step][:n].numpy()
 
 
-def _run_case(name, check_inter=False, check_grads=True, rtol=2e-5):
+def _run_case(name, check_inter=False, check_grads=True, rtol=2e-5, tot_rtol=1e-4):
     fx, meta = load_golden(name)
     cfg, B, K = meta["cfg"], meta["B"], meta["K"]
     sd = {k: v.clone().requires_grad_(O.param_shapes(cfg)[k][1]) for k, v in O.procedural_state_dict(cfg).items()}
@@ -61,7 +61,7 @@ def _run_case(name, check_inter=False, check_grads=True, rtol=2e-5):
             if f"grad.{n}" in fx:
                 np.testing.assert_allclose(g.numpy(), fx[f"grad.{n}"], rtol=2e-3, atol=2e-5 * max(gn, 1e-3))
         tot = float(torch.sqrt(sum((p.grad.double() ** 2).sum() for p in sd.values() if p.grad is not None)))
-        assert abs(tot - float(fx["grad_total_norm"])) <= 1e-4 * float(fx["grad_total_norm"])
+        assert abs(tot - float(fx["grad_total_norm"])) <= tot_rtol * float(fx["grad_total_norm"]), (tot, float(fx["grad_total_norm"]))
 
 
 def test_tiny3_forward_backward():
@@ -79,6 +79,86 @@ def test_c2_base_full_size():
 @pytest.mark.slow
 def test_c3_base_full_size():
     _run_case("c3_base", check_grads=False)
+
+
+def test_c4_large_oracle_pinned():
+    """Large (24 x 1024, 3 modalities) at B=1: the oracle itself against the reference's vectors (loss, tokens, gradient norms)."""
+    # 24 fp32 layers: the total gradient norm gets the per-parameter tolerance (2e-4; measured 1.1e-4) instead of 1e-4
+    _run_case("c4_large", tot_rtol=2e-4)
+
+
+def test_c5_large_cls_oracle_pinned():
+    fx, meta = load_golden("c5_large_cls")
+    cfg, B = meta["cfg"], meta["B"]
+    sd = O.procedural_state_dict(cfg)
+    d = cfg["in_domains"][0]
+    x = O.synthetic_batch(cfg, B, seed=meta["data_seed"])[d]
+    D = cfg["dim"]
+    nw = torch.from_numpy(1.0 + 0.2 * O.procedural_uniform("cls.norm.weight", D))
+    nb = torch.from_numpy(0.04 * O.procedural_uniform("cls.norm.bias", D))
+    with torch.no_grad():
+        pooled = O.cls_global_features(cfg, sd, x, nw, nb)
+    np.testing.assert_allclose(pooled.numpy(), fx["pooled"], rtol=1e-4, atol=2e-5)
+
+
+def _optstate_inputs(fx, meta, n):
+    cfg, B, K = meta["cfg"], meta["B"], meta["K"]
+    batches, masks = [], []
+    for it in range(n):
+        x = O.synthetic_batch(cfg, B, seed=800 + it)
+        if it == 2:                                     # the generator's out-of-range batch (gradient-norm spike)
+            x = {d: (t * 4.0 if t.is_floating_point() else t) for d, t in x.items()}
+        batches.append(x)
+        _, ik, ir = O.generate_masks_from_noise(fx[f"p.{it}"], [fx[f"u.{it}.{d}"] for d in cfg["in_domains"]], fx[f"g.{it}"], K)
+        masks.append((_t(ik), _t(ir)))
+    return cfg, batches, masks
+
+
+def _cmp_final(final, fx, tag):
+    for n_ in ("encoder.0.mlp.fc1.weight", "encoder.1.attn.qkv.bias", "global_tokens"):
+        got, want = _sub(final[n_], 512), fx[f"{tag}.final.{n_}"]
+        if n_.endswith("qkv.bias"):
+            # the k-bias gradient is zero in exact arithmetic (softmax shift invariance): Adam turns its roundoff into +-lr steps,
+            # so only the q and v thirds are comparable
+            third = got.shape[0] // 3
+            keep = np.r_[0:third, 2 * third:3 * third]
+            got, want = got[keep], want[keep]
+        np.testing.assert_allclose(got, want, rtol=1e-4, atol=2e-5)
+
+
+def test_clip_skip_and_optimizer_state_match_reference_scaler():
+    """F1: the step boundary restated in oracle.train_steps against the reference's NativeScalerWithGradNormCount + torch AdamW
+    (mutils/native_scaler.py:19-34): clipping (and skip_grad ignored beside it), skipping (AdamW `step` falls behind the iteration
+    counter), and the moments after two plain steps."""
+    fx, meta = load_golden("tiny3_optstate")
+    steps = meta["steps"]
+    cfg, batches, masks = _optstate_inputs(fx, meta, steps)
+    sd0 = O.procedural_state_dict(cfg)
+    # plain: moments
+    curve, norms, final, st = O.train_steps(cfg, sd0, batches[:2], masks[:2], fx["lrs"], fx["wds"], return_state=True)
+    np.testing.assert_allclose(norms, fx["plain.norms"], rtol=2e-4)
+    np.testing.assert_allclose(curve, fx["plain.losses"], rtol=2e-5)
+    assert st["step"] == 2 and np.all(fx["plain.steps"] == 2.0)
+    for i, n in enumerate(fx["plain.order"]):
+        m, v = st["exp_avg"][str(n)], st["exp_avg_sq"][str(n)]
+        np.testing.assert_allclose(_sub(m, 512), fx[f"plain.exp_avg.{i}"], rtol=2e-3, atol=2e-5 * float(m.abs().max()) + 1e-9)
+        np.testing.assert_allclose(_sub(v, 512), fx[f"plain.exp_avg_sq.{i}"], rtol=4e-3, atol=4e-5 * float(v.abs().max()) + 1e-12)
+    # clip (skip_grad given as well: must be ignored)
+    curve, norms, final, st = O.train_steps(cfg, sd0, batches[:3], masks[:3], fx["lrs"], fx["wds"], clip_grad=float(fx["clip.value"]),
+                                            skip_grad=1e-3, return_state=True)
+    np.testing.assert_allclose(norms, fx["clip.norms"], rtol=3e-4)
+    np.testing.assert_allclose(curve, fx["clip.losses"], rtol=5e-5)
+    assert st["step"] == 3 and not any(st["skipped"])
+    _cmp_final(final, fx, "clip")
+    # skip
+    curve, norms, final, st = O.train_steps(cfg, sd0, batches, masks, fx["lrs"], fx["wds"], skip_grad=float(fx["skip.value"]),
+                                            return_state=True)
+    np.testing.assert_allclose(norms, fx["skip.norms"], rtol=3e-4)
+    np.testing.assert_allclose(curve, fx["skip.losses"], rtol=5e-5)
+    applied = np.diff(np.concatenate([[0.0], fx["skip.adam_steps"]])) > 0
+    assert list(~applied) == st["skipped"] and st["step"] == int(fx["skip.adam_steps"][-1])
+    assert any(st["skipped"]) and not all(st["skipped"])
+    _cmp_final(final, fx, "skip")
 
 
 def test_posemb_quirk_and_tables():

@@ -51,37 +51,184 @@ def test_five_step_adamw_curve_matches_reference():
         assert abs(got - ref) <= 2e-3 * max(ref, 1e-2) + 5e-3 * sd[str(n)].numel() ** 0.5 * 1e-1, (str(n), got, ref)
 
 
-def test_graph_replay_equals_eager_and_updates_weights():
+def _noise_dev(cfg, B, K, seed):
+    from oracle import mirage_oracle as O
+    (p, u, g), tm, ids_keep, ids_restore = O.synthetic_masks(cfg, B, K, seed=seed)
+    noise = (torch.from_numpy(p).to(DEV), torch.cat([torch.from_numpy(a) for a in u], 1).to(DEV), torch.from_numpy(g).to(DEV))
+    return noise, torch.from_numpy(ids_keep), torch.from_numpy(ids_restore)
+
+
+def test_graph_replay_equals_eager_bit_exactly():
+    """Same weights, same batches, same mask noise: three optimizer steps through the captured hipGraph (after its warm-up
+    iterations, which must leave no trace) and three eager steps give bit-identical losses, counters and weights."""
     from mirage_amd import builder, optim
     from mirage_amd.trainer import TrainStep
     from oracle import mirage_oracle as O
     import test_model_gpu as T
     fx, meta = load_golden("tiny2")
     cfg = meta["cfg"]
+    B, Kk = 4, 32
+    batches = [{d: t.to(DEV) for d, t in O.synthetic_batch(cfg, B, seed=1 + i).items()} for i in range(3)]
+    noises = [_noise_dev(cfg, B, Kk, 50 + i)[0] for i in range(3)]
     results = []
     for use_graph in (False, True):
         model, args, _ = T._build(cfg)
         model.train()
         loss_fns = builder.get_losses(args)
-        opt = optim.FusedAdamW(model, [1e-3] * 16, [0.05] * 16)
-        batch = {d: t.to(DEV) for d, t in O.synthetic_batch(cfg, 4, seed=1).items()}
-        ts = TrainStep(model, loss_fns, opt, batch, 32, use_graph=use_graph)
-        ts.load(batch)
-        torch.manual_seed(123)
-        torch.cuda.manual_seed(123)
+        opt = optim.FusedAdamW(model, [1e-3, 8e-4, 5e-4] + [1e-4] * 13, [0.05] * 16)     # non-zero lr from step 0: warm-up updates would show
+        ts = TrainStep(model, loss_fns, opt, batches[0], Kk, use_graph=use_graph, feed_mask_noise=True)
+        ts.load(batches[0])
+        for dst, src in zip(ts.static_noise, noises[0]):
+            dst.copy_(src)
         if use_graph:
-            w0 = model.encoder[0].mlp.fc1.weight.detach().clone()
-            ts.warmup_and_capture(warm_iters=1)
+            ts.warmup_and_capture(warm_iters=2)
         losses = []
         for i in range(3):
-            ts.step(batch)
+            ts.step(batches[i], noise=noises[i])
             losses.append(float(ts.loss))
-        results.append((losses, int(opt.step_dev.item()), model.encoder[0].mlp.fc1.weight.detach().clone()))
-    (le, se, we), (lg, sg, wg) = results
-    assert se == 3 and sg == 3 + 1              # eager: 3 steps; graph: 1 eager warm-up step + 3 replays (capture itself does not execute)
-    assert all(np.isfinite(le)) and all(np.isfinite(lg))
-    assert le[-1] < le[0] and lg[-1] < lg[0]    # both optimise
-    assert float((wg - we).abs().max()) < 0.05  # same trajectory up to different mask draws
+        torch.cuda.synchronize()
+        results.append((losses, opt.step_dev.tolist(), opt.arena.flat_p.detach().clone(), opt.exp_avg.clone(), float(opt.grad_norm)))
+    (le, se, we, me, ge), (lg, sg, wg, mg, gg) = results
+    assert se == [3, 3] and sg == [3, 3], (se, sg)          # warm-up iterations are not counted
+    assert le == lg, (le, lg)
+    assert ge == gg
+    assert torch.equal(we, wg), float((we - wg).abs().max())
+    assert torch.equal(me, mg)
+    assert le[-1] < le[0]
+
+
+def test_clip_and_skip_match_reference_scaler():
+    """F1: clip_grad / skip_grad through the fused optimizer against the reference's NativeScalerWithGradNormCount + torch AdamW
+    (fixture tiny3_optstate; mutils/native_scaler.py:19-34): norms returned, which iterations are skipped, AdamW's step count
+    (bias correction) and the final weights."""
+    from mirage_amd import builder, optim
+    from oracle import mirage_oracle as O
+    import test_model_gpu as T
+    fx, meta = load_golden("tiny3_optstate")
+    cfg, B, Kk, steps = meta["cfg"], meta["B"], meta["K"], meta["steps"]
+    doms = cfg["in_domains"]
+
+    def run(n, **kw):
+        model, args, _ = T._build(cfg)
+        model.train()
+        loss_fns = builder.get_losses(args)
+        opt = optim.FusedAdamW(model, fx["lrs"], fx["wds"], betas=(0.9, 0.95), eps=1e-8, **kw)
+        norms, losses, tsteps = [], [], []
+        for it in range(n):
+            x = O.synthetic_batch(cfg, B, seed=800 + it)
+            if it == 2:
+                x = {d: (t * 4.0 if t.is_floating_point() else t) for d, t in x.items()}
+            x = {d: t.to(DEV) for d, t in x.items()}
+            noise = (torch.from_numpy(fx[f"p.{it}"]).to(DEV), torch.cat([torch.from_numpy(fx[f"u.{it}.{d}"]) for d in doms], 1).to(DEV),
+                     torch.from_numpy(fx[f"g.{it}"]).to(DEV))
+            preds, masks = model({d: x[d] for d in doms}, num_encoded_tokens=Kk, mask_noise=noise)
+            loss = sum(loss_fns[d](preds[d], x[d], mask=masks[d]) for d in preds)
+            opt.zero_grad()
+            loss.backward()
+            norms.append(float(opt.step())); losses.append(float(loss)); tsteps.append(int(opt.step_dev[1]))
+        return model, opt, norms, losses, tsteps
+
+    def cmp_final(model, tag):
+        sd = model.state_dict()
+        for n_ in ("encoder.0.mlp.fc1.weight", "encoder.1.attn.qkv.bias", "global_tokens"):
+            got, want = T._sub(sd[n_].float().cpu(), 512).numpy(), fx[f"{tag}.final.{n_}"]
+            if n_.endswith("qkv.bias"):                # k-bias: zero gradient in exact arithmetic, Adam amplifies roundoff
+                third = got.shape[0] // 3
+                keep = np.r_[0:third, 2 * third:3 * third]
+                got, want = got[keep], want[keep]
+            # bf16 gradients through Adam: a sign-like update of size ~lr per step; allow a fraction of the total movement
+            np.testing.assert_allclose(got, want, rtol=0, atol=0.35 * float(np.sum(fx["lrs"][:steps])))
+        for n, ref in zip(fx["names"], fx[f"{tag}.final_norms"]):
+            got = float(sd[str(n)].double().norm())
+            assert abs(got - ref) <= 2e-3 * max(ref, 1e-2) + 5e-4 * sd[str(n)].numel() ** 0.5, (str(n), got, ref)
+
+    # clipping active every step; skip_grad given too and ignored
+    model, opt, norms, losses, tsteps = run(3, clip_grad=float(fx["clip.value"]), skip_grad=1e-3)
+    np.testing.assert_allclose(norms, fx["clip.norms"], rtol=3e-2)
+    np.testing.assert_allclose(losses, fx["clip.losses"], rtol=1e-2)
+    assert tsteps == [1, 2, 3] and opt.step_dev.tolist() == [3, 3]
+    cmp_final(model, "clip")
+    T.report("tiny3_clip", norm_rel=float(np.max(np.abs(np.array(norms) / fx["clip.norms"] - 1))), loss_rel=float(np.max(np.abs(np.array(losses) / fx["clip.losses"] - 1))))
+    # skipping: iteration 2 (the spiked batch) is over the threshold
+    model, opt, norms, losses, tsteps = run(steps, skip_grad=float(fx["skip.value"]))
+    np.testing.assert_allclose(norms, fx["skip.norms"], rtol=3e-2)
+    np.testing.assert_allclose(losses, fx["skip.losses"], rtol=1e-2)
+    assert tsteps == [int(v) for v in fx["skip.adam_steps"]], (tsteps, fx["skip.adam_steps"])
+    assert opt.step_dev.tolist() == [steps, int(fx["skip.adam_steps"][-1])]
+    cmp_final(model, "skip")
+    T.report("tiny3_skip", norm_rel=float(np.max(np.abs(np.array(norms) / fx["skip.norms"] - 1))), loss_rel=float(np.max(np.abs(np.array(losses) / fx["skip.losses"] - 1))))
+    # the skipped iteration left weights and moments untouched: replay iterations 0-1, then one skipped step
+    model, opt, _, _, _ = run(2, skip_grad=float(fx["skip.value"]))
+    w, m = opt.arena.flat_p.clone(), opt.exp_avg.clone()
+    opt.skip_grad = 1e-6                                # anything is over this threshold
+    opt.step()
+    assert torch.equal(w, opt.arena.flat_p) and torch.equal(m, opt.exp_avg) and opt.step_dev.tolist() == [3, 2]
+
+
+def test_optimizer_state_dict_is_torch_adamw_format(tmp_path):
+    """F3: checkpoint['optimizer'] in the reference's format (mutils/checkpoint.py:14-20,62-66): structure and per-parameter
+    numbering equal to the reference optimizer's state_dict (fixture), moments after two steps equal to the reference's, the dict
+    loads into a real torch.optim.AdamW, and a reference-style dict loads back into the fused optimizer."""
+    import json as _json
+    from mirage_amd import builder, optim
+    from oracle import mirage_oracle as O
+    import test_model_gpu as T
+    fx, meta = load_golden("tiny3_optstate")
+    cfg, B, Kk = meta["cfg"], meta["B"], meta["K"]
+    doms = cfg["in_domains"]
+    model, args, _ = T._build(cfg)
+    model.train()
+    loss_fns = builder.get_losses(args)
+    opt = optim.FusedAdamW(model, fx["lrs"], fx["wds"], betas=(0.9, 0.95), eps=1e-8)
+    for it in range(2):
+        x = {d: t.to(DEV) for d, t in O.synthetic_batch(cfg, B, seed=800 + it).items()}
+        noise = (torch.from_numpy(fx[f"p.{it}"]).to(DEV), torch.cat([torch.from_numpy(fx[f"u.{it}.{d}"]) for d in doms], 1).to(DEV),
+                 torch.from_numpy(fx[f"g.{it}"]).to(DEV))
+        preds, masks = model({d: x[d] for d in doms}, num_encoded_tokens=Kk, mask_noise=noise)
+        loss = sum(loss_fns[d](preds[d], x[d], mask=masks[d]) for d in preds)
+        opt.zero_grad(); loss.backward(); opt.step()
+    sd = opt.state_dict()
+    order = [str(n) for n in fx["plain.order"]]
+    assert sd["mrg_param_names"] == order                                  # torch's parameter numbering
+    ref_groups = _json.loads(str(fx["plain.groups"]))
+    assert [g["params"] for g in sd["param_groups"]] == [g["params"] for g in ref_groups]
+    for mine, ref in zip(sd["param_groups"], ref_groups):
+        assert set(ref) <= set(mine), set(ref) - set(mine)
+        for k in ("lr", "weight_decay", "eps", "lr_scale"):
+            assert abs(float(mine[k]) - float(ref[k])) <= 1e-12 + 1e-6 * abs(float(ref[k])), (k, mine[k], ref[k])
+        assert [float(b) for b in mine["betas"]] == [float(b) for b in ref["betas"]]
+    assert sorted({k for v in sd["state"].values() for k in v}) == [str(k) for k in fx["plain.state_keys"]]
+    st0 = sd["state"][0]["step"]
+    assert str(st0.dtype) == str(fx["plain.step_dtype"]) and list(st0.shape) == list(fx["plain.step_shape"])
+    worst = 0.0
+    for i, n in enumerate(order):
+        assert float(sd["state"][i]["step"]) == float(fx["plain.steps"][i])
+        assert tuple(sd["state"][i]["exp_avg"].shape) == tuple(dict(model.named_parameters())[n].shape)
+        for key in ("exp_avg", "exp_avg_sq"):
+            got, want = T._sub(sd["state"][i][key], 512).double(), torch.from_numpy(fx[f"plain.{key}.{i}"]).double()
+            scale = float(want.norm()) + 1e-12 * 512
+            if float(want.abs().max()) < 1e-7:        # k-bias: zero in exact arithmetic
+                continue
+            err = float((got - want).norm()) / scale
+            worst = max(worst, err)
+            assert err <= (6e-2 if key == "exp_avg" else 1e-1), (n, key, err)
+    T.report("tiny3_optstate", moments_worst_rel=worst)
+    # our dict loads into a real torch AdamW over the same parameters ...
+    groups = optim.get_parameter_groups(model, 0.05, model.no_weight_decay())
+    tref = torch.optim.AdamW([{"params": g["params"], "weight_decay": g["weight_decay"], "lr_scale": 1.0} for g in groups], lr=1e-3, betas=(0.9, 0.95))
+    tref.load_state_dict({"state": sd["state"], "param_groups": sd["param_groups"]})
+    back = tref.state_dict()
+    # ... and what torch writes loads into a fresh fused optimizer with identical arenas (through a file, like the driver)
+    path = str(tmp_path / "opt.pth")
+    torch.save({"optimizer": back}, path)
+    model2, _, _ = T._build(cfg)
+    opt2 = optim.FusedAdamW(model2, fx["lrs"], fx["wds"], betas=(0.9, 0.95), eps=1e-8)
+    opt2.load_state_dict(torch.load(path, map_location="cpu", weights_only=False)["optimizer"])
+    assert torch.equal(opt2.exp_avg, opt.exp_avg) and torch.equal(opt2.exp_avg_sq, opt.exp_avg_sq)
+    assert opt2.step_dev.tolist() == [2, 2]
+    with pytest.raises(ValueError):
+        bad = {"state": back["state"], "param_groups": back["param_groups"][:1]}
+        opt2.load_state_dict(bad)
 
 
 def test_driver_artifacts_and_resume(tmp_path):

@@ -283,6 +283,97 @@ def run_train_curve(name, cfg, B, K, steps=5):
     print("   curve", curve)
 
 
+def run_optstate_case(name, cfg, B, K, steps=4):
+    """Step boundary with the reference's own scaler (mutils/native_scaler.py:10-34, GradScaler disabled = the fp32 / bf16 path):
+    (a) plain: optimizer.state_dict() after 2 steps -- the checkpoint['optimizer'] format (mutils/checkpoint.py:14-20);
+    (b) clip_grad: 3 steps with clipping active; (c) skip_grad: `steps` steps with a threshold between the observed norms, so
+    that some updates are skipped and AdamW's per-parameter `step` falls behind the iteration counter."""
+    import warnings
+    from mutils.native_scaler import NativeScalerWithGradNormCount
+    print(f"== {name}: optimizer state / clip / skip")
+    loss_fns = reference_losses(cfg)
+    args = types.SimpleNamespace(opt="adamw", weight_decay=0.05, lr=1e-3, opt_eps=1e-8, opt_betas=[0.9, 0.95], momentum=0.9)
+    with contextlib.redirect_stdout(io.StringIO()):
+        lrs = cosine_scheduler(args.lr, 1e-4, epochs=steps, niter_per_ep=1, warmup_epochs=1, start_warmup_value=5e-4)
+        wds = cosine_scheduler(0.05, 0.02, epochs=steps, niter_per_ep=1)
+    fx = {"lrs": lrs, "wds": wds}
+    for it in range(steps):
+        p, u, g = replay_mask_noise(cfg, B, 900 + it)
+        fx[f"p.{it}"] = p; fx[f"g.{it}"] = g
+        for d, ud in zip(cfg["in_domains"], u):
+            fx[f"u.{it}.{d}"] = ud
+
+    def run(n_steps, clip_grad=None, skip_grad=None):
+        with contextlib.redirect_stdout(io.StringIO()):
+            model = build_reference(cfg)
+        model.load_state_dict(O.procedural_state_dict(cfg), strict=True)
+        model.train()
+        with contextlib.redirect_stdout(io.StringIO()), warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            opt = create_optimizer(args, model)
+            scaler = NativeScalerWithGradNormCount(enabled=False)
+        norms, losses, adam_steps = [], [], []
+        for it in range(n_steps):
+            for gr in opt.param_groups:                      # run_pretraining.py:683-688
+                gr["lr"] = lrs[it] * gr["lr_scale"]
+                if gr["weight_decay"] > 0:
+                    gr["weight_decay"] = wds[it]
+            x = O.synthetic_batch(cfg, B, seed=800 + it)
+            if it == 2:                                      # one out-of-range batch: a gradient-norm spike for the skip branch
+                x = {d: (t * 4.0 if t.is_floating_point() else t) for d, t in x.items()}
+            torch.manual_seed(900 + it)
+            with contextlib.redirect_stdout(io.StringIO()):
+                preds, masks = model({d: x[d] for d in cfg["in_domains"]}, num_encoded_tokens=K, alphas=1.0)
+            loss = sum(loss_fns[d](preds[d].float(), x[d], mask=masks.get(d)) for d in preds)
+            opt.zero_grad()
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore")
+                norm = scaler(loss, opt, clip_grad=clip_grad, skip_grad=skip_grad, parameters=model.parameters())
+            norms.append(float(norm)); losses.append(float(loss))
+            st = [float(v["step"]) for v in opt.state.values()]
+            adam_steps.append(max(st) if st else 0.0)
+        return model, opt, norms, losses, adam_steps
+
+    # (a) plain, 2 steps: the state dict
+    model, opt, norms, losses, adam_steps = run(2)
+    sd = opt.state_dict()
+    id2name = {id(p): n for n, p in model.named_parameters()}
+    order = [id2name[id(p)] for gr in opt.param_groups for p in gr["params"]]
+    fx["plain.order"] = np.array(order)                       # parameter index -> name, as torch numbers them
+    fx["plain.groups"] = np.array(json.dumps([{k: (v if k != "params" else list(v)) for k, v in gr.items()} for gr in sd["param_groups"]],
+                                             default=float))
+    fx["plain.state_keys"] = np.array(sorted({k for v in sd["state"].values() for k in v}))
+    fx["plain.step_dtype"] = np.array(str(next(iter(sd["state"].values()))["step"].dtype))
+    fx["plain.step_shape"] = np.array(list(next(iter(sd["state"].values()))["step"].shape), dtype=np.int64)
+    fx["plain.steps"] = np.array([float(sd["state"][i]["step"]) for i in range(len(order))])
+    for i, n in enumerate(order):
+        fx[f"plain.exp_avg.{i}"], _ = subsample(sd["state"][i]["exp_avg"], 512)
+        fx[f"plain.exp_avg_sq.{i}"], _ = subsample(sd["state"][i]["exp_avg_sq"], 512)
+    fx["plain.norms"] = np.array(norms); fx["plain.losses"] = np.array(losses)
+    # (b) clipping active on every step
+    clip = 0.25 * min(norms)
+    model, opt, cn, cl, cs = run(3, clip_grad=clip, skip_grad=1e-3)          # skip_grad must be ignored when clip_grad is set
+    fx["clip.value"] = np.array(clip); fx["clip.norms"] = np.array(cn); fx["clip.losses"] = np.array(cl); fx["clip.adam_steps"] = np.array(cs)
+    fx["clip.final_norms"] = np.array([p.detach().double().norm().item() for _, p in model.named_parameters()])
+    for n_ in ("encoder.0.mlp.fc1.weight", "encoder.1.attn.qkv.bias", "global_tokens"):
+        fx[f"clip.final.{n_}"], _ = subsample(dict(model.named_parameters())[n_], 512)
+    # (c) skipping: threshold from a dry run so that both branches are taken
+    _, _, dry, _, _ = run(steps)
+    srt = sorted(dry)
+    thr = 0.5 * (srt[-1] + srt[-2])                          # the iteration with the largest norm is skipped, the ones before it are not
+    model, opt, sn, sl, ss = run(steps, skip_grad=thr)
+    taken = [b > a for a, b in zip([0.0] + ss[:-1], ss)]
+    assert any(taken) and not all(taken), (thr, sn, ss)
+    fx["skip.value"] = np.array(thr); fx["skip.norms"] = np.array(sn); fx["skip.losses"] = np.array(sl); fx["skip.adam_steps"] = np.array(ss)
+    fx["skip.final_norms"] = np.array([p.detach().double().norm().item() for _, p in model.named_parameters()])
+    for n_ in ("encoder.0.mlp.fc1.weight", "encoder.1.attn.qkv.bias", "global_tokens"):
+        fx[f"skip.final.{n_}"], _ = subsample(dict(model.named_parameters())[n_], 512)
+    fx["names"] = np.array([n for n, _ in model.named_parameters()])
+    fx["meta"] = np.array(json.dumps(dict(cfg=cfg, B=B, K=K, steps=steps, lr=args.lr)))
+    np.savez_compressed(os.path.join(OUT, f"{name}.npz"), **fx)
+    print("   plain norms", norms, "clip", clip, cn, "skip thr", thr, sn, ss)
+
+
 def run_harness_fixtures(cfg):
     """Schedules, param groups, posemb quirk, mask generator on its own."""
     fx = {}
@@ -401,6 +492,7 @@ def main():
         "tiny2": lambda: run_case("tiny2", tiny_cfg(("bscan", "slo")), B=2, K=32, data_seed=12, mask_seed=22, keep_intermediate=True),
         "tiny3_curve": lambda: run_train_curve("tiny3_curve", tiny_cfg(three), B=4, K=24, steps=5),
         "harness": lambda: run_harness_fixtures(tiny_cfg(three)),
+        "tiny3_optstate": lambda: run_optstate_case("tiny3_optstate", tiny_cfg(three), B=4, K=24, steps=4),
         "tiny3_droppath": lambda: run_droppath_case("tiny3_droppath", dict(O.make_config(model="tiny", in_domains=three, input_size=64, patch_size=8,
                                                     layermap_size=16, layermap_patch=2, decoder_dim=64, decoder_depth=2, decoder_heads=2,
                                                     dim=128, depth=4, heads=2, drop_path_rate=0.4)), B=6, K=24, data_seed=13, mask_seed=23),
