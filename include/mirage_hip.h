@@ -79,7 +79,7 @@ typedef struct mrg_gemm_desc {
     const int* row_map;
     const float* add_tab; const int* add_row; int ldt;
     int splitk; float* ws;
-    int variant;   /* 0 = heuristic choice; 1..10 force a kernel variant (see MRG_GEMM_* below); used by the host-side autotuner */
+    int variant;   /* 0 = heuristic choice; 1..11 force a kernel variant (see MRG_GEMM_* below); used by the host-side autotuner */
     void* ev_start; void* ev_stop;   /* optional hipEvent_t pair recorded on `stream` around the main GEMM kernel only (not the
                                         split-K finishing kernel): lets a benchmark time exactly what rocprofv3 reports per kernel */
     const float* row_scale;          /* optional [M]: (acc + bias -> act) is multiplied by row_scale[row] before add_tab / resid are
@@ -91,7 +91,7 @@ typedef struct mrg_gemm_desc {
     int defer_reduce;                /* splitk > 1 only: leave the split-K slabs ws[splitk][M*N] unreduced -- the caller sums them
                                         later with mrg_reduce_batch (C must be contiguous fp32, no bias / accumulate / C2) */
 } mrg_gemm_desc;
-enum { MRG_GEMM_AUTO = 0, MRG_GEMM_GLDS3 = 1, MRG_GEMM_GLDS4 = 2, MRG_GEMM_PIPE128 = 3, MRG_GEMM_PIPE256 = 4, MRG_GEMM_PIPE256X3 = 5, MRG_GEMM_PIPE256SQ = 6, MRG_GEMM_WS256 = 7, MRG_GEMM_GLDS64 = 8, MRG_GEMM_SQP = 9, MRG_GEMM_G256 = 10 };
+enum { MRG_GEMM_AUTO = 0, MRG_GEMM_GLDS3 = 1, MRG_GEMM_GLDS4 = 2, MRG_GEMM_PIPE128 = 3, MRG_GEMM_PIPE256 = 4, MRG_GEMM_PIPE256X3 = 5, MRG_GEMM_PIPE256SQ = 6, MRG_GEMM_WS256 = 7, MRG_GEMM_GLDS64 = 8, MRG_GEMM_SQP = 9, MRG_GEMM_G256 = 10, MRG_GEMM_P8 = 11 };
 
 int mrg_gemm(const mrg_gemm_desc* d, hipStream_t stream);
 

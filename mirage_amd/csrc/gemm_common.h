@@ -1,0 +1,476 @@
+// Shared pieces of the bf16 MFMA GEMM kernels (gemm.hip, gemm8p.hip): argument block, tile loaders, LDS fragment reads,
+// fused epilogue rows.  The argument block is a named type (it crosses translation units); the device helpers live in an anonymous namespace.
+#pragma once
+#include "common.h"
+#include "mirage_hip.h"
+#include <cstdlib>
+
+namespace mrg_detail {
+
+
+constexpr int BM = 128, BN = 128, BK = 64;
+constexpr int TILE_BYTES = 128 * 64 * 2;  // 16 KiB per operand tile
+
+struct GemmArgs {
+    const bf16_t* A; const bf16_t* B;
+    int M, N, K, lda, ldb;
+    const int* a_map; const int* b_map;
+    const int* m_dev; const int* k_dev;
+    int a_aligned, b_aligned;
+    // epilogue
+    void* C; int ldc; int c_f32;
+    bf16_t* C2; int ldc2;
+    const float* bias;
+    const float* resid; int ldr;
+    int accumulate;
+    int act;
+    bf16_t* aux_out; const bf16_t* aux_in; int ldaux;
+    const int* row_map;
+    const float* add_tab; const int* add_row; int ldt;
+    const float* row_scale;
+    float* colsum;             // [tiles_m][N]: column sums of the final C values per 128-row tile (single-stage kernel only)
+    int splitk; float* ws;
+    int tiles_m, tiles_n;
+    int epi_kind;  // 0 generic epilogue; lean paths: 1 (+bias) -> bf16 C; 2 (+bias)(*row_scale) + fp32 residual -> fp32 C (+ bf16 twin);
+                   // 3 bias + GELU with fp16 GELU' side output; 4 multiply by the fp16 side input -> bf16 C (1 and 4 also with column sums);
+                   // 5 bias + GELU -> bf16 C; 6 bias + table row -> fp32 C at a mapped row (patch embedding)
+    int side_drain; // MRG_GEMM_SIDE_DRAIN (bit 0: batched drain of the lean epilogues, bit 1: of the split-K slab stores; default 3)
+    int xcd_split; // MRG_GEMM_XCD_SPLIT (default 1): split-K index slowest in the XCD band order
+    int nt;       // MRG_GEMM_NT: 0 plain stores, 1 streaming (nontemporal) stores for C / C2 / aux_out, 2 (default) for aux_out only
+    int ablate;   // MRG_GEMM_ABLATE (256x128 kernel only, for roofline analysis): 1 = no DMA, 2 = DMA only, 3 = DMA + LDS reads, no MFMA
+};
+
+}  // namespace mrg_detail
+using namespace mrg_detail;
+
+// launcher of the 256 x 256 8-phase kernel (gemm8p.hip); returns false when the problem is outside its domain
+bool mrg_gemm8p_launch(const mrg_detail::GemmArgs& g, int a_mode, int b_mode, bool vec, int splitk, hipStream_t stream);
+
+namespace {
+
+// ---- global -> register staging -------------------------------------------------------------------
+// KCONTIG tile: [128 rows][64 k]; chunk q (16 B): row = q>>3, c = q&7
+// KSTRIDED tile: [64 k][128 rows]; chunk q: kr = q>>4, c = q&15
+template <int MODE, bool ALIGNED>
+__device__ __forceinline__ void load_tile(uint4 (&r)[4], const bf16_t* __restrict__ P, int ld, int row0, int nrows,
+                                          int k0, int kmax, const int* __restrict__ map, int tid) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int q = tid + 256 * j;
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (MODE == MRG_OP_KCONTIG) {
+            const int row = row0 + (q >> 3);
+            const int k = k0 + ((q & 7) << 3);
+            if (row < nrows && k < kmax) {
+                const long src = (long)(map ? map[row] : row) * ld + k;
+                if (ALIGNED) {
+                    v = *reinterpret_cast<const uint4*>(P + src);
+                } else {
+                    bf16_t e[8];
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) e[i] = (k + i < kmax) ? P[src + i] : (bf16_t)0;
+                    v = make_uint4(e[0] | (e[1] << 16), e[2] | (e[3] << 16), e[4] | (e[5] << 16), e[6] | (e[7] << 16));
+                }
+            }
+        } else {
+            const int k = k0 + (q >> 4);
+            const int row = row0 + ((q & 15) << 3);
+            if (k < kmax && row < nrows) {
+                const long src = (long)(map ? map[k] : k) * ld + row;
+                if (ALIGNED) {
+                    v = *reinterpret_cast<const uint4*>(P + src);
+                } else {
+                    bf16_t e[8];
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) e[i] = (row + i < nrows) ? P[src + i] : (bf16_t)0;
+                    v = make_uint4(e[0] | (e[1] << 16), e[2] | (e[3] << 16), e[4] | (e[5] << 16), e[6] | (e[7] << 16));
+                }
+            }
+        }
+        r[j] = v;
+    }
+}
+
+template <int MODE>
+__device__ __forceinline__ void store_tile(const uint4 (&r)[4], char* lds, int tid) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int q = tid + 256 * j;
+        int off;
+        if (MODE == MRG_OP_KCONTIG) {
+            const int row = q >> 3, c = q & 7;
+            off = row * 128 + ((c ^ ((row >> 1) & 7)) << 4);
+        } else {
+            const int kr = q >> 4, c = q & 15;
+            off = kr * 256 + ((c ^ ((kr & 3) << 2)) << 4);
+        }
+        *reinterpret_cast<uint4*>(lds + off) = r[j];
+    }
+}
+
+// ---- LDS -> MFMA fragment -------------------------------------------------------------------------
+// 32x32x16 operand: lane l holds row (l&31), k-slots 8*(l>>5)..+7 of the 16-deep step kk.
+template <int MODE>
+__device__ __forceinline__ bf16x8 read_frag(const char* lds, uint32_t lds_base, int row_in_tile, int kk, int lane) {
+    if (MODE == MRG_OP_KCONTIG) {
+        const int row = row_in_tile + (lane & 31);
+        const int c = kk * 2 + (lane >> 5);
+        return *reinterpret_cast<const bf16x8*>(lds + row * 128 + ((c ^ ((row >> 1) & 7)) << 4));
+    } else {
+        // k-row of this lane = 16 kk + 8 (lane >> 5) + (i >> 2) [+ 4]: the swizzle only sees k-row & 3 = (i >> 2) & 3, so the lane
+        // part of the address is independent of kk and of the +4 row and both become immediate offsets of the LDS instruction
+        const int i = lane & 15;
+        const int col = row_in_tile + (lane & 16) + ((i & 3) << 2);
+        const int krl = ((lane >> 5) << 3) + (i >> 2);
+        const uint32_t a0 = lds_base + krl * 256 + ((((col >> 3) ^ ((krl & 3) << 2))) << 4) + ((col & 4) << 1);
+        const s16x4 lo = lds_read_tr16_off(a0, kk * 4096);
+        const s16x4 hi = lds_read_tr16_off(a0, kk * 4096 + 1024);
+        bf16x8 f;
+        f[0] = lo[0]; f[1] = lo[1]; f[2] = lo[2]; f[3] = lo[3];
+        f[4] = hi[0]; f[5] = hi[1]; f[6] = hi[2]; f[7] = hi[3];
+        return f;
+    }
+}
+
+// two batches of four row segments (see drain_side); row_of, ct, cl, col, bv, Meff are the caller's
+#define MRG_DRAIN8_W(KIND_, CS_, CSP_, W_) do { \
+        drain_side<KIND_, CS_, 4, W_>(g, ct, cl, col, bv, Meff, [&](int it, int& rl, int& row) { row_of(it, rl, row); }, CSP_); \
+        drain_side<KIND_, CS_, 4, W_>(g, ct, cl, col, bv, Meff, [&](int it, int& rl, int& row) { row_of(it + 4, rl, row); }, CSP_); } while (0)
+#define MRG_DRAIN8(KIND_, CS_, CSP_) do { \
+        drain_side<KIND_, CS_, 4, BN>(g, ct, cl, col, bv, Meff, [&](int it, int& rl, int& row) { row_of(it, rl, row); }, CSP_); \
+        drain_side<KIND_, CS_, 4, BN>(g, ct, cl, col, bv, Meff, [&](int it, int& rl, int& row) { row_of(it + 4, rl, row); }, CSP_); } while (0)
+
+// a / b for 0 <= a < 2^22, b > 0 without the ~40-instruction integer division (v_rcp_f32 is within 1 ulp, so the quotient is
+// off by at most one before the fix-up); the tile-coordinate prologue has four of them per workgroup
+__device__ __forceinline__ int fast_udiv(int a, int b) {
+    int q = (int)((float)a * __builtin_amdgcn_rcpf((float)b));
+    int r = a - q * b;
+    if (r < 0) { --q; r += b; }
+    if (r >= b) ++q;
+    return q;
+}
+
+// XCD-aware workgroup order.  Workgroups are dispatched round-robin over the 8 XCDs (each with its own L2) in linear order
+// (x fastest, then y); XCD x is given one contiguous band of the logical (split, tile) space with the split-K index slowest, so the
+// workgroups sharing an L2 work on the same k-range and on neighbouring tiles (with the split index taken from blockIdx.y instead,
+// every XCD streams every k-range: 2.4x the operand bytes from HBM on the fc1/fc2 wgrad shapes, profiles/r01_c2_pmc_traffic.md).
+__device__ __forceinline__ void wg_remap(int nwg, int xcd_split, int& bid, int& ksplit) {
+    if (xcd_split) {
+        const int L = blockIdx.x + blockIdx.y * gridDim.x, total = nwg * gridDim.y;
+        const int q = total >> 3, r = total & 7, xcd = L & 7, idx = L >> 3;
+        const int lin = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+        ksplit = gridDim.y > 1 ? fast_udiv(lin, nwg) : 0;
+        bid = lin - ksplit * nwg;
+    } else {
+        const int b = blockIdx.x;
+        const int q = nwg >> 3, r = nwg & 7, xcd = b & 7, idx = b >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+        ksplit = blockIdx.y;
+    }
+}
+
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void st_out(u32x2* p, const u32x2 v, int nt) {
+    if (nt) asm volatile("global_store_dwordx2 %0, %1, off nt" :: "v"(p), "v"(v) : "memory"); else *p = v;
+}
+__device__ __forceinline__ void st_out(f32x4v* p, const f32x4v v, int nt) {
+    if (nt) asm volatile("global_store_dwordx4 %0, %1, off nt" :: "v"(p), "v"(v) : "memory"); else *p = v;
+}
+
+// one output row segment (4 consecutive columns) of the fused epilogue
+template <bool VEC, bool CS = false>
+__device__ __forceinline__ void epi_row(const GemmArgs& g, const float4 a4, const float (&bv)[4], float* ws, int row, int col, int nv,
+                                        float* cs = nullptr) {
+        float v[4] = {a4.x, a4.y, a4.z, a4.w};
+        if (ws) {
+            float* w = ws + (long)row * g.N + col;
+            if (VEC) *reinterpret_cast<float4*>(w) = a4;
+            else { for (int e = 0; e < nv; ++e) w[e] = v[e]; }
+            return;
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] += bv[e];
+        if (g.act == MRG_ACT_GELU) {
+            if (g.aux_out) {
+                bf16_t* ao = g.aux_out + (long)row * g.ldaux + col;
+                if (VEC) st_out(reinterpret_cast<u32x2*>(ao), u32x2{pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3])}, g.nt);
+                else { for (int e = 0; e < nv; ++e) ao[e] = f2bf(v[e]); }
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = gelu_f(v[e]);
+        } else if (g.act == MRG_ACT_GELU_SAVE_GRAD) {
+            float gd[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float c, p;
+                gelu_parts(v[e], c, p);
+                gd[e] = c + v[e] * p;
+                v[e] = v[e] * c;
+            }
+            if (g.aux_out) {
+                _Float16* ao = reinterpret_cast<_Float16*>(g.aux_out) + (long)row * g.ldaux + col;
+                if (VEC) {
+                    typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+                    const h2 lo = {(_Float16)gd[0], (_Float16)gd[1]}, hi = {(_Float16)gd[2], (_Float16)gd[3]};
+                    st_out(reinterpret_cast<u32x2*>(ao), u32x2{*reinterpret_cast<const uint32_t*>(&lo), *reinterpret_cast<const uint32_t*>(&hi)}, g.nt);
+                } else { for (int e = 0; e < nv; ++e) ao[e] = (_Float16)gd[e]; }
+            }
+        } else if (g.act == MRG_ACT_MUL_AUX_F16) {
+            const _Float16* ai = reinterpret_cast<const _Float16*>(g.aux_in) + (long)row * g.ldaux + col;
+            if (VEC) {
+                typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+                const h4 x4 = *reinterpret_cast<const h4*>(ai);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] *= (float)x4[e];
+            } else { for (int e = 0; e < nv; ++e) v[e] *= (float)ai[e]; }
+        } else if (g.act == MRG_ACT_GELU_BWD) {
+            const bf16_t* ai = g.aux_in + (long)row * g.ldaux + col;
+            float x[4] = {0.f, 0.f, 0.f, 0.f};
+            if (VEC) {
+                const uint2 u = *reinterpret_cast<const uint2*>(ai);
+                x[0] = __uint_as_float(u.x << 16); x[1] = __uint_as_float(u.x & 0xffff0000u);
+                x[2] = __uint_as_float(u.y << 16); x[3] = __uint_as_float(u.y & 0xffff0000u);
+            } else { for (int e = 0; e < nv; ++e) x[e] = bf2f(ai[e]); }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] *= gelu_grad_f(x[e]);
+        }
+        if (g.row_scale) {
+            const float rs = g.row_scale[row];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] *= rs;
+        }
+        if (g.add_tab) {
+            const float* t = g.add_tab + (long)g.add_row[row] * g.ldt + col;
+            if (VEC) { const float4 t4 = *reinterpret_cast<const float4*>(t); v[0] += t4.x; v[1] += t4.y; v[2] += t4.z; v[3] += t4.w; }
+            else { for (int e = 0; e < nv; ++e) v[e] += t[e]; }
+        }
+        if (g.resid) {
+            const float* t = g.resid + (long)row * g.ldr + col;
+            if (VEC) { const float4 t4 = *reinterpret_cast<const float4*>(t); v[0] += t4.x; v[1] += t4.y; v[2] += t4.z; v[3] += t4.w; }
+            else { for (int e = 0; e < nv; ++e) v[e] += t[e]; }
+        }
+        if (CS) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) cs[e] += e < nv ? v[e] : 0.f;
+        }
+        const long orow = g.row_map ? g.row_map[row] : row;
+        if (g.c_f32) {
+            float* c = reinterpret_cast<float*>(g.C) + orow * g.ldc + col;
+            if (VEC) {
+                if (g.accumulate) { const float4 o = *reinterpret_cast<const float4*>(c); v[0] += o.x; v[1] += o.y; v[2] += o.z; v[3] += o.w; }
+                st_out(reinterpret_cast<f32x4v*>(c), f32x4v{v[0], v[1], v[2], v[3]}, g.nt == 1);
+            } else {
+                for (int e = 0; e < nv; ++e) { if (g.accumulate) v[e] += c[e]; c[e] = v[e]; }
+            }
+        } else {
+            bf16_t* c = reinterpret_cast<bf16_t*>(g.C) + orow * g.ldc + col;
+            if (VEC) st_out(reinterpret_cast<u32x2*>(c), u32x2{pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3])}, g.nt == 1);
+            else { for (int e = 0; e < nv; ++e) c[e] = f2bf(v[e]); }
+        }
+        if (g.C2) {
+            bf16_t* c = g.C2 + orow * g.ldc2 + col;
+            if (VEC) st_out(reinterpret_cast<u32x2*>(c), u32x2{pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3])}, g.nt == 1);
+            else { for (int e = 0; e < nv; ++e) c[e] = f2bf(v[e]); }
+        }
+}
+
+// Lean epilogues for the two commonest cases: the generic epi_row spends ~40 scalar instructions per 4 outputs on branches that are
+// uniform over the whole launch (at K = 768 the epilogue + prologue of a 128 x 128 tile issue more instructions than its main loop).
+template <bool VEC, bool CS = false>
+__device__ __forceinline__ void epi_row_bf16(const GemmArgs& g, const float4 a4, const float (&bv)[4], int row, int col, int nv, float* cs = nullptr) {
+    const float v[4] = {a4.x + bv[0], a4.y + bv[1], a4.z + bv[2], a4.w + bv[3]};
+    bf16_t* c = reinterpret_cast<bf16_t*>(g.C) + (long)row * g.ldc + col;
+    if (VEC) *reinterpret_cast<u32x2*>(c) = u32x2{pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3])};
+    else { for (int e = 0; e < nv; ++e) c[e] = f2bf(v[e]); }
+    if (CS) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) cs[e] += e < nv ? v[e] : 0.f;
+    }
+}
+// fc1 forward: bias -> GELU; stores gelu(x) as bf16 and gelu'(x) as fp16 (MRG_ACT_GELU_SAVE_GRAD)
+template <bool VEC>
+__device__ __forceinline__ void epi_row_gelu_save(const GemmArgs& g, const float4 a4, const float (&bv)[4], int row, int col, int nv) {
+    float v[4] = {a4.x + bv[0], a4.y + bv[1], a4.z + bv[2], a4.w + bv[3]}, gd[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        float c, p;
+        gelu_parts(v[e], c, p);
+        gd[e] = c + v[e] * p;
+        v[e] = v[e] * c;
+    }
+    _Float16* ao = reinterpret_cast<_Float16*>(g.aux_out) + (long)row * g.ldaux + col;
+    bf16_t* c = reinterpret_cast<bf16_t*>(g.C) + (long)row * g.ldc + col;
+    if (VEC) {
+        typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+        const h2 lo = {(_Float16)gd[0], (_Float16)gd[1]}, hi = {(_Float16)gd[2], (_Float16)gd[3]};
+        st_out(reinterpret_cast<u32x2*>(ao), u32x2{*reinterpret_cast<const uint32_t*>(&lo), *reinterpret_cast<const uint32_t*>(&hi)}, g.nt);
+        *reinterpret_cast<u32x2*>(c) = u32x2{pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3])};
+    } else {
+        for (int e = 0; e < nv; ++e) { ao[e] = (_Float16)gd[e]; c[e] = f2bf(v[e]); }
+    }
+}
+// patch embedding: bias + positional row (table lookup) -> fp32 C at a mapped row (token-select fused into the projection)
+template <bool VEC>
+__device__ __forceinline__ void epi_row_embed(const GemmArgs& g, const float4 a4, const float (&bv)[4], int row, int col, int nv) {
+    float v[4] = {a4.x + bv[0], a4.y + bv[1], a4.z + bv[2], a4.w + bv[3]};
+    const float* t = g.add_tab + (long)g.add_row[row] * g.ldt + col;
+    float* c = reinterpret_cast<float*>(g.C) + (long)g.row_map[row] * g.ldc + col;
+    if (VEC) {
+        const float4 t4 = *reinterpret_cast<const float4*>(t);
+        *reinterpret_cast<float4*>(c) = make_float4(v[0] + t4.x, v[1] + t4.y, v[2] + t4.z, v[3] + t4.w);
+    } else {
+        for (int e = 0; e < nv; ++e) c[e] = v[e] + t[e];
+    }
+}
+// inference fc1: bias -> GELU -> bf16 (MRG_ACT_GELU without a saved pre-activation)
+template <bool VEC>
+__device__ __forceinline__ void epi_row_gelu(const GemmArgs& g, const float4 a4, const float (&bv)[4], int row, int col, int nv) {
+    const float v[4] = {gelu_f(a4.x + bv[0]), gelu_f(a4.y + bv[1]), gelu_f(a4.z + bv[2]), gelu_f(a4.w + bv[3])};
+    bf16_t* c = reinterpret_cast<bf16_t*>(g.C) + (long)row * g.ldc + col;
+    if (VEC) *reinterpret_cast<u32x2*>(c) = u32x2{pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3])};
+    else { for (int e = 0; e < nv; ++e) c[e] = f2bf(v[e]); }
+}
+// fc2 dgrad: multiply by the saved fp16 GELU' (MRG_ACT_MUL_AUX_F16), optional column sums (the fc1 bias gradient)
+template <bool VEC, bool CS = false>
+__device__ __forceinline__ void epi_row_mulaux(const GemmArgs& g, const float4 a4, const float (&bv)[4], int row, int col, int nv, float* cs = nullptr) {
+    float v[4] = {a4.x + bv[0], a4.y + bv[1], a4.z + bv[2], a4.w + bv[3]};
+    const _Float16* ai = reinterpret_cast<const _Float16*>(g.aux_in) + (long)row * g.ldaux + col;
+    bf16_t* c = reinterpret_cast<bf16_t*>(g.C) + (long)row * g.ldc + col;
+    if (VEC) {
+        typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+        const h4 x4 = *reinterpret_cast<const h4*>(ai);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] *= (float)x4[e];
+        *reinterpret_cast<u32x2*>(c) = u32x2{pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3])};
+    } else {
+        for (int e = 0; e < nv; ++e) { v[e] *= (float)ai[e]; c[e] = f2bf(v[e]); }
+    }
+    if (CS) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) cs[e] += e < nv ? v[e] : 0.f;
+    }
+}
+template <bool VEC>
+__device__ __forceinline__ void epi_row_resid(const GemmArgs& g, const float4 a4, const float (&bv)[4], int row, int col, int nv) {
+    float v[4] = {a4.x + bv[0], a4.y + bv[1], a4.z + bv[2], a4.w + bv[3]};
+    if (g.row_scale) {
+        const float rs = g.row_scale[row];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] *= rs;
+    }
+    const float* t = g.resid + (long)row * g.ldr + col;
+    float* c = reinterpret_cast<float*>(g.C) + (long)row * g.ldc + col;
+    if (VEC) {
+        const float4 t4 = *reinterpret_cast<const float4*>(t);
+        v[0] += t4.x; v[1] += t4.y; v[2] += t4.z; v[3] += t4.w;
+        *reinterpret_cast<float4*>(c) = make_float4(v[0], v[1], v[2], v[3]);
+        if (g.C2) *reinterpret_cast<u32x2*>(g.C2 + (long)row * g.ldc2 + col) = u32x2{pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3])};
+    } else {
+        for (int e = 0; e < nv; ++e) { v[e] += t[e]; c[e] = v[e]; if (g.C2) g.C2[(long)row * g.ldc2 + col + e] = f2bf(v[e]); }
+    }
+}
+template <bool VEC>
+__device__ __forceinline__ void epi_any(const GemmArgs& g, const float4 a4, const float (&bv)[4], float* ws, int row, int col, int nv) {
+    if (g.epi_kind == 1) epi_row_bf16<VEC>(g, a4, bv, row, col, nv);
+    else if (g.epi_kind == 2) epi_row_resid<VEC>(g, a4, bv, row, col, nv);
+    else if (g.epi_kind == 3) epi_row_gelu_save<VEC>(g, a4, bv, row, col, nv);
+    else if (g.epi_kind == 4) epi_row_mulaux<VEC>(g, a4, bv, row, col, nv);
+    else if (g.epi_kind == 5) epi_row_gelu<VEC>(g, a4, bv, row, col, nv);
+    else if (g.epi_kind == 6) epi_row_embed<VEC>(g, a4, bv, row, col, nv);
+    else epi_row<VEC>(g, a4, bv, ws, row, col, nv);
+}
+template <bool VEC>
+__device__ __forceinline__ void epi_any_cs(const GemmArgs& g, const float4 a4, const float (&bv)[4], float* ws, int row, int col, int nv, float* cs) {
+    if (g.epi_kind == 1) epi_row_bf16<VEC, true>(g, a4, bv, row, col, nv, cs);
+    else if (g.epi_kind == 4) epi_row_mulaux<VEC, true>(g, a4, bv, row, col, nv, cs);
+    else epi_row<VEC, true>(g, a4, bv, ws, row, col, nv, cs);
+}
+
+// Two-phase drain of one staged pass for the epilogues that read a side operand per output (fp32 residual, fp16 GELU'): the side
+// operands of all NIT row segments are requested before the first one is consumed.  The row-at-a-time loop exposes one global
+// round trip per iteration (8-16 dependent ones per thread and pass).  row_of(it, rl, row): staging row / output row of step it.
+template <int KIND, bool CS, int NIT, int CTW, typename RowOf>
+__device__ __forceinline__ void drain_side(const GemmArgs& g, const float* ct, int cl, int col, const float (&bv)[4], int Meff,
+                                           RowOf row_of, float* cs) {
+    typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+    float4 a[NIT], t[NIT];
+    h4 x[NIT];
+    float rs[NIT];
+    int rows[NIT];
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        int rl, row;
+        row_of(it, rl, row);
+        rows[it] = row;
+        const long rr = row < Meff ? row : Meff - 1;              // clamped: the load is unconditional, only the store is masked
+        a[it] = *reinterpret_cast<const float4*>(ct + rl * CTW + cl);
+        if (KIND == 2) {
+            t[it] = *reinterpret_cast<const float4*>(g.resid + rr * g.ldr + col);
+            rs[it] = g.row_scale ? g.row_scale[rr] : 1.f;
+        } else if (KIND == 4) {
+            x[it] = *reinterpret_cast<const h4*>(reinterpret_cast<const _Float16*>(g.aux_in) + rr * g.ldaux + col);
+        }
+    }
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        const int row = rows[it];
+        if (row < Meff) {
+            if (KIND == 7) { *reinterpret_cast<float4*>(cs + (long)row * g.N + col) = a[it]; continue; }      // split-K slab (cs = slab base)
+            if (KIND == 1) { epi_row_bf16<true, CS>(g, a[it], bv, row, col, 4, cs); continue; }
+            if (KIND == 3) { epi_row_gelu_save<true>(g, a[it], bv, row, col, 4); continue; }
+            if (KIND == 5) { epi_row_gelu<true>(g, a[it], bv, row, col, 4); continue; }
+            float v[4] = {a[it].x + bv[0], a[it].y + bv[1], a[it].z + bv[2], a[it].w + bv[3]};
+            if (KIND == 2) {
+                if (g.row_scale) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] *= rs[it];
+                }
+                v[0] += t[it].x; v[1] += t[it].y; v[2] += t[it].z; v[3] += t[it].w;
+                *reinterpret_cast<float4*>(reinterpret_cast<float*>(g.C) + (long)row * g.ldc + col) = make_float4(v[0], v[1], v[2], v[3]);
+                if (g.C2) *reinterpret_cast<u32x2*>(g.C2 + (long)row * g.ldc2 + col) = u32x2{pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3])};
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] *= (float)x[it][e];
+                *reinterpret_cast<u32x2*>(reinterpret_cast<bf16_t*>(g.C) + (long)row * g.ldc + col) = u32x2{pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3])};
+                if (CS) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) cs[e] += v[e];
+                }
+            }
+        }
+    }
+}
+
+
+// K-multiple-of-64 fast loader: per operand one wave-uniform 64-bit base (advanced by scalar adds per k-tile) plus a constant 32-bit
+// per-lane byte offset per 1 KiB LDS block, so a DMA is s_mov m0 + global_load_lds with an SGPR base: no per-lane 64-bit pointers
+// (48 VGPRs in the general loader), no pointer increments and no zero-page selects in the k loop.  Rows past the operand's edge are
+// clamped to a valid row instead of zero-filled (their products land in output rows / columns that are never stored).
+template <int MODE>
+__device__ __forceinline__ uint32_t glds_lane_off(int ld, int row0, int nrows, int b, int lane) {
+    if (MODE == MRG_OP_KCONTIG) {
+        const int r = b * 8 + (lane >> 3);
+        const int c = (lane & 7) ^ ((r >> 1) & 7);
+        const int rr = min(row0 + r, nrows - 1) - row0;
+        return (uint32_t)(rr * ld * 2 + (c << 4));
+    } else {
+        const int kr = b * 4 + (lane >> 4);
+        const int c = (lane & 15) ^ ((kr & 3) << 2);
+        const int col = (row0 + (c << 3) < nrows) ? (c << 3) : 0;
+        return (uint32_t)(kr * ld * 2 + col * 2);
+    }
+}
+// LDS-DMA with a scalar base: global address = sbase + voff, LDS destination = lds_wave_base + 16 * lane
+__device__ __forceinline__ void glds16_s(const char* sbase, uint32_t voff, uint32_t lds_wave_base) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(lds_wave_base) : "memory");
+}
+__device__ __forceinline__ const char* uniform_ptr(const char* p) {
+    const uint64_t v = (uint64_t)p;
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v), hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
+    return (const char*)(((uint64_t)hi << 32) | lo);
+}
+
+}  // namespace

@@ -125,6 +125,67 @@ def test_gemm_every_variant_same_result(K, variant):
     assert float((part[901:] - 3.0).abs().max()) == 0.0
 
 
+@pytest.mark.parametrize("M,N,Kd,splitk", [(8256, 768, 768, 1), (640, 512, 64, 1), (1000, 328, 128, 1), (512, 256, 1152, 3), (300, 264, 192, 1)])
+def test_gemm_p8_all_layouts(K, M, N, Kd, splitk):
+    """256 x 256 8-phase kernel (gemm8p.hip): forward (x W^T), dgrad (dy W) and wgrad (dy^T x) operand layouts with ragged M / N
+    edges (last tile rows past M, half-tiles starting past the edge), 1..18 k-tiles, split-K, against fp32 matmuls of the same
+    bf16 inputs.  Random asymmetric data: a transposed or permuted tile cannot pass."""
+    from mirage_amd import _lib as L
+    A = rnd(M, Kd, dtype=BF16, seed=61); W = rnd(N, Kd, scale=0.05, dtype=BF16, seed=62); b = rnd(N, seed=63)
+    Wt = rnd(Kd, N, scale=0.05, dtype=BF16, seed=64)
+    K.TUNE["force"] = L.MRG_GEMM_P8
+    try:
+        out = K.gemm(A, W, M, N, Kd, bias=b, out_dtype=BF16, splitk=1)
+        o32 = K.gemm(A, W, M, N, Kd, out_dtype=F32, splitk=splitk)
+        dg = K.gemm(A, Wt, M, N, Kd, b_mode=L.MRG_OP_KSTRIDED, out_dtype=F32, splitk=splitk)
+        if M % 8 == 0 and N % 8 == 0:
+            dy = rnd(Kd * 4, M, dtype=BF16, seed=65)[:, :] ; x = rnd(Kd * 4, N, scale=0.05, dtype=BF16, seed=66)      # tokens = 4 Kd
+            wg = K.gemm(dy, x, M, N, Kd * 4, a_mode=L.MRG_OP_KSTRIDED, b_mode=L.MRG_OP_KSTRIDED, out_dtype=F32, splitk=max(splitk, 2))
+        else:
+            wg = None
+    finally:
+        K.TUNE["force"] = None
+    lin = A.float() @ W.float().t()
+    torch.testing.assert_close(o32, lin, rtol=2e-3, atol=2e-3 * float(lin.abs().max()))
+    assert rel_rms(out.float(), lin + b) < 4e-3
+    ref = A.float() @ Wt.float()
+    torch.testing.assert_close(dg, ref, rtol=2e-3, atol=2e-3 * float(ref.abs().max()))
+    if wg is not None:
+        r3 = dy.float().t() @ x.float()
+        torch.testing.assert_close(wg, r3, rtol=3e-3, atol=3e-3 * float(r3.abs().max()))
+
+
+def test_gemm_p8_fused_epilogues_and_repeatability(K):
+    """The lean epilogues through the 8-phase kernel (fp32 residual + bf16 twin, GELU with the fp16 GELU' side output, multiply by
+    the side input) and run-to-run bit-identity over 20 launches (a staging race would show up as a rare differing tile)."""
+    from mirage_amd import _lib as L
+    M, N, Kd = 2112, 1024, 768
+    A = rnd(M, Kd, dtype=BF16, seed=71); W = rnd(N, Kd, scale=0.05, dtype=BF16, seed=72); b = rnd(N, seed=73)
+    res = rnd(M, N, seed=74)
+    K.TUNE["force"] = L.MRG_GEMM_P8
+    try:
+        o = torch.empty(M, N, device=dev()); o2 = torch.empty(M, N, dtype=BF16, device=dev())
+        K.gemm(A, W, M, N, Kd, bias=b, out=o, out2=o2, resid=res)
+        aux = torch.empty(M, N, dtype=torch.float16, device=dev())
+        act = K.gemm(A, W, M, N, Kd, bias=b, act=L.MRG_ACT_GELU_SAVE_GRAD, aux_out=aux)
+        mul = K.gemm(A, W, M, N, Kd, act=L.MRG_ACT_MUL_AUX_F16, aux_in=aux)
+        first = K.gemm(A, W, M, N, Kd, bias=b, out_dtype=F32).clone()
+        for _ in range(20):
+            again = K.gemm(A, W, M, N, Kd, bias=b, out_dtype=F32)
+            assert torch.equal(first, again)
+    finally:
+        K.TUNE["force"] = None
+    lin = A.float() @ W.float().t() + b
+    torch.testing.assert_close(o, lin + res, rtol=2e-3, atol=2e-3 * float(lin.abs().max()))
+    assert torch.equal(o2, o.to(BF16))
+    assert rel_rms(act.float(), torch.nn.functional.gelu(lin)) < 5e-3
+    xg = lin.double()
+    gd = 0.5 * (1 + torch.erf(xg / 2 ** 0.5)) + xg * torch.exp(-0.5 * xg * xg) / (2 * 3.141592653589793) ** 0.5
+    assert rel_rms(aux.float(), gd.float()) < 3e-3
+    assert rel_rms(mul.float(), (lin - b) * aux.float()) < 5e-3
+    torch.testing.assert_close(first, lin, rtol=2e-3, atol=2e-3 * float(lin.abs().max()))
+
+
 def test_gemm_epilogues(K):
     from mirage_amd import _lib as L
     M, N, Kd = 517, 384, 256
