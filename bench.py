@@ -352,7 +352,7 @@ def _run(real_stdout: int):
         torch.cuda.synchronize()
         vname = {0: "auto", 1: "gemm_glds_kernel", 2: "gemm_glds_kernel", 3: "gemm_pipe_kernel", 4: "gemm_pipe256_kernel",
                  5: "gemm_pipe256_kernel", 6: "gemm_pipe256sq_kernel", 7: "gemm_ws256_kernel", 8: "gemm_glds64_kernel",
-                 10: "gemm_g256_kernel"}
+                 10: "gemm_g256_kernel", 11: "gemm_p8_kernel"}
         mname = {(0, 0): "forward x*W^T", (0, 1): "dgrad dy*W", (1, 1): "wgrad dy^T*x"}
         groups = {}
         shapes = {}
@@ -407,7 +407,7 @@ def _run(real_stdout: int):
         if os.environ.get("MRG_TUNE_SAVE") == "1":
             K.save_tune_cache()
         if os.environ.get("MRG_TUNE_LOG") == "1":
-            names = {1: "glds3", 2: "glds4", 3: "pipe128", 4: "pipe256", 5: "pipe256x3", 6: "pipe256sq", 7: "ws256", 8: "glds64", 10: "g256"}
+            names = {1: "glds3", 2: "glds4", 3: "pipe128", 4: "pipe256", 5: "pipe256x3", 6: "pipe256sq", 7: "ws256", 8: "glds64", 10: "g256", 11: "p8"}
             for key, (v, sk), us in K.TUNE["log"]:
                 am, bm, M_, N_, K_ = key[:5]
                 print(f"tune mode=({am},{bm}) {M_}x{N_}x{K_} act={key[5]} -> {names.get(v, v)} splitk={sk} {us:.1f} us {2.0 * M_ * N_ * K_ / us / 1e6:.0f} TF/s",

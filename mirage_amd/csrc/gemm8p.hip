@@ -95,7 +95,7 @@ struct P8Frag {
     }
 };
 
-template <int AMODE, int BMODE, bool VEC>
+template <int AMODE, int BMODE, bool VEC, int PHASES>
 __global__ __launch_bounds__(512) void gemm_p8_kernel(const GemmArgs g) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tiles_m = (g.M + 255) / 256, tiles_n = (g.N + 255) / 256;
@@ -148,8 +148,16 @@ __global__ __launch_bounds__(512) void gemm_p8_kernel(const GemmArgs g) {
     const long step_a = AMODE == MRG_OP_KCONTIG ? BK * 2 : (long)BK * g.lda * 2, step_b = BMODE == MRG_OP_KCONTIG ? BK * 2 : (long)BK * g.ldb * 2;
     const uint32_t dst_w = sbase + (uint32_t)(wave * 2048);            // this wave's two 1 KiB blocks inside any half-tile
     // slot s of k-tile T (relative to t0): 0 = A half 0, 1 = B half 0, 2 = B half 1, 3 = A half 1 (order of first use = last read)
+    // MRG_GEMM_ABLATE bits (roofline analysis, builds with -DMRG_P8_ABLATE only: the run-time checks alone cost ~20 %):
+    // 1 no DMA in the loop, 2 no MFMA, 4 no LDS fragment reads, 8 no setprio, 16 no stagger
+#ifdef MRG_P8_ABLATE
+    const int abl = g.ablate;
+#else
+    constexpr int abl = 0;
+#endif
+    bool in_loop = false;
     auto stage = [&](int T, int slot) {
-        if (T >= nt) return;
+        if (T >= nt || (in_loop && (abl & 1))) return;
         const int buf = T & 1;
         if (slot == 0 || slot == 3) {
             const int h = slot == 3;
@@ -176,44 +184,94 @@ __global__ __launch_bounds__(512) void gemm_p8_kernel(const GemmArgs g) {
         if (nt >= 2) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
-        if (wm == 1) __builtin_amdgcn_s_barrier();               // the second M-half runs one barrier behind the first
+        if (wm == 1 && !(abl & 16)) __builtin_amdgcn_s_barrier();               // the second M-half runs one barrier behind the first
         __builtin_amdgcn_sched_barrier(0);
+        in_loop = true;
 
-        bf16x8 fa[2][4], fb0[4], fb1[4];
+        bf16x8 fa[2][4] = {}, fb0[4] = {}, fb1[4] = {};
         // The MFMAs are pure register instructions: nothing but data dependences keeps the compiler from floating them across
         // the barriers / priority changes (sched_barrier only pins what instruction selection already ordered).  The two empty
         // asm statements make the cluster's accumulators "produced" after the first barrier and "consumed" before the second.
 #define P8_MFMA(I0, J, FB) do { \
         __builtin_amdgcn_s_barrier(); \
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); \
-        __builtin_amdgcn_s_setprio(1); \
+        if (!(abl & 8)) __builtin_amdgcn_s_setprio(1); \
         asm volatile("" : "+v"(acc[I0][J]), "+v"(acc[I0 + 1][J]) :: "memory"); \
+        if (!(abl & 2)) { \
         _Pragma("unroll") for (int kk = 0; kk < 4; ++kk) { \
             acc[I0][J] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[0][kk], FB[kk], acc[I0][J], 0, 0, 0); \
             acc[I0 + 1][J] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[1][kk], FB[kk], acc[I0 + 1][J], 0, 0, 0); \
-        } \
+        } } else { asm volatile("" :: "v"(fa[0][0]), "v"(fa[1][3]), "v"(FB[0]), "v"(FB[3])); } \
         asm volatile("" : "+v"(acc[I0][J]), "+v"(acc[I0 + 1][J]) :: "memory"); \
         __builtin_amdgcn_s_setprio(0); \
         __builtin_amdgcn_s_barrier(); \
         asm volatile("" ::: "memory"); } while (0)
 
+        if constexpr (PHASES == 2) {
+            // Two phases per k-tile (half the barriers): phase 0 = A0 x (B0, B1), phase 1 = A1 x (B0, B1), 16 MFMAs each.  A1 of the
+            // next k-tile is staged in phase 0, A0 / B0 / B1 of the one after in phase 1 (their previous contents were last read
+            // in phase 0); the wait before the second phase's barrier leaves those three half-tiles in flight.
+#define P8_MFMA16(I0) do { \
+        __builtin_amdgcn_s_barrier(); \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); \
+        if (!(abl & 8)) __builtin_amdgcn_s_setprio(1); \
+        asm volatile("" : "+v"(acc[I0][0]), "+v"(acc[I0 + 1][0]), "+v"(acc[I0][1]), "+v"(acc[I0 + 1][1]) :: "memory"); \
+        if (!(abl & 2)) { \
+        _Pragma("unroll") for (int kk = 0; kk < 4; ++kk) { \
+            acc[I0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[0][kk], fb0[kk], acc[I0][0], 0, 0, 0); \
+            acc[I0 + 1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[1][kk], fb0[kk], acc[I0 + 1][0], 0, 0, 0); \
+            acc[I0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[0][kk], fb1[kk], acc[I0][1], 0, 0, 0); \
+            acc[I0 + 1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[1][kk], fb1[kk], acc[I0 + 1][1], 0, 0, 0); \
+        } } else { asm volatile("" :: "v"(fa[0][0]), "v"(fa[1][3]), "v"(fb0[0]), "v"(fb1[3])); } \
+        asm volatile("" : "+v"(acc[I0][0]), "+v"(acc[I0 + 1][0]), "+v"(acc[I0][1]), "+v"(acc[I0 + 1][1]) :: "memory"); \
+        __builtin_amdgcn_s_setprio(0); \
+        __builtin_amdgcn_s_barrier(); \
+        asm volatile("" ::: "memory"); } while (0)
+            for (int t = 0; t < nt; ++t) {
+                if (!(abl & 4)) {
+#pragma unroll
+                    for (int kk = 0; kk < 4; ++kk) { fb0[kk] = frb.read(0, 0, kk); fb1[kk] = frb.read(1, 0, kk); }
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int kk = 0; kk < 4; ++kk) { fa[0][kk] = fra.read(0, 0, kk); fa[1][kk] = fra.read(0, 1, kk); }
+                }
+                stage(t + 1, 3);
+                P8_MFMA16(0);
+                if (!(abl & 4)) {
+#pragma unroll
+                    for (int kk = 0; kk < 4; ++kk) { fa[0][kk] = fra.read(1, 0, kk); fa[1][kk] = fra.read(1, 1, kk); }
+                }
+                stage(t + 2, 0); stage(t + 2, 1); stage(t + 2, 2);
+                if (t + 2 < nt) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                P8_MFMA16(2);
+                fra.toggle(); frb.toggle();
+            }
+#undef P8_MFMA16
+        } else {
         for (int t = 0; t < nt; ++t) {
             // ---- phase 0: quadrant (A0, B0)
+            if (!(abl & 4)) {
 #pragma unroll
-            for (int kk = 0; kk < 4; ++kk) fb0[kk] = frb.read(0, 0, kk);
-            __builtin_amdgcn_sched_barrier(0);
+                for (int kk = 0; kk < 4; ++kk) fb0[kk] = frb.read(0, 0, kk);
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int kk = 0; kk < 4; ++kk) { fa[0][kk] = fra.read(0, 0, kk); fa[1][kk] = fra.read(0, 1, kk); }
+                for (int kk = 0; kk < 4; ++kk) { fa[0][kk] = fra.read(0, 0, kk); fa[1][kk] = fra.read(0, 1, kk); }
+            }
             stage(t + 1, 3);
             P8_MFMA(0, 0, fb0);
             // ---- phase 1: quadrant (A0, B1)
+            if (!(abl & 4)) {
 #pragma unroll
-            for (int kk = 0; kk < 4; ++kk) fb1[kk] = frb.read(1, 0, kk);
+                for (int kk = 0; kk < 4; ++kk) fb1[kk] = frb.read(1, 0, kk);
+            }
             stage(t + 2, 0);
             P8_MFMA(0, 1, fb1);
             // ---- phase 2: quadrant (A1, B1)
+            if (!(abl & 4)) {
 #pragma unroll
-            for (int kk = 0; kk < 4; ++kk) { fa[0][kk] = fra.read(1, 0, kk); fa[1][kk] = fra.read(1, 1, kk); }
+                for (int kk = 0; kk < 4; ++kk) { fa[0][kk] = fra.read(1, 0, kk); fa[1][kk] = fra.read(1, 1, kk); }
+            }
             stage(t + 2, 1);
             P8_MFMA(2, 1, fb1);
             // ---- phase 3: quadrant (A1, B0); k-tile t+1 must have landed before the next phase reads it
@@ -223,8 +281,9 @@ __global__ __launch_bounds__(512) void gemm_p8_kernel(const GemmArgs g) {
             P8_MFMA(2, 0, fb0);
             fra.toggle(); frb.toggle();
         }
+        }
 #undef P8_MFMA
-        if (wm == 0) __builtin_amdgcn_s_barrier();               // re-align the two halves
+        if (wm == 0 && !(abl & 16)) __builtin_amdgcn_s_barrier();               // re-align the two halves
     }
     // ---- epilogue: four 64-row x 256-col slabs through a 64 KiB fp32 staging tile
     float* ct = reinterpret_cast<float*>(smem);
@@ -285,13 +344,16 @@ bool mrg_gemm8p_launch(const mrg_detail::GemmArgs& g, int a_mode, int b_mode, bo
     if (a_mode == MRG_OP_KSTRIDED && (g.M % 8 != 0)) return false;
     if (b_mode == MRG_OP_KSTRIDED && (g.N % 8 != 0)) return false;
     const dim3 grid(cdiv(g.M, 256) * cdiv(g.N, 256), splitk), block(512);
-#define MRG_P8(AM, BM_, V) do { const void* fn = (const void*)gemm_p8_kernel<AM, BM_, V>; \
+    static const int phases = [] { const char* e = getenv("MRG_P8_PHASES"); return e ? atoi(e) : 2; }();   // phases per k-tile: 2 (default) or 4
+#define MRG_P8_(AM, BM_, V, PH) do { const void* fn = (const void*)gemm_p8_kernel<AM, BM_, V, PH>; \
         (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, P8_LDS); \
-        hipLaunchKernelGGL((gemm_p8_kernel<AM, BM_, V>), grid, block, (size_t)P8_LDS, stream, g); } while (0)
+        hipLaunchKernelGGL((gemm_p8_kernel<AM, BM_, V, PH>), grid, block, (size_t)P8_LDS, stream, g); } while (0)
+#define MRG_P8(AM, BM_, V) do { if (phases == 4) MRG_P8_(AM, BM_, V, 4); else MRG_P8_(AM, BM_, V, 2); } while (0)
     if (a_mode == MRG_OP_KCONTIG && b_mode == MRG_OP_KCONTIG) { if (vec) MRG_P8(0, 0, true); else MRG_P8(0, 0, false); }
     else if (a_mode == MRG_OP_KCONTIG && b_mode == MRG_OP_KSTRIDED) { if (vec) MRG_P8(0, 1, true); else MRG_P8(0, 1, false); }
     else if (a_mode == MRG_OP_KSTRIDED && b_mode == MRG_OP_KSTRIDED) { if (vec) MRG_P8(1, 1, true); else MRG_P8(1, 1, false); }
     else return false;
 #undef MRG_P8
+#undef MRG_P8_
     return true;
 }

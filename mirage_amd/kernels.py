@@ -142,6 +142,12 @@ def _autotune(d, key, splitk, allow_split, dev):
     if d.K % 64 == 0 and d.M > 128 and not d.colsum_out and not d.k_dev:   # single-stage 256x128 (wins when there are many tiles per CU)
         for s_ in splits:
             cands.append((L.MRG_GEMM_G256, s_))
+    # 256 x 256 8-phase kernel (gemm8p.hip): one workgroup per CU, so it needs about a CU's worth of tiles per round
+    if d.K % 64 == 0 and d.M > 128 and d.N > 128 and not d.colsum_out and not d.k_dev and not d.a_map and not d.m_dev:
+        t8 = ((d.M + 255) // 256) * ((d.N + 255) // 256)
+        for s_ in splits:
+            if t8 * s_ >= 192:
+                cands.append((L.MRG_GEMM_P8, s_))
     best, best_t = (L.MRG_GEMM_AUTO, splitk), float("inf")
     for v, s_ in cands:
         _gemm_launch(d, s_, v, dev)
