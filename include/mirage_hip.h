@@ -252,6 +252,11 @@ int mrg_row_scale_bf16(const float* src, const float* row_scale, void* dst_bf16,
  * do_affine = 0 skips the resampling (args.affine false, :56).  Image output: fp32 [B, H, W] in [0,1]; label output: int64. */
 int mrg_augment_image(const uint8_t* src_u8, float* dst, const float* params, int B, int H, int W, int do_affine, hipStream_t stream);
 int mrg_augment_label(const uint8_t* src_u8, long* dst, const float* params, int B, int H, int W, int do_affine, hipStream_t stream);
+/* TF.resize branch of the same transform (mutils/datasets_pretrain.py:66-81), applied after the affine step when the raw sample
+ * size differs from args.input_size[task]: images fp32 [B,Hi,Wi] -> [B,Ho,Wo] bilinear with antialiasing (torchvision resizes
+ * tensors with antialias=True: aten _upsample_bilinear2d_aa), label maps int64 nearest (aten upsample_nearest2d). */
+int mrg_resize_image(const float* src, float* dst, int B, int Hi, int Wi, int Ho, int Wo, hipStream_t stream);
+int mrg_resize_label(const long* src, long* dst, int B, int Hi, int Wi, int Ho, int Wo, hipStream_t stream);
 
 #ifdef __cplusplus
 }

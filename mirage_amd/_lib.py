@@ -99,6 +99,8 @@ SIGNATURES = {
     "mrg_reduce_batch": (ci, [vp, ci, vp]),
     "mrg_augment_image": (ci, [vp, vp, vp, ci, ci, ci, ci, vp]),
     "mrg_augment_label": (ci, [vp, vp, vp, ci, ci, ci, ci, vp]),
+    "mrg_resize_image": (ci, [vp, vp, ci, ci, ci, ci, ci, vp]),
+    "mrg_resize_label": (ci, [vp, vp, ci, ci, ci, ci, ci, vp]),
 }
 
 if not os.path.exists(LIB_PATH):

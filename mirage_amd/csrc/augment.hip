@@ -73,6 +73,65 @@ __global__ __launch_bounds__(256) void augment_kernel(const AugArgs a) {
     else reinterpret_cast<float*>(a.dst)[o] = out;
 }
 
+// ---- TF.resize branch (datasets_pretrain.py:66-81): raw data whose size differs from args.input_size[task] is resized AFTER the
+// affine transform -- images with BILINEAR (torchvision >= 0.17 resizes tensors with antialias=True: aten
+// _upsample_bilinear2d_aa), label maps with NEAREST (aten upsample_nearest2d, legacy index rule floor(dst * in / out)).
+// Bilinear-antialias weights as aten/native/cuda/UpSampleBilinear2d.cu computes them: scale = in / out, support = max(scale, 1),
+// center = scale * (i + 0.5), taps [int(center - support + 0.5), int(center + support + 0.5)) clipped to the image, triangle
+// filter of width support around center - 0.5, normalised to sum 1; the 2-D result is the separable product.
+__device__ __forceinline__ void aa_taps(int i, float scale, int in_size, int& lo, int& n, float& total, float& center, float& invscale) {
+    const float support = scale >= 1.0f ? scale : 1.0f;
+    invscale = scale >= 1.0f ? 1.0f / scale : 1.0f;
+    center = scale * ((float)i + 0.5f);
+    lo = max((int)(center - support + 0.5f), 0);
+    n = min((int)(center + support + 0.5f), in_size) - lo;
+    float tot = 0.0f;
+    for (int j = 0; j < n; ++j) {
+        const float x = fabsf(((float)(j + lo) - center + 0.5f) * invscale);
+        tot += x < 1.0f ? 1.0f - x : 0.0f;
+    }
+    total = tot;
+}
+
+__global__ __launch_bounds__(256) void resize_bilinear_aa_kernel(const float* __restrict__ src, float* __restrict__ dst, int B, int Hi, int Wi,
+                                                                 int Ho, int Wo) {
+    const int b = blockIdx.z;
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= Wo || y >= Ho) return;
+    const float sx = (float)Wi / (float)Wo, sy = (float)Hi / (float)Ho;
+    int x0, nx, y0, ny;
+    float itx, cx, isx, ity, cy, isy;
+    aa_taps(x, sx, Wi, x0, nx, itx, cx, isx);
+    aa_taps(y, sy, Hi, y0, ny, ity, cy, isy);
+    const float* img = src + (long)b * Hi * Wi;
+    float acc = 0.0f;
+    for (int jy = 0; jy < ny; ++jy) {
+        const float dy = fabsf(((float)(jy + y0) - cy + 0.5f) * isy);
+        float wy = dy < 1.0f ? 1.0f - dy : 0.0f;
+        if (ity != 0.0f) wy /= ity;                                      // aten: weights are divided by their sum
+        float row = 0.0f;
+        for (int jx = 0; jx < nx; ++jx) {
+            const float dx = fabsf(((float)(jx + x0) - cx + 0.5f) * isx);
+            float wx = dx < 1.0f ? 1.0f - dx : 0.0f;
+            if (itx != 0.0f) wx /= itx;
+            row += wx * img[(long)(y0 + jy) * Wi + x0 + jx];
+        }
+        acc += wy * row;
+    }
+    dst[((long)b * Ho + y) * Wo + x] = acc;
+}
+
+__global__ __launch_bounds__(256) void resize_nearest_kernel(const long* __restrict__ src, long* __restrict__ dst, int B, int Hi, int Wi, int Ho, int Wo) {
+    const int b = blockIdx.z;
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= Wo || y >= Ho) return;
+    const float sx = (float)Wi / (float)Wo, sy = (float)Hi / (float)Ho;
+    const int xs = min((int)floorf((float)x * sx), Wi - 1), ys = min((int)floorf((float)y * sy), Hi - 1);
+    dst[((long)b * Ho + y) * Wo + x] = src[((long)b * Hi + ys) * Wi + xs];
+}
+
 int launch(const uint8_t* src, void* dst, const float* params, int B, int H, int W, int do_affine, bool label, hipStream_t stream,
            const char* who) {
     MRG_REQUIRE(src && dst && params, MRG_ERR_ARG, "%s: null pointer", who);
@@ -94,4 +153,18 @@ extern "C" int mrg_augment_image(const uint8_t* src_u8, float* dst, const float*
 extern "C" int mrg_augment_label(const uint8_t* src_u8, long* dst, const float* params, int B, int H, int W, int do_affine,
                                  hipStream_t stream) {
     return launch(src_u8, dst, params, B, H, W, do_affine, true, stream, "mrg_augment_label");
+}
+
+extern "C" int mrg_resize_image(const float* src, float* dst, int B, int Hi, int Wi, int Ho, int Wo, hipStream_t stream) {
+    MRG_REQUIRE(src && dst, MRG_ERR_ARG, "mrg_resize_image: null pointer");
+    MRG_REQUIRE(B > 0 && B <= 65535 && Hi > 0 && Wi > 0 && Ho > 0 && Wo > 0, MRG_ERR_SHAPE, "mrg_resize_image: bad shape");
+    hipLaunchKernelGGL(resize_bilinear_aa_kernel, dim3(cdiv(Wo, 64), cdiv(Ho, 4), B), dim3(256), 0, stream, src, dst, B, Hi, Wi, Ho, Wo);
+    return mrg_check_launch("mrg_resize_image");
+}
+
+extern "C" int mrg_resize_label(const long* src, long* dst, int B, int Hi, int Wi, int Ho, int Wo, hipStream_t stream) {
+    MRG_REQUIRE(src && dst, MRG_ERR_ARG, "mrg_resize_label: null pointer");
+    MRG_REQUIRE(B > 0 && B <= 65535 && Hi > 0 && Wi > 0 && Ho > 0 && Wo > 0, MRG_ERR_SHAPE, "mrg_resize_label: bad shape");
+    hipLaunchKernelGGL(resize_nearest_kernel, dim3(cdiv(Wo, 64), cdiv(Ho, 4), B), dim3(256), 0, stream, src, dst, B, Hi, Wi, Ho, Wo);
+    return mrg_check_launch("mrg_resize_label");
 }

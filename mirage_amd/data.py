@@ -75,8 +75,8 @@ def kernel_params(task: str, H: int, W: int, flip: bool, shift: float, affine_pa
 
 class DataAugmentationForMIRAGE:
     """Batch-level GPU counterpart of the reference class of the same name (datasets_pretrain.py:18-83).  args fields used:
-    hflip (probability), intensity_shift (sigma), affine (bool), input_size (per-task target size; samples must already have
-    it -- the TF.resize branch of the reference is for differently sized raw data and is not implemented here)."""
+    hflip (probability), intensity_shift (sigma), affine (bool), input_size (per-task target size; raw samples of another size
+    are resized after the affine step, datasets_pretrain.py:66-81)."""
 
     def __init__(self, args, seed: int = 0):
         self.args = args
@@ -108,16 +108,135 @@ class DataAugmentationForMIRAGE:
                 raise ValueError(f"mirage_amd.data: task {t!r} must be a uint8 [B, H, W] tensor, got {src.dtype} {tuple(src.shape)}")
             B, H, W = src.shape
             want = getattr(self.args, "input_size", {}).get(t) if isinstance(getattr(self.args, "input_size", None), dict) else None
-            if want is not None and tuple(want) != (H, W):
-                raise NotImplementedError(f"mirage_amd.data: task {t!r} is {H}x{W}, expected {tuple(want)} (resize is not implemented)")
             prm = np.stack([kernel_params(t, H, W, flips[b], float(shifts[t][b]), affs[b]) for b in range(B)])
             prm = torch.from_numpy(prm).to(src.device, non_blocking=True)
             if t in LABEL_TASKS:
-                out[t] = K.augment_label(src, prm, self.do_affine)
+                y = K.augment_label(src, prm, self.do_affine)
+                if want is not None and tuple(want) != (H, W):          # datasets_pretrain.py:66-81: NEAREST for label maps
+                    y = K.resize_label(y, want)
+                out[t] = y
             else:
-                out[t] = K.augment_image(src, prm, self.do_affine).unsqueeze(1)
+                y = K.augment_image(src, prm, self.do_affine)
+                if want is not None and tuple(want) != (H, W):          # BILINEAR (antialiased, as torchvision resizes tensors)
+                    y = K.resize_image(y, want)
+                out[t] = y.unsqueeze(1)
         return out
 
     def __call__(self, batch_u8: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
         B = next(iter(batch_u8.values())).shape[0]
         return self.apply(batch_u8, *self.draw(list(batch_u8.keys()), B))
+
+
+class PrefetchingNpyLoader:
+    """Asynchronous feed of <root>/<task>/*.npy samples (the reference's DataLoader settings,
+    run_pretraining.py:478-487: shuffle, drop_last, prefetch_factor 2, pinned memory, persistent workers).
+
+    Pipeline per batch (all stages overlap the training step of the previous batch):
+      reader threads (np.load releases the GIL; `num_workers` of them, created before anything touches the GPU is not required --
+      they never call into HIP) fill one slot of a ring of PINNED uint8 staging buffers [B, H, W] per task
+      -> the consumer enqueues the H2D copies (bytes: 4x less PCIe than fp32) and the augmentation kernels on a dedicated copy
+         stream into fresh device tensors and records an event
+      -> the training stream waits on that event only when it takes the batch (one step later).
+    The host never blocks on the GPU except when a staging slot is about to be refilled while its copy is still in flight.
+    Samples are matched across tasks by sorted file order (mutils/dataset_folder.py:32-51); rank r of `world` takes every
+    world-th batch of the epoch's permutation (the reference is single-process)."""
+
+    def __init__(self, files: Dict[str, Sequence[str]], batch_size: int, device, augment: Optional[DataAugmentationForMIRAGE] = None,
+                 rank: int = 0, world: int = 1, seed: int = 0, num_workers: int = 8, prefetch: int = 2, shuffle: bool = True):
+        import concurrent.futures
+        self.files = {t: list(v) for t, v in files.items()}
+        self.tasks = list(self.files.keys())
+        n = min(len(v) for v in self.files.values())
+        if n <= 0:
+            raise ValueError("PrefetchingNpyLoader: no samples")
+        self.n, self.B, self.device, self.augment = n, int(batch_size), torch.device(device), augment
+        self.rank, self.world, self.shuffle = rank, world, shuffle
+        self.rng = np.random.default_rng(seed)
+        self.steps = n // (self.B * world)                               # drop_last
+        self.prefetch = max(1, int(prefetch))
+        self.pool = concurrent.futures.ThreadPoolExecutor(max_workers=max(1, int(num_workers)), thread_name_prefix="mrg-npy")
+        # one assembler per batch in preparation: it fans the B x n_tasks reads out over the reader pool and waits for them
+        self.assemblers = concurrent.futures.ThreadPoolExecutor(max_workers=self.prefetch + 1, thread_name_prefix="mrg-batch")
+        self.copy_stream = torch.cuda.Stream(device=self.device)
+        first = {t: np.load(self.files[t][0]) for t in self.tasks}
+        self.shapes = {t: tuple(a.shape[-2:]) for t, a in first.items()}
+        # ring of pinned staging slots: prefetch batches being filled / queued + one being copied
+        self.slots = [{t: torch.empty((self.B,) + self.shapes[t], dtype=torch.uint8).pin_memory() for t in self.tasks}
+                      for _ in range(self.prefetch + 1)]
+        self.slot_free = [None] * len(self.slots)                         # event: the H2D copy out of this slot has completed
+
+    def __len__(self):
+        return self.steps
+
+    def _fill(self, slot: int, ids) -> int:
+        """Reader side: B x n_tasks np.load calls spread over the pool, straight into the pinned slot."""
+        ev = self.slot_free[slot]
+        if ev is not None:
+            ev.synchronize()                                              # the previous copy out of this slot must be done
+        bufs = {t: self.slots[slot][t].numpy() for t in self.tasks}
+
+        def one(t, b, i):
+            a = np.load(self.files[t][i])
+            if a.shape[-2:] != self.shapes[t]:
+                raise ValueError(f"{self.files[t][i]}: shape {a.shape} differs from the first sample's {self.shapes[t]}")
+            bufs[t][b] = a.astype(np.uint8, copy=False)
+
+        futs = [self.pool.submit(one, t, b, int(i)) for t in self.tasks for b, i in enumerate(ids)]
+        for f in futs:
+            f.result()
+        return slot
+
+    def _upload(self, slot: int):
+        """Consumer side: H2D + augmentation on the copy stream; returns (batch, ready event)."""
+        with torch.cuda.stream(self.copy_stream):
+            dev = {t: self.slots[slot][t].to(self.device, non_blocking=True) for t in self.tasks}
+            done = torch.cuda.Event()
+            done.record(self.copy_stream)
+            self.slot_free[slot] = done
+            if self.augment is not None:
+                batch = self.augment(dev)
+            else:
+                batch = {t: (v.long() if t in LABEL_TASKS else (v.float() / 255.0).unsqueeze(1)) for t, v in dev.items()}
+            ready = torch.cuda.Event()
+            ready.record(self.copy_stream)
+        return batch, ready
+
+    def __iter__(self):
+        import collections
+        perm = self.rng.permutation(self.n) if self.shuffle else np.arange(self.n)
+        B, W, R = self.B, self.world, self.rank
+        batches = [perm[(s * W + R) * B:(s * W + R + 1) * B] for s in range(self.steps)]
+        inflight = collections.deque()                                   # futures of slots being filled, in batch order
+        nxt = 0
+
+        def submit():
+            nonlocal nxt
+            if nxt < len(batches):
+                slot = nxt % len(self.slots)
+                inflight.append(self.assemblers.submit(self._fill, slot, batches[nxt]))
+                nxt += 1
+
+        for _ in range(min(self.prefetch, len(batches))):
+            submit()
+        pending = None
+        for _ in range(len(batches)):
+            slot = inflight.popleft().result()
+            cur = self._upload(slot)                                      # enqueued before the previous batch's step is launched
+            submit()
+            if pending is not None:
+                yield self._take(pending)
+            pending = cur
+        if pending is not None:
+            yield self._take(pending)
+
+    def _take(self, item):
+        batch, ready = item
+        main = torch.cuda.current_stream(self.device)
+        main.wait_event(ready)
+        for v in batch.values():
+            v.record_stream(main)                                         # allocated on the copy stream, consumed on this one
+        return batch
+
+    def close(self):
+        self.assemblers.shutdown(wait=False, cancel_futures=True)
+        self.pool.shutdown(wait=False, cancel_futures=True)

@@ -546,3 +546,21 @@ def augment_label(src_u8: torch.Tensor, params: torch.Tensor, do_affine: bool = 
     """uint8 [B, H, W] class ids -> int64 [B, H, W]: flip, bilinear affine + round (the reference's label path)."""
     return _augment(src_u8, params, do_affine, True)
 
+
+
+def resize_image(x: torch.Tensor, size) -> torch.Tensor:
+    """fp32 [B, Hi, Wi] -> [B, Ho, Wo], bilinear with antialiasing (TF.resize on tensors; datasets_pretrain.py:76-81)."""
+    B, Hi, Wi = x.shape
+    Ho, Wo = int(size[0]), int(size[1])
+    out = torch.empty((B, Ho, Wo), dtype=F32, device=x.device)
+    check(lib.mrg_resize_image(x.contiguous().data_ptr(), out.data_ptr(), B, Hi, Wi, Ho, Wo, _s()), "mrg_resize_image")
+    return out
+
+
+def resize_label(x: torch.Tensor, size) -> torch.Tensor:
+    """int64 [B, Hi, Wi] -> [B, Ho, Wo], nearest (TF.resize(..., NEAREST) for label maps; datasets_pretrain.py:71-81)."""
+    B, Hi, Wi = x.shape
+    Ho, Wo = int(size[0]), int(size[1])
+    out = torch.empty((B, Ho, Wo), dtype=torch.int64, device=x.device)
+    check(lib.mrg_resize_label(x.contiguous().data_ptr(), out.data_ptr(), B, Hi, Wi, Ho, Wo, _s()), "mrg_resize_label")
+    return out

@@ -78,6 +78,7 @@ def get_args(argv=None):
     p.add_argument("--affine", action="store_true", help="random affine transformations (run_pretraining.py:240-244)")
     p.add_argument("--no_affine", action="store_false", dest="affine")
     p.set_defaults(affine=True)
+    p.add_argument("--num_workers", default=10, type=int, help="reader threads of the asynchronous .npy feed (run_pretraining.py:256)")
     p.add_argument("--no_augment", action="store_true", help="feed the .npy samples unchanged (no flip / shift / affine)")
     p.add_argument("--data_path", required=True, type=str, help="'synthetic' or a folder with <domain>/*.npy")
     p.add_argument("--steps_per_epoch", default=None, type=int, help="synthetic data only")
@@ -127,40 +128,17 @@ class SyntheticData:
             yield self.pool[i % len(self.pool)]
 
 
-class NpyFolderData:
-    """<root>/<domain>/*.npy, uint8 images / integer layer maps (mutils/datasets_pretrain.py:86-207, dataset_folder.py:32-51).
-    Samples are matched by sorted file order, shipped to the GPU as bytes and augmented there by
-    mirage_amd.data.DataAugmentationForMIRAGE (the reference's CPU transform of the same name, datasets_pretrain.py:18-83)."""
-
-    def __init__(self, args, device, rank, world, seed):
-        from .data import DataAugmentationForMIRAGE
-        self.augment = None if getattr(args, "no_augment", False) else DataAugmentationForMIRAGE(args, seed=seed * 1000 + rank)
-        self.files = {d: sorted(glob.glob(os.path.join(args.data_path, d, "*.npy"))) for d in args.all_domains}
-        n = min(len(v) for v in self.files.values())
-        assert n > 0, f"no .npy files under {args.data_path}/<domain>/"
-        self.idx = np.arange(n)
-        self.args, self.device, self.rank, self.world = args, device, rank, world
-        self.rng = np.random.default_rng(seed)
-        self.steps = n // (args.batch_size * world)
-
-    def __len__(self):
-        return self.steps
-
-    def __iter__(self):
-        perm = self.rng.permutation(self.idx)
-        B = self.args.batch_size
-        for s in range(self.steps):
-            ids = perm[(s * self.world + self.rank) * B:(s * self.world + self.rank + 1) * B]
-            b = {}
-            for d in self.args.all_domains:
-                arrs = np.stack([np.load(self.files[d][i]) for i in ids])
-                if self.augment is not None:
-                    b[d] = torch.from_numpy(np.ascontiguousarray(arrs.astype(np.uint8))).to(self.device)
-                elif d == "bscanlayermap":
-                    b[d] = torch.from_numpy(arrs.astype(np.int64)).to(self.device)
-                else:
-                    b[d] = (torch.from_numpy(arrs.astype(np.float32)) / 255.0).unsqueeze(1).to(self.device)
-            yield self.augment(b) if self.augment is not None else b
+def npy_folder_loader(args, device, rank, world, seed):
+    """<root>/<domain>/*.npy, uint8 images / integer layer maps (mutils/datasets_pretrain.py:86-207, dataset_folder.py:32-51) through
+    the asynchronous feed of mirage_amd.data.PrefetchingNpyLoader: reader threads -> pinned uint8 staging -> H2D + GPU augmentation
+    (mirage_amd.data.DataAugmentationForMIRAGE, the reference's CPU transform of the same name, datasets_pretrain.py:18-83) on a
+    copy stream, double-buffered against the training step (run_pretraining.py:478-487: shuffle, drop_last, prefetch 2, pinned)."""
+    from .data import DataAugmentationForMIRAGE, PrefetchingNpyLoader
+    augment = None if getattr(args, "no_augment", False) else DataAugmentationForMIRAGE(args, seed=seed * 1000 + rank)
+    files = {d: sorted(glob.glob(os.path.join(args.data_path, d, "*.npy"))) for d in args.all_domains}
+    assert min(len(v) for v in files.values()) > 0, f"no .npy files under {args.data_path}/<domain>/"
+    return PrefetchingNpyLoader(files, args.batch_size, device, augment=augment, rank=rank, world=world, seed=seed,
+                                num_workers=getattr(args, "num_workers", 8) or 8, prefetch=2)
 
 
 def save_model(args, epoch, model, optimizer):
@@ -228,7 +206,7 @@ def main(args):
     if args.data_path == "synthetic":
         data = SyntheticData(args, device, args.steps_per_epoch or 100, 1234 + rank)
     else:
-        data = NpyFolderData(args, device, rank, world, args.seed)
+        data = npy_folder_loader(args, device, rank, world, args.seed)
     steps_per_epoch = len(data)
     total_batch = args.batch_size * world
     args.lr = args.blr * total_batch / 256

@@ -145,3 +145,14 @@ def affine_numpy(img: np.ndarray, matrix: Sequence[float]) -> np.ndarray:
                     val += w * float(img[yy, xx]); mask += w
             out[i, j] = val * mask
     return out
+
+
+def resize_sample(img: torch.Tensor, size, label: bool) -> torch.Tensor:
+    """TF.resize branch (mutils/datasets_pretrain.py:66-81): after the affine step a sample whose size differs from
+    args.input_size[task] is resized -- label maps with InterpolationMode.NEAREST, images with BILINEAR.  For tensors torchvision
+    0.20.1 (_functional_tensor.resize) calls torch.nn.functional.interpolate(size=..., mode=..., align_corners=False [bilinear],
+    antialias=True [bilinear; the default since 0.17]); integer inputs are cast to float for the call and back.  img: [H, W]."""
+    x = img[None, None].float()
+    if label:
+        return torch.nn.functional.interpolate(x, size=tuple(size), mode="nearest")[0, 0].to(img.dtype)
+    return torch.nn.functional.interpolate(x, size=tuple(size), mode="bilinear", align_corners=False, antialias=True)[0, 0]

@@ -72,8 +72,8 @@ def test_whole_batch_dict_and_errors():
     out = aug(batch)
     assert out["bscan"].shape == (4, 1, 64, 64) and out["slo"].shape == (4, 1, 64, 64) and out["bscanlayermap"].shape == (4, 16, 16)
     assert 0.0 <= float(out["bscan"].min()) and float(out["bscan"].max()) <= 1.0
-    with pytest.raises(NotImplementedError):
-        aug({"bscan": torch.zeros(2, 32, 32, dtype=torch.uint8, device=DEV)})
+    small = aug({"bscan": torch.zeros(2, 32, 32, dtype=torch.uint8, device=DEV)})       # raw size != input_size: the TF.resize branch
+    assert small["bscan"].shape == (2, 1, 64, 64)
     with pytest.raises(ValueError):
         aug({"bscan": torch.zeros(2, 64, 64, dtype=torch.float32, device=DEV)})
 
@@ -100,3 +100,70 @@ def test_driver_trains_from_npy_folder_with_gpu_augmentation(tmp_path):
     R.main(args)
     lines = [json.loads(l) for l in open(os.path.join(out, "miragepre_base", "log.txt"))]
     assert len(lines) == 2 and all(np.isfinite(l["[Epoch] loss"]) for l in lines)
+
+
+def test_resize_branch_matches_aten():
+    """TF.resize branch (mutils/datasets_pretrain.py:66-81): torchvision resizes tensors through aten's interpolate -- bilinear with
+    antialias=True for images, nearest for label maps.  The HIP kernels against torch's CPU kernels of the same ops, down- and
+    up-scaling, non-integer ratios."""
+    from mirage_amd import kernels as K
+    from oracle import augment_oracle as A
+    g = torch.Generator().manual_seed(5)
+    for (hi, wi), (ho, wo) in (((512, 512), (128, 128)), ((96, 160), (128, 128)), ((300, 200), (224, 224)), ((64, 64), (512, 512))):
+        x = torch.rand(3, hi, wi, generator=g)
+        want = torch.stack([A.resize_sample(x[b], (ho, wo), label=False) for b in range(3)])
+        got = K.resize_image(x.to(DEV), (ho, wo)).cpu()
+        torch.testing.assert_close(got, want, rtol=0, atol=2e-6)
+        lab = torch.randint(0, 13, (3, hi, wi), generator=g)
+        wantl = torch.stack([A.resize_sample(lab[b], (ho, wo), label=True) for b in range(3)])
+        gotl = K.resize_label(lab.to(DEV), (ho, wo)).cpu()
+        assert torch.equal(gotl, wantl)
+
+
+def test_prefetching_loader_matches_synchronous_reads(tmp_path):
+    """Asynchronous feed (reader threads -> pinned staging -> copy stream, run_pretraining.py:478-487 semantics): without
+    augmentation and shuffling every batch equals the directly loaded files (drop_last, rank sharding, two epochs, ring reuse);
+    with raw samples of another size the resize branch brings them to args.input_size; shuffled epochs are permutations."""
+    import types
+    from mirage_amd.data import PrefetchingNpyLoader, DataAugmentationForMIRAGE
+    rng = np.random.default_rng(3)
+    root = tmp_path / "d"
+    n, B = 23, 4
+    files = {}
+    for d, (hw, hi) in {"bscan": (64, 256), "bscanlayermap": (32, 13)}.items():
+        (root / d).mkdir(parents=True)
+        for i in range(n):
+            np.save(root / d / f"s{i:03d}.npy", rng.integers(0, hi, (hw, hw), dtype=np.uint8))
+        files[d] = sorted(str(p) for p in (root / d).glob("*.npy"))
+    for world in (1, 2):
+        for rank in range(world):
+            ld = PrefetchingNpyLoader(files, B, DEV, augment=None, rank=rank, world=world, seed=0, num_workers=4, prefetch=2, shuffle=False)
+            assert len(ld) == n // (B * world)
+            for epoch in range(2):
+                got = list(ld)
+                assert len(got) == len(ld)
+                for s, b in enumerate(got):
+                    ids = range((s * world + rank) * B, (s * world + rank + 1) * B)
+                    img = np.stack([np.load(files["bscan"][i]) for i in ids]).astype(np.float32) / 255.0
+                    lab = np.stack([np.load(files["bscanlayermap"][i]) for i in ids]).astype(np.int64)
+                    assert b["bscan"].shape == (B, 1, 64, 64) and b["bscan"].dtype == torch.float32
+                    np.testing.assert_allclose(b["bscan"][:, 0].cpu().numpy(), img, rtol=0, atol=1e-7)
+                    assert np.array_equal(b["bscanlayermap"].cpu().numpy(), lab)
+            ld.close()
+    # shuffled: every epoch is a permutation of the first steps * B indices of a random order, different between epochs
+    ld = PrefetchingNpyLoader(files, B, DEV, augment=None, seed=1, num_workers=4, shuffle=True)
+    sums = []
+    for epoch in range(2):
+        vals = torch.cat([b["bscan"].flatten(1).sum(1) for b in ld]).cpu().numpy()
+        assert len(vals) == (n // B) * B and len(np.unique(np.round(vals, 3))) == len(vals)
+        sums.append(vals)
+    assert not np.array_equal(sums[0], sums[1])
+    ld.close()
+    # augmentation on the copy stream + resize branch: raw 64x64 / 32x32 samples, model input 128x128 / 16x16
+    args = types.SimpleNamespace(hflip=0.5, intensity_shift=0.1, affine=True, input_size={"bscan": (128, 128), "bscanlayermap": (16, 16)})
+    ld = PrefetchingNpyLoader(files, B, DEV, augment=DataAugmentationForMIRAGE(args, seed=7), seed=0, num_workers=4)
+    b = next(iter(ld))
+    assert b["bscan"].shape == (B, 1, 128, 128) and b["bscanlayermap"].shape == (B, 16, 16)
+    assert float(b["bscan"].min()) >= 0.0 and float(b["bscan"].max()) <= 1.0 + 1e-6
+    assert int(b["bscanlayermap"].min()) >= 0 and int(b["bscanlayermap"].max()) <= 12
+    ld.close()
