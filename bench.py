@@ -194,6 +194,11 @@ def _run(real_stdout: int):
             _E2._Lanes.enabled = False
         if os.environ.get("MRG_SIDE") == "0":
             _E2._Side.enabled = False
+    if any(os.environ.get(k) for k in ("MRG_LANES_FWD", "MRG_LANES_BWD", "MRG_LANES_ORDER")):
+        from mirage_amd import engine as _E5
+        _E5._Lanes.fwd = os.environ.get("MRG_LANES_FWD", "1") != "0"
+        _E5._Lanes.bwd = os.environ.get("MRG_LANES_BWD", "1") != "0"
+        _E5._Lanes.main_first = os.environ.get("MRG_LANES_ORDER", "0") == "1"
     if os.environ.get("MRG_TAPER") == "0" or os.environ.get("MRG_REDUCE_EARLY") == "0":
         from mirage_amd import engine as _E3
         _E3._Side.taper = os.environ.get("MRG_TAPER") != "0"
@@ -244,7 +249,10 @@ def _run(real_stdout: int):
     model_name, doms, B, Kk, train = CONFIGS[a.config]
     if a.batch:
         B = a.batch
-    args = builder.make_args(doms, doms if train else ())
+    out_doms = doms if train else ()
+    if os.environ.get("MRG_BENCH_OUT"):                     # experiment knob: fewer output adapters (marginal cost of a decoder)
+        out_doms = tuple(os.environ["MRG_BENCH_OUT"].split("-"))
+    args = builder.make_args(doms, out_doms)
     torch.manual_seed(0)
     model = builder.get_model(args, model_name, with_decoders=train).to(dev)
     model.train(train)

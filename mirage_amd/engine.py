@@ -535,6 +535,7 @@ class _Lanes:
     chain of ~25 short launches on [B*256, 256]-sized problems that cannot fill 256 CUs on its own."""
     streams = []
     enabled = True
+    fwd = bwd = True        # experiment knobs (MRG_LANES_FWD / MRG_LANES_BWD = 0)
 
     @classmethod
     def get(cls, i, device):
@@ -544,23 +545,28 @@ class _Lanes:
             cls.streams[i] = torch.cuda.Stream(device=device)
         return cls.streams[i]
 
+    main_first = False      # experiment knob (MRG_LANES_ORDER=1): issue job 0 (calling stream) before the lane jobs
+
     @classmethod
-    def run_all(cls, jobs, device):
+    def run_all(cls, jobs, device, enabled=None):
         """jobs: list of zero-arg callables; job 0 runs on the current stream, the others on lane streams."""
         main = torch.cuda.current_stream(device)
-        if len(jobs) == 1 or not cls.enabled:
+        if len(jobs) == 1 or not (cls.enabled if enabled is None else enabled):
             return [job() for job in jobs]
         ev = torch.cuda.Event()
         ev.record(main)
         out = [None] * len(jobs)
         lanes = []
+        if cls.main_first:
+            out[0] = jobs[0]()
         for i, job in enumerate(jobs[1:], start=1):
             st = cls.get(i - 1, device)
             st.wait_event(ev)
             with torch.cuda.stream(st):
                 out[i] = job()
             lanes.append(st)
-        out[0] = jobs[0]()
+        if not cls.main_first:
+            out[0] = jobs[0]()
         for st in lanes:
             main.wait_stream(st)
         return out
@@ -577,7 +583,7 @@ class DecodersFn(torch.autograd.Function):
             enc16 = to_bf16(enc32)
         doms_l, start_l = list(dom_names), list(dom_start)
         jobs = [(lambda ad=ad: decoder_fwd(ad, enc32, enc16, ids_keep, ids_restore, doms_l, start_l, ng, save)) for ad in adapters]
-        res = _Lanes.run_all(jobs, enc32.device)
+        res = _Lanes.run_all(jobs, enc32.device, enabled=_Lanes.enabled and _Lanes.fwd)
         imgs = [r[0] for r in res]
         saved = [r[1] for r in res]
         ctx.adapters, ctx.saved, ctx.shape = adapters, saved, enc32.shape
@@ -590,7 +596,7 @@ class DecodersFn(torch.autograd.Function):
         d_enc = torch.empty(ctx.shape, dtype=F32, device=dev)
         todo = [(ad, sv, d_img) for ad, sv, d_img in zip(ctx.adapters, ctx.saved, d_imgs) if d_img is not None]
         jobs = [(lambda ad=ad, sv=sv, d_img=d_img: decoder_bwd(ad, sv, d_img)) for ad, sv, d_img in todo]
-        d_ctxs = _Lanes.run_all(jobs, dev)
+        d_ctxs = _Lanes.run_all(jobs, dev, enabled=_Lanes.enabled and _Lanes.bwd)
         for i, ((ad, _, _), d_ctx16) in enumerate(zip(todo, d_ctxs)):
             decoder_bwd_finish(ad, d_ctx16, d_enc, i == 0)
         ctx.saved = None
