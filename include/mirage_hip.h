@@ -26,7 +26,7 @@ extern "C" {
 typedef struct ihipStream_t* hipStream_t;
 #endif
 
-#define MRG_ABI_VERSION 4   /* 2: mrg_gemm_desc grew row_scale / defer_reduce, act codes 3, 4, reduce_batch / augment / row_scale entry points; 3: colsum_out, attention colsum_*; 4: step = int[2], mrg_step_inc takes the skip decision */
+#define MRG_ABI_VERSION 5   /* 2: mrg_gemm_desc grew row_scale / defer_reduce, act codes 3, 4, reduce_batch / augment / row_scale entry points; 3: colsum_out, attention colsum_*; 4: step = int[2], mrg_step_inc takes the skip decision; 5: splitk_counters, MRG_GEMM_P8, resize entry points */
 
 enum { MRG_DT_BF16 = 0, MRG_DT_F32 = 1 };
 enum { MRG_OP_KCONTIG = 0, MRG_OP_KSTRIDED = 1 };
@@ -90,6 +90,12 @@ typedef struct mrg_gemm_desc {
                                         of the layer whose output gradient this GEMM produces; forces the single-stage 128x128 kernel */
     int defer_reduce;                /* splitk > 1 only: leave the split-K slabs ws[splitk][M*N] unreduced -- the caller sums them
                                         later with mrg_reduce_batch (C must be contiguous fp32, no bias / accumulate / C2) */
+    int* splitk_counters;            /* splitk > 1 only, optional: ceil(M/128) * ceil(N/128) ints, ZERO on entry and left zero on exit.
+                                        With them the split is finished inside the launch: every k-slice workgroup stores its slab,
+                                        takes a ticket on its tile's counter, and the last arriver sums the slabs in slice order
+                                        (deterministic) and applies the epilogue -- no second kernel, the slabs are consumed while
+                                        they are still in L2 / Infinity Cache.  Kernel variants without the protocol fall back to
+                                        the separate reduction kernel */
 } mrg_gemm_desc;
 enum { MRG_GEMM_AUTO = 0, MRG_GEMM_GLDS3 = 1, MRG_GEMM_GLDS4 = 2, MRG_GEMM_PIPE128 = 3, MRG_GEMM_PIPE256 = 4, MRG_GEMM_PIPE256X3 = 5, MRG_GEMM_PIPE256SQ = 6, MRG_GEMM_WS256 = 7, MRG_GEMM_GLDS64 = 8, MRG_GEMM_SQP = 9, MRG_GEMM_G256 = 10, MRG_GEMM_P8 = 11 };
 

@@ -28,7 +28,7 @@ class GemmDesc(C.Structure):
                 ("C", vp), ("ldc", ci), ("c_dtype", ci), ("C2", vp), ("ldc2", ci), ("bias", vp),
                 ("resid", vp), ("ldr", ci), ("accumulate", ci), ("act", ci),
                 ("aux_out", vp), ("aux_in", vp), ("ldaux", ci), ("row_map", vp),
-                ("add_tab", vp), ("add_row", vp), ("ldt", ci), ("splitk", ci), ("ws", vp), ("variant", ci), ("ev_start", vp), ("ev_stop", vp), ("row_scale", vp), ("colsum_out", vp), ("defer_reduce", ci)]
+                ("add_tab", vp), ("add_row", vp), ("ldt", ci), ("splitk", ci), ("ws", vp), ("variant", ci), ("ev_start", vp), ("ev_stop", vp), ("row_scale", vp), ("colsum_out", vp), ("defer_reduce", ci), ("splitk_counters", vp)]
 
 
 class AttnDesc(C.Structure):
@@ -115,7 +115,7 @@ for _name, (_res, _args) in SIGNATURES.items():
     _fn.argtypes = _args
 
 ABI_VERSION = lib.mrg_version()
-EXPECTED_ABI_VERSION = 4       # must match MRG_ABI_VERSION in include/mirage_hip.h: the ctypes structs above mirror that layout
+EXPECTED_ABI_VERSION = 5       # must match MRG_ABI_VERSION in include/mirage_hip.h: the ctypes structs above mirror that layout
 if ABI_VERSION != EXPECTED_ABI_VERSION:
     raise ImportError(f"{LIB_PATH} reports ABI version {ABI_VERSION}, the Python bindings expect {EXPECTED_ABI_VERSION}: rebuild it "
                       "(python -c 'import __graft_entry__ as g; g.build()')")

@@ -108,22 +108,24 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs g) {
     __syncthreads();
     const int cl = (tid & 31) << 2;
     const int col = n0 + cl;
-    if (col >= g.N) return;
-    const int nv = min(4, g.N - col);
     float* ws = g.splitk > 1 ? g.ws + (long)ksplit * g.M * g.N : nullptr;
-    float bv[4] = {0.f, 0.f, 0.f, 0.f};
-    if (g.bias && !ws) {
+    if (col < g.N) {
+        const int nv = min(4, g.N - col);
+        float bv[4] = {0.f, 0.f, 0.f, 0.f};
+        if (g.bias && !ws) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) if (e < nv) bv[e] = g.bias[col + e];
-    }
+            for (int e = 0; e < 4; ++e) if (e < nv) bv[e] = g.bias[col + e];
+        }
 #pragma unroll 1
-    for (int it = 0; it < 16; ++it) {
-        const int rl = (tid >> 5) + (it << 3);
-        const int row = m0 + rl;
-        if (row >= Meff) break;
-        const float4 a4 = *reinterpret_cast<const float4*>(ct + rl * BN + cl);
-        epi_any<VEC>(g, a4, bv, ws, row, col, nv);
+        for (int it = 0; it < 16; ++it) {
+            const int rl = (tid >> 5) + (it << 3);
+            const int row = m0 + rl;
+            if (row >= Meff) break;
+            const float4 a4 = *reinterpret_cast<const float4*>(ct + rl * BN + cl);
+            epi_any<VEC>(g, a4, bv, ws, row, col, nv);
+        }
     }
+    if (ws && g.tile_cnt) splitk_finish<VEC>(g, bid, m0, n0, BM, BN, Meff, smem, tid, 256);
 }
 
 // =====================================================================================================
@@ -317,6 +319,7 @@ __global__ __launch_bounds__(256, OCC) void gemm_glds_kernel(const GemmArgs g) {
             }
         }
     }
+    if (!CSUM && ws && g.tile_cnt) splitk_finish<VEC>(g, bid, m0, n0, BM, BN, Meff, smem, tid, 256);
     if (CSUM) {   // column sums of this tile's final values (e.g. the bias gradient of the layer whose output gradient C is)
         __syncthreads();
 #pragma unroll
@@ -463,35 +466,37 @@ __global__ __launch_bounds__(256, 2) void gemm_pipe_kernel(const GemmArgs g) {
     __syncthreads();
     const int cl = (tid & 31) << 2;
     const int col = n0 + cl;
-    if (col >= g.N) return;
-    const int nv = min(4, g.N - col);
     float* ws = g.splitk > 1 ? g.ws + (long)ksplit * g.M * g.N : nullptr;
-    float bv[4] = {0.f, 0.f, 0.f, 0.f};
-    if (g.bias && !ws) {
+    if (col < g.N) {
+        const int nv = min(4, g.N - col);
+        float bv[4] = {0.f, 0.f, 0.f, 0.f};
+        if (g.bias && !ws) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) if (e < nv) bv[e] = g.bias[col + e];
-    }
-    if (VEC && ((ws && (g.side_drain & 2)) || (!ws && (g.side_drain & 1) && g.epi_kind >= 1 && g.epi_kind <= 5))) {
-#pragma unroll
-        for (int hh = 0; hh < 2; ++hh) {
-            auto row_of = [&](int it, int& rl, int& row) { rl = (tid >> 5) + ((it + 8 * hh) << 3); row = m0 + rl; };
-            if (ws) MRG_DRAIN8(7, false, ws);
-            else if (g.epi_kind == 2) MRG_DRAIN8(2, false, nullptr);
-            else if (g.epi_kind == 4) MRG_DRAIN8(4, false, nullptr);
-            else if (g.epi_kind == 1) MRG_DRAIN8(1, false, nullptr);
-            else if (g.epi_kind == 3) MRG_DRAIN8(3, false, nullptr);
-            else MRG_DRAIN8(5, false, nullptr);
+            for (int e = 0; e < 4; ++e) if (e < nv) bv[e] = g.bias[col + e];
         }
-        return;
-    }
+        if (VEC && ((ws && (g.side_drain & 2)) || (!ws && (g.side_drain & 1) && g.epi_kind >= 1 && g.epi_kind <= 5))) {
+#pragma unroll
+            for (int hh = 0; hh < 2; ++hh) {
+                auto row_of = [&](int it, int& rl, int& row) { rl = (tid >> 5) + ((it + 8 * hh) << 3); row = m0 + rl; };
+                if (ws) MRG_DRAIN8(7, false, ws);
+                else if (g.epi_kind == 2) MRG_DRAIN8(2, false, nullptr);
+                else if (g.epi_kind == 4) MRG_DRAIN8(4, false, nullptr);
+                else if (g.epi_kind == 1) MRG_DRAIN8(1, false, nullptr);
+                else if (g.epi_kind == 3) MRG_DRAIN8(3, false, nullptr);
+                else MRG_DRAIN8(5, false, nullptr);
+            }
+        } else {
 #pragma unroll 1
-    for (int it = 0; it < 16; ++it) {
-        const int rl = (tid >> 5) + (it << 3);
-        const int row = m0 + rl;
-        if (row >= Meff) break;
-        const float4 a4 = *reinterpret_cast<const float4*>(ct + rl * BN + cl);
-        epi_any<VEC>(g, a4, bv, ws, row, col, nv);
+            for (int it = 0; it < 16; ++it) {
+                const int rl = (tid >> 5) + (it << 3);
+                const int row = m0 + rl;
+                if (row >= Meff) break;
+                const float4 a4 = *reinterpret_cast<const float4*>(ct + rl * BN + cl);
+                epi_any<VEC>(g, a4, bv, ws, row, col, nv);
+            }
+        }
     }
+    if (ws && g.tile_cnt) splitk_finish<VEC>(g, bid, m0, n0, BM, BN, Meff, smem, tid, 256);
 }
 
 // 256 x 128 output tile = two stacked 128 x 128 sub-tiles that share one B tile (87 instead of 64 flop per byte moved
@@ -726,6 +731,7 @@ __global__ __launch_bounds__(768) void gemm_ws256_kernel(const GemmArgs g) {
         }
         // take part in the epilogue barriers
         __syncthreads(); __syncthreads(); __syncthreads(); __syncthreads();
+        if (g.splitk > 1 && g.tile_cnt) splitk_finish<VEC>(g, bid, m0, n0, 256, BN, Meff, smem, tid, 768);   // same barriers as the compute waves
         return;
     }
     // ---------------------------------------------------------------------- compute waves
@@ -808,6 +814,7 @@ __global__ __launch_bounds__(768) void gemm_ws256_kernel(const GemmArgs g) {
             }
         }
     }
+    if (ws && g.tile_cnt) splitk_finish<VEC>(g, bid, m0, n0, 256, BN, Meff, smem, tid, 768);
 }
 
 // 256 x 256 output tile (128 flop per operand byte): 8 waves as 2 (M) x 4 (N), each 128 x 64 (8 accumulator tiles), operands as
@@ -1223,7 +1230,7 @@ extern "C" int mrg_gemm(const mrg_gemm_desc* d, hipStream_t stream) {
     g.bias = d->bias; g.resid = d->resid; g.ldr = d->ldr; g.accumulate = d->accumulate; g.act = d->act;
     g.aux_out = (bf16_t*)d->aux_out; g.aux_in = (const bf16_t*)d->aux_in; g.ldaux = d->ldaux;
     g.row_map = d->row_map; g.add_tab = d->add_tab; g.add_row = d->add_row; g.ldt = d->ldt; g.row_scale = d->row_scale; g.colsum = d->colsum_out;
-    g.splitk = splitk; g.ws = d->ws;
+    g.splitk = splitk; g.ws = d->ws; g.tile_cnt = nullptr;
     MRG_REQUIRE(d->variant >= 0 && d->variant <= MRG_GEMM_P8, MRG_ERR_ARG, "mrg_gemm: bad variant");
     g.tiles_m = cdiv(d->M, BM); g.tiles_n = cdiv(d->N, BN);
     { static const int abl = [] { const char* e = getenv("MRG_GEMM_ABLATE"); return e ? atoi(e) : 0; }(); g.ablate = abl; }
@@ -1287,7 +1294,11 @@ extern "C" int mrg_gemm(const mrg_gemm_desc* d, hipStream_t stream) {
         if (d->ev_stop) (void)hipEventRecord((hipEvent_t)d->ev_stop, stream);
         return mrg_check_launch("mrg_gemm");
     }
+    // split-K finished inside the launch (splitk_finish) when the caller supplies arrival counters and the selected kernel has the
+    // protocol (generic, single-stage / two-stage 128 x 128, warp-specialised 256 x 128, 8-phase 256 x 256)
+    bool inkernel = false;
     auto finish_splitk = [&]() -> int {
+        if (inkernel) return 0;
         if (splitk > 1 && d->defer_reduce) {
             // the caller sums the split-K slabs ws[splitk][M*N] itself (mrg_reduce_batch): plain fp32 overwrite only
             MRG_REQUIRE(g.c_f32 && !d->accumulate && !d->bias && !d->C2 && d->ldc == d->N, MRG_ERR_UNSUPPORTED,
@@ -1301,6 +1312,11 @@ extern "C" int mrg_gemm(const mrg_gemm_desc* d, hipStream_t stream) {
         }
         return 0;
     };
+    const bool will_sq = !d->colsum_out && fast && !mapped && d->variant == MRG_GEMM_PIPE256SQ && d->M > 128 && d->N > 128;
+    const bool will_ws = !d->colsum_out && fast && !mapped && d->variant == MRG_GEMM_WS256 && d->M > 128;
+    const bool will_g256 = fast && d->variant == MRG_GEMM_G256 && kf && !d->colsum_out && d->M > 128;
+    inkernel = splitk > 1 && d->splitk_counters && !d->defer_reduce && !d->colsum_out && !will_sq && !will_g256 && !(use_big && !will_ws);
+    g.tile_cnt = inkernel ? d->splitk_counters : nullptr;
     if (fast && !mapped && d->variant == MRG_GEMM_P8 && !d->colsum_out && d->M > 128 && d->N > 128 &&
         mrg_gemm8p_launch(g, d->a_mode, d->b_mode, vec, splitk, stream)) {
         if (d->ev_stop) (void)hipEventRecord((hipEvent_t)d->ev_stop, stream);

@@ -334,6 +334,7 @@ __global__ __launch_bounds__(512) void gemm_p8_kernel(const GemmArgs g) {
             }
         }
     }
+    if (ws && g.tile_cnt) splitk_finish<VEC>(g, bid, m0, n0, 256, 256, Meff, smem, tid, 512);
 }
 
 }  // namespace

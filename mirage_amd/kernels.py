@@ -106,12 +106,45 @@ class Deferred:
 TIMING = {"on": False, "records": []}     # bench.py: (kernel variant, mode, flops, start event, stop event) per GEMM launch
 
 
+# Arrival counters of the in-launch split-K finish (mrg_gemm_desc.splitk_counters): regions of one zero-initialised int32 ring, one
+# region per GEMM call; every launch leaves its region zero again, so a captured graph reuses its regions on every replay and the
+# eager path wraps around after ~1M tiles (several steps' worth: no two launches in flight share a region)
+# Measured on the C2 step (same box, 30 steps): off 10.90 ms; on for every split-K GEMM 12.79 ms; on for <= 4 slices of >= 64 tiles
+# (the encoder weight gradients) 11.21 ms; <= 2 slices 10.95 ms.  The last arriver reads its tile's slabs alone (cross-XCD,
+# ~60-100 GB/s per workgroup) inside the weight-gradient kernel, while the batched reduction launch does the same work with the whole
+# chip off the critical path -- fewer HBM bytes (the slabs are consumed from cache), more time.  Default: off (A/B: MRG_SPLITK_INKERNEL=1).
+SPLITK_INKERNEL = os.environ.get("MRG_SPLITK_INKERNEL", "0") != "0"
+SPLITK_INKERNEL_MAX = int(os.environ.get("MRG_SPLITK_INKERNEL_MAX", "4"))
+SPLITK_INKERNEL_MIN_TILES = int(os.environ.get("MRG_SPLITK_INKERNEL_MIN_TILES", "64"))
+_cnt_ring = {}
+
+
+def _splitk_counters(ntiles: int, device):
+    ring = _cnt_ring.get(device)
+    if ring is None:
+        ring = [torch.zeros(1 << 20, dtype=torch.int32, device=device), 0]
+        _cnt_ring[device] = ring
+    buf, pos = ring
+    n = (ntiles + 63) // 64 * 64
+    if pos + n > buf.numel():
+        pos = 0
+    ring[1] = pos + n
+    return buf.data_ptr() + 4 * pos
+
+
 def _gemm_launch(d, splitk, variant, dev, defer_out=None):
     d.splitk = splitk
     d.variant = variant
     d.defer_reduce = 0
+    d.splitk_counters = None
     if splitk > 1:
-        if defer_out is not None:
+        if (SPLITK_INKERNEL and not d.colsum_out and splitk <= SPLITK_INKERNEL_MAX
+                and ((d.M + 127) // 128) * ((d.N + 127) // 128) >= SPLITK_INKERNEL_MIN_TILES):
+            # slabs in the per-stream workspace (rewritten by every split-K GEMM of the stream, so they stay cache-resident) and
+            # reduced by the last-arriving workgroup of each tile inside the launch
+            d.ws = _workspace(splitk * d.M * d.N * 4, dev).data_ptr()
+            d.splitk_counters = _splitk_counters(((d.M + 127) // 128) * ((d.N + 127) // 128), dev)
+        elif defer_out is not None:
             # own slab (kept alive until the batched reduction) instead of the shared workspace
             ws = torch.empty(splitk * d.M * d.N, dtype=F32, device=dev)
             d.ws = ws.data_ptr()

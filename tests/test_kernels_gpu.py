@@ -186,6 +186,49 @@ def test_gemm_p8_fused_epilogues_and_repeatability(K):
     torch.testing.assert_close(first, lin, rtol=2e-3, atol=2e-3 * float(lin.abs().max()))
 
 
+@pytest.mark.parametrize("variant", [0, 1, 3, 7, 11])
+def test_gemm_splitk_finished_inside_the_launch(K, variant):
+    """Split-K with the last-arriver reduction inside the launch (mrg_gemm_desc.splitk_counters): bit-identical to the separate
+    reduction kernel (slabs are summed in slice order either way), repeatable over many launches (arrival order varies), counters
+    left at zero, bias / bf16 output through the last arriver, and correct when two streams run split-K GEMMs at once."""
+    from mirage_amd import _lib as L
+    Mtok, Nout, Kin, sk = 4128, 512, 384, 6
+    dy = rnd(Mtok, Nout, dtype=BF16, seed=81); x = rnd(Mtok, Kin, dtype=BF16, seed=82); b = rnd(Kin, seed=83)
+    ref = dy.float().t() @ x.float()
+    K.TUNE["force"] = variant if variant else None
+    K.TUNE["enabled"] = False
+    try:
+        def run(**kw):
+            return K.gemm(dy, x, Nout, Kin, Mtok, a_mode=L.MRG_OP_KSTRIDED, b_mode=L.MRG_OP_KSTRIDED, splitk=sk, **kw)
+        K.SPLITK_INKERNEL = False
+        old = run(out_dtype=F32).clone()
+        old_b = run(out_dtype=BF16, bias=b).clone()
+        K.SPLITK_INKERNEL = True
+        new = run(out_dtype=F32).clone()
+        assert torch.equal(new, old), float((new - old).abs().max())
+        assert torch.equal(run(out_dtype=BF16, bias=b), old_b)
+        for _ in range(25):
+            assert torch.equal(run(out_dtype=F32), new)
+        ring = K._cnt_ring[dev()][0]
+        assert int(ring.abs().sum()) == 0
+        # two streams at once, each with its own counters and workspace
+        s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+        outs = []
+        torch.cuda.synchronize()
+        for st in (s1, s2, s1, s2):
+            with torch.cuda.stream(st):
+                outs.append(run(out_dtype=F32))
+        torch.cuda.synchronize()
+        for o in outs:
+            assert torch.equal(o, new)
+        assert int(ring.abs().sum()) == 0
+    finally:
+        K.TUNE["force"] = None
+        K.TUNE["enabled"] = True
+        K.SPLITK_INKERNEL = True
+    torch.testing.assert_close(new, ref, rtol=3e-3, atol=3e-3 * float(ref.abs().max()))
+
+
 def test_gemm_epilogues(K):
     from mirage_amd import _lib as L
     M, N, Kd = 517, 384, 256
