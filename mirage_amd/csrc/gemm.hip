@@ -163,7 +163,11 @@ __device__ __forceinline__ void glds_setup(const bf16_t* P, int ld, int row0, in
     }
 }
 
-template <int AMODE, int BMODE, bool VEC, int OCC, bool CSUM = false, bool KF = false>
+// DIRECT: the MFMA operands are swapped (the A fragment feeds the matrix core's B port), so a lane ends up with output ROW lane & 31
+// and, per accumulator quad, four CONSECUTIVE columns: the fused epilogue runs straight on the registers and stores 8 B (bf16 x 4) /
+// 16 B (fp32 x 4) per quad -- no fp32 round trip of the tile through LDS (64 ds_write_b32 + 16 ds_read_b128 per lane, at the LDS's
+// ~64-80 B/clk store rate about 1000 cycles per tile) and none of its four barriers.
+template <int AMODE, int BMODE, bool VEC, int OCC, bool CSUM = false, bool KF = false, bool DIRECT = false>
 __global__ __launch_bounds__(256, OCC) void gemm_glds_kernel(const GemmArgs g) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int nwg = g.tiles_m * g.tiles_n;
@@ -269,8 +273,46 @@ __global__ __launch_bounds__(256, OCC) void gemm_glds_kernel(const GemmArgs g) {
             for (int i = 0; i < 2; ++i)
 #pragma unroll
                 for (int j = 0; j < 2; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = DIRECT ? __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0)
+                                       : __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
         }
+    }
+    if constexpr (DIRECT) {
+        // ---- epilogue on the accumulator registers: lane = row (lane & 31) of each 32-row tile, quad q of accumulator tile (i, j) =
+        // columns j*32 + 8q + 4*(lane >> 5) .. +3
+        float* ws = g.splitk > 1 ? g.ws + (long)ksplit * g.M * g.N : nullptr;
+        const int hc = (lane >> 5) << 2;
+        const bool bias_vec = VEC && ((reinterpret_cast<uintptr_t>(g.bias) & 15) == 0);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            float bq[4][4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int col = n0 + wn * 64 + j * 32 + 8 * q + hc;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) bq[q][e] = 0.f;
+                if (g.bias && !ws && col < g.N) {
+                    if (bias_vec) { const float4 b4 = *reinterpret_cast<const float4*>(g.bias + col); bq[q][0] = b4.x; bq[q][1] = b4.y; bq[q][2] = b4.z; bq[q][3] = b4.w; }
+                    else { for (int e = 0; e < 4; ++e) if (col + e < g.N) bq[q][e] = g.bias[col + e]; }
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int row = m0 + wm * 64 + i * 32 + (lane & 31);
+                if (row < Meff) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int col = n0 + wn * 64 + j * 32 + 8 * q + hc;
+                        if (col < g.N) {
+                            const float4 a4 = make_float4(acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]);
+                            epi_any<VEC>(g, a4, bq[q], ws, row, col, min(4, g.N - col));
+                        }
+                    }
+                }
+            }
+        }
+        if (ws && g.tile_cnt) splitk_finish<VEC>(g, bid, m0, n0, BM, BN, Meff, smem, tid, 256);
+        return;
     }
     // ---- epilogue in two passes of 64 rows x 128 cols fp32 (32 KiB)
     float* ct = reinterpret_cast<float*>(smem);
@@ -1238,6 +1280,7 @@ extern "C" int mrg_gemm(const mrg_gemm_desc* d, hipStream_t stream) {
     { static const int xs = [] { const char* e = getenv("MRG_GEMM_XCD_SPLIT"); return e ? atoi(e) : 1; }(); g.xcd_split = xs; }
     { static const int sd = [] { const char* e = getenv("MRG_GEMM_SIDE_DRAIN"); return e ? atoi(e) : 3; }(); g.side_drain = sd; }
     static const int kfast = [] { const char* e = getenv("MRG_GEMM_KFAST"); return e ? atoi(e) : 1; }();
+    static const int epi_direct = [] { const char* e = getenv("MRG_EPI_DIRECT"); return e ? atoi(e) : 0; }();   // register-direct epilogue of the single-stage 128 x 128 kernel: measured SLOWER (12.95 vs 11.02 ms/step at C2)
     const bool kf = kfast && (d->K % BK == 0) && !d->k_dev && !d->a_map;      // scalar-base loaders
     {   // lean epilogue selection (uniform over the launch)
         static const int lean = [] { const char* e = getenv("MRG_GEMM_LEAN"); return e ? atoi(e) : 1; }();
@@ -1362,6 +1405,8 @@ extern "C" int mrg_gemm(const mrg_gemm_desc* d, hipStream_t stream) {
         hipLaunchKernelGGL((gemm_ws256_kernel<AM, BM_, V>), dim3(cdiv(d->M, 256) * g.tiles_n, splitk), dim3(768), (size_t)(9 * TILE_BYTES), stream, g); } } while (0)
 #define MRG_FAST(AM, BM_, V) do { if (use_ws) MRG_WS(AM, BM_, V); else if (use_sq) MRG_SQ(AM, BM_, V); else if (use_big) MRG_BIG(AM, BM_, V); else if (use_pipe && kf && V) hipLaunchKernelGGL((gemm_pipe_kernel<AM, BM_, true, true>), grid, block, (size_t)(4 * TILE_BYTES), stream, g); \
                                   else if (use_pipe) hipLaunchKernelGGL((gemm_pipe_kernel<AM, BM_, V>), grid, block, (size_t)(4 * TILE_BYTES), stream, g); \
+                                  else if (occ4 && kf && V && epi_direct) hipLaunchKernelGGL((gemm_glds_kernel<AM, BM_, true, 4, false, true, true>), grid, block, (size_t)(2 * TILE_BYTES), stream, g); \
+                                  else if (kf && V && epi_direct) hipLaunchKernelGGL((gemm_glds_kernel<AM, BM_, true, 3, false, true, true>), grid, block, (size_t)(2 * TILE_BYTES), stream, g); \
                                   else if (occ4 && kf && V) hipLaunchKernelGGL((gemm_glds_kernel<AM, BM_, true, 4, false, true>), grid, block, (size_t)(2 * TILE_BYTES), stream, g); \
                                   else if (kf && V) hipLaunchKernelGGL((gemm_glds_kernel<AM, BM_, true, 3, false, true>), grid, block, (size_t)(2 * TILE_BYTES), stream, g); \
                                   else if (occ4) hipLaunchKernelGGL((gemm_glds_kernel<AM, BM_, V, 4>), grid, block, (size_t)(2 * TILE_BYTES), stream, g); \

@@ -204,6 +204,8 @@ def test_gemm_splitk_finished_inside_the_launch(K, variant):
         old = run(out_dtype=F32).clone()
         old_b = run(out_dtype=BF16, bias=b).clone()
         K.SPLITK_INKERNEL = True
+        lim = (K.SPLITK_INKERNEL_MAX, K.SPLITK_INKERNEL_MIN_TILES)
+        K.SPLITK_INKERNEL_MAX, K.SPLITK_INKERNEL_MIN_TILES = 64, 1          # this problem: 6 slices of 12 tiles
         new = run(out_dtype=F32).clone()
         assert torch.equal(new, old), float((new - old).abs().max())
         assert torch.equal(run(out_dtype=BF16, bias=b), old_b)
@@ -225,7 +227,11 @@ def test_gemm_splitk_finished_inside_the_launch(K, variant):
     finally:
         K.TUNE["force"] = None
         K.TUNE["enabled"] = True
-        K.SPLITK_INKERNEL = True
+        K.SPLITK_INKERNEL = False
+        try:
+            K.SPLITK_INKERNEL_MAX, K.SPLITK_INKERNEL_MIN_TILES = lim
+        except NameError:
+            pass
     torch.testing.assert_close(new, ref, rtol=3e-3, atol=3e-3 * float(ref.abs().max()))
 
 
