@@ -194,11 +194,12 @@ def _run(real_stdout: int):
             _E2._Lanes.enabled = False
         if os.environ.get("MRG_SIDE") == "0":
             _E2._Side.enabled = False
-    if any(os.environ.get(k) for k in ("MRG_LANES_FWD", "MRG_LANES_BWD", "MRG_LANES_ORDER")):
+    if any(os.environ.get(k) for k in ("MRG_LANES_FWD", "MRG_LANES_BWD", "MRG_LANES_ORDER", "MRG_LANES_ALL")):
         from mirage_amd import engine as _E5
         _E5._Lanes.fwd = os.environ.get("MRG_LANES_FWD", "1") != "0"
         _E5._Lanes.bwd = os.environ.get("MRG_LANES_BWD", "1") != "0"
         _E5._Lanes.main_first = os.environ.get("MRG_LANES_ORDER", "0") == "1"
+        _E5._Lanes.all_lanes = os.environ.get("MRG_LANES_ALL", "0") == "1"
     if os.environ.get("MRG_TAPER") == "0" or os.environ.get("MRG_REDUCE_EARLY") == "0":
         from mirage_amd import engine as _E3
         _E3._Side.taper = os.environ.get("MRG_TAPER") != "0"

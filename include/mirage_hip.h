@@ -26,7 +26,7 @@ extern "C" {
 typedef struct ihipStream_t* hipStream_t;
 #endif
 
-#define MRG_ABI_VERSION 5   /* 2: mrg_gemm_desc grew row_scale / defer_reduce, act codes 3, 4, reduce_batch / augment / row_scale entry points; 3: colsum_out, attention colsum_*; 4: step = int[2], mrg_step_inc takes the skip decision; 5: splitk_counters, MRG_GEMM_P8, resize entry points */
+#define MRG_ABI_VERSION 6   /* 2: mrg_gemm_desc grew row_scale / defer_reduce, act codes 3, 4, reduce_batch / augment / row_scale entry points; 3: colsum_out, attention colsum_*; 4: step = int[2], mrg_step_inc takes the skip decision; 5: splitk_counters, MRG_GEMM_P8, resize entry points; 6: mrg_adamw_desc.sumsq_out, mrg_sumsq_finish */
 
 enum { MRG_DT_BF16 = 0, MRG_DT_F32 = 1 };
 enum { MRG_OP_KCONTIG = 0, MRG_OP_KSTRIDED = 1 };
@@ -239,7 +239,12 @@ typedef struct mrg_adamw_desc {
     const float* lr_table; const float* wd_table; const int* step; int table_len;
     float lr_scale, beta1, beta2, eps;
     const float* grad_norm; float clip_norm, skip_norm;
+    float* sumsq_out;   /* optional fp32 [mrg_adamw_nblocks(n)]: per-block partial sums of g^2 over this launch's range -- the global
+                           gradient norm for logging (native_scaler.py:46-61) then costs no extra pass over the gradients:
+                           mrg_sumsq_finish(all partials) = sqrt(sum).  Not with skip_norm (the norm is needed before the update). */
 } mrg_adamw_desc;
+int mrg_adamw_nblocks(long n);
+int mrg_sumsq_finish(const float* partials, int n, float* out, hipStream_t stream);
 int mrg_sumsq_nblocks(long n);
 int mrg_grad_norm(const float* g, long n, float* partials, float* out, hipStream_t stream);
 int mrg_adamw(const mrg_adamw_desc* d, hipStream_t stream);

@@ -60,7 +60,7 @@ class AdamWDesc(C.Structure):
     _fields_ = [("p", vp), ("g", vp), ("m", vp), ("v", vp), ("shadow_bf16", vp), ("n", cl), ("n_decay", cl),
                 ("lr_table", vp), ("wd_table", vp), ("step", vp), ("table_len", ci),
                 ("lr_scale", cf), ("beta1", cf), ("beta2", cf), ("eps", cf),
-                ("grad_norm", vp), ("clip_norm", cf), ("skip_norm", cf)]
+                ("grad_norm", vp), ("clip_norm", cf), ("skip_norm", cf), ("sumsq_out", vp)]
 
 
 # name -> (restype, argtypes); kept in sync with include/mirage_hip.h (tests/test_abi.py checks the exports)
@@ -92,6 +92,8 @@ SIGNATURES = {
     "mrg_sumsq_nblocks": (ci, [cl]),
     "mrg_grad_norm": (ci, [vp, cl, vp, vp, vp]),
     "mrg_adamw": (ci, [C.POINTER(AdamWDesc), vp]),
+    "mrg_adamw_nblocks": (ci, [cl]),
+    "mrg_sumsq_finish": (ci, [vp, ci, vp, vp]),
     "mrg_step_inc": (ci, [vp, vp, C.c_float, C.c_float, vp]),
     "mrg_cast_bf16": (ci, [vp, vp, cl, vp]),
     "mrg_row_scale_bf16": (ci, [vp, vp, vp, cl, ci, vp]),
@@ -115,7 +117,7 @@ for _name, (_res, _args) in SIGNATURES.items():
     _fn.argtypes = _args
 
 ABI_VERSION = lib.mrg_version()
-EXPECTED_ABI_VERSION = 5       # must match MRG_ABI_VERSION in include/mirage_hip.h: the ctypes structs above mirror that layout
+EXPECTED_ABI_VERSION = 6       # must match MRG_ABI_VERSION in include/mirage_hip.h: the ctypes structs above mirror that layout
 if ABI_VERSION != EXPECTED_ABI_VERSION:
     raise ImportError(f"{LIB_PATH} reports ABI version {ABI_VERSION}, the Python bindings expect {EXPECTED_ABI_VERSION}: rebuild it "
                       "(python -c 'import __graft_entry__ as g; g.build()')")

@@ -44,6 +44,7 @@ struct AdamArgs {
     const float* lr_table; const float* wd_table; const int* step; int table_len;
     float lr_scale, beta1, beta2, eps;
     const float* grad_norm; float clip_norm, skip_norm;
+    float* sumsq_out;      // optional [gridDim.x]: this launch's partial sums of g^2 (the gradient is read here anyway)
 };
 
 __global__ __launch_bounds__(256) void adamw_kernel(const AdamArgs a) {
@@ -71,9 +72,11 @@ __global__ __launch_bounds__(256) void adamw_kernel(const AdamArgs a) {
     if (gs < 0.f) return;
     const float b1 = a.beta1, b2 = a.beta2;
     const long n4 = a.n >> 2;
+    float ss = 0.f;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
         float4 p = reinterpret_cast<float4*>(a.p)[i];
         float4 g = reinterpret_cast<const float4*>(a.g)[i];
+        ss += (g.x * g.x + g.y * g.y) + (g.z * g.z + g.w * g.w);
         float4 m = reinterpret_cast<float4*>(a.m)[i];
         float4 v = reinterpret_cast<float4*>(a.v)[i];
         float* pp = &p.x; float* gp = &g.x; float* mp = &m.x; float* vp = &v.x;
@@ -91,6 +94,13 @@ __global__ __launch_bounds__(256) void adamw_kernel(const AdamArgs a) {
         reinterpret_cast<float4*>(a.m)[i] = m;
         reinterpret_cast<float4*>(a.v)[i] = v;
         if (a.shadow) reinterpret_cast<uint2*>(a.shadow)[i] = make_uint2(pack_bf2(p.x, p.y), pack_bf2(p.z, p.w));
+    }
+    if (a.sumsq_out) {        // deterministic two-stage sum: per-block partial here, mrg_sumsq_finish over all launches' partials later
+        __shared__ float red[4];
+        ss = wave_sum(ss);
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = ss;
+        __syncthreads();
+        if (threadIdx.x == 0) a.sumsq_out[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
     }
 }
 
@@ -144,6 +154,19 @@ extern "C" int mrg_grad_norm(const float* g, long n, float* partials, float* out
     return mrg_check_launch("mrg_grad_norm/finish");
 }
 
+extern "C" int mrg_adamw_nblocks(long n) {
+    long nb = (n / 4 + 255) / 256;
+    if (nb > 4096) nb = 4096;
+    if (nb < 1) nb = 1;
+    return (int)nb;
+}
+
+extern "C" int mrg_sumsq_finish(const float* partials, int n, float* out, hipStream_t stream) {
+    MRG_REQUIRE(partials && out && n > 0, MRG_ERR_ARG, "mrg_sumsq_finish: bad argument");
+    hipLaunchKernelGGL(sumsq_finish_kernel, dim3(1), dim3(256), 0, stream, partials, n, out);
+    return mrg_check_launch("mrg_sumsq_finish");
+}
+
 extern "C" int mrg_adamw(const mrg_adamw_desc* d, hipStream_t stream) {
     MRG_REQUIRE(d && d->p && d->g && d->m && d->v && d->lr_table && d->wd_table && d->step, MRG_ERR_ARG, "mrg_adamw: null pointer");
     MRG_REQUIRE(d->n > 0 && d->n % 4 == 0 && d->n_decay >= 0 && d->n_decay <= d->n && d->table_len > 0, MRG_ERR_SHAPE,
@@ -155,8 +178,9 @@ extern "C" int mrg_adamw(const mrg_adamw_desc* d, hipStream_t stream) {
     a.lr_table = d->lr_table; a.wd_table = d->wd_table; a.step = d->step; a.table_len = d->table_len;
     a.lr_scale = d->lr_scale; a.beta1 = d->beta1; a.beta2 = d->beta2; a.eps = d->eps;
     a.grad_norm = d->grad_norm; a.clip_norm = d->clip_norm; a.skip_norm = d->skip_norm;
-    long nb = (d->n / 4 + 255) / 256;
-    if (nb > 4096) nb = 4096;
+    a.sumsq_out = d->sumsq_out;
+    MRG_REQUIRE(!(d->sumsq_out && d->skip_norm > 0.f && d->grad_norm), MRG_ERR_UNSUPPORTED, "mrg_adamw: sumsq_out with skip_norm (the norm must exist before the update)");
+    long nb = mrg_adamw_nblocks(d->n);
     hipLaunchKernelGGL(adamw_kernel, dim3((unsigned)nb), dim3(256), 0, stream, a);
     return mrg_check_launch("mrg_adamw");
 }

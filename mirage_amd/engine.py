@@ -546,6 +546,7 @@ class _Lanes:
         return cls.streams[i]
 
     main_first = False      # experiment knob (MRG_LANES_ORDER=1): issue job 0 (calling stream) before the lane jobs
+    all_lanes = False
 
     @classmethod
     def run_all(cls, jobs, device, enabled=None):
@@ -557,6 +558,16 @@ class _Lanes:
         ev.record(main)
         out = [None] * len(jobs)
         lanes = []
+        if cls.all_lanes:                      # experiment knob (MRG_LANES_ALL=1): every job on a lane stream, none on the caller's
+            for i, job in enumerate(jobs):
+                st = cls.get(i, device)
+                st.wait_event(ev)
+                with torch.cuda.stream(st):
+                    out[i] = job()
+                lanes.append(st)
+            for st in lanes:
+                main.wait_stream(st)
+            return out
         if cls.main_first:
             out[0] = jobs[0]()
         for i, job in enumerate(jobs[1:], start=1):

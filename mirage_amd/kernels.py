@@ -527,14 +527,24 @@ def grad_norm(g: torch.Tensor, out: torch.Tensor):
 
 
 def adamw(p, g, m, v, shadow, n_decay, lr_table, wd_table, step, beta1, beta2, eps, lr_scale=1.0, grad_norm_t=None, clip_norm=0.0,
-          skip_norm=0.0):
+          skip_norm=0.0, sumsq_out=None):
+    """sumsq_out: optional fp32 tensor with >= adamw_nblocks(p.numel()) entries receiving this launch's partial sums of g^2."""
     d = L.AdamWDesc()
     d.p, d.g, d.m, d.v, d.shadow_bf16 = p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), _p(shadow)
     d.n, d.n_decay = p.numel(), n_decay
     d.lr_table, d.wd_table, d.step, d.table_len = lr_table.data_ptr(), wd_table.data_ptr(), step.data_ptr(), lr_table.numel()
     d.lr_scale, d.beta1, d.beta2, d.eps = lr_scale, beta1, beta2, eps
     d.grad_norm, d.clip_norm, d.skip_norm = _p(grad_norm_t), clip_norm or 0.0, skip_norm or 0.0
+    d.sumsq_out = _p(sumsq_out)
     check(lib.mrg_adamw(C.byref(d), _s()), "mrg_adamw")
+
+
+def adamw_nblocks(n: int) -> int:
+    return lib.mrg_adamw_nblocks(n)
+
+
+def sumsq_finish(partials: torch.Tensor, n: int, out: torch.Tensor):
+    check(lib.mrg_sumsq_finish(partials.data_ptr(), n, out.data_ptr(), _s()), "mrg_sumsq_finish")
 
 
 def step_inc(step: torch.Tensor, grad_norm_t=None, clip_norm=0.0, skip_norm=0.0):

@@ -6,6 +6,7 @@ mutils/native_scaler.py:64-88 cosine_scheduler, :46-61 get_grad_norm_, :10-34 cl
 run_pretraining.py:496-515 (lr = blr * batch / 256, per-step lr/wd arrays), :683-688 (per-step assignment).
 """
 import math
+import os
 from typing import Dict, List, Optional
 
 import numpy as np
@@ -84,6 +85,11 @@ class FusedAdamW:
         self.clip_grad = clip_grad
         self.skip_grad = skip_grad if clip_grad is None else None
         self._host_step = 0
+        # without clip / skip the gradient norm is only logged: the AdamW launches emit partial sums of g^2 over their ranges
+        # (the gradient is read there anyway) and one tiny kernel finishes them -- no separate pass over the gradient arena
+        self.fuse_norm = not self.clip_grad and not self.skip_grad and os.environ.get("MRG_FUSE_NORM", "1") != "0"
+        self._ss = torch.zeros(1 << 19, dtype=torch.float32, device=dev) if self.fuse_norm else None     # <= 4096 partials per launch, <= 128 launches
+        self._ss_pos = 0
         self.param_groups = [
             {"params": [arena.params[n] for n in arena.names_decay], "names": arena.names_decay, "weight_decay": float(self._wd_host[0]),
              "lr": float(self._lr_host[0]), "lr_scale": 1.0},
@@ -107,8 +113,15 @@ class FusedAdamW:
         a = self.arena
         for s, e in ranges:
             nd = max(0, min(e, a.n_decay) - s)
+            ss = None
+            if self.fuse_norm:
+                nb = K.adamw_nblocks(e - s)
+                if self._ss_pos + nb > self._ss.numel():
+                    raise RuntimeError("FusedAdamW: partial-sum buffer exhausted (too many update ranges in one step)")
+                ss = self._ss[self._ss_pos:self._ss_pos + nb]
+                self._ss_pos += nb
             K.adamw(a.flat_p[s:e], a.flat_g[s:e], self.exp_avg[s:e], self.exp_avg_sq[s:e], a.flat_bf16[s:e], nd, self.lr_table,
-                    self.wd_table, self.step_dev, self.betas[0], self.betas[1], self.eps)
+                    self.wd_table, self.step_dev, self.betas[0], self.betas[1], self.eps, sumsq_out=ss)
 
     def step(self, done_ranges=None):
         """global grad norm (native_scaler.py:46-61) -> AdamW (+clip / skip) -> counters.  `done_ranges`: sorted, disjoint
@@ -117,17 +130,21 @@ class FusedAdamW:
         join_side_stream()
         a = self.arena
         g = a.flat_g
-        K.grad_norm(g, self.grad_norm)
-        if done_ranges:
+        if not self.fuse_norm:
+            K.grad_norm(g, self.grad_norm)
+        if done_ranges or self.fuse_norm:
             assert not self.clip_grad and not self.skip_grad
             rest, pos = [], 0
-            for s, e in done_ranges:
+            for s, e in (done_ranges or []):
                 if s > pos:
                     rest.append((pos, s))
                 pos = max(pos, e)
             if pos < a.n_trainable:
                 rest.append((pos, a.n_trainable))
             self.step_ranges(rest)
+            if self.fuse_norm:
+                K.sumsq_finish(self._ss, self._ss_pos, self.grad_norm)
+                self._ss_pos = 0
         else:
             K.adamw(a.flat_p[:a.n_trainable], g, self.exp_avg, self.exp_avg_sq, a.flat_bf16[:a.n_trainable], a.n_decay, self.lr_table,
                     self.wd_table, self.step_dev, self.betas[0], self.betas[1], self.eps, grad_norm_t=self.grad_norm,
