@@ -208,6 +208,9 @@ def _run(real_stdout: int):
         from mirage_amd import engine as _E4
         _E4.FUSE_ATTN_BIAS = os.environ.get("MRG_ATTN_BIAS") != "0"
         _E4.FUSE_EPI_COLSUM = os.environ.get("MRG_EPI_COLSUM") != "0"
+    if os.environ.get("MRG_EMBED_GATHER") == "0":
+        from mirage_amd import engine as _E6
+        _E6.EMBED_WGRAD_GATHER = False
     if os.environ.get("MRG_SIDE_BLOCKS"):          # experiment knob: transformer blocks per side-stream fork
         from mirage_amd import engine as _E
         _E._Side.blocks_per_flush = int(os.environ["MRG_SIDE_BLOCKS"])

@@ -167,6 +167,11 @@ int mrg_attn_bwd(const mrg_attn_desc* d, hipStream_t stream);
  */
 int mrg_embed_plan(const long* ids_keep, int B, int K, int N, int ndom, const int* dom_start_host, int* rows, int* toks,
                    int* srcb, int* counts, hipStream_t stream);
+/* dst bf16 [cap, D] = rows map[0 .. *count_dev) of src bf16 (row stride src_ld elements), zero beyond the count: the gradient rows of
+ * one modality's kept tokens, compacted, so that the patch-embedding weight gradient (torch conv2d backward-weight of
+ * mirage/input_adapters.py:101,229) is a plain k-strided GEMM over contiguous rows. */
+int mrg_gather_rows_bf16(const void* src_bf16, long src_ld, const int* map, const int* count_dev, int cap, int D, void* dst_bf16,
+                         hipStream_t stream);
 int mrg_im2col_image(const float* img, const int* srcb, const int* toks, const int* count_dev, int cap, int C, int H, int W,
                      int P, void* out_bf16, hipStream_t stream);
 int mrg_im2col_layermap(const long* labels, const float* class_emb, const int* srcb, const int* toks, const int* count_dev,

@@ -11,6 +11,8 @@ import torch  # noqa: F401  (must precede CDLL: one HIP runtime per process)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libmirage_hip.so")
+if os.environ.get("MRG_LIB_PATH"):          # A/B of two builds of the same ABI (tools only)
+    LIB_PATH = os.environ["MRG_LIB_PATH"]
 
 MRG_DT_BF16, MRG_DT_F32 = 0, 1
 MRG_OP_KCONTIG, MRG_OP_KSTRIDED = 0, 1
@@ -76,6 +78,7 @@ SIGNATURES = {
     "mrg_attn_fwd": (ci, [C.POINTER(AttnDesc), vp]),
     "mrg_attn_bwd": (ci, [C.POINTER(AttnDesc), vp]),
     "mrg_embed_plan": (ci, [vp, ci, ci, ci, ci, C.POINTER(ci), vp, vp, vp, vp, vp]),
+    "mrg_gather_rows_bf16": (ci, [vp, cl, vp, vp, ci, ci, vp, vp]),
     "mrg_im2col_image": (ci, [vp, vp, vp, vp, ci, ci, ci, ci, ci, vp, vp]),
     "mrg_im2col_layermap": (ci, [vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, vp, vp]),
     "mrg_class_emb_grad_slices": (ci, []),

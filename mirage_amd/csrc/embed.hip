@@ -194,7 +194,34 @@ __global__ void fill_global_kernel(float* __restrict__ x, const float* __restric
     }
 }
 
+// dst[i][:] = i < *count ? src[map[i]][:] : 0 for i < cap: the kept-token rows of one modality, compacted (bf16, D % 8 == 0).  Lets the
+// patch-embedding weight gradient run on the LDS-DMA GEMM kernels: a gathered (row-mapped) operand whose rows are the CONTRACTION
+// index can only be fetched by the generic per-lane loader (64 TF/s on these shapes)
+__global__ __launch_bounds__(256) void gather_rows_kernel(const bf16_t* __restrict__ src, long src_ld, const int* __restrict__ map,
+                                                          const int* __restrict__ count_dev, int cap, int D, bf16_t* __restrict__ dst) {
+    const int cpr = D >> 3;                     // 16-byte chunks per row
+    const int count = min(*count_dev, cap);
+    const long total = (long)cap * cpr;
+    for (long q = (long)blockIdx.x * 256 + threadIdx.x; q < total; q += (long)gridDim.x * 256) {
+        const int row = (int)(q / cpr), c = (int)(q - (long)row * cpr);
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (row < count) v = *reinterpret_cast<const uint4*>(src + (long)map[row] * src_ld + c * 8);
+        *reinterpret_cast<uint4*>(dst + (long)row * D + c * 8) = v;
+    }
+}
+
 }  // namespace
+
+extern "C" int mrg_gather_rows_bf16(const void* src_bf16, long src_ld, const int* map, const int* count_dev, int cap, int D, void* dst_bf16,
+                                    hipStream_t stream) {
+    MRG_REQUIRE(src_bf16 && map && count_dev && dst_bf16, MRG_ERR_ARG, "mrg_gather_rows_bf16: null pointer");
+    MRG_REQUIRE(cap > 0 && D > 0 && D % 8 == 0 && src_ld % 8 == 0, MRG_ERR_SHAPE, "mrg_gather_rows_bf16: D and src_ld must be multiples of 8");
+    MRG_REQUIRE((((uintptr_t)src_bf16 | (uintptr_t)dst_bf16) & 15) == 0, MRG_ERR_ARG, "mrg_gather_rows_bf16: misaligned");
+    const long total = (long)cap * (D / 8);
+    const unsigned nb = (unsigned)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
+    hipLaunchKernelGGL(gather_rows_kernel, dim3(nb), dim3(256), 0, stream, (const bf16_t*)src_bf16, src_ld, map, count_dev, cap, D, (bf16_t*)dst_bf16);
+    return mrg_check_launch("mrg_gather_rows_bf16");
+}
 
 extern "C" int mrg_embed_plan(const long* ids_keep, int B, int K, int N, int ndom, const int* dom_start_host, int* rows, int* toks,
                               int* srcb, int* counts, hipStream_t stream) {

@@ -388,6 +388,15 @@ def _int_array(vals: Sequence[int]):
     return (C.c_int * len(vals))(*vals)
 
 
+def gather_rows_bf16(src: torch.Tensor, row_map: torch.Tensor, count_dev: torch.Tensor, cap: int) -> torch.Tensor:
+    """bf16 [*, D] -> compact bf16 [cap, D]: rows row_map[0 .. count) of src, zero beyond the (device-side) count."""
+    D = src.shape[-1]
+    out = torch.empty((cap, D), dtype=BF16, device=src.device)
+    check(lib.mrg_gather_rows_bf16(src.data_ptr(), src.stride(-2), row_map.data_ptr(), count_dev.data_ptr(), cap, D, out.data_ptr(), _s()),
+          "mrg_gather_rows_bf16")
+    return out
+
+
 def embed_plan(ids_keep: torch.Tensor, N: int, dom_start: Sequence[int]):
     _need_cuda(ids_keep, "ids_keep")
     B, K = ids_keep.shape
