@@ -21,7 +21,7 @@ def run(tag, mk, iters=24):
     """mk(i) -> zero-arg launcher using buffer set i"""
     res = {}
     scratch = torch.empty(64 << 20, dtype=torch.float32, device=dev)       # 256 MiB
-    for mode in ("hot", "rot_out", "rot_all", "rot_all+evict"):
+    for mode in (("hot", "rot_A", "rot_B", "rot_all") if os.environ.get("GAP_AB") else ("hot", "rot_out", "rot_all", "rot_all+evict")):
         fns = [mk(i, mode) for i in range(POOL)]
         for f in fns:
             f()
@@ -53,13 +53,14 @@ def main():
         res = bufs((M, N), torch.float32) if kind == "resid" else None
         aux = [torch.empty(M, N, dtype=torch.float16, device=dev) for _ in range(POOL)] if kind == "gelu" else None
         def mk(i, mode):
-            io = 0 if mode == "hot" else i
-            ii = i if mode.startswith("rot_all") else 0
+            io = 0 if mode in ("hot", "rot_A", "rot_B") else i
+            ia = i if (mode.startswith("rot_all") or mode == "rot_A") else 0
+            iw = i if (mode.startswith("rot_all") or mode == "rot_B") else 0
             if kind == "bias":
-                return lambda: K.gemm(A[ii], W[ii], M, N, Kd, bias=b, out=out16[io])
+                return lambda: K.gemm(A[ia], W[iw], M, N, Kd, bias=b, out=out16[io])
             if kind == "resid":
-                return lambda: K.gemm(A[ii], W[ii], M, N, Kd, bias=b, out=out32[io], resid=res[ii])
-            return lambda: K.gemm(A[ii], W[ii], M, N, Kd, bias=b, out=out16[io], act=L.MRG_ACT_GELU_SAVE_GRAD, aux_out=aux[io])
+                return lambda: K.gemm(A[ia], W[iw], M, N, Kd, bias=b, out=out32[io], resid=res[ia])
+            return lambda: K.gemm(A[ia], W[iw], M, N, Kd, bias=b, out=out16[io], act=L.MRG_ACT_GELU_SAVE_GRAD, aux_out=aux[io])
         run(f"{name} {M}x{N}x{Kd} ({kind})", mk)
         del A, W, out16, out32, res, aux
     # dgrad of fc2 (multiply by GELU' + column sums) and of fc1
