@@ -274,6 +274,9 @@ int mrg_augment_label(const uint8_t* src_u8, long* dst, const float* params, int
 int mrg_resize_image(const float* src, float* dst, int B, int Hi, int Wi, int Ho, int Wo, hipStream_t stream);
 int mrg_resize_label(const long* src, long* dst, int B, int Hi, int Wi, int Ho, int Wo, hipStream_t stream);
 
+/* Profiling aid: *slot = wall_clock64() (constant 100 MHz counter) when `stream` reaches this point; capturable into a hipGraph. */
+int mrg_debug_timestamp(unsigned long long* slot, hipStream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

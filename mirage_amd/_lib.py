@@ -68,6 +68,7 @@ class AdamWDesc(C.Structure):
 # name -> (restype, argtypes); kept in sync with include/mirage_hip.h (tests/test_abi.py checks the exports)
 SIGNATURES = {
     "mrg_version": (ci, []),
+    "mrg_debug_timestamp": (ci, [vp, vp]),
     "mrg_last_error_string": (C.c_char_p, []),
     "mrg_gemm": (ci, [C.POINTER(GemmDesc), vp]),
     "mrg_ln_fwd": (ci, [vp, vp, vp, vp, vp, vp, vp, ci, ci, cf, vp]),

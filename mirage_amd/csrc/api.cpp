@@ -25,3 +25,15 @@ int mrg_check_launch(const char* what) {
 
 extern "C" const char* mrg_last_error_string() { return g_err; }
 extern "C" int mrg_version() { return MRG_ABI_VERSION; }
+
+// ---- phase timestamps inside a captured step (profiling aid): one lane stores the constant-rate wall clock (100 MHz) when the
+// stream reaches this point.  A graph-safe alternative to rocprofv3 for the phase structure of a replay, whose host-side
+// interception makes short replays host-bound (tools/step_phases.py).
+namespace {
+__global__ void timestamp_kernel(unsigned long long* slot) { if (threadIdx.x == 0) *slot = wall_clock64(); }
+}
+extern "C" int mrg_debug_timestamp(unsigned long long* slot, hipStream_t stream) {
+    MRG_REQUIRE(slot != nullptr, MRG_ERR_ARG, "mrg_debug_timestamp: null pointer");
+    hipLaunchKernelGGL(timestamp_kernel, dim3(1), dim3(64), 0, stream, slot);
+    return mrg_check_launch("mrg_debug_timestamp");
+}

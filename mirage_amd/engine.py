@@ -284,6 +284,7 @@ class EncoderFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, blocks, save, want_bf16, defer_join, dps, *params):
         ctx.defer_join = defer_join
+        K.timestamp("enc_fwd_start")
         x32 = x
         saved_all = []
         x16 = None
@@ -292,6 +293,7 @@ class EncoderFn(torch.autograd.Function):
             x32, x16, sv = block_fwd(blk, x32, save, want_bf16_out=(want_bf16 and i == n - 1), dp=dps[i] if dps else None)
             saved_all.append(sv)
         ctx.blocks, ctx.saved = blocks, saved_all
+        K.timestamp("enc_fwd_end")
         if want_bf16:
             ctx.mark_non_differentiable(x16)
             return x32, x16
@@ -300,12 +302,14 @@ class EncoderFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dout, _unused):
         _Side.begin_backward()
+        K.timestamp("enc_bwd_start")
         dx32 = dout.contiguous()
         dx16 = None
         n = len(ctx.blocks)
         for i, (blk, sv) in enumerate(zip(reversed(ctx.blocks), reversed(ctx.saved))):
             dx32, dx16 = block_bwd(blk, sv, dx32, dx16, remaining=(n - 1 - i) if _Side.taper else None)
         ctx.saved = None
+        K.timestamp("enc_bwd_chain_end")
         # hand the bf16 twin of the returned gradient to the embedding backward: keyed by the tensor OBJECT (identity
         # is checked on lookup, so a recycled address can never alias); at most one entry is alive
         _TWINS.clear()
@@ -434,6 +438,7 @@ class EmbedFn(torch.autograd.Function):
 def decoder_fwd(ad, enc32: torch.Tensor, enc16: torch.Tensor, ids_keep, ids_restore, dom_names: Sequence[str],
                 dom_start: Sequence[int], ng: int, save: bool):
     """SpatialOutputAdapter.forward (mirage/output_adapters.py:248-296)."""
+    K.timestamp(f"dec_fwd_start.{ad.task}")
     B, N, D = enc32.shape
     Kk = N - ng
     T = dom_start[-1]
@@ -476,6 +481,7 @@ def decoder_fwd(ad, enc32: torch.Tensor, enc16: torch.Tensor, ids_keep, ids_rest
     y, _, _ = lin_fwd(x16, ad.out_proj)                                                  # :288
     g = ad.image_size[0] // (ad.stride_level * ad.P_H)
     img = K.patch_rearrange(y.view(B, Tq, -1), True, B, ad.num_channels, g, ad.P_H)      # :291-294
+    K.timestamp(f"dec_fwd_end.{ad.task}")
     saved = None
     if save:
         saved = (desc, task_embs, queries, context, qn, mq, rq, cn, mc, rc, qp, kv, o, lse, x1, on, mo, ro, h_pre, h_act, x2,
@@ -489,6 +495,7 @@ def decoder_bwd(ad, saved, d_img: torch.Tensor):
     (desc, task_embs, queries, context, qn, mq, rq, cn, mc, rc, qp, kv, o, lse, x1, on, mo, ro, h_pre, h_act, x2, blk_saved, x16,
      enc16, (B, N, Tq, Dd, H, hd, g)) = saved
     dev = d_img.device
+    K.timestamp(f"dec_bwd_start.{ad.task}")
     blocks = list(ad.decoder_transformer) if isinstance(ad.decoder_transformer, torch.nn.Sequential) else []
     d_y = K.patch_rearrange(d_img.contiguous(), False, B, ad.num_channels, g, ad.P_H).view(B * Tq, -1)
     if d_y.dtype != BF16:
@@ -530,6 +537,7 @@ def decoder_bwd(ad, saved, d_img: torch.Tensor):
         if Wp.bias.requires_grad:
             K.colsum(d_ctx.view(B * N, Dd), grad_buffer(Wp.bias))
     _Side.run(_pc_grads, d_ctx16, enc16, d_ctx)
+    K.timestamp(f"dec_bwd_end.{ad.task}")
     return d_ctx16
 
 

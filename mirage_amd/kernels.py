@@ -616,3 +616,19 @@ def resize_label(x: torch.Tensor, size) -> torch.Tensor:
     out = torch.empty((B, Ho, Wo), dtype=torch.int64, device=x.device)
     check(lib.mrg_resize_label(x.contiguous().data_ptr(), out.data_ptr(), B, Hi, Wi, Ho, Wo, _s()), "mrg_resize_label")
     return out
+
+
+# ------------------------------------------------------------------------------------------- phase timestamps (profiling aid)
+TS = {"buf": None, "names": [], "on": os.environ.get("MRG_TS") == "1"}
+
+
+def timestamp(name: str):
+    """MRG_TS=1: record the device wall clock when the current stream reaches this point (graph-capturable); tools/step_phases.py"""
+    if not TS["on"]:
+        return
+    if TS["buf"] is None:
+        TS["buf"] = torch.zeros(256, dtype=torch.int64, device="cuda")
+    if name not in TS["names"]:
+        TS["names"].append(name)
+    i = TS["names"].index(name)
+    check(lib.mrg_debug_timestamp(TS["buf"].data_ptr() + 8 * i, _s()), "mrg_debug_timestamp")

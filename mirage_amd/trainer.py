@@ -134,6 +134,8 @@ class TrainStep:
 
     # -- pieces ----------------------------------------------------------------------------------------
     def _fwd_bwd(self):
+        from . import kernels as _K
+        _K.timestamp("step_start")
         x = self.static_x
         preds, masks = self.model({d: x[d] for d in self.in_domains}, num_encoded_tokens=self.K, alphas=self.alphas,
                                   sample_tasks_uniformly=self.uniform, mask_noise=self.static_noise)
@@ -179,12 +181,15 @@ class TrainStep:
         self.model._mrg_h_mid = None
 
     def _opt(self):
+        from . import kernels as _K
+        _K.timestamp("opt_start")
         if self._early is not None:
             self.opt.step(done_ranges=self._early_all)
         elif self._first_merged is not None:
             self.opt.step(done_ranges=self._first_merged)
         else:
             self.opt.step()
+        _K.timestamp("step_end")
 
     def _eager(self):
         if self.split:
