@@ -17,6 +17,7 @@
 // [B, N, H*hd] layout the proj GEMM consumes: the reference's reshape/permute/transpose copies do not exist.
 #include "common.h"
 #include "mirage_hip.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -522,6 +523,321 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dkv_kernel(const AttnArgs a) 
     }
 }
 
+// ------------------------------------------------ fused backward for short self-attention rows ----------------------------
+// Nq == Nk in (96, 160], hd 64 (the encoder rows of the MIRAGE path: 99 and 129 tokens): ONE launch produces dQ, dK and dV.
+// One workgroup per (batch, head), one wave per 32-row tile.  The scores of a (query block, key tile) pair are computed once:
+//   phase A (wave = key tile):  S, dP -> P, dS (accumulator layout: lane = key, registers = queries);  dV^T += dO^T P and
+//                               dK^T += Q^T dS straight from the registers;  dS also goes to LDS as packed bf16,
+//                               T[query block][key][32 queries] (8-byte stores, XOR-swizzled: stores and transposed reads are
+//                               conflict free).  Two query blocks are in flight per wave (four independent MFMA chains; the
+//                               exponentials of one block run under the matrix instructions of the other);
+//   phase B (wave = query tile): dQ^T += K^T dS^T with both operands by ds_read_b64_tr_b16 (T gives lane = query, k-slots = keys
+//                               in the same permutation frag_cols_tr uses for K).
+// The three outputs are accumulated TRANSPOSED (lane = token row, registers = 4 consecutive head-dim columns), packed to bf16,
+// staged per wave in LDS and written as full 128-B lines; the bias-gradient column sums are formed in that pass.
+// LDS holds only NR = N + 1 (rounded to 4) rows per tile: row NR - 1 is a zero row that every out-of-range row index is clamped
+// to (N = 99: 78 KiB, two workgroups per CU; N = 129: 111 KiB, one).
+// Against the query-owner + key-owner pair of kernels: 5 instead of 7 tile products, Q / K / V / dO are read once, one launch.
+constexpr int FUSED_SP = 144;                     // staging pitch (bytes) of a 64-column bf16 row: 16-B aligned, 36 banks
+template <int NT> struct FusedCfg { static constexpr int ROWS = NT * 32; };
+static inline int fused_nr(int N, int rows) { const int nr = (N + 1 + 3) & ~3; return nr < rows ? nr : rows; }
+static inline size_t fused_lds(int nr, int nt) { return (size_t)4 * nr * 128 + (size_t)nt * nr * 64 + (size_t)2 * nt * 32 * 4 + 32 * 64; }
+
+// byte offset inside a T block of the 8-byte chunk `c` (4 queries, c in 0..7) of key row `r`.  The row pitch of 64 B is 16 banks
+// and the chunk index is XORed with (r >> 2): the 32 lanes of an 8-byte store (32 keys, one chunk) and of a transposed read
+// (4 keys x 8 chunks) each touch 64 distinct banks.
+__device__ __forceinline__ int t_off(int r, int c) { return r * 64 + ((c ^ ((r >> 2) & 7)) << 3); }
+
+// fragment reads with the row index clamped to the zero row (CL: only the last 32-row tile can reach beyond NR)
+__device__ __forceinline__ bf16x8 fz_rows(const bool CL, const char* lds, int row0, int kk, int lane, int nr1) {
+    int r = row0 + (lane & 31);
+    if (CL) r = min(r, nr1);
+    return *reinterpret_cast<const bf16x8*>(lds + tile_off<64, SWZ_ROW>(r, kk * 2 + (lane >> 5)));
+}
+__device__ __forceinline__ bf16x8 fz_cols_tr(const bool CL, uint32_t lds_base, int row0, int mf, int dj, int lane, int nr1) {
+    const int i = lane & 15;
+    const int d = dj * 32 + (lane & 16) + ((i & 3) << 2);
+    int r0 = row0 + 16 * mf + 4 * (lane >> 5) + (i >> 2);
+    int r1 = r0 + 8;
+    if (CL) { r0 = min(r0, nr1); r1 = min(r1, nr1); }
+    const s16x4 lo = lds_read_tr16(lds_base + tile_off<64, SWZ_ROW>(r0, d >> 3) + ((d & 4) << 1));
+    const s16x4 hi = lds_read_tr16(lds_base + tile_off<64, SWZ_ROW>(r1, d >> 3) + ((d & 4) << 1));
+    bf16x8 f;
+    f[0] = lo[0]; f[1] = lo[1]; f[2] = lo[2]; f[3] = lo[3];
+    f[4] = hi[0]; f[5] = hi[1]; f[6] = hi[2]; f[7] = hi[3];
+    return f;
+}
+
+// transposed accumulator (lane = token row of the tile, register r = column 8 (r >> 2) + 4 (lane >> 5) + (r & 3) of the 32-column
+// block dj) -> packed bf16 in this wave's staging tile
+__device__ __forceinline__ void fused_stage(char* stg, const f32x16 (&acc)[2], int lane) {
+    const int rr = lane & 31, hf = lane >> 5;
+#pragma unroll
+    for (int dj = 0; dj < 2; ++dj)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            uint2 w;
+            w.x = pack_bf2(acc[dj][4 * g + 0], acc[dj][4 * g + 1]);
+            w.y = pack_bf2(acc[dj][4 * g + 2], acc[dj][4 * g + 3]);
+            *reinterpret_cast<uint2*>(stg + rr * FUSED_SP + (dj * 32 + 8 * g + 4 * hf) * 2) = w;
+        }
+}
+// staging tile -> global rows row0 .. row0 + 31 (valid below N) as 16-B stores, 8 lanes per 128-B row; returns this lane's partial
+// column sums (columns 8 (lane & 7) .. + 7 over the rows it stored) in cs[8]
+__device__ __forceinline__ void fused_flush(const char* stg, bf16_t* __restrict__ dst, long rs, int row0, int N, int lane, float (&cs)[8]) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) cs[e] = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int rr = (lane >> 3) + 8 * j, c = lane & 7;
+        const uint4 v = *reinterpret_cast<const uint4*>(stg + rr * FUSED_SP + c * 16);
+        if (row0 + rr < N) {
+            *reinterpret_cast<uint4*>(dst + (long)(row0 + rr) * rs + c * 8) = v;
+            const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                cs[2 * e] += __uint_as_float(w[e] << 16);
+                cs[2 * e + 1] += __uint_as_float(w[e] & 0xffff0000u);
+            }
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        cs[e] += __shfl_xor(cs[e], 8, 64);
+        cs[e] += __shfl_xor(cs[e], 16, 64);
+        cs[e] += __shfl_xor(cs[e], 32, 64);
+    }
+}
+
+template <int NT>
+__global__ __launch_bounds__(64 * NT, 2) void attn_bwd_fused_kernel(const AttnArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int HD = 64, KS = 4, DJ = 2, ROWS = NT * 32, NTHR = 64 * NT;
+    const int NR = a.chunk_rows, nr1 = NR - 1;
+    const int TB = NR * 64;                            // bytes of one T block: [NR keys][32 queries] bf16
+    char* ldsQ = smem;
+    char* ldsDO = smem + NR * 128;
+    char* ldsK = smem + 2 * NR * 128;
+    char* ldsV = smem + 3 * NR * 128;
+    char* ldsT = smem + 4 * NR * 128;
+    float* ldsL = reinterpret_cast<float*>(ldsT + NT * TB);
+    float* ldsD = ldsL + ROWS;
+    const uint32_t ldsQ_u = lds_addr(ldsQ), ldsDO_u = lds_addr(ldsDO), ldsK_u = lds_addr(ldsK), ldsT_u = lds_addr(ldsT);
+    const int h = blockIdx.x, b = blockIdx.y;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hf = lane >> 5;
+    const int N = a.Nq;
+    const float sc = a.scale * LOG2E;
+    const int row = wave * 32 + (lane & 31);          // this lane's key row in phase A
+#ifdef MRG_ATTN_TS      // debug build: phase timestamps of every workgroup (100 MHz wall clock) into the unused dsum workspace
+    unsigned long long* ts = reinterpret_cast<unsigned long long*>(a.dsum) + ((long)b * a.H + h) * 8;
+#define MRG_TS(i) do { if (tid == 0) ts[i] = wall_clock64(); } while (0)
+#else
+#define MRG_TS(i) do { } while (0)
+#endif
+    MRG_TS(0);
+
+    // ---- staging: Q, dO, K, V rows [0, NR) (zero beyond N) with 16-B loads, 8 lanes per 128-B row; dsum[q] = sum_d dO * O on the way
+    {
+        typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+        const bf16_t* qp = a.q + (long)b * a.q_bs + h * HD;
+        const bf16_t* kp = a.k + (long)b * a.k_bs + h * HD;
+        const bf16_t* vp = a.v + (long)b * a.v_bs + h * HD;
+        const bf16_t* dop = a.d_o + (long)b * a.do_bs + h * HD;
+        const bf16_t* op = a.o + (long)b * a.o_bs + h * HD;
+        // log-sum-exp of this thread's row (ROWS <= NTHR): requested with the tile loads, consumed after them
+        const float lse_v = (tid < N) ? a.lse[((long)b * a.H + h) * N + tid] : INFINITY;     // invalid query -> p = exp2(-inf) = 0
+        const int total = NR * 8;
+        constexpr int PER = (ROWS * 8 + NTHR - 1) / NTHR;      // 4
+        u32x4 vq[PER], vdo[PER], vk[PER], vv[PER], vo[PER];
+        const u32x4 z = {0u, 0u, 0u, 0u};
+#pragma unroll
+        for (int j = 0; j < PER; ++j) {
+            const int q = tid + j * NTHR, r = q >> 3, c = q & 7;
+            const bool ok = q < total && r < N;
+            const long ro = ok ? (long)r : 0l;
+            vq[j] = *reinterpret_cast<const u32x4*>(qp + ro * a.q_rs + c * 8);
+            vdo[j] = *reinterpret_cast<const u32x4*>(dop + ro * a.do_rs + c * 8);
+            vk[j] = *reinterpret_cast<const u32x4*>(kp + ro * a.k_rs + c * 8);
+            vv[j] = *reinterpret_cast<const u32x4*>(vp + ro * a.v_rs + c * 8);
+            vo[j] = *reinterpret_cast<const u32x4*>(op + ro * a.o_rs + c * 8);
+        }
+        MRG_TS(1);
+        if (tid < ROWS) {
+            ldsL[tid] = lse_v * LOG2E;
+            if (tid >= N) ldsD[tid] = 0.f;
+        }
+#pragma unroll
+        for (int j = 0; j < PER; ++j) {
+            const int q = tid + j * NTHR, r = q >> 3, c = q & 7;
+            const bool ok = q < total && r < N;
+            float dsm = 0.f;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                dsm += __uint_as_float(vo[j][e] << 16) * __uint_as_float(vdo[j][e] << 16);
+                dsm += __uint_as_float(vo[j][e] & 0xffff0000u) * __uint_as_float(vdo[j][e] & 0xffff0000u);
+            }
+            dsm += __shfl_xor(dsm, 1, 64);
+            dsm += __shfl_xor(dsm, 2, 64);
+            dsm += __shfl_xor(dsm, 4, 64);
+            if (q < total) {
+                const int off = tile_off<HD, SWZ_ROW>(r, c);
+                *reinterpret_cast<u32x4*>(ldsQ + off) = ok ? vq[j] : z;
+                *reinterpret_cast<u32x4*>(ldsDO + off) = ok ? vdo[j] : z;
+                *reinterpret_cast<u32x4*>(ldsK + off) = ok ? vk[j] : z;
+                *reinterpret_cast<u32x4*>(ldsV + off) = ok ? vv[j] : z;
+                if (ok && c == 0) ldsD[r] = dsm;
+            }
+        }
+    }
+    __syncthreads();
+    MRG_TS(2);
+
+    // ---- phase A: this wave's key tile against every query block, two blocks at a time
+    f32x16 dvT[DJ], dkT[DJ];
+#pragma unroll
+    for (int dj = 0; dj < DJ; ++dj)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { dvT[dj][r] = 0.f; dkT[dj][r] = 0.f; }
+    {
+        constexpr bool WL = true;                      // this wave's own tile may be the last one: clamp (uniform per wave)
+        // dS store of this lane's key row: rows beyond NR go to a dump row of their own (branch-free: the stores stay inside the
+        // scheduling region of the matrix instructions)
+        char* tw = row < NR ? ldsT + row * 64 : reinterpret_cast<char*>(ldsD + ROWS) + (lane & 31) * 64;
+        const int twq = row < NR ? TB : 0;
+        const int tws = (row >> 2) & 7;
+        bf16x8 kf[KS], vf[KS];
+#pragma unroll
+        for (int kk = 0; kk < KS; ++kk) {
+            kf[kk] = fz_rows(WL, ldsK, wave * 32, kk, lane, nr1);
+            vf[kk] = fz_rows(WL, ldsV, wave * 32, kk, lane, nr1);
+        }
+#define MRG_SDP(QB, S, DP) { \
+            _Pragma("unroll") for (int r = 0; r < 16; ++r) { S[r] = 0.f; DP[r] = 0.f; } \
+            _Pragma("unroll") for (int kk = 0; kk < KS; ++kk) { \
+                S = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fz_rows((QB) == NT - 1, ldsQ, (QB) * 32, kk, lane, nr1), kf[kk], S, 0, 0, 0); \
+                DP = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fz_rows((QB) == NT - 1, ldsDO, (QB) * 32, kk, lane, nr1), vf[kk], DP, 0, 0, 0); } }
+#define MRG_TAIL(QB, S, DP) { \
+            _Pragma("unroll") for (int mf = 0; mf < 2; ++mf) { \
+                f32x16 pr; \
+                _Pragma("unroll") for (int g = 2 * mf; g < 2 * mf + 2; ++g) { \
+                    const int qrow = (QB) * 32 + 8 * g + 4 * hf; \
+                    const float4 l4 = *reinterpret_cast<const float4*>(ldsL + qrow); \
+                    const float4 d4 = *reinterpret_cast<const float4*>(ldsD + qrow); \
+                    const float ls[4] = {l4.x, l4.y, l4.z, l4.w}, ds[4] = {d4.x, d4.y, d4.z, d4.w}; \
+                    _Pragma("unroll") for (int e = 0; e < 4; ++e) { \
+                        const int r = g * 4 + e; \
+                        const float p = fast_exp2(S[r] * sc - ls[e]); \
+                        pr[r] = p; \
+                        S[r] = p * (DP[r] - ds[e]) * a.scale; } } \
+                const bf16x8 pa = pack8(pr, mf); \
+                const bf16x8 da = pack8(S, mf); \
+                { \
+                    const uint2* w2 = reinterpret_cast<const uint2*>(&da); \
+                    _Pragma("unroll") for (int x = 0; x < 2; ++x) \
+                        *reinterpret_cast<uint2*>(tw + (QB) * twq + (((4 * mf + 2 * x + hf) ^ tws) << 3)) = w2[x]; } \
+                _Pragma("unroll") for (int dj = 0; dj < DJ; ++dj) { \
+                    dvT[dj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fz_cols_tr((QB) == NT - 1, ldsDO_u, (QB) * 32, mf, dj, lane, nr1), pa, dvT[dj], 0, 0, 0); \
+                    dkT[dj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fz_cols_tr((QB) == NT - 1, ldsQ_u, (QB) * 32, mf, dj, lane, nr1), da, dkT[dj], 0, 0, 0); } } }
+#pragma unroll
+        for (int qp2 = 0; qp2 < NT / 2; ++qp2) {
+            __builtin_amdgcn_sched_barrier(0);
+            f32x16 s0, dp0, s1, dp1;
+            MRG_SDP(2 * qp2, s0, dp0)
+            MRG_SDP(2 * qp2 + 1, s1, dp1)
+            MRG_TAIL(2 * qp2, s0, dp0)
+            MRG_TAIL(2 * qp2 + 1, s1, dp1)
+        }
+        if (NT & 1) {
+            __builtin_amdgcn_sched_barrier(0);
+            f32x16 s0, dp0;
+            MRG_SDP(NT - 1, s0, dp0)
+            MRG_TAIL(NT - 1, s0, dp0)
+        }
+#undef MRG_SDP
+#undef MRG_TAIL
+    }
+    MRG_TS(3);
+    __syncthreads();                                   // T complete; Q, dO, V are dead: their area becomes the per-wave staging tiles
+    MRG_TS(4);
+    char* stg = smem + wave * (32 * FUSED_SP);
+    float cs[3][8];
+    fused_stage(stg, dvT, lane);
+    fused_flush(stg, a.dv + (long)b * a.dv_bs + h * HD, a.dv_rs, wave * 32, N, lane, cs[2]);
+    fused_stage(stg, dkT, lane);
+    fused_flush(stg, a.dk + (long)b * a.dk_bs + h * HD, a.dk_rs, wave * 32, N, lane, cs[1]);
+    MRG_TS(5);
+
+    // ---- phase B: this wave's query tile (T block `wave`), contraction over all keys
+    {
+        f32x16 dqT[DJ];
+#pragma unroll
+        for (int dj = 0; dj < DJ; ++dj)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) dqT[dj][r] = 0.f;
+        const int i16 = lane & 15;
+        const int chunk = ((lane & 16) >> 2) + (i16 & 3);
+        const uint32_t tb = ldsT_u + wave * TB;
+#pragma unroll
+        for (int kb = 0; kb < NT; ++kb)
+#pragma unroll
+            for (int mf = 0; mf < 2; ++mf) {
+                int r0 = kb * 32 + 16 * mf + 4 * hf + (i16 >> 2);
+                int r1 = r0 + 8;
+                if (kb == NT - 1) { r0 = min(r0, nr1); r1 = min(r1, nr1); }
+                const s16x4 lo = lds_read_tr16(tb + t_off(r0, chunk));
+                const s16x4 hi = lds_read_tr16(tb + t_off(r1, chunk));
+                bf16x8 da;
+                da[0] = lo[0]; da[1] = lo[1]; da[2] = lo[2]; da[3] = lo[3];
+                da[4] = hi[0]; da[5] = hi[1]; da[6] = hi[2]; da[7] = hi[3];
+#pragma unroll
+                for (int dj = 0; dj < DJ; ++dj)
+                    dqT[dj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fz_cols_tr(kb == NT - 1, ldsK_u, kb * 32, mf, dj, lane, nr1), da, dqT[dj], 0, 0, 0);
+            }
+        MRG_TS(6);
+        fused_stage(stg, dqT, lane);
+        fused_flush(stg, a.dq + (long)b * a.dq_bs + h * HD, a.dq_rs, wave * 32, N, lane, cs[0]);
+    }
+    MRG_TS(7);
+    if (a.cs_q) {   // per-(batch, head) column sums of dQ / dK / dV: the bias gradients before the reduction over the batch
+        __syncthreads();                               // every wave is done with K and T
+        float* red = reinterpret_cast<float*>(ldsK);
+        if (lane < 8) {
+#pragma unroll
+            for (int m = 0; m < 3; ++m)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) red[(wave * 3 + m) * HD + lane * 8 + e] = cs[m][e];
+        }
+        __syncthreads();
+        for (int c = tid; c < 3 * HD; c += NTHR) {
+            float t = 0.f;
+            for (int w = 0; w < NT; ++w) t += red[w * 3 * HD + c];
+            float* dst = c < HD ? a.cs_q : (c < 2 * HD ? a.cs_k : a.cs_v);
+            dst[(long)b * a.cs_bs + h * HD + (c % HD)] = t;
+        }
+    }
+}
+
+template <int NT>
+int launch_bwd_fused(const AttnArgs& a0, hipStream_t stream) {
+    AttnArgs a = a0;
+    a.chunk_rows = fused_nr(a.Nq, NT * 32);
+    const size_t sh = fused_lds(a.chunk_rows, NT);
+    static size_t attr_sh = 0;
+    if (sh > 65536 && sh > attr_sh) {
+        (void)hipFuncSetAttribute((const void*)attn_bwd_fused_kernel<NT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
+        attr_sh = sh;
+    }
+    hipLaunchKernelGGL(attn_bwd_fused_kernel<NT>, dim3(a.H, a.B), dim3(64 * NT), sh, stream, a);
+    return mrg_check_launch("mrg_attn_bwd/fused");
+}
+
+// MRG_ATTN_FUSED=0 selects the query-owner + key-owner pair of kernels for every shape (A/B knob; the fused kernel is the default)
+bool fused_enabled() {
+    static int on = -1;
+    if (on < 0) { const char* e = getenv("MRG_ATTN_FUSED"); on = (e && e[0] == '0') ? 0 : 1; }
+    return on == 1;
+}
+
 // waves per workgroup so that every wave owns the same number of 32-row tiles: ceil(tiles / ceil(tiles / 8))
 static int waves_for(int ntiles) {
     const int rounds = (ntiles + 7) / 8;
@@ -592,6 +908,8 @@ extern "C" int mrg_attn_bwd(const mrg_attn_desc* d, hipStream_t stream) {
     AttnArgs a;
     fill(a, d);
     const int HD = d->head_dim;
+    if (HD == 64 && a.Nq == a.Nk && a.Nq > 96 && a.Nq <= 160 && fused_enabled())
+        return a.Nq > 128 ? launch_bwd_fused<5>(a, stream) : launch_bwd_fused<4>(a, stream);
     dim3 grid(a.H, a.B);
     {   // dQ: K,V chunk in LDS
         dim3 block(64 * waves_for((a.Nq + 31) / 32));

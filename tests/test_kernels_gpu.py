@@ -326,7 +326,8 @@ def _attn_ref(q, k, v, scale):
     return att @ v, att
 
 
-@pytest.mark.parametrize("B,H,N,hd", [(3, 12, 129, 64), (2, 16, 99, 64), (2, 16, 257, 64), (2, 8, 256, 32), (2, 2, 65, 32), (1, 2, 700, 64), (2, 3, 25, 64)])
+@pytest.mark.parametrize("B,H,N,hd", [(3, 12, 129, 64), (2, 16, 99, 64), (2, 16, 257, 64), (2, 8, 256, 32), (2, 2, 65, 32), (1, 2, 700, 64), (2, 3, 25, 64),
+                                      (2, 4, 97, 64), (2, 4, 128, 64), (2, 2, 130, 64), (1, 4, 160, 64), (1, 2, 161, 64), (2, 2, 96, 64)])
 def test_self_attention_fwd_bwd(K, B, H, N, hd):
     D = H * hd
     qkv = rnd(B, N, 3 * D, dtype=BF16, seed=30)

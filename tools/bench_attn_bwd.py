@@ -12,7 +12,7 @@ def run(B, H, N, hd, tag, iters=20):
     d_o = torch.randn(B, N, Dm, device=dev).to(BF16)
     dqkv = torch.empty_like(qkv)
     dq, dk, dv = dqkv[..., :Dm], dqkv[..., Dm:2 * Dm], dqkv[..., 2 * Dm:]
-    gb = [torch.zeros(Dm, device=dev) for _ in range(3)]
+    gb = None if os.environ.get('NOBIAS') else [torch.zeros(Dm, device=dev) for _ in range(3)]
     def f(): K.attn_bwd(q, k, v, o, lse, d_o, dq, dk, dv, B, H, N, N, hd, hd ** -0.5, st, st, st, st, st, st, bias_grads=gb)
     for _ in range(3): f()
     torch.cuda.synchronize()
