@@ -11,6 +11,7 @@ stream / LayerNorm statistics / softmax / accumulators / parameters / gradients;
 """
 from typing import Dict, List, Optional, Sequence, Tuple
 
+import os
 import torch
 
 from . import _lib as L
@@ -146,11 +147,11 @@ def lin_fwd(x16: torch.Tensor, lin, *, out_dtype=BF16, resid: Optional[torch.Ten
     Kin = W.numel() // N
     M = x16.numel() // Kin
     oshape = x16.shape[:-1] + (N,)
-    out = torch.empty(oshape, dtype=out_dtype, device=x16.device)
-    out2 = torch.empty(oshape, dtype=BF16, device=x16.device) if want_bf16_copy else None
+    out = K.new(oshape, out_dtype, x16.device)
+    out2 = K.new(oshape, BF16, x16.device) if want_bf16_copy else None
     # with save_pre the epilogue stores gelu'(pre-activation) in fp16 (values in [-0.13, 1.13], 11 significant bits) instead of
     # the pre-activation itself: the backward GEMM then multiplies by it and needs no erf / exp (-18 us per fc2 dgrad at C2)
-    pre = torch.empty(oshape, dtype=torch.float16, device=x16.device) if (gelu and save_pre) else None
+    pre = K.new(oshape, torch.float16, x16.device) if (gelu and save_pre) else None
     act = L.MRG_ACT_NONE if not gelu else (L.MRG_ACT_GELU_SAVE_GRAD if pre is not None else L.MRG_ACT_GELU)
     K.gemm(x16, W, M, N, Kin, lda=Kin, ldb=Kin, out=out, ldc=N, out2=out2, bias=lin.bias,
            resid=resid, act=act, aux_out=pre, row_scale=row_scale)
@@ -277,6 +278,58 @@ class BlockFn(torch.autograd.Function):
         return (dx32, None, None, None) + (None,) * 12
 
 
+# The encoder forward is one serial chain of launches that alternate between matrix-bound (qkv, fc1), memory-bound (LayerNorm,
+# residual epilogues) and latency-bound (attention) kernels, each with its own tile-count tail.  Two half-batch chains on two streams
+# fill each other's tails and phase gaps (profiles/r02_experiments.md: encoder forward -7.6 % at C2).  The activations the backward
+# pass needs are full-batch tensors: chain A allocates them and works on the first halves, chain B on the second (kernels.Halves),
+# so the backward pass (full batch, weight gradients over all rows in one GEMM) is unchanged.  MRG_TWO_CHAINS=0 switches it off.
+TWO_CHAINS = os.environ.get("MRG_TWO_CHAINS", "1") != "0"
+TWO_CHAINS_MIN_ROWS = int(os.environ.get("MRG_TWO_CHAINS_MIN_ROWS", "16"))
+_CHAIN_STREAM = {}
+
+
+def _encoder_fwd_two_chains(x: torch.Tensor, blocks, save: bool, want_bf16: bool):
+    main = torch.cuda.current_stream()
+    s2 = _CHAIN_STREAM.get(x.device)
+    if s2 is None:
+        s2 = _CHAIN_STREAM[x.device] = torch.cuda.Stream(device=x.device)
+    capturing = torch.cuda.is_current_stream_capturing()
+    h = x.shape[0] // 2
+    xa, xb = x[:h], x[h:]
+    n = len(blocks)
+    ev = torch.cuda.Event()
+    ev.record(main)
+    s2.wait_event(ev)
+    saved_all = []
+    x_in_full = x
+    xa16 = None
+    for i, blk in enumerate(blocks):
+        last = want_bf16 and i == n - 1
+        K.Halves.begin(1)
+        try:
+            xa, xa16, sa = block_fwd(blk, xa, save, want_bf16_out=last)
+        finally:
+            K.Halves.end()
+        if not capturing:
+            main.synchronize()                     # eager (warm-up) runs: first-use autotuning must not time against the other chain
+        K.Halves.begin(2)
+        try:
+            with torch.cuda.stream(s2):
+                xb, _, _ = block_fwd(blk, xb, save, want_bf16_out=last)
+        finally:
+            K.Halves.end()
+        if not capturing:
+            s2.synchronize()
+        if save:
+            sv = tuple(K.Halves.full_of(t) for t in sa)
+            saved_all.append((x_in_full,) + sv[1:])
+        else:
+            saved_all.append(None)
+        x_in_full = K.Halves.full_of(xa)
+    main.wait_stream(s2)
+    return x_in_full, (K.Halves.full_of(xa16) if xa16 is not None else None), saved_all
+
+
 class EncoderFn(torch.autograd.Function):
     """nn.Sequential(Block x depth) (mirage/model.py:82-94,409) as one node: the (fp32, bf16) gradient pair flows
     between blocks without touching autograd."""
@@ -289,9 +342,12 @@ class EncoderFn(torch.autograd.Function):
         saved_all = []
         x16 = None
         n = len(blocks)
-        for i, blk in enumerate(blocks):
-            x32, x16, sv = block_fwd(blk, x32, save, want_bf16_out=(want_bf16 and i == n - 1), dp=dps[i] if dps else None)
-            saved_all.append(sv)
+        if TWO_CHAINS and not dps and x.shape[0] % 2 == 0 and x.is_contiguous() and x.shape[0] * x.shape[1] >= TWO_CHAINS_MIN_ROWS:
+            x32, x16, saved_all = _encoder_fwd_two_chains(x, blocks, save, want_bf16)
+        else:
+            for i, blk in enumerate(blocks):
+                x32, x16, sv = block_fwd(blk, x32, save, want_bf16_out=(want_bf16 and i == n - 1), dp=dps[i] if dps else None)
+                saved_all.append(sv)
         ctx.blocks, ctx.saved = blocks, saved_all
         K.timestamp("enc_fwd_end")
         if want_bf16:

@@ -30,6 +30,52 @@ def _need_cuda(t: torch.Tensor, what: str):
         raise RuntimeError(f"mirage_amd: {what} must live on the GPU (got {t.device}); there is no CPU path")
 
 
+# ------------------------------------------------------------------------------------------------ half-batch placement
+class Halves:
+    """Output placement for two half-batch chains (engine.EncoderFn): while chain A (mode 1) runs, every activation it allocates
+    through new() is the first half (along dim 0) of a full-batch tensor; chain B (mode 2) replays the same sequence of
+    allocations and receives the second halves.  The full tensors are what the (full-batch) backward pass saves."""
+    mode = 0
+    fulls = []
+    idx = 0
+
+    @classmethod
+    def begin(cls, mode: int):
+        cls.mode = mode
+        if mode == 1:
+            cls.fulls = []
+        cls.idx = 0
+
+    @classmethod
+    def end(cls):
+        cls.mode = 0
+
+    @staticmethod
+    def full_of(t: Optional[torch.Tensor]) -> Optional[torch.Tensor]:
+        """full-batch tensor of a first-half activation produced under mode 1 (any later .view() of it included)"""
+        if t is None or not torch.is_tensor(t):
+            return t
+        root = t._base if t._base is not None else t
+        return root.view((2 * t.shape[0],) + tuple(t.shape[1:]))
+
+
+def new(shape, dtype, device) -> torch.Tensor:
+    """torch.empty for activations that are batch-major along dim 0 (see Halves)."""
+    if Halves.mode == 0:
+        return torch.empty(shape, dtype=dtype, device=device)
+    shape = tuple(shape)
+    full_shape = (2 * shape[0],) + shape[1:]
+    if Halves.mode == 1:
+        f = torch.empty(full_shape, dtype=dtype, device=device)
+        Halves.fulls.append(f)
+        return f[:shape[0]]
+    f = Halves.fulls[Halves.idx]
+    Halves.idx += 1
+    if tuple(f.shape) != full_shape or f.dtype != dtype:
+        raise RuntimeError(f"mirage_amd: half-batch chains diverged ({tuple(f.shape)} {f.dtype} vs {full_shape} {dtype})")
+    return f[shape[0]:]
+
+
 # ------------------------------------------------------------------------------------------------ GEMM
 _ws_cache = {}
 
@@ -288,9 +334,9 @@ def ln_fwd(x: torch.Tensor, gamma, beta, eps: float, out_dtype=BF16):
     _need_cuda(x, "LayerNorm input")
     D = x.shape[-1]
     M = x.numel() // D
-    y = torch.empty(x.shape, dtype=out_dtype, device=x.device)
-    mean = torch.empty(M, dtype=F32, device=x.device)
-    rstd = torch.empty(M, dtype=F32, device=x.device)
+    y = new(x.shape, out_dtype, x.device)
+    mean = new((M,), F32, x.device)
+    rstd = new((M,), F32, x.device)
     check(lib.mrg_ln_fwd(x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), y.data_ptr() if out_dtype == BF16 else None,
                          y.data_ptr() if out_dtype == F32 else None, mean.data_ptr(), rstd.data_ptr(), M, D, eps, _s()), "mrg_ln_fwd")
     return y, mean, rstd
@@ -341,8 +387,8 @@ def _attn_desc(q, k, v, o, lse, B, H, Nq, Nk, hd, scale, strides):
 def attn_fwd(q, k, v, B, H, Nq, Nk, hd, scale, q_strides, k_strides, v_strides, need_lse=True):
     """q/k/v: bf16 tensors (possibly views into fused projection buffers); strides = (batch, row) in elements."""
     _need_cuda(q, "attention input")
-    o = torch.empty((B, Nq, H * hd), dtype=BF16, device=q.device)
-    lse = torch.empty((B, H, Nq), dtype=F32, device=q.device) if need_lse else None
+    o = new((B, Nq, H * hd), BF16, q.device)
+    lse = new((B, H, Nq), F32, q.device) if need_lse else None
     d = _attn_desc(q, k, v, o, lse, B, H, Nq, Nk, hd, scale, (q_strides, k_strides, v_strides, (Nq * H * hd, H * hd)))
     check(lib.mrg_attn_fwd(C.byref(d), _s()), "mrg_attn_fwd")
     return o, lse
