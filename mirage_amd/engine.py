@@ -282,8 +282,11 @@ class BlockFn(torch.autograd.Function):
 # residual epilogues) and latency-bound (attention) kernels, each with its own tile-count tail.  Two half-batch chains on two streams
 # fill each other's tails and phase gaps (profiles/r02_experiments.md: encoder forward -7.6 % at C2).  The activations the backward
 # pass needs are full-batch tensors: chain A allocates them and works on the first halves, chain B on the second (kernels.Halves),
-# so the backward pass (full batch, weight gradients over all rows in one GEMM) is unchanged.  MRG_TWO_CHAINS=0 switches it off.
-TWO_CHAINS = os.environ.get("MRG_TWO_CHAINS", "1") != "0"
+# so the backward pass (full batch, weight gradients over all rows in one GEMM) is unchanged.
+# MRG_TWO_CHAINS: 0 off; 1 (default) forward-only passes (feature extraction, C5: -3 %); 2 also the training forward (C2 / C4: -0.7 %
+# same box -- left off by default because two overlapping half-size launches have no exclusive duration, which would blur the
+# per-launch roofline accounting of bench.py and of the rocprof traces for a gain inside the box-to-box noise).
+TWO_CHAINS = int(os.environ.get("MRG_TWO_CHAINS", "1"))
 TWO_CHAINS_MIN_ROWS = int(os.environ.get("MRG_TWO_CHAINS_MIN_ROWS", "16"))
 _CHAIN_STREAM = {}
 
@@ -342,7 +345,7 @@ class EncoderFn(torch.autograd.Function):
         saved_all = []
         x16 = None
         n = len(blocks)
-        if TWO_CHAINS and not dps and x.shape[0] % 2 == 0 and x.is_contiguous() and x.shape[0] * x.shape[1] >= TWO_CHAINS_MIN_ROWS:
+        if (TWO_CHAINS == 2 or (TWO_CHAINS == 1 and not save)) and not dps and x.shape[0] % 2 == 0 and x.is_contiguous() and x.shape[0] * x.shape[1] >= TWO_CHAINS_MIN_ROWS:
             x32, x16, saved_all = _encoder_fwd_two_chains(x, blocks, save, want_bf16)
         else:
             for i, blk in enumerate(blocks):

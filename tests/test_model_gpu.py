@@ -156,6 +156,15 @@ def test_c2_base_end_to_end():
     _case("c2_base")
 
 
+@pytest.mark.parametrize("name", ["tiny3", "c2_base"])
+def test_training_forward_as_two_half_batch_chains(monkeypatch, name):
+    # MRG_TWO_CHAINS=2: the training forward as two half-batch chains on two streams (engine._encoder_fwd_two_chains); the saved
+    # activations are full-batch tensors assembled from the halves, so losses AND gradients must meet the same golden bounds
+    from mirage_amd import engine
+    monkeypatch.setattr(engine, "TWO_CHAINS", 2)
+    _case(name)
+
+
 def test_c3_base_end_to_end():
     _case("c3_base")
 
