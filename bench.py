@@ -364,7 +364,7 @@ def _run(real_stdout: int):
         torch.cuda.synchronize()
         vname = {0: "auto", 1: "gemm_glds_kernel", 2: "gemm_glds_kernel", 3: "gemm_pipe_kernel", 4: "gemm_pipe256_kernel",
                  5: "gemm_pipe256_kernel", 6: "gemm_pipe256sq_kernel", 7: "gemm_ws256_kernel", 8: "gemm_glds64_kernel",
-                 10: "gemm_g256_kernel", 11: "gemm_p8_kernel"}
+                 10: "gemm_g256_kernel", 11: "gemm_p8_kernel", 12: "gemm_p8_group_kernel"}
         mname = {(0, 0): "forward x*W^T", (0, 1): "dgrad dy*W", (1, 1): "wgrad dy^T*x"}
         groups = {}
         shapes = {}

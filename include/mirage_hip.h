@@ -26,7 +26,7 @@ extern "C" {
 typedef struct ihipStream_t* hipStream_t;
 #endif
 
-#define MRG_ABI_VERSION 6   /* 2: mrg_gemm_desc grew row_scale / defer_reduce, act codes 3, 4, reduce_batch / augment / row_scale entry points; 3: colsum_out, attention colsum_*; 4: step = int[2], mrg_step_inc takes the skip decision; 5: splitk_counters, MRG_GEMM_P8, resize entry points; 6: mrg_adamw_desc.sumsq_out, mrg_sumsq_finish */
+#define MRG_ABI_VERSION 7   /* 7: mrg_wgrad_group, mrg_debug_timestamp; 2: mrg_gemm_desc grew row_scale / defer_reduce, act codes 3, 4, reduce_batch / augment / row_scale entry points; 3: colsum_out, attention colsum_*; 4: step = int[2], mrg_step_inc takes the skip decision; 5: splitk_counters, MRG_GEMM_P8, resize entry points; 6: mrg_adamw_desc.sumsq_out, mrg_sumsq_finish */
 
 enum { MRG_DT_BF16 = 0, MRG_DT_F32 = 1 };
 enum { MRG_OP_KCONTIG = 0, MRG_OP_KSTRIDED = 1 };
@@ -100,6 +100,20 @@ typedef struct mrg_gemm_desc {
 enum { MRG_GEMM_AUTO = 0, MRG_GEMM_GLDS3 = 1, MRG_GEMM_GLDS4 = 2, MRG_GEMM_PIPE128 = 3, MRG_GEMM_PIPE256 = 4, MRG_GEMM_PIPE256X3 = 5, MRG_GEMM_PIPE256SQ = 6, MRG_GEMM_WS256 = 7, MRG_GEMM_GLDS64 = 8, MRG_GEMM_SQP = 9, MRG_GEMM_G256 = 10, MRG_GEMM_P8 = 11 };
 
 int mrg_gemm(const mrg_gemm_desc* d, hipStream_t stream);
+
+/* Grouped weight gradients: C_p[M_p, N_p] (fp32, row stride ldc_p, OVERWRITTEN) = A_p^T B_p for p < count, with A_p = dY bf16 [K, M_p]
+ * (row stride lda_p) and B_p = X bf16 [K, N_p] (row stride ldb_p): both operands contracted over their leading (token) axis, i.e.
+ * the `grad_weight = grad_output^T @ input` mm of nn.Linear's backward (mirage/utils.py:155-157,177,186 under autograd) for several
+ * Linears / transformer blocks in ONE launch without split-K.  K (tokens) is common and a multiple of 64; operands 16-B aligned,
+ * M_p, N_p, lda_p, ldb_p multiples of 8.  ev_start / ev_stop: optional hipEvent_t recorded on `stream` around the launch. */
+#define MRG_WGRAD_GROUP_MAX 16
+typedef struct mrg_wgrad_group_desc {
+    int count, K;
+    const void* A[MRG_WGRAD_GROUP_MAX]; const void* B[MRG_WGRAD_GROUP_MAX]; void* C[MRG_WGRAD_GROUP_MAX];
+    int M[MRG_WGRAD_GROUP_MAX], N[MRG_WGRAD_GROUP_MAX], lda[MRG_WGRAD_GROUP_MAX], ldb[MRG_WGRAD_GROUP_MAX], ldc[MRG_WGRAD_GROUP_MAX];
+    void* ev_start; void* ev_stop;
+} mrg_wgrad_group_desc;
+int mrg_wgrad_group(const mrg_wgrad_group_desc* d, hipStream_t stream);
 
 /* ---------------------------------------------------------------------------------------------------
  * LayerNorm (eps passed by caller; the path uses 1e-6: mirage/model.py:57).  Replaces aten native_layer_norm

@@ -1430,3 +1430,41 @@ extern "C" int mrg_gemm(const mrg_gemm_desc* d, hipStream_t stream) {
     if (rc) return rc;
     return finish_splitk();
 }
+
+// Grouped weight gradients (gemm8p.hip gemm_p8_group_kernel): C_p[M_p, N_p] (fp32, overwritten) = A_p^T B_p, A_p = dY [K, M_p],
+// B_p = X [K, N_p] -- the mm of every nn.Linear backward of a group of encoder blocks (mirage/utils.py:155-157,177,186) in one launch.
+extern "C" int mrg_wgrad_group(const mrg_wgrad_group_desc* d, hipStream_t stream) {
+    MRG_REQUIRE(d != nullptr, MRG_ERR_ARG, "mrg_wgrad_group: null descriptor");
+    MRG_REQUIRE(d->count >= 1 && d->count <= MRG_WGRAD_GROUP_MAX, MRG_ERR_SHAPE, "mrg_wgrad_group: count %d not in [1, %d]", d->count, MRG_WGRAD_GROUP_MAX);
+    MRG_REQUIRE(d->K > 0 && d->K % BK == 0, MRG_ERR_SHAPE, "mrg_wgrad_group: K = %d must be a positive multiple of %d", d->K, BK);
+    static_assert(MRG_WGRAD_GROUP_MAX == P8_GROUP_MAX, "group size of the C ABI and of the kernel arguments");
+    P8GroupArgs ga;
+    GemmArgs& g = ga.base;
+    g = GemmArgs();
+    g.K = d->K;
+    g.a_aligned = 1; g.b_aligned = 1;
+    g.c_f32 = 1; g.splitk = 1; g.epi_kind = 0; g.act = MRG_ACT_NONE;
+    { static const int nt = [] { const char* e = getenv("MRG_GEMM_NT"); return e ? atoi(e) : 2; }(); g.nt = nt; }
+    { static const int sd = [] { const char* e = getenv("MRG_GEMM_SIDE_DRAIN"); return e ? atoi(e) : 3; }(); g.side_drain = sd; }
+    ga.nprob = d->count;
+    bool vec = true;
+    int tiles = 0;
+    for (int p = 0; p < d->count; ++p) {
+        MRG_REQUIRE(d->A[p] && d->B[p] && d->C[p], MRG_ERR_ARG, "mrg_wgrad_group: null operand pointer (problem %d)", p);
+        MRG_REQUIRE(d->M[p] > 0 && d->N[p] > 0, MRG_ERR_SHAPE, "mrg_wgrad_group: bad shape (problem %d)", p);
+        MRG_REQUIRE(d->M[p] % 8 == 0 && d->N[p] % 8 == 0 && d->lda[p] % 8 == 0 && d->ldb[p] % 8 == 0 &&
+                    (((uintptr_t)d->A[p] | (uintptr_t)d->B[p]) & 15) == 0, MRG_ERR_UNSUPPORTED,
+                    "mrg_wgrad_group: operands must be 16-B aligned with M, N, lda, ldb multiples of 8 (problem %d)", p);
+        ga.tile_start[p] = tiles;
+        tiles += cdiv(d->M[p], 256) * cdiv(d->N[p], 256);
+        ga.A[p] = (const bf16_t*)d->A[p]; ga.B[p] = (const bf16_t*)d->B[p]; ga.C[p] = d->C[p];
+        ga.M[p] = d->M[p]; ga.N[p] = d->N[p]; ga.lda[p] = d->lda[p]; ga.ldb[p] = d->ldb[p]; ga.ldc[p] = d->ldc[p];
+        vec = vec && (d->N[p] % 4 == 0) && (d->ldc[p] % 4 == 0) && (((uintptr_t)d->C[p]) % 16 == 0);
+    }
+    for (int p = d->count; p <= P8_GROUP_MAX; ++p) ga.tile_start[p] = tiles;
+    for (int p = d->count; p < P8_GROUP_MAX; ++p) { ga.A[p] = nullptr; ga.B[p] = nullptr; ga.C[p] = nullptr; ga.M[p] = ga.N[p] = ga.lda[p] = ga.ldb[p] = ga.ldc[p] = 0; }
+    if (d->ev_start) (void)hipEventRecord((hipEvent_t)d->ev_start, stream);
+    MRG_REQUIRE(mrg_gemm8p_group_launch(ga, vec, stream), MRG_ERR_SHAPE, "mrg_wgrad_group: nothing to launch");
+    if (d->ev_stop) (void)hipEventRecord((hipEvent_t)d->ev_stop, stream);
+    return mrg_check_launch("mrg_wgrad_group");
+}

@@ -95,13 +95,10 @@ struct P8Frag {
     }
 };
 
+// one 256 x 256 output tile (tile `bid` of the problem in grouped row-major order, k-range `ksplit` of g.splitk)
 template <int AMODE, int BMODE, bool VEC, int PHASES>
-__global__ __launch_bounds__(512) void gemm_p8_kernel(const GemmArgs g) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
+__device__ __forceinline__ void p8_tile(const GemmArgs& g, const int bid, const int ksplit, char* smem) {
     const int tiles_m = (g.M + 255) / 256, tiles_n = (g.N + 255) / 256;
-    const int nwg = tiles_m * tiles_n;
-    int bid, ksplit;
-    wg_remap(nwg, g.xcd_split, bid, ksplit);
     constexpr int GROUP_M = 4;
     int tm, tn;
     {
@@ -337,7 +334,51 @@ __global__ __launch_bounds__(512) void gemm_p8_kernel(const GemmArgs g) {
     if (ws && g.tile_cnt) splitk_finish<VEC>(g, bid, m0, n0, 256, 256, Meff, smem, tid, 512);
 }
 
+template <int AMODE, int BMODE, bool VEC, int PHASES>
+__global__ __launch_bounds__(512) void gemm_p8_kernel(const GemmArgs g) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int nwg = ((g.M + 255) / 256) * ((g.N + 255) / 256);
+    int bid, ksplit;
+    wg_remap(nwg, g.xcd_split, bid, ksplit);
+    p8_tile<AMODE, BMODE, VEC, PHASES>(g, bid, ksplit, smem);
+}
+
+// Grouped weight gradients: up to P8_GROUP_MAX independent problems C_p (fp32, overwritten) = A_p^T B_p with BOTH operands contracted
+// over their leading (token) axis, in ONE launch and WITHOUT split-K.  A single weight gradient of the encoder has 9-36 output
+// tiles of 256 x 256 -- too few for 256 CUs, hence split-K, fp32 slabs (66 MB per fc1 gradient at C2) and a reduction pass.  The
+// weight gradients of several Linears / blocks are independent and become available together (the side stream is forked once per
+// group of blocks), so their tiles fill the chip side by side and every tile contracts over ALL tokens (129 / 99 k-tiles: the
+// 8-phase loop at its long-K rate).  XCD x gets one contiguous band of the concatenated tile list (tiles of a problem that share an
+// A panel are neighbours).  Measured (tools/debug/exp_group_wgrad.py): 100-106 us per Base block at C2 against 197 us for the four
+// tuned split-K GEMMs + reductions, 130 against 215 us per Large block at C4.
+template <bool VEC, int PHASES>
+__global__ __launch_bounds__(512) void gemm_p8_group_kernel(const P8GroupArgs ga) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int total = ga.tile_start[ga.nprob];
+    int bid, ksplit;
+    wg_remap(total, 0, bid, ksplit);
+    int p = 0;
+    while (p + 1 < ga.nprob && bid >= ga.tile_start[p + 1]) ++p;
+    GemmArgs g = ga.base;
+    g.A = ga.A[p]; g.B = ga.B[p]; g.C = ga.C[p];
+    g.M = ga.M[p]; g.N = ga.N[p]; g.lda = ga.lda[p]; g.ldb = ga.ldb[p]; g.ldc = ga.ldc[p];
+    p8_tile<MRG_OP_KSTRIDED, MRG_OP_KSTRIDED, VEC, PHASES>(g, bid - ga.tile_start[p], 0, smem);
+}
+
 }  // namespace
+
+bool mrg_gemm8p_group_launch(const mrg_detail::P8GroupArgs& ga, bool vec, hipStream_t stream) {
+    const int total = ga.tile_start[ga.nprob];
+    if (total <= 0) return false;
+    static const int phases = [] { const char* e = getenv("MRG_P8_PHASES"); return e ? atoi(e) : 2; }();
+#define MRG_P8G(V, PH) do { const void* fn = (const void*)gemm_p8_group_kernel<V, PH>; \
+        (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, P8_LDS); \
+        hipLaunchKernelGGL((gemm_p8_group_kernel<V, PH>), dim3(total), dim3(512), (size_t)P8_LDS, stream, ga); } while (0)
+    if (vec) { if (phases == 4) MRG_P8G(true, 4); else MRG_P8G(true, 2); }
+    else { if (phases == 4) MRG_P8G(false, 4); else MRG_P8G(false, 2); }
+#undef MRG_P8G
+    return true;
+}
 
 bool mrg_gemm8p_launch(const mrg_detail::GemmArgs& g, int a_mode, int b_mode, bool vec, int splitk, hipStream_t stream) {
     if (g.K % BK != 0 || g.a_map || g.b_map || g.m_dev || g.k_dev || g.colsum) return false;

@@ -41,11 +41,22 @@ struct GemmArgs {
     int ablate;   // MRG_GEMM_ABLATE (256x128 kernel only, for roofline analysis): 1 = no DMA, 2 = DMA only, 3 = DMA + LDS reads, no MFMA
 };
 
+// grouped weight-gradient launch of the 8-phase kernel (gemm8p.hip): per-problem operands, everything else from `base`
+constexpr int P8_GROUP_MAX = 16;
+struct P8GroupArgs {
+    GemmArgs base;
+    int nprob;
+    int tile_start[P8_GROUP_MAX + 1];        // first tile of problem p in the concatenated tile list
+    const bf16_t* A[P8_GROUP_MAX]; const bf16_t* B[P8_GROUP_MAX]; void* C[P8_GROUP_MAX];
+    int M[P8_GROUP_MAX], N[P8_GROUP_MAX], lda[P8_GROUP_MAX], ldb[P8_GROUP_MAX], ldc[P8_GROUP_MAX];
+};
+
 }  // namespace mrg_detail
 using namespace mrg_detail;
 
 // launcher of the 256 x 256 8-phase kernel (gemm8p.hip); returns false when the problem is outside its domain
 bool mrg_gemm8p_launch(const mrg_detail::GemmArgs& g, int a_mode, int b_mode, bool vec, int splitk, hipStream_t stream);
+bool mrg_gemm8p_group_launch(const mrg_detail::P8GroupArgs& ga, bool vec, hipStream_t stream);
 
 namespace {
 

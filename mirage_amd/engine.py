@@ -50,6 +50,7 @@ class _Side:
         """Queue fn for the side stream; it is issued at the next flush() (end of a transformer block's backward, end of a
         decoder's backward, or join())."""
         if not cls.enabled:
+            K.WgradGroup.begin()                 # same grouping as on the side stream, launched at the block's end (block_done / join)
             fn()
             return
         cur = torch.cuda.current_stream()
@@ -71,8 +72,10 @@ class _Side:
         jobs, cls.queue = cls.queue, []
         with torch.cuda.stream(cls.stream):
             cls.stream.wait_event(ev)
+            K.WgradGroup.begin()                 # the plain weight gradients of this flush go out as ONE grouped launch without split-K
             for fn in jobs:
                 fn()
+            K.WgradGroup.flush()
             if cls.reduce_early:
                 # finish the split-K slabs / column-sum partials produced so far (the event above covers the LayerNorm partials of
                 # the calling stream): only the last group's reductions are then left for the tail of the step
@@ -88,6 +91,8 @@ class _Side:
         queued by the LAST blocks has nothing left to overlap with, so the forks get finer towards the end
         (12 blocks -> flush after 4, 8, 10, 11, 12) instead of leaving a third of the weight-gradient GEMMs exposed."""
         cls._blocks += 1
+        if not cls.enabled:
+            K.WgradGroup.flush()
         if cls.early_opt is not None and blk is not None:
             if cls.enabled:
                 cls.finished.append(blk)
@@ -108,6 +113,7 @@ class _Side:
     @classmethod
     def join(cls):
         cls.flush()
+        K.WgradGroup.flush()                     # side stream off: what the last blocks queued
         cls._blocks = 0
         if K.Deferred.tasks:
             main = torch.cuda.current_stream()

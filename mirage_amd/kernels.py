@@ -256,6 +256,12 @@ def gemm(A: torch.Tensor, B: torch.Tensor, M: int, N: int, K: int, *, a_mode=L.M
     _need_cuda(A, "GEMM operand")
     if out is None:
         out = torch.empty((M, N), dtype=out_dtype, device=A.device)
+    if (WgradGroup.collecting and a_mode == L.MRG_OP_KSTRIDED and b_mode == L.MRG_OP_KSTRIDED and tune_split
+            and WgradGroup.eligible(A, B, M, N, K, lda, ldb, out, ldc, out2, bias, resid, accumulate, act, aux_out, aux_in, row_map, add_tab,
+                                    a_map, b_map, m_dev, k_dev, row_scale, colsum)):
+        WgradGroup.tasks.append((A, B, M, N, K, lda if lda is not None else A.stride(0), ldb if ldb is not None else B.stride(0), out,
+                                 ldc if ldc is not None else out.stride(-2), splitk))
+        return out
     d = L.GemmDesc()
     d.A, d.B = A.data_ptr(), B.data_ptr()
     d.M, d.N, d.K = M, N, K
@@ -312,6 +318,75 @@ def gemm(A: torch.Tensor, B: torch.Tensor, M: int, N: int, K: int, *, a_mode=L.M
     if cs_part is not None:
         reduce_slices(cs_part, 0, colsum, N, N, cs_part.shape[0])
     return out
+
+
+class WgradGroup:
+    """Weight gradients of several Linears in ONE launch without split-K (mrg_wgrad_group, gemm8p.hip).  While `collecting`
+    (engine._Side: the side-stream jobs of a flush), gemm() calls that are plain weight gradients -- both operands contracted over
+    the token axis, fp32 overwrite, nothing fused -- are queued instead of launched; flush() launches them grouped by K.  A single
+    weight gradient has 9-36 output tiles of 256 x 256: alone it needs split-K slabs and a reduction to fill 256 CUs; side by side
+    the gradients of a few blocks fill them with every tile contracting over all tokens (C2: 100-106 us per block against 197 us,
+    C4: 130 against 215; tools/debug/exp_group_wgrad.py).  MRG_WGRAD_GROUP=0: the per-GEMM tuned split-K path."""
+    enabled = os.environ.get("MRG_WGRAD_GROUP", "1") != "0"
+    min_tiles = int(os.environ.get("MRG_WGRAD_GROUP_MIN_TILES", "64"))     # smaller groups go through the per-GEMM path
+    max_k = int(os.environ.get("MRG_WGRAD_GROUP_MAX_K", "12288"))          # a tile's k-loop is K / 64 steps of ~1.6 us
+    collecting = False
+    tasks = []
+
+    @classmethod
+    def begin(cls):
+        cls.collecting = cls.enabled
+
+    @staticmethod
+    def eligible(A, B, M, N, K, lda, ldb, out, ldc, out2, bias, resid, accumulate, act, aux_out, aux_in, row_map, add_tab, a_map, b_map,
+                 m_dev, k_dev, row_scale, colsum) -> bool:
+        if (out2 is not None or bias is not None or resid is not None or accumulate or act != L.MRG_ACT_NONE or aux_out is not None
+                or aux_in is not None or row_map is not None or add_tab is not None or a_map is not None or b_map is not None
+                or m_dev is not None or k_dev is not None or row_scale is not None or colsum is not None):
+            return False
+        if out.dtype != F32 or K % 64 or K > WgradGroup.max_k or M % 8 or N % 8 or M < 256 or N < 256:
+            return False
+        la = lda if lda is not None else A.stride(0)
+        lb = ldb if ldb is not None else B.stride(0)
+        return la % 8 == 0 and lb % 8 == 0 and A.data_ptr() % 16 == 0 and B.data_ptr() % 16 == 0
+
+    @classmethod
+    def flush(cls):
+        """launch what was collected (on the current stream) and stop collecting"""
+        cls.collecting = False
+        tasks, cls.tasks = cls.tasks, []
+        if not tasks:
+            return
+        by_k = {}
+        for t in tasks:
+            by_k.setdefault(t[4], []).append(t)
+        for K_, ts in by_k.items():
+            tiles = sum(((t[2] + 255) // 256) * ((t[3] + 255) // 256) for t in ts)
+            if tiles < cls.min_tiles:
+                for (A, B, M, N, K, lda, ldb, out, ldc, splitk) in ts:       # too few tiles to fill the chip without split-K
+                    gemm(A, B, M, N, K, a_mode=L.MRG_OP_KSTRIDED, b_mode=L.MRG_OP_KSTRIDED, lda=lda, ldb=ldb, out=out, ldc=ldc,
+                         splitk=splitk, tune_split=True)
+                continue
+            for i in range(0, len(ts), L.MRG_WGRAD_GROUP_MAX):
+                wgrad_group(ts[i:i + L.MRG_WGRAD_GROUP_MAX], K_)
+
+
+def wgrad_group(ts, K: int):
+    """one mrg_wgrad_group launch: ts = [(A, B, M, N, K, lda, ldb, out, ldc, _)], out_p[M_p, N_p] = A_p^T B_p (fp32, overwritten)"""
+    d = L.WgradGroupDesc()
+    d.count, d.K = len(ts), K
+    fl = 0.0
+    for p, (A, B, M, N, _, lda, ldb, out, ldc, _s_) in enumerate(ts):
+        d.A[p], d.B[p], d.C[p] = A.data_ptr(), B.data_ptr(), out.data_ptr()
+        d.M[p], d.N[p], d.lda[p], d.ldb[p], d.ldc[p] = M, N, lda, ldb, ldc
+        fl += 2.0 * M * N * K
+    if TIMING["on"]:
+        st, en = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        st.record(); en.record()
+        d.ev_start, d.ev_stop = st.cuda_event, en.cuda_event
+        tiles = sum(((t[2] + 255) // 256) * ((t[3] + 255) // 256) for t in ts)
+        TIMING["records"].append((L.MRG_GEMM_P8_GROUP, (L.MRG_OP_KSTRIDED, L.MRG_OP_KSTRIDED), fl, st, en, (tiles * 256, 256, K, 1)))
+    check(lib.mrg_wgrad_group(C.byref(d), _s()), "mrg_wgrad_group")
 
 
 if os.environ.get("MRG_TUNE_FRESH") != "1":      # retuning: start from an empty table

@@ -321,6 +321,47 @@ def test_colsum(K):
 
 
 # ------------------------------------------------------------------------------------------- attention
+def test_grouped_weight_gradients_match_per_problem_reference(K):
+    # mrg_wgrad_group: C_p = A_p^T B_p (fp32, overwritten) for several problems in one launch without split-K; shapes with whole and
+    # ragged 256 x 256 tiles, operands that are column slices of wider buffers (row strides > widths)
+    from mirage_amd import _lib as L
+    T = 64 * 7
+    shapes = [(768, 256), (256, 768), (2304, 768), (264, 320), (1032, 256), (256, 256)]
+    wide_a = rnd(T, 4096, dtype=BF16, seed=71); wide_b = rnd(T, 2048, dtype=BF16, seed=72)
+    tasks, outs = [], []
+    ca = cb = 0
+    for (M, N) in shapes:
+        if ca + M > wide_a.shape[1]: ca = 0
+        if cb + N > wide_b.shape[1]: cb = 0
+        A = wide_a[:, ca:ca + M]; B = wide_b[:, cb:cb + N]
+        ca += M; cb += N
+        out = torch.full((M, N), float("nan"), device=dev())
+        tasks.append((A, B, M, N, T, wide_a.stride(0), wide_b.stride(0), out, N, 1)); outs.append((A, B, out))
+    K.wgrad_group(tasks, T)
+    for (A, B, out) in outs:
+        want = A.float().t() @ B.float()
+        assert torch.isfinite(out).all()
+        assert rel_rms(out, want) < 2e-3, rel_rms(out, want)
+    # the collecting front end: plain weight-gradient gemm() calls are queued and leave as one grouped launch; a gradient with a
+    # fused extra (accumulate) is not eligible and runs at once
+    keep_min, K.WgradGroup.min_tiles = K.WgradGroup.min_tiles, 1      # group even this small set
+    K.WgradGroup.begin()
+    got = [torch.zeros(M, N, device=dev()) for (M, N) in shapes]
+    for (A, B, _), o, (M, N) in zip(outs, got, shapes):
+        K.gemm(A, B, M, N, T, a_mode=L.MRG_OP_KSTRIDED, b_mode=L.MRG_OP_KSTRIDED, lda=wide_a.stride(0), ldb=wide_b.stride(0), out=o, ldc=N,
+               splitk=2, tune_split=True)
+    assert len(K.WgradGroup.tasks) == (len(shapes) if K.WgradGroup.enabled else 0)
+    acc = torch.ones(256, 256, device=dev())
+    K.gemm(outs[-1][0], outs[-1][1], 256, 256, T, a_mode=L.MRG_OP_KSTRIDED, b_mode=L.MRG_OP_KSTRIDED, lda=wide_a.stride(0),
+           ldb=wide_b.stride(0), out=acc, ldc=256, accumulate=True, tune_split=True)
+    K.WgradGroup.flush()
+    K.WgradGroup.min_tiles = keep_min
+    assert not K.WgradGroup.tasks and not K.WgradGroup.collecting
+    for (A, B, out), o in zip(outs, got):
+        assert rel_rms(o, A.float().t() @ B.float()) < 2e-3
+    assert rel_rms(acc, 1.0 + outs[-1][0].float().t() @ outs[-1][1].float()) < 2e-3
+
+
 def _attn_ref(q, k, v, scale):
     att = torch.softmax((q @ k.transpose(-1, -2)) * scale, dim=-1)
     return att @ v, att
