@@ -328,8 +328,11 @@ class WgradGroup:
     the gradients of a few blocks fill them with every tile contracting over all tokens (C2: 100-106 us per block against 197 us,
     C4: 130 against 215; tools/debug/exp_group_wgrad.py).  MRG_WGRAD_GROUP=0: the per-GEMM tuned split-K path."""
     enabled = os.environ.get("MRG_WGRAD_GROUP", "1") != "0"
-    min_tiles = int(os.environ.get("MRG_WGRAD_GROUP_MIN_TILES", "64"))     # smaller groups go through the per-GEMM path
-    max_k = int(os.environ.get("MRG_WGRAD_GROUP_MAX_K", "12288"))          # a tile's k-loop is K / 64 steps of ~1.6 us
+    # smaller groups go through the per-GEMM path; a tile's k-loop is K / 64 steps of ~1.6 us (K = 16384: the output adapters' 256-wide
+    # gradients, 38 tiles per adapter for 410 us beside the encoder's backward -- C2 10.05 -> 9.90 ms, C4 21.56 -> 21.44 same box;
+    # 64 / 12288 = encoder blocks only)
+    min_tiles = int(os.environ.get("MRG_WGRAD_GROUP_MIN_TILES", "16"))
+    max_k = int(os.environ.get("MRG_WGRAD_GROUP_MAX_K", "16384"))
     collecting = False
     tasks = []
 
