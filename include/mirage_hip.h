@@ -105,13 +105,17 @@ int mrg_gemm(const mrg_gemm_desc* d, hipStream_t stream);
  * (row stride lda_p) and B_p = X bf16 [K, N_p] (row stride ldb_p): both operands contracted over their leading (token) axis, i.e.
  * the `grad_weight = grad_output^T @ input` mm of nn.Linear's backward (mirage/utils.py:155-157,177,186 under autograd) for several
  * Linears / transformer blocks in ONE launch without split-K.  K (tokens) is common and a multiple of 64; operands 16-B aligned,
- * M_p, N_p, lda_p, ldb_p multiples of 8.  ev_start / ev_stop: optional hipEvent_t recorded on `stream` around the launch. */
+ * M_p, N_p, lda_p, ldb_p multiples of 8.  ev_start / ev_stop: optional hipEvent_t recorded on `stream` around the launch.
+ * splitk > 1 (groups with too few tiles for the chip): every tile's k-range is cut into `splitk` parts that write fp32 slabs instead of
+ * C: problem p's slabs [splitk][M_p * N_p] start at ws + splitk * sum_{q<p} M_q N_q floats (C_p must be contiguous, ldc_p == N_p) and the
+ * CALLER sums them into C_p (mrg_reduce_batch). */
 #define MRG_WGRAD_GROUP_MAX 16
 typedef struct mrg_wgrad_group_desc {
     int count, K;
     const void* A[MRG_WGRAD_GROUP_MAX]; const void* B[MRG_WGRAD_GROUP_MAX]; void* C[MRG_WGRAD_GROUP_MAX];
     int M[MRG_WGRAD_GROUP_MAX], N[MRG_WGRAD_GROUP_MAX], lda[MRG_WGRAD_GROUP_MAX], ldb[MRG_WGRAD_GROUP_MAX], ldc[MRG_WGRAD_GROUP_MAX];
     void* ev_start; void* ev_stop;
+    int splitk; float* ws;
 } mrg_wgrad_group_desc;
 int mrg_wgrad_group(const mrg_wgrad_group_desc* d, hipStream_t stream);
 

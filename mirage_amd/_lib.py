@@ -40,7 +40,8 @@ MRG_WGRAD_GROUP_MAX = 16
 class WgradGroupDesc(C.Structure):
     _fields_ = [("count", ci), ("K", ci), ("A", vp * MRG_WGRAD_GROUP_MAX), ("B", vp * MRG_WGRAD_GROUP_MAX), ("C", vp * MRG_WGRAD_GROUP_MAX),
                 ("M", ci * MRG_WGRAD_GROUP_MAX), ("N", ci * MRG_WGRAD_GROUP_MAX), ("lda", ci * MRG_WGRAD_GROUP_MAX),
-                ("ldb", ci * MRG_WGRAD_GROUP_MAX), ("ldc", ci * MRG_WGRAD_GROUP_MAX), ("ev_start", vp), ("ev_stop", vp)]
+                ("ldb", ci * MRG_WGRAD_GROUP_MAX), ("ldc", ci * MRG_WGRAD_GROUP_MAX), ("ev_start", vp), ("ev_stop", vp),
+                ("splitk", ci), ("ws", vp)]
 
 
 class AttnDesc(C.Structure):

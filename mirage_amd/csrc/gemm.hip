@@ -1443,12 +1443,16 @@ extern "C" int mrg_wgrad_group(const mrg_wgrad_group_desc* d, hipStream_t stream
     g = GemmArgs();
     g.K = d->K;
     g.a_aligned = 1; g.b_aligned = 1;
-    g.c_f32 = 1; g.splitk = 1; g.epi_kind = 0; g.act = MRG_ACT_NONE;
+    const int splitk = d->splitk > 1 ? d->splitk : 1;
+    MRG_REQUIRE(splitk == 1 || d->ws, MRG_ERR_ARG, "mrg_wgrad_group: split-K needs a workspace");
+    MRG_REQUIRE(splitk <= (d->K / BK), MRG_ERR_SHAPE, "mrg_wgrad_group: split-K factor %d exceeds the %d k-tiles", splitk, d->K / BK);
+    g.c_f32 = 1; g.splitk = splitk; g.ws = d->ws; g.epi_kind = 0; g.act = MRG_ACT_NONE; g.xcd_split = 1;
     { static const int nt = [] { const char* e = getenv("MRG_GEMM_NT"); return e ? atoi(e) : 2; }(); g.nt = nt; }
     { static const int sd = [] { const char* e = getenv("MRG_GEMM_SIDE_DRAIN"); return e ? atoi(e) : 3; }(); g.side_drain = sd; }
     ga.nprob = d->count;
     bool vec = true;
     int tiles = 0;
+    long mn_before = 0;
     for (int p = 0; p < d->count; ++p) {
         MRG_REQUIRE(d->A[p] && d->B[p] && d->C[p], MRG_ERR_ARG, "mrg_wgrad_group: null operand pointer (problem %d)", p);
         MRG_REQUIRE(d->M[p] > 0 && d->N[p] > 0, MRG_ERR_SHAPE, "mrg_wgrad_group: bad shape (problem %d)", p);
@@ -1456,13 +1460,17 @@ extern "C" int mrg_wgrad_group(const mrg_wgrad_group_desc* d, hipStream_t stream
                     (((uintptr_t)d->A[p] | (uintptr_t)d->B[p]) & 15) == 0, MRG_ERR_UNSUPPORTED,
                     "mrg_wgrad_group: operands must be 16-B aligned with M, N, lda, ldb multiples of 8 (problem %d)", p);
         ga.tile_start[p] = tiles;
+        ga.ws_off[p] = (long)splitk * mn_before;
+        mn_before += (long)d->M[p] * d->N[p];
+        MRG_REQUIRE(splitk == 1 || (d->ldc[p] == d->N[p]), MRG_ERR_UNSUPPORTED, "mrg_wgrad_group: split-K slabs need contiguous C (problem %d)", p);
         tiles += cdiv(d->M[p], 256) * cdiv(d->N[p], 256);
         ga.A[p] = (const bf16_t*)d->A[p]; ga.B[p] = (const bf16_t*)d->B[p]; ga.C[p] = d->C[p];
         ga.M[p] = d->M[p]; ga.N[p] = d->N[p]; ga.lda[p] = d->lda[p]; ga.ldb[p] = d->ldb[p]; ga.ldc[p] = d->ldc[p];
         vec = vec && (d->N[p] % 4 == 0) && (d->ldc[p] % 4 == 0) && (((uintptr_t)d->C[p]) % 16 == 0);
     }
     for (int p = d->count; p <= P8_GROUP_MAX; ++p) ga.tile_start[p] = tiles;
-    for (int p = d->count; p < P8_GROUP_MAX; ++p) { ga.A[p] = nullptr; ga.B[p] = nullptr; ga.C[p] = nullptr; ga.M[p] = ga.N[p] = ga.lda[p] = ga.ldb[p] = ga.ldc[p] = 0; }
+    for (int p = d->count; p < P8_GROUP_MAX; ++p) { ga.A[p] = nullptr; ga.B[p] = nullptr; ga.C[p] = nullptr; ga.M[p] = ga.N[p] = ga.lda[p] = ga.ldb[p] = ga.ldc[p] = 0; ga.ws_off[p] = 0; }
+    if (splitk > 1) vec = vec && (((uintptr_t)d->ws) % 16 == 0);
     if (d->ev_start) (void)hipEventRecord((hipEvent_t)d->ev_start, stream);
     MRG_REQUIRE(mrg_gemm8p_group_launch(ga, vec, stream), MRG_ERR_SHAPE, "mrg_wgrad_group: nothing to launch");
     if (d->ev_stop) (void)hipEventRecord((hipEvent_t)d->ev_stop, stream);

@@ -356,13 +356,14 @@ __global__ __launch_bounds__(512) void gemm_p8_group_kernel(const P8GroupArgs ga
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int total = ga.tile_start[ga.nprob];
     int bid, ksplit;
-    wg_remap(total, 0, bid, ksplit);
+    wg_remap(total, 1, bid, ksplit);             // gridDim.y = split-K factor (1 for groups that fill the chip by themselves)
     int p = 0;
     while (p + 1 < ga.nprob && bid >= ga.tile_start[p + 1]) ++p;
     GemmArgs g = ga.base;
     g.A = ga.A[p]; g.B = ga.B[p]; g.C = ga.C[p];
     g.M = ga.M[p]; g.N = ga.N[p]; g.lda = ga.lda[p]; g.ldb = ga.ldb[p]; g.ldc = ga.ldc[p];
-    p8_tile<MRG_OP_KSTRIDED, MRG_OP_KSTRIDED, VEC, PHASES>(g, bid - ga.tile_start[p], 0, smem);
+    if (g.splitk > 1) g.ws = ga.base.ws + ga.ws_off[p];
+    p8_tile<MRG_OP_KSTRIDED, MRG_OP_KSTRIDED, VEC, PHASES>(g, bid - ga.tile_start[p], ksplit, smem);
 }
 
 }  // namespace
@@ -373,7 +374,7 @@ bool mrg_gemm8p_group_launch(const mrg_detail::P8GroupArgs& ga, bool vec, hipStr
     static const int phases = [] { const char* e = getenv("MRG_P8_PHASES"); return e ? atoi(e) : 2; }();
 #define MRG_P8G(V, PH) do { const void* fn = (const void*)gemm_p8_group_kernel<V, PH>; \
         (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, P8_LDS); \
-        hipLaunchKernelGGL((gemm_p8_group_kernel<V, PH>), dim3(total), dim3(512), (size_t)P8_LDS, stream, ga); } while (0)
+        hipLaunchKernelGGL((gemm_p8_group_kernel<V, PH>), dim3(total, ga.base.splitk), dim3(512), (size_t)P8_LDS, stream, ga); } while (0)
     if (vec) { if (phases == 4) MRG_P8G(true, 4); else MRG_P8G(true, 2); }
     else { if (phases == 4) MRG_P8G(false, 4); else MRG_P8G(false, 2); }
 #undef MRG_P8G

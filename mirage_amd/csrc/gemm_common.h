@@ -49,6 +49,7 @@ struct P8GroupArgs {
     int tile_start[P8_GROUP_MAX + 1];        // first tile of problem p in the concatenated tile list
     const bf16_t* A[P8_GROUP_MAX]; const bf16_t* B[P8_GROUP_MAX]; void* C[P8_GROUP_MAX];
     int M[P8_GROUP_MAX], N[P8_GROUP_MAX], lda[P8_GROUP_MAX], ldb[P8_GROUP_MAX], ldc[P8_GROUP_MAX];
+    long ws_off[P8_GROUP_MAX];               // split-K (base.splitk > 1): problem p's slabs [splitk][M_p * N_p] start at base.ws + ws_off[p]
 };
 
 }  // namespace mrg_detail

@@ -332,6 +332,10 @@ class WgradGroup:
     # gradients, 38 tiles per adapter for 410 us beside the encoder's backward -- C2 10.05 -> 9.90 ms, C4 21.56 -> 21.44 same box;
     # 64 / 12288 = encoder blocks only)
     min_tiles = int(os.environ.get("MRG_WGRAD_GROUP_MIN_TILES", "16"))
+    # optional split-K 2 inside groups with fewer tiles than this (the exposed last groups of a backward pass): measured neutral
+    # (C2 9.93 vs 9.95 ms, C4 21.66 vs 21.65: the slabs and their reduction cost what the fuller launch gains) -> off by default
+    split_below = int(os.environ.get("MRG_WGRAD_GROUP_SPLIT_BELOW", "0"))
+    split_max_k = int(os.environ.get("MRG_WGRAD_GROUP_SPLIT_MAX_K", "12288"))
     max_k = int(os.environ.get("MRG_WGRAD_GROUP_MAX_K", "16384"))
     collecting = False
     tasks = []
@@ -371,14 +375,28 @@ class WgradGroup:
                          splitk=splitk, tune_split=True)
                 continue
             for i in range(0, len(ts), L.MRG_WGRAD_GROUP_MAX):
-                wgrad_group(ts[i:i + L.MRG_WGRAD_GROUP_MAX], K_)
+                chunk = ts[i:i + L.MRG_WGRAD_GROUP_MAX]
+                ctiles = sum(((t[2] + 255) // 256) * ((t[3] + 255) // 256) for t in chunk)
+                # a group that covers less than ~2/3 of the CUs (the last blocks of the backward pass, whose launch is exposed at the
+                # end of the step) cuts every tile's k-range in two: slabs + the batched reduction, as the per-GEMM path does
+                sk = 2 if (ctiles <= cls.split_below and K_ // 64 >= 32 and K_ <= cls.split_max_k and Deferred.active
+                           and all(t[8] == t[3] and Deferred.ok(t[7], t[2] * t[3], t[2] * t[3]) for t in chunk)) else 1
+                wgrad_group(chunk, K_, sk)
 
 
-def wgrad_group(ts, K: int):
-    """one mrg_wgrad_group launch: ts = [(A, B, M, N, K, lda, ldb, out, ldc, _)], out_p[M_p, N_p] = A_p^T B_p (fp32, overwritten)"""
+def wgrad_group(ts, K: int, splitk: int = 1):
+    """one mrg_wgrad_group launch: ts = [(A, B, M, N, K, lda, ldb, out, ldc, _)], out_p[M_p, N_p] = A_p^T B_p (fp32, overwritten);
+    splitk > 1: slabs + deferred batched reduction (only inside a backward pass: Deferred.active)"""
     d = L.WgradGroupDesc()
     d.count, d.K = len(ts), K
     fl = 0.0
+    if splitk > 1:
+        ws = torch.empty(splitk * sum(t[2] * t[3] for t in ts), dtype=F32, device=ts[0][0].device)
+        d.splitk, d.ws = splitk, ws.data_ptr()
+        off = 0
+        for (_, _, M, N, _, _, _, out, _, _) in ts:
+            Deferred.add(ws, splitk * off, out, M * N, M * N, splitk)
+            off += M * N
     for p, (A, B, M, N, _, lda, ldb, out, ldc, _s_) in enumerate(ts):
         d.A[p], d.B[p], d.C[p] = A.data_ptr(), B.data_ptr(), out.data_ptr()
         d.M[p], d.N[p], d.lda[p], d.ldb[p], d.ldc[p] = M, N, lda, ldb, ldc

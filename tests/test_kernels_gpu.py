@@ -342,6 +342,18 @@ def test_grouped_weight_gradients_match_per_problem_reference(K):
         want = A.float().t() @ B.float()
         assert torch.isfinite(out).all()
         assert rel_rms(out, want) < 2e-3, rel_rms(out, want)
+    # split-K inside the group (small groups): slabs + the batched reduction
+    for (_, _, out) in outs:
+        out.fill_(float("nan"))
+    K.Deferred.active = True
+    try:
+        K.wgrad_group(tasks, T, 2)
+        K.Deferred.flush()
+    finally:
+        K.Deferred.active = False
+        K.Deferred.release()
+    for (A, B, out) in outs:
+        assert rel_rms(out, A.float().t() @ B.float()) < 2e-3
     # the collecting front end: plain weight-gradient gemm() calls are queued and leave as one grouped launch; a gradient with a
     # fused extra (accumulate) is not eligible and runs at once
     keep_min, K.WgradGroup.min_tiles = K.WgradGroup.min_tiles, 1      # group even this small set
