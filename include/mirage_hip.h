@@ -109,7 +109,7 @@ int mrg_gemm(const mrg_gemm_desc* d, hipStream_t stream);
  * splitk > 1 (groups with too few tiles for the chip): every tile's k-range is cut into `splitk` parts that write fp32 slabs instead of
  * C: problem p's slabs [splitk][M_p * N_p] start at ws + splitk * sum_{q<p} M_q N_q floats (C_p must be contiguous, ldc_p == N_p) and the
  * CALLER sums them into C_p (mrg_reduce_batch). */
-#define MRG_WGRAD_GROUP_MAX 16
+#define MRG_WGRAD_GROUP_MAX 48
 typedef struct mrg_wgrad_group_desc {
     int count, K;
     const void* A[MRG_WGRAD_GROUP_MAX]; const void* B[MRG_WGRAD_GROUP_MAX]; void* C[MRG_WGRAD_GROUP_MAX];

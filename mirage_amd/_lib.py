@@ -34,7 +34,7 @@ class GemmDesc(C.Structure):
                 ("add_tab", vp), ("add_row", vp), ("ldt", ci), ("splitk", ci), ("ws", vp), ("variant", ci), ("ev_start", vp), ("ev_stop", vp), ("row_scale", vp), ("colsum_out", vp), ("defer_reduce", ci), ("splitk_counters", vp)]
 
 
-MRG_WGRAD_GROUP_MAX = 16
+MRG_WGRAD_GROUP_MAX = 48
 
 
 class WgradGroupDesc(C.Structure):

@@ -42,7 +42,7 @@ struct GemmArgs {
 };
 
 // grouped weight-gradient launch of the 8-phase kernel (gemm8p.hip): per-problem operands, everything else from `base`
-constexpr int P8_GROUP_MAX = 16;
+constexpr int P8_GROUP_MAX = 48;
 struct P8GroupArgs {
     GemmArgs base;
     int nprob;

@@ -37,8 +37,11 @@ class _Side:
     pending = False
     queue = []         # deferred jobs: one fork (event + cross-stream edge) per flush instead of one per Linear -- inside a
                        # hipGraph every cross-stream edge costs ~16 us of dependent-launch latency on this runtime
-    blocks_per_flush = 4
-    taper = True
+    # blocks per fork.  With grouped weight gradients (kernels.WgradGroup) a flush is ONE launch whose efficiency grows with its tile
+    # count, so the forks are coarser than when every Linear had its own split-K launches (was 4 with finer forks towards the end):
+    # same box, C2 9.79 -> 9.69 ms, C4 21.27 -> 20.8 ms
+    blocks_per_flush = int(os.environ.get("MRG_SIDE_BLOCKS", "6"))
+    taper = os.environ.get("MRG_SIDE_TAPER", "0") != "0"
     reduce_early = True
     _blocks = 0
     origin = None      # stream the queued jobs were produced on (the decoders' lanes queue from their own streams)
