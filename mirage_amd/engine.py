@@ -41,7 +41,11 @@ class _Side:
     # count, so the forks are coarser than when every Linear had its own split-K launches (was 4 with finer forks towards the end):
     # same box, C2 9.79 -> 9.69 ms, C4 21.27 -> 20.8 ms
     blocks_per_flush = int(os.environ.get("MRG_SIDE_BLOCKS", "6"))
-    taper = os.environ.get("MRG_SIDE_TAPER", "0") != "0"
+    # the group queued by the LAST blocks has nothing left to overlap with: 0 (default) no special case (12 blocks -> 6, 6); 1 the old
+    # halving taper (4, 4, 2, 1, 1 at 4 per flush); 2 the last MRG_SIDE_TAIL blocks form their own group (12 blocks -> 6, 4, 2).
+    # Measured same box: 0 and 2 tie (C2 9.87 / 9.88 ms, C4 21.18 / 21.35): the grouped launch is as fast alone as shared
+    taper = int(os.environ.get("MRG_SIDE_TAPER", "0"))
+    tail_blocks = int(os.environ.get("MRG_SIDE_TAIL", "2"))
     reduce_early = True
     _blocks = 0
     origin = None      # stream the queued jobs were produced on (the decoders' lanes queue from their own streams)
@@ -101,7 +105,11 @@ class _Side:
                 cls.finished.append(blk)
             else:
                 cls.early_opt([blk])             # no side stream, no deferred reductions: the gradients are final already
-        need = cls.blocks_per_flush if remaining is None else min(cls.blocks_per_flush, max(1, remaining))
+        need = cls.blocks_per_flush
+        if remaining is not None and cls.taper == 1:
+            need = min(cls.blocks_per_flush, max(1, remaining))
+        elif remaining is not None and cls.taper == 2 and remaining == cls.tail_blocks:
+            need = 1
         if cls._blocks >= need:
             cls._blocks = 0
             cls.flush()
