@@ -98,8 +98,8 @@ class _Side:
         queued by the LAST blocks has nothing left to overlap with, so the forks get finer towards the end
         (12 blocks -> flush after 4, 8, 10, 11, 12) instead of leaving a third of the weight-gradient GEMMs exposed."""
         cls._blocks += 1
-        if not cls.enabled:
-            K.WgradGroup.flush()
+        if not cls.enabled and cls.early_opt is not None:
+            K.WgradGroup.flush()                 # the optimizer update below needs this block's gradients now
         if cls.early_opt is not None and blk is not None:
             if cls.enabled:
                 cls.finished.append(blk)
@@ -113,6 +113,8 @@ class _Side:
         if cls._blocks >= need:
             cls._blocks = 0
             cls.flush()
+            if not cls.enabled:
+                K.WgradGroup.flush()             # side stream off: same grouping cadence, on the calling stream
 
     @classmethod
     def begin_backward(cls):
