@@ -80,8 +80,12 @@ class _Side:
         with torch.cuda.stream(cls.stream):
             cls.stream.wait_event(ev)
             K.WgradGroup.begin()                 # the plain weight gradients of this flush go out as ONE grouped launch without split-K
-            for fn in jobs:
-                fn()
+            try:
+                for fn in jobs:
+                    fn()
+            except BaseException:
+                K.WgradGroup.collecting, K.WgradGroup.tasks = False, []
+                raise
             K.WgradGroup.flush()
             if cls.reduce_early:
                 # finish the split-K slabs / column-sum partials produced so far (the event above covers the LayerNorm partials of
