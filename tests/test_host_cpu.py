@@ -98,3 +98,34 @@ def test_hf_directory_layout_roundtrip(tmp_path):
     m3 = MIRAGEhf(input_size=64, patch_size=8, modalities="bscan-slo", size="tiny", dim_tokens=64, depth=2, num_heads=2)
     msg = m3.load_state_dict(m.model.state_dict(), strict=False)
     assert len(msg.missing_keys) == 0
+
+
+def test_half_batch_placement_and_weight_gradient_collector_rules():
+    # kernels.Halves: chain A allocates full-batch tensors and works on the first halves, chain B receives the second halves of the
+    # SAME tensors in the same order; full_of() recovers the full tensor from any view of a first half (no GPU needed: placement only)
+    import pytest
+    from mirage_amd import kernels as K, _lib as L
+    K.Halves.begin(1)
+    a1 = K.new((4, 3, 8), torch.float32, "cpu"); a2 = K.new((12,), torch.float32, "cpu")
+    K.Halves.end()
+    K.Halves.begin(2)
+    b1 = K.new((4, 3, 8), torch.float32, "cpu"); b2 = K.new((12,), torch.float32, "cpu")
+    K.Halves.end()
+    a1.fill_(1.0); b1.fill_(2.0); a2.fill_(3.0); b2.fill_(4.0)
+    f1 = K.Halves.full_of(a1.view(12, 8)); f2 = K.Halves.full_of(a2)
+    assert f1.shape == (24, 8) and torch.equal(f1[:12], torch.ones(12, 8)) and torch.equal(f1[12:], torch.full((12, 8), 2.0))
+    assert f2.shape == (24,) and torch.equal(f2[12:], torch.full((12,), 4.0))
+    assert K.Halves.full_of(None) is None and K.new((2,), torch.float32, "cpu").shape == (2,)        # mode 0: plain torch.empty
+    K.Halves.begin(2)
+    with pytest.raises(RuntimeError, match="diverged"):
+        K.new((4, 3, 9), torch.float32, "cpu")
+    K.Halves.end()
+    # kernels.WgradGroup.eligible: only plain weight gradients (fp32 overwrite, nothing fused, aligned, whole 64-token k-tiles)
+    A = torch.zeros(128, 512, dtype=torch.bfloat16); B = torch.zeros(128, 256, dtype=torch.bfloat16); out = torch.zeros(512, 256)
+    none = dict(out2=None, bias=None, resid=None, accumulate=False, act=L.MRG_ACT_NONE, aux_out=None, aux_in=None, row_map=None, add_tab=None,
+                a_map=None, b_map=None, m_dev=None, k_dev=None, row_scale=None, colsum=None)
+    ok = lambda **kw: K.WgradGroup.eligible(A, B, kw.pop("M", 512), kw.pop("N", 256), kw.pop("K", 128), None, None, kw.pop("out", out), None,
+                                            **{**none, **kw})
+    assert ok()
+    assert not ok(accumulate=True) and not ok(bias=torch.zeros(256)) and not ok(a_map=torch.zeros(4, dtype=torch.int32))
+    assert not ok(K=100) and not ok(M=128) and not ok(out=out.bfloat16()) and not ok(K=K.WgradGroup.max_k + 64)
