@@ -116,8 +116,66 @@ struct AttnArgs {
     float* cs_q; float* cs_k; float* cs_v; long cs_bs;   // optional per-(batch, head) column sums of dQ / dK / dV (bias gradients)
 };
 
+// ---- transposed accumulators -> full-line stores (forward output, fused backward outputs) ----------------------------------
+// An output accumulated with the MFMA operands swapped has lane = token row of the 32-row tile and register r = column
+// 8 (r >> 2) + 4 (lane >> 5) + (r & 3) of the 32-column block dj: per-row factors (softmax rescale, 1 / l) are lane-local, four
+// consecutive columns pack into one 8-byte LDS store, and the wave's staging tile is read back as 16-B chunks so that a store
+// instruction covers whole rows (8 lanes per 128-B row at hd 64).  Straight from the usual layout (lane = column) a lane could only
+// store 2 bytes at a time.
+constexpr int FUSED_SP = 144;                     // staging pitch (bytes) of a 64-column bf16 row: 16-B aligned, 36 banks
+template <int DJ>
+__device__ __forceinline__ void fused_stage(char* stg, const f32x16 (&acc)[DJ], int lane) {
+    const int rr = lane & 31, hf = lane >> 5;
+#pragma unroll
+    for (int dj = 0; dj < DJ; ++dj)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            uint2 w;
+            w.x = pack_bf2(acc[dj][4 * g + 0], acc[dj][4 * g + 1]);
+            w.y = pack_bf2(acc[dj][4 * g + 2], acc[dj][4 * g + 3]);
+            *reinterpret_cast<uint2*>(stg + rr * FUSED_SP + (dj * 32 + 8 * g + 4 * hf) * 2) = w;
+        }
+}
+// staging tile -> global rows row0 .. row0 + 31 (valid below N) as 16-B stores; CS: also this lane's partial column sums (columns
+// 8 (lane & 7) .. + 7 over the rows it stored, reduced over the lanes that share the chunk) in cs[8] (hd 64 only)
+template <int DJ, bool CS>
+__device__ __forceinline__ void fused_flush(const char* stg, bf16_t* __restrict__ dst, long rs, int row0, int N, int lane, float (&cs)[8]) {
+    constexpr int CPR = DJ * 4;                    // 16-B chunks per row: 8 (hd 64) or 4 (hd 32)
+    constexpr int RPI = 64 / CPR;                  // rows per store instruction
+    if (CS) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) cs[e] = 0.f;
+    }
+#pragma unroll
+    for (int j = 0; j < 32 / RPI; ++j) {
+        const int rr = lane / CPR + RPI * j, c = lane % CPR;
+        const uint4 v = *reinterpret_cast<const uint4*>(stg + rr * FUSED_SP + c * 16);
+        if (row0 + rr < N) {
+            *reinterpret_cast<uint4*>(dst + (long)(row0 + rr) * rs + c * 8) = v;
+            if (CS) {
+                const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    cs[2 * e] += __uint_as_float(w[e] << 16);
+                    cs[2 * e + 1] += __uint_as_float(w[e] & 0xffff0000u);
+                }
+            }
+        }
+    }
+    if (CS) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            cs[e] += __shfl_xor(cs[e], 8, 64);
+            cs[e] += __shfl_xor(cs[e], 16, 64);
+            cs[e] += __shfl_xor(cs[e], 32, 64);
+        }
+    }
+}
+
 // ================================================ forward ===============================================
-template <int HD, int CB>
+// STAGE: the output tile goes through a per-wave LDS staging tile (behind K / V) and leaves as full rows; otherwise (K / V + staging
+// would cost the second workgroup per CU) as 8-byte stores from the registers.
+template <int HD, int CB, bool STAGE>
 __global__ __launch_bounds__(512, 2) void attn_fwd_kernel(const AttnArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int KS = HD / 16, DJ = HD / 32, ROWS = CB * 32;
@@ -208,13 +266,11 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_kernel(const AttnArgs a) {
             ls += __shfl_xor(ls, 32, 64);
             l_run = l_run * alpha + ls;
             m_run = m_new;
-            if (ch > 0) {
+            if (ch > 0) {                            // o is accumulated transposed (lane = query): the row factor is lane-local
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const float al = __shfl(alpha, acc_row(r, lane), 64);
+                for (int r = 0; r < 16; ++r)
 #pragma unroll
-                    for (int dj = 0; dj < DJ; ++dj) o[dj][r] *= al;
-                }
+                    for (int dj = 0; dj < DJ; ++dj) o[dj][r] *= alpha;
             }
 #pragma unroll
             for (int kb = 0; kb < CB; ++kb) {
@@ -225,7 +281,7 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_kernel(const AttnArgs a) {
                         const bf16x8 pa = pack8(s[kb], mf);
 #pragma unroll
                         for (int dj = 0; dj < DJ; ++dj)
-                            o[dj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa, frag_cols_tr<HD, SWZ_TR>(ldsV_u, lbase + kb * 32, mf, dj, lane), o[dj], 0, 0, 0);
+                            o[dj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_cols_tr<HD, SWZ_TR>(ldsV_u, lbase + kb * 32, mf, dj, lane), pa, o[dj], 0, 0, 0);
                     }
                 }
             }
@@ -234,13 +290,26 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_kernel(const AttnArgs a) {
         const float linv = 1.f / l_run;
         bf16_t* op = a.o + (long)b * a.o_bs + h * HD;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int row = acc_row(r, lane);
-            const float li = __shfl(linv, row, 64);
-            const int qr = q0 + row;
+        for (int dj = 0; dj < DJ; ++dj)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[dj][r] *= linv;
+        if (STAGE) {
+            char* stg = smem + 2 * lds_rows * HD * 2 + wave * (32 * FUSED_SP);
+            float unused[8];
+            fused_stage<DJ>(stg, o, lane);
+            fused_flush<DJ, false>(stg, op, a.o_rs, q0, a.Nq, lane, unused);
+        } else {
+            const int qr = q0 + (lane & 31);
             if (qr < a.Nq) {
 #pragma unroll
-                for (int dj = 0; dj < DJ; ++dj) op[(long)qr * a.o_rs + dj * 32 + (lane & 31)] = f2bf(o[dj][r] * li);
+                for (int dj = 0; dj < DJ; ++dj)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        uint2 w;
+                        w.x = pack_bf2(o[dj][4 * g + 0], o[dj][4 * g + 1]);
+                        w.y = pack_bf2(o[dj][4 * g + 2], o[dj][4 * g + 3]);
+                        *reinterpret_cast<uint2*>(op + (long)qr * a.o_rs + dj * 32 + 8 * g + 4 * (lane >> 5)) = w;
+                    }
             }
         }
         if (a.lse && lane < 32 && q0 + lane < a.Nq)
@@ -538,7 +607,6 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dkv_kernel(const AttnArgs a) 
 // LDS holds only NR = N + 1 (rounded to 4) rows per tile: row NR - 1 is a zero row that every out-of-range row index is clamped
 // to (N = 99: 78 KiB, two workgroups per CU; N = 129: 111 KiB, one).
 // Against the query-owner + key-owner pair of kernels: 5 instead of 7 tile products, Q / K / V / dO are read once, one launch.
-constexpr int FUSED_SP = 144;                     // staging pitch (bytes) of a 64-column bf16 row: 16-B aligned, 36 banks
 template <int NT> struct FusedCfg { static constexpr int ROWS = NT * 32; };
 static inline int fused_nr(int N, int rows) { const int nr = (N + 1 + 3) & ~3; return nr < rows ? nr : rows; }
 static inline size_t fused_lds(int nr, int nt) { return (size_t)4 * nr * 128 + (size_t)nt * nr * 64 + (size_t)2 * nt * 32 * 4 + 32 * 64; }
@@ -566,47 +634,6 @@ __device__ __forceinline__ bf16x8 fz_cols_tr(const bool CL, uint32_t lds_base, i
     f[0] = lo[0]; f[1] = lo[1]; f[2] = lo[2]; f[3] = lo[3];
     f[4] = hi[0]; f[5] = hi[1]; f[6] = hi[2]; f[7] = hi[3];
     return f;
-}
-
-// transposed accumulator (lane = token row of the tile, register r = column 8 (r >> 2) + 4 (lane >> 5) + (r & 3) of the 32-column
-// block dj) -> packed bf16 in this wave's staging tile
-__device__ __forceinline__ void fused_stage(char* stg, const f32x16 (&acc)[2], int lane) {
-    const int rr = lane & 31, hf = lane >> 5;
-#pragma unroll
-    for (int dj = 0; dj < 2; ++dj)
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            uint2 w;
-            w.x = pack_bf2(acc[dj][4 * g + 0], acc[dj][4 * g + 1]);
-            w.y = pack_bf2(acc[dj][4 * g + 2], acc[dj][4 * g + 3]);
-            *reinterpret_cast<uint2*>(stg + rr * FUSED_SP + (dj * 32 + 8 * g + 4 * hf) * 2) = w;
-        }
-}
-// staging tile -> global rows row0 .. row0 + 31 (valid below N) as 16-B stores, 8 lanes per 128-B row; returns this lane's partial
-// column sums (columns 8 (lane & 7) .. + 7 over the rows it stored) in cs[8]
-__device__ __forceinline__ void fused_flush(const char* stg, bf16_t* __restrict__ dst, long rs, int row0, int N, int lane, float (&cs)[8]) {
-#pragma unroll
-    for (int e = 0; e < 8; ++e) cs[e] = 0.f;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int rr = (lane >> 3) + 8 * j, c = lane & 7;
-        const uint4 v = *reinterpret_cast<const uint4*>(stg + rr * FUSED_SP + c * 16);
-        if (row0 + rr < N) {
-            *reinterpret_cast<uint4*>(dst + (long)(row0 + rr) * rs + c * 8) = v;
-            const uint32_t w[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                cs[2 * e] += __uint_as_float(w[e] << 16);
-                cs[2 * e + 1] += __uint_as_float(w[e] & 0xffff0000u);
-            }
-        }
-    }
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-        cs[e] += __shfl_xor(cs[e], 8, 64);
-        cs[e] += __shfl_xor(cs[e], 16, 64);
-        cs[e] += __shfl_xor(cs[e], 32, 64);
-    }
 }
 
 template <int NT>
@@ -761,10 +788,10 @@ __global__ __launch_bounds__(64 * NT, 2) void attn_bwd_fused_kernel(const AttnAr
     MRG_TS(4);
     char* stg = smem + wave * (32 * FUSED_SP);
     float cs[3][8];
-    fused_stage(stg, dvT, lane);
-    fused_flush(stg, a.dv + (long)b * a.dv_bs + h * HD, a.dv_rs, wave * 32, N, lane, cs[2]);
-    fused_stage(stg, dkT, lane);
-    fused_flush(stg, a.dk + (long)b * a.dk_bs + h * HD, a.dk_rs, wave * 32, N, lane, cs[1]);
+    fused_stage<2>(stg, dvT, lane);
+    fused_flush<2, true>(stg, a.dv + (long)b * a.dv_bs + h * HD, a.dv_rs, wave * 32, N, lane, cs[2]);
+    fused_stage<2>(stg, dkT, lane);
+    fused_flush<2, true>(stg, a.dk + (long)b * a.dk_bs + h * HD, a.dk_rs, wave * 32, N, lane, cs[1]);
     MRG_TS(5);
 
     // ---- phase B: this wave's query tile (T block `wave`), contraction over all keys
@@ -794,8 +821,8 @@ __global__ __launch_bounds__(64 * NT, 2) void attn_bwd_fused_kernel(const AttnAr
                     dqT[dj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fz_cols_tr(kb == NT - 1, ldsK_u, kb * 32, mf, dj, lane, nr1), da, dqT[dj], 0, 0, 0);
             }
         MRG_TS(6);
-        fused_stage(stg, dqT, lane);
-        fused_flush(stg, a.dq + (long)b * a.dq_bs + h * HD, a.dq_rs, wave * 32, N, lane, cs[0]);
+        fused_stage<2>(stg, dqT, lane);
+        fused_flush<2, true>(stg, a.dq + (long)b * a.dq_bs + h * HD, a.dq_rs, wave * 32, N, lane, cs[0]);
     }
     MRG_TS(7);
     if (a.cs_q) {   // per-(batch, head) column sums of dQ / dK / dV: the bias gradients before the reduction over the batch
@@ -854,9 +881,14 @@ int launch_fwd(const AttnArgs& a0, hipStream_t stream) {
 #define MRG_FWD(CB_) do { const bool fits = (size_t)2 * nkb * 32 * HD * 2 <= 80 * 1024; \
         a.chunk_rows = fits ? nkb * 32 : CB_ * 32; \
         if (a.chunk_rows < CB_ * 32) a.chunk_rows = CB_ * 32; \
-        const size_t sh = (size_t)2 * a.chunk_rows * HD * 2; \
-        if (sh > 65536) (void)hipFuncSetAttribute((const void*)attn_fwd_kernel<HD, CB_>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
-        hipLaunchKernelGGL((attn_fwd_kernel<HD, CB_>), grid, block, sh, stream, a); } while (0)
+        const size_t kv = (size_t)2 * a.chunk_rows * HD * 2; \
+        const size_t stg = (size_t)(block.x / 64) * 32 * FUSED_SP; \
+        const bool stage = kv + stg <= 80 * 1024;        /* staging must not cost the second workgroup per CU */ \
+        const size_t sh = stage ? kv + stg : kv; \
+        if (stage) { if (sh > 65536) (void)hipFuncSetAttribute((const void*)attn_fwd_kernel<HD, CB_, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+                     hipLaunchKernelGGL((attn_fwd_kernel<HD, CB_, true>), grid, block, sh, stream, a); } \
+        else { if (sh > 65536) (void)hipFuncSetAttribute((const void*)attn_fwd_kernel<HD, CB_, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+               hipLaunchKernelGGL((attn_fwd_kernel<HD, CB_, false>), grid, block, sh, stream, a); } } while (0)
     // Scores are kept in registers one chunk of CB key blocks at a time with an online-softmax rescale between chunks.  Small
     // chunks win on these short rows: CB = 1 needs 128 VGPRs (4 waves per SIMD) against 256 for CB = 5, and the kernel is bound
     // by latency chains, not MFMA throughput (C2 30.7 -> 23.2 us, C5 400 -> 297 us; tools/bench_attn_fwd.py)
