@@ -398,6 +398,11 @@ def _run(real_stdout: int):
                     "unit": "TFLOP/s", "frac": round(fl / tsec / MFMA_BF16_PEAK, 4), "traffic": traffic, "traffic_source": traffic_src,
                     "launches_per_step": n, "avg_launch_us": round(1e6 * tsec / n, 2), "launch_mix": modes,
                     "all_gemm_achieved": round(all_fl / all_t / 1e12, 2),
+                    # every GEMM kernel family of the instrumented step, largest total time first (the dominant one above is the first):
+                    # launches, total ms, achieved TFLOP/s and fraction of the bf16 MFMA peak
+                    "families": [{"kernel": m, "launches": gg[2], "ms": round(gg[1] * 1e3, 3), "achieved": round(gg[0] / gg[1] / 1e12, 1),
+                                  "frac": round(gg[0] / gg[1] / MFMA_BF16_PEAK, 4)}
+                                 for m, gg in sorted(groups.items(), key=lambda kv: -kv[1][1])],
                     "whole_step_achieved": round(value / world * fpi / 1e12, 2),
                     "whole_step_frac": round(value / world * fpi / MFMA_BF16_PEAK, 4)}
         result = {
