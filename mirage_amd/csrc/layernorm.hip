@@ -8,6 +8,7 @@
 // bias gradient of the residual-producing Linear (= colsum of the incoming residual gradient), finished by
 // mrg_colsum_partials: deterministic two-stage reduction, no atomics.
 #include "common.h"
+#include <stdlib.h>
 #include "mirage_hip.h"
 
 namespace {
@@ -22,9 +23,16 @@ __device__ __forceinline__ float4 bf4_to_f4(uint2 u) {
 __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
                                                      const float* __restrict__ beta, bf16_t* __restrict__ y,
                                                      float* __restrict__ y32, float* __restrict__ mean,
-                                                     float* __restrict__ rstd, int M, int D, float eps) {
+                                                     float* __restrict__ rstd, int M, int D, float eps, int band) {
     const int lane = threadIdx.x & 63;
-    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    // band: workgroups are dispatched round-robin over the 8 XCDs; give XCD x one contiguous band of rows -- the band of A rows the
+    // consuming GEMM's workgroups on the same XCD read (gemm_common.h wg_remap), so that they find them in their own L2
+    int blk = blockIdx.x;
+    if (band) {
+        const int nblk = gridDim.x, q = nblk >> 3, r = nblk & 7, xcd = blk & 7, idx = blk >> 3;
+        blk = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int row = blk * 4 + (threadIdx.x >> 6);
     if (row >= M) return;
     const int nv = D >> 2;
     const float4* xr = reinterpret_cast<const float4*>(x + (long)row * D);
@@ -333,8 +341,9 @@ extern "C" int mrg_ln_fwd(const float* x, const float* gamma, const float* beta,
                           float* rstd, int M, int D, float eps, hipStream_t stream) {
     MRG_REQUIRE(x && gamma && beta && mean && rstd && (y_bf16 || y_f32), MRG_ERR_ARG, "mrg_ln_fwd: null pointer");
     MRG_REQUIRE(M > 0 && D > 0 && D % 4 == 0 && D <= 1024, MRG_ERR_SHAPE, "mrg_ln_fwd: need D %% 4 == 0 and D <= 1024 (D=%d)", D);
+    static const int band = [] { const char* e = getenv("MRG_LN_BAND"); return e ? atoi(e) : 1; }();   // same box: C2 9.527 -> 9.500 ms (3 of 3 pairs), C4 within noise
     hipLaunchKernelGGL(ln_fwd_kernel, dim3(cdiv(M, 4)), dim3(256), 0, stream, x, gamma, beta, (bf16_t*)y_bf16, y_f32, mean, rstd, M,
-                       D, eps);
+                       D, eps, band);
     return mrg_check_launch("mrg_ln_fwd");
 }
 
