@@ -112,6 +112,194 @@ def cpu_baseline(model_name, doms, K, train, budget_s=25.0):
                       f"{n_threads} threads of {os.cpu_count()} host cores"}
 
 
+def measure(a, cfg_name, steps, warmup, batch, rank, world, dev, force_dp, ranks_seen):
+    """Build one configuration from scratch, warm it up, capture it, time `steps` steps (barrier + synchronize on both sides, max over
+    ranks) and run the instrumented roofline step.  Returns the JSON-ready result dict (rank 0; None elsewhere)."""
+    from mirage_amd import builder, kernels as K, optim
+    from mirage_amd import _lib as L
+    from mirage_amd.dp import GradReducer, broadcast_params
+    from mirage_amd.trainer import TrainStep
+
+    model_name, doms, B, Kk, train = CONFIGS[cfg_name]
+    if batch:
+        B = batch
+    out_doms = doms if train else ()
+    if os.environ.get("MRG_BENCH_OUT"):                     # experiment knob: fewer output adapters (marginal cost of a decoder)
+        out_doms = tuple(os.environ["MRG_BENCH_OUT"].split("-"))
+    args = builder.make_args(doms, out_doms)
+    torch.manual_seed(0)
+    model = builder.get_model(args, model_name, with_decoders=train).to(dev)
+    model.train(train)
+    # weights come from the common seed above (and are broadcast from rank 0); mask / stochastic-depth draws use a per-rank stream
+    # (SURVEY.md section 8e: "own mask RNG stream (seed+rank)")
+    torch.manual_seed(4321 + rank)
+    torch.cuda.manual_seed(4321 + rank)
+    pool = synth_batches(doms, B, 4, 1234 + rank, dev)
+
+    if train:
+        total_steps = steps + warmup + 64
+        lr = 1e-4 * (B * world) / 256                      # run_pretraining.py:497 with the global batch
+        lrs = optim.cosine_scheduler(lr, 0.0, 1, total_steps, warmup_epochs=1, warmup_steps=max(1, total_steps // 10))
+        wds = optim.cosine_scheduler(0.05, 0.05, 1, total_steps)
+        opt = optim.FusedAdamW(model, lrs, wds, betas=(0.9, 0.95), eps=1e-8)
+        broadcast_params(opt.arena.flat_p)
+        opt.arena.refresh_shadow(force=True)
+        reducer = GradReducer(opt.arena.flat_g, force=force_dp) if (world > 1 or force_dp) else None
+        loss_fns = builder.get_losses(args)
+        ts = TrainStep(model, loss_fns, opt, pool[0], Kk, use_graph=not a.no_graph, reducer=reducer,
+                       overlap=os.environ.get("MRG_DP_OVERLAP", "1") != "0")
+        ts.load(pool[0])
+        ts.warmup_and_capture()
+
+        def run_step(i):
+            ts.step(pool[i % len(pool)])
+    else:
+        static = {d: torch.empty_like(pool[0][d]) for d in doms}
+        graph = None
+
+        def fwd():
+            with torch.no_grad():
+                return model(static, mask_inputs=False)[0]
+
+        for d in doms:
+            static[d].copy_(pool[0][d])
+        fwd()
+        torch.cuda.synchronize()
+        if not a.no_graph:
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                out_static = fwd()
+
+        def run_step(i):
+            for d in doms:
+                static[d].copy_(pool[i % len(pool)][d], non_blocking=True)
+            if graph is not None:
+                graph.replay()
+            else:
+                fwd()
+
+    multi = world > 1 or force_dp
+    for i in range(warmup):
+        run_step(i)
+    if multi:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        run_step(warmup + i)
+    torch.cuda.synchronize()
+    if multi:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if multi:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    ms_per_step = 1e3 * elapsed / steps
+    value = B * world * steps / elapsed
+    fpi = flops_per_image(model_name, doms, Kk, train)
+
+    result = None
+    if rank == 0:
+        # ---- roofline of the dominant kernel: instrumented eager step, events on the launch stream -------------
+        K.TIMING["records"].clear()
+        K.TIMING["on"] = True
+        # park the GPU behind a long spin kernel so that the whole eager step is already queued when it starts executing:
+        # the per-launch events then measure kernel durations, not the python launch gaps
+        torch.cuda._sleep(int(0.12 * 2.4e9))
+        # weight-gradient GEMMs stay on the launch stream for this one step: in the graph-replayed steps the kernels run (almost)
+        # exclusively (profiles/r01_c2_timeline.md), whereas a fully pre-queued eager step would overlap the two streams
+        # maximally and inflate every per-launch duration
+        from mirage_amd import engine as _E
+        side_was = _E._Side.enabled
+        _E._Side.enabled = False
+        try:
+            if train:
+                # forward + losses + backward only, with the reducer detached: rank 0 runs this step alone, so nothing in it
+                # may be collective (the other ranks are already waiting at the final barrier); the optimizer is skipped because
+                # the gradients of a detached step are this rank's only
+                keep = (ts.reducer, ts.split, ts._early, getattr(model, "_mrg_split_at", None))
+                ts.reducer, ts.split, ts._early = None, None, None
+                model._mrg_split_at = None
+                try:
+                    ts._fwd_bwd()
+                    _E.join_side_stream()
+                finally:
+                    ts.reducer, ts.split, ts._early, model._mrg_split_at = keep
+            else:
+                fwd()
+        finally:
+            K.TIMING["on"] = False
+            _E._Side.enabled = side_was
+        torch.cuda.synchronize()
+        vname = {0: "auto", 1: "gemm_glds_kernel", 2: "gemm_glds_kernel", 3: "gemm_pipe_kernel", 4: "gemm_pipe256_kernel",
+                 5: "gemm_pipe256_kernel", 6: "gemm_pipe256sq_kernel", 7: "gemm_ws256_kernel", 8: "gemm_glds64_kernel",
+                 10: "gemm_g256_kernel", 11: "gemm_p8_kernel", 12: "gemm_p8_group_kernel"}
+        mname = {(0, 0): "forward x*W^T", (0, 1): "dgrad dy*W", (1, 1): "wgrad dy^T*x"}
+        groups = {}
+        shapes = {}
+        for variant, mode, fl, s, e, shp in K.TIMING["records"]:
+            sg = shapes.setdefault((mode, shp, variant), [0.0, 0])
+            sg[0] += s.elapsed_time(e) * 1e-3; sg[1] += 1
+            g = groups.setdefault(vname.get(variant, "auto"), [0.0, 0.0, 0, {}])
+            dt = s.elapsed_time(e) * 1e-3
+            g[0] += fl; g[1] += dt; g[2] += 1
+            g[3][mname[mode]] = g[3].get(mname[mode], 0) + 1
+        if os.environ.get("MRG_GEMM_TABLE") == "1":                   # per-shape GEMM time of one (multi-stream, eager) step
+            for (mode, shp, variant), (tt, n) in sorted(shapes.items(), key=lambda kv: -kv[1][0]):
+                print(f"gemm {mname[mode]:14s} {shp[0]:6d}x{shp[1]:5d}x{shp[2]:6d} sk={shp[3]:2d} v={variant} n={n:3d} total {tt * 1e3:7.3f} ms "
+                      f"avg {tt / n * 1e6:7.1f} us {2.0 * shp[0] * shp[1] * shp[2] * n / tt / 1e12:6.0f} TF/s", file=sys.stderr)
+        dom = max(groups, key=lambda m: groups[m][1])
+        fl, tsec, n, modes = groups[dom]
+        all_fl = sum(g[0] for g in groups.values()); all_t = sum(g[1] for g in groups.values())
+        # HBM bytes per launch of the dominant kernel come from a separate rocprofv3 --pmc pass (counters cannot be read from
+        # inside the process): the committed summary of that pass is quoted and its file named in `traffic_source`
+        traffic, traffic_src = None, None
+        for tname in ("r02_c2_pmc_traffic.json", "r01_c2_pmc_traffic.json"):
+            tfile = os.path.join(ROOT, "profiles", tname)
+            if cfg_name == "c2" and os.path.exists(tfile):
+                tj = json.load(open(tfile))
+                cand = [v for k, v in tj.items() if k.startswith(dom.split("<")[0])]
+                if cand:
+                    traffic = int(sum(v["hbm_bytes_per_launch"] * v["launches"] for v in cand) / max(1, sum(v["launches"] for v in cand)))
+                    traffic_src = "profiles/" + tname
+                    break
+        roofline = {"bound": "mfma", "kernel": dom, "achieved": round(fl / tsec / 1e12, 2), "peak": MFMA_BF16_PEAK / 1e12,
+                    "unit": "TFLOP/s", "frac": round(fl / tsec / MFMA_BF16_PEAK, 4), "traffic": traffic, "traffic_source": traffic_src,
+                    "launches_per_step": n, "avg_launch_us": round(1e6 * tsec / n, 2), "launch_mix": modes,
+                    "all_gemm_achieved": round(all_fl / all_t / 1e12, 2),
+                    # every GEMM kernel family of the instrumented step, largest total time first (the dominant one above is the first):
+                    # launches, total ms, achieved TFLOP/s and fraction of the bf16 MFMA peak
+                    "families": [{"kernel": m, "launches": gg[2], "ms": round(gg[1] * 1e3, 3), "achieved": round(gg[0] / gg[1] / 1e12, 1),
+                                  "frac": round(gg[0] / gg[1] / MFMA_BF16_PEAK, 4)}
+                                 for m, gg in sorted(groups.items(), key=lambda kv: -kv[1][1])],
+                    "whole_step_achieved": round(value / world * fpi / 1e12, 2),
+                    "whole_step_frac": round(value / world * fpi / MFMA_BF16_PEAK, 4)}
+        result = {
+            "metric": "pretrain images/sec (node) MIRAGE-Base 512/32 bscan+slo; MFMA % of peak" if cfg_name == "c2" else f"images/sec (node) {cfg_name}",
+            "value": round(value, 2), "unit": "images/sec", "n_gpus": world, "ranks_seen": ranks_seen, "steps": steps, "warmup": warmup,
+            "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": f"{cfg_name}: {model_name} 512/32 {'+'.join(doms)}, per-GPU batch {B}, {Kk} of {256 * len(doms)} tokens encoded, "
+                                   f"{'fwd+loss+bwd+AdamW' if train else 'encoder forward only'}",
+                       "global_batch": B * world, "parallelism": f"dp{world}", "hipgraph": not a.no_graph,
+                       "gflop_per_image": round(fpi / 1e9, 2)},
+            "mfma_frac_of_peak": round(value / world * fpi / MFMA_BF16_PEAK, 4),
+            "roofline": roofline,
+        }
+        if train:
+            result["final_loss"] = round(float(ts.loss), 5)
+        if os.environ.get("MRG_TUNE_LOG") == "1":
+            names = {1: "glds3", 2: "glds4", 3: "pipe128", 4: "pipe256", 5: "pipe256x3", 6: "pipe256sq", 7: "ws256", 8: "glds64", 10: "g256", 11: "p8"}
+            for key, (v, sk), us in K.TUNE["log"]:
+                am, bm, M_, N_, K_ = key[:5]
+                print(f"tune mode=({am},{bm}) {M_}x{N_}x{K_} act={key[5]} -> {names.get(v, v)} splitk={sk} {us:.1f} us {2.0 * M_ * N_ * K_ / us / 1e6:.0f} TF/s",
+                      file=sys.stderr)
+        result["gemm_table"] = {"file": os.path.basename(K._TUNE_FILE), "entries": K.TUNE["table_entries"], "shapes_from_table": len(K.TUNE["table_used"]),
+                                "shapes_tuned_at_warmup": len(K.TUNE["log"])}
+    return result
+
+
 def main():
     # stdout carries exactly one JSON line: native libraries write there too (RCCL prints a version banner through C stdio
     # when its first communicator comes up), so fd 1 points at stderr until the result is ready
@@ -182,6 +370,7 @@ def _run(real_stdout: int):
     ap.add_argument("--batch", type=int, default=None, help="per-GPU batch override (debug)")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-other-configs", action="store_true", help="skip the C4 / C5 measurements attached to the default C2 line")
     a = ap.parse_args()
 
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -245,190 +434,43 @@ def _run(real_stdout: int):
             raise SystemExit(f"bench.py: {dist.get_world_size()} ranks joined, --gpus {a.gpus} asked for")
     ranks_seen = dist.get_world_size() if dist.is_initialized() else 1
 
-    from mirage_amd import builder, kernels as K, optim
-    from mirage_amd import _lib as L
-    from mirage_amd.dp import GradReducer, broadcast_params
-    from mirage_amd.trainer import TrainStep
-
-    model_name, doms, B, Kk, train = CONFIGS[a.config]
-    if a.batch:
-        B = a.batch
-    out_doms = doms if train else ()
-    if os.environ.get("MRG_BENCH_OUT"):                     # experiment knob: fewer output adapters (marginal cost of a decoder)
-        out_doms = tuple(os.environ["MRG_BENCH_OUT"].split("-"))
-    args = builder.make_args(doms, out_doms)
-    torch.manual_seed(0)
-    model = builder.get_model(args, model_name, with_decoders=train).to(dev)
-    model.train(train)
-    # weights come from the common seed above (and are broadcast from rank 0); mask / stochastic-depth draws use a per-rank stream
-    # ("own mask RNG stream (seed+rank)")
-    torch.manual_seed(4321 + rank)
-    torch.cuda.manual_seed(4321 + rank)
-    pool = synth_batches(doms, B, 4, 1234 + rank, dev)
-
-    if train:
-        total_steps = a.steps + a.warmup + 64
-        lr = 1e-4 * (B * world) / 256                      # run_pretraining.py:497 with the global batch
-        lrs = optim.cosine_scheduler(lr, 0.0, 1, total_steps, warmup_epochs=1, warmup_steps=max(1, total_steps // 10))
-        wds = optim.cosine_scheduler(0.05, 0.05, 1, total_steps)
-        opt = optim.FusedAdamW(model, lrs, wds, betas=(0.9, 0.95), eps=1e-8)
-        broadcast_params(opt.arena.flat_p)
-        opt.arena.refresh_shadow(force=True)
-        reducer = GradReducer(opt.arena.flat_g, force=force_dp) if (world > 1 or force_dp) else None
-        loss_fns = builder.get_losses(args)
-        ts = TrainStep(model, loss_fns, opt, pool[0], Kk, use_graph=not a.no_graph, reducer=reducer,
-                       overlap=os.environ.get("MRG_DP_OVERLAP", "1") != "0")
-        ts.load(pool[0])
-        ts.warmup_and_capture()
-
-        def run_step(i):
-            ts.step(pool[i % len(pool)])
-    else:
-        static = {d: torch.empty_like(pool[0][d]) for d in doms}
-        graph = None
-
-        def fwd():
-            with torch.no_grad():
-                return model(static, mask_inputs=False)[0]
-
-        for d in doms:
-            static[d].copy_(pool[0][d])
-        fwd()
-        torch.cuda.synchronize()
-        if not a.no_graph:
-            graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):
-                out_static = fwd()
-
-        def run_step(i):
-            for d in doms:
-                static[d].copy_(pool[i % len(pool)][d], non_blocking=True)
-            if graph is not None:
-                graph.replay()
-            else:
-                fwd()
-
-    multi = world > 1 or force_dp
-    for i in range(a.warmup):
-        run_step(i)
-    if multi:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for i in range(a.steps):
-        run_step(a.warmup + i)
-    torch.cuda.synchronize()
-    if multi:
-        dist.barrier()
-    elapsed = time.perf_counter() - t0
-    if multi:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-    ms_per_step = 1e3 * elapsed / a.steps
-    value = B * world * a.steps / elapsed
-    fpi = flops_per_image(model_name, doms, Kk, train)
-
-    result = None
+    from mirage_amd import kernels as K
+    result = measure(a, a.config, a.steps, a.warmup, a.batch, rank, world, dev, force_dp, ranks_seen)
     if rank == 0:
-        # ---- roofline of the dominant kernel: instrumented eager step, events on the launch stream -------------
-        K.TIMING["records"].clear()
-        K.TIMING["on"] = True
-        # park the GPU behind a long spin kernel so that the whole eager step is already queued when it starts executing:
-        # the per-launch events then measure kernel durations, not the python launch gaps
-        torch.cuda._sleep(int(0.12 * 2.4e9))
-        # weight-gradient GEMMs stay on the launch stream for this one step: in the graph-replayed steps the kernels run (almost)
-        # exclusively (profiles/r01_c2_timeline.md), whereas a fully pre-queued eager step would overlap the two streams
-        # maximally and inflate every per-launch duration
-        from mirage_amd import engine as _E
-        side_was = _E._Side.enabled
-        _E._Side.enabled = False
-        try:
-            if train:
-                # forward + losses + backward only, with the reducer detached: rank 0 runs this step alone, so nothing in it
-                # may be collective (the other ranks are already waiting at the final barrier); the optimizer is skipped because
-                # the gradients of a detached step are this rank's only
-                keep = (ts.reducer, ts.split, ts._early, getattr(model, "_mrg_split_at", None))
-                ts.reducer, ts.split, ts._early = None, None, None
-                model._mrg_split_at = None
+        model_name, doms, _, Kk, train = CONFIGS[a.config]
+        # The 40 % target of BASELINE.json is stated on the Large model: the same single line also carries the Large configurations
+        # (C4: the pre_mirage_98_1600e shape at per-GPU batch 64; C5: encoder-only forward at batch 256), each built from scratch in
+        # this process after the headline's buffers are gone and timed exactly like the headline (warm-up, graph capture, K steps
+        # between synchronisations).  The headline value / config above stay C2.
+        if world == 1 and a.config == "c2" and not a.batch and not a.no_other_configs and not force_dp:
+            import gc
+            others = {}
+            for name, (st, wu) in (("c4", (20, 3)), ("c5", (10, 2))):
+                gc.collect()
+                torch.cuda.empty_cache()
+                K.TUNE["log"].clear()
                 try:
-                    ts._fwd_bwd()
-                    _E.join_side_stream()
-                finally:
-                    ts.reducer, ts.split, ts._early, model._mrg_split_at = keep
-            else:
-                fwd()
-        finally:
-            K.TIMING["on"] = False
-            _E._Side.enabled = side_was
-        torch.cuda.synchronize()
-        vname = {0: "auto", 1: "gemm_glds_kernel", 2: "gemm_glds_kernel", 3: "gemm_pipe_kernel", 4: "gemm_pipe256_kernel",
-                 5: "gemm_pipe256_kernel", 6: "gemm_pipe256sq_kernel", 7: "gemm_ws256_kernel", 8: "gemm_glds64_kernel",
-                 10: "gemm_g256_kernel", 11: "gemm_p8_kernel", 12: "gemm_p8_group_kernel"}
-        mname = {(0, 0): "forward x*W^T", (0, 1): "dgrad dy*W", (1, 1): "wgrad dy^T*x"}
-        groups = {}
-        shapes = {}
-        for variant, mode, fl, s, e, shp in K.TIMING["records"]:
-            sg = shapes.setdefault((mode, shp, variant), [0.0, 0])
-            sg[0] += s.elapsed_time(e) * 1e-3; sg[1] += 1
-            g = groups.setdefault(vname.get(variant, "auto"), [0.0, 0.0, 0, {}])
-            dt = s.elapsed_time(e) * 1e-3
-            g[0] += fl; g[1] += dt; g[2] += 1
-            g[3][mname[mode]] = g[3].get(mname[mode], 0) + 1
-        if os.environ.get("MRG_GEMM_TABLE") == "1":                   # per-shape GEMM time of one (multi-stream, eager) step
-            for (mode, shp, variant), (tt, n) in sorted(shapes.items(), key=lambda kv: -kv[1][0]):
-                print(f"gemm {mname[mode]:14s} {shp[0]:6d}x{shp[1]:5d}x{shp[2]:6d} sk={shp[3]:2d} v={variant} n={n:3d} total {tt * 1e3:7.3f} ms "
-                      f"avg {tt / n * 1e6:7.1f} us {2.0 * shp[0] * shp[1] * shp[2] * n / tt / 1e12:6.0f} TF/s", file=sys.stderr)
-        dom = max(groups, key=lambda m: groups[m][1])
-        fl, tsec, n, modes = groups[dom]
-        all_fl = sum(g[0] for g in groups.values()); all_t = sum(g[1] for g in groups.values())
-        # HBM bytes per launch of the dominant kernel come from a separate rocprofv3 --pmc pass (counters cannot be read from
-        # inside the process): the committed summary of that pass is quoted and its file named in `traffic_source`
-        traffic, traffic_src = None, None
-        for tname in ("r02_c2_pmc_traffic.json", "r01_c2_pmc_traffic.json"):
-            tfile = os.path.join(ROOT, "profiles", tname)
-            if a.config == "c2" and os.path.exists(tfile):
-                tj = json.load(open(tfile))
-                cand = [v for k, v in tj.items() if k.startswith(dom.split("<")[0])]
-                if cand:
-                    traffic = int(sum(v["hbm_bytes_per_launch"] * v["launches"] for v in cand) / max(1, sum(v["launches"] for v in cand)))
-                    traffic_src = "profiles/" + tname
-                    break
-        roofline = {"bound": "mfma", "kernel": dom, "achieved": round(fl / tsec / 1e12, 2), "peak": MFMA_BF16_PEAK / 1e12,
-                    "unit": "TFLOP/s", "frac": round(fl / tsec / MFMA_BF16_PEAK, 4), "traffic": traffic, "traffic_source": traffic_src,
-                    "launches_per_step": n, "avg_launch_us": round(1e6 * tsec / n, 2), "launch_mix": modes,
-                    "all_gemm_achieved": round(all_fl / all_t / 1e12, 2),
-                    # every GEMM kernel family of the instrumented step, largest total time first (the dominant one above is the first):
-                    # launches, total ms, achieved TFLOP/s and fraction of the bf16 MFMA peak
-                    "families": [{"kernel": m, "launches": gg[2], "ms": round(gg[1] * 1e3, 3), "achieved": round(gg[0] / gg[1] / 1e12, 1),
-                                  "frac": round(gg[0] / gg[1] / MFMA_BF16_PEAK, 4)}
-                                 for m, gg in sorted(groups.items(), key=lambda kv: -kv[1][1])],
-                    "whole_step_achieved": round(value / world * fpi / 1e12, 2),
-                    "whole_step_frac": round(value / world * fpi / MFMA_BF16_PEAK, 4)}
-        result = {
-            "metric": "pretrain images/sec (node) MIRAGE-Base 512/32 bscan+slo; MFMA % of peak" if a.config == "c2" else f"images/sec (node) {a.config}",
-            "value": round(value, 2), "unit": "images/sec", "n_gpus": world, "ranks_seen": ranks_seen, "steps": a.steps, "warmup": a.warmup,
-            "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "bf16", "data": "synthetic",
-            "config": {"workload": f"{a.config}: {model_name} 512/32 {'+'.join(doms)}, per-GPU batch {B}, {Kk} of {256 * len(doms)} tokens encoded, "
-                                   f"{'fwd+loss+bwd+AdamW' if train else 'encoder forward only'}",
-                       "global_batch": B * world, "parallelism": f"dp{world}", "hipgraph": not a.no_graph,
-                       "gflop_per_image": round(fpi / 1e9, 2)},
-            "mfma_frac_of_peak": round(value / world * fpi / MFMA_BF16_PEAK, 4),
-            "roofline": roofline,
-        }
+                    r = measure(a, name, st, wu, None, rank, world, dev, False, ranks_seen)
+                except Exception as exc:          # the headline must survive a failure here; the failure is reported, not hidden
+                    others[name] = {"error": f"{type(exc).__name__}: {exc}"[:300]}
+                    continue
+                rf = r["roofline"]
+                others[name] = {"workload": r["config"]["workload"], "value": r["value"], "unit": r["unit"], "steps": st, "warmup": wu,
+                                "ms_per_step": r["ms_per_step"], "gflop_per_image": r["config"]["gflop_per_image"],
+                                "whole_step_frac": rf["whole_step_frac"],
+                                "roofline": {"kernel": rf["kernel"], "achieved": rf["achieved"], "frac": rf["frac"], "unit": rf["unit"],
+                                             "launches_per_step": rf["launches_per_step"], "avg_launch_us": rf["avg_launch_us"],
+                                             "families": rf["families"]},
+                                "gemm_table": r.get("gemm_table")}
+                if "final_loss" in r:
+                    others[name]["final_loss"] = r["final_loss"]
+            result["other_configs"] = others
+            gc.collect()
+            torch.cuda.empty_cache()
         if world == 1 and not a.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(model_name, doms, Kk, train)
-        if train:
-            result["final_loss"] = round(float(ts.loss), 5)
         if os.environ.get("MRG_TUNE_SAVE") == "1":
             K.save_tune_cache()
-        if os.environ.get("MRG_TUNE_LOG") == "1":
-            names = {1: "glds3", 2: "glds4", 3: "pipe128", 4: "pipe256", 5: "pipe256x3", 6: "pipe256sq", 7: "ws256", 8: "glds64", 10: "g256", 11: "p8"}
-            for key, (v, sk), us in K.TUNE["log"]:
-                am, bm, M_, N_, K_ = key[:5]
-                print(f"tune mode=({am},{bm}) {M_}x{N_}x{K_} act={key[5]} -> {names.get(v, v)} splitk={sk} {us:.1f} us {2.0 * M_ * N_ * K_ / us / 1e6:.0f} TF/s",
-                      file=sys.stderr)
         _emit(real_stdout, json.dumps(result))
     if world > 1 or force_dp:
         dist.barrier()

@@ -264,7 +264,8 @@ typedef struct mrg_adamw_desc {
     const float* grad_norm; float clip_norm, skip_norm;
     float* sumsq_out;   /* optional fp32 [mrg_adamw_nblocks(n)]: per-block partial sums of g^2 over this launch's range -- the global
                            gradient norm for logging (native_scaler.py:46-61) then costs no extra pass over the gradients:
-                           mrg_sumsq_finish(all partials) = sqrt(sum).  Not with skip_norm (the norm is needed before the update). */
+                           mrg_sumsq_finish(all partials) = sqrt(sum).  Rejected together with grad_norm and clip_norm > 0 or skip_norm > 0
+                           (clipping / skipping need the norm BEFORE the update: use mrg_grad_norm first). */
 } mrg_adamw_desc;
 int mrg_adamw_nblocks(long n);
 int mrg_sumsq_finish(const float* partials, int n, float* out, hipStream_t stream);

@@ -186,7 +186,8 @@ extern "C" int mrg_adamw(const mrg_adamw_desc* d, hipStream_t stream) {
     a.lr_scale = d->lr_scale; a.beta1 = d->beta1; a.beta2 = d->beta2; a.eps = d->eps;
     a.grad_norm = d->grad_norm; a.clip_norm = d->clip_norm; a.skip_norm = d->skip_norm;
     a.sumsq_out = d->sumsq_out;
-    MRG_REQUIRE(!(d->sumsq_out && d->skip_norm > 0.f && d->grad_norm), MRG_ERR_UNSUPPORTED, "mrg_adamw: sumsq_out with skip_norm (the norm must exist before the update)");
+    MRG_REQUIRE(!(d->sumsq_out && d->grad_norm && (d->skip_norm > 0.f || d->clip_norm > 0.f)), MRG_ERR_UNSUPPORTED,
+                "mrg_adamw: sumsq_out with clip_norm / skip_norm (the norm must exist before the update)");
     long nb = mrg_adamw_nblocks(d->n);
     hipLaunchKernelGGL(adamw_kernel, dim3((unsigned)nb), dim3(256), 0, stream, a);
     return mrg_check_launch("mrg_adamw");

@@ -177,9 +177,15 @@ class PrefetchingNpyLoader:
 
         def one(t, b, i):
             a = np.load(self.files[t][i])
-            if a.shape[-2:] != self.shapes[t]:
-                raise ValueError(f"{self.files[t][i]}: shape {a.shape} differs from the first sample's {self.shapes[t]}")
-            bufs[t][b] = a.astype(np.uint8, copy=False)
+            if a.shape[-2:] != self.shapes[t] or a.size != self.shapes[t][0] * self.shapes[t][1]:
+                raise ValueError(f"{self.files[t][i]}: shape {a.shape} differs from the first sample's {self.shapes[t]} (one [H, W] plane per file)")
+            # the staging slots are uint8 (docs/pretraining.md: 8-bit images, layer ids 0..12): anything else would wrap silently
+            if a.dtype != np.uint8:
+                if not np.issubdtype(a.dtype, np.integer):
+                    raise ValueError(f"{self.files[t][i]}: dtype {a.dtype}; the asynchronous feed stages 8-bit integers (uint8 images / label maps)")
+                if a.size and (int(a.min()) < 0 or int(a.max()) > 255):
+                    raise ValueError(f"{self.files[t][i]}: values outside 0..255 cannot be staged as uint8")
+            bufs[t][b] = a.reshape(self.shapes[t]).astype(np.uint8, copy=False)
 
         futs = [self.pool.submit(one, t, b, int(i)) for t in self.tasks for b, i in enumerate(ids)]
         for f in futs:

@@ -314,12 +314,26 @@ TWO_CHAINS_MIN_ROWS = int(os.environ.get("MRG_TWO_CHAINS_MIN_ROWS", "16"))
 _CHAIN_STREAM = {}
 
 
+_CHAIN_SETTLED = set()          # (shape, save) of eager two-chain passes that ran without a single first-use autotuning
+
+
 def _encoder_fwd_two_chains(x: torch.Tensor, blocks, save: bool, want_bf16: bool):
+    """Cross-stream lifetimes: chain B (stream s2) reads and writes the second halves of tensors that chain A allocated on the main
+    stream.  Two rules keep the caching allocator from handing such a block to the main stream while s2 still works on it (under graph
+    capture nothing else would order them): (i) the full-batch tensors of block i stay referenced here until (ii) the main stream has
+    waited on s2's end-of-block-i event, which happens before chain A of block i + 2 starts -- a lag of one block, so the two chains
+    still overlap freely within a block pair.  Tensors that chain B allocates itself belong to s2's pool and are recorded on the main
+    stream by the final wait_stream."""
     main = torch.cuda.current_stream()
     s2 = _CHAIN_STREAM.get(x.device)
     if s2 is None:
         s2 = _CHAIN_STREAM[x.device] = torch.cuda.Stream(device=x.device)
     capturing = torch.cuda.is_current_stream_capturing()
+    # eager passes: first-use autotuning must not time its candidates against the other chain, so the chains alternate with host
+    # synchronisations until one whole pass of this shape has run without tuning anything; after that they overlap as in a graph
+    skey = (tuple(x.shape), bool(save), len(blocks))
+    sync_blocks = (not capturing) and K.TUNE["enabled"] and skey not in _CHAIN_SETTLED
+    tuned_before = len(K.TUNE["log"])
     h = x.shape[0] // 2
     xa, xb = x[:h], x[h:]
     n = len(blocks)
@@ -329,23 +343,32 @@ def _encoder_fwd_two_chains(x: torch.Tensor, blocks, save: bool, want_bf16: bool
     saved_all = []
     x_in_full = x
     xa16 = None
+    keep = []                                   # (end-of-block event on s2, that block's full-batch tensors), oldest first
     for i, blk in enumerate(blocks):
         last = want_bf16 and i == n - 1
+        if len(keep) >= 2:                      # block i - 2 is finished on BOTH streams from here on: its tensors may be recycled
+            ev_old, _fulls_old = keep.pop(0)
+            main.wait_event(ev_old)
+            del _fulls_old
         K.Halves.begin(1)
         try:
             xa, xa16, sa = block_fwd(blk, xa, save, want_bf16_out=last)
         finally:
             K.Halves.end()
-        if not capturing:
-            main.synchronize()                     # eager (warm-up) runs: first-use autotuning must not time against the other chain
+        fulls_i = list(K.Halves.fulls)
+        if sync_blocks:
+            main.synchronize()
         K.Halves.begin(2)
         try:
             with torch.cuda.stream(s2):
                 xb, _, _ = block_fwd(blk, xb, save, want_bf16_out=last)
+                ev_i = torch.cuda.Event()
+                ev_i.record(s2)
         finally:
             K.Halves.end()
-        if not capturing:
+        if sync_blocks:
             s2.synchronize()
+        keep.append((ev_i, fulls_i + [x_in_full]))
         if save:
             sv = tuple(K.Halves.full_of(t) for t in sa)
             saved_all.append((x_in_full,) + sv[1:])
@@ -353,6 +376,10 @@ def _encoder_fwd_two_chains(x: torch.Tensor, blocks, save: bool, want_bf16: bool
             saved_all.append(None)
         x_in_full = K.Halves.full_of(xa)
     main.wait_stream(s2)
+    keep.clear()
+    K.Halves.fulls = []
+    if not capturing and len(K.TUNE["log"]) == tuned_before:
+        _CHAIN_SETTLED.add(skey)
     return x_in_full, (K.Halves.full_of(xa16) if xa16 is not None else None), saved_all
 
 

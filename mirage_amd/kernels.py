@@ -91,7 +91,11 @@ def _workspace(nbytes: int, device) -> torch.Tensor:
 
 _tune_cache = {}
 _TUNE_REPS = 6
-TUNE = {"enabled": True, "log": [], "hits": None}     # hits: optional set collecting the table keys a run actually uses
+# hits: optional set collecting the table keys a run actually uses; table_entries / table_used: size of the committed table and the
+# distinct shapes of this process that were served from it (everything else was tuned at warm-up and is in "log") -- reported by
+# bench.py / run_pretraining so that a run says which variant table it ran on
+TUNE = {"enabled": True, "log": [], "hits": None, "table_entries": 0, "table_used": set()}
+_table_keys = set()
 _TUNE_FILE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "gemm_tune_gfx950.json")
 
 
@@ -103,6 +107,8 @@ def load_tune_cache(path: str = _TUNE_FILE) -> int:
     with open(path) as f:
         for k, v in json.load(f).items():
             _tune_cache[tuple(json.loads(k))] = tuple(v)
+            _table_keys.add(tuple(json.loads(k)))
+    TUNE["table_entries"] = len(_table_keys)
     return len(_tune_cache)
 
 
@@ -302,6 +308,8 @@ def gemm(A: torch.Tensor, B: torch.Tensor, M: int, N: int, K: int, *, a_mode=L.M
             hit = _autotune(d, key, splitk, tune_split, A.device)
         if hit is not None:
             variant, splitk = hit
+            if key in _table_keys:
+                TUNE["table_used"].add(key)
     if TUNE.get("force") is not None:                              # tests / tools: pin one kernel variant
         variant = TUNE["force"]
     if TIMING["on"]:
@@ -339,9 +347,16 @@ class WgradGroup:
     max_k = int(os.environ.get("MRG_WGRAD_GROUP_MAX_K", "16384"))
     collecting = False
     tasks = []
+    origin = None      # stream the queued tasks' operands (dy, x) were produced on: the grouped launch must go out on THAT stream
 
     @classmethod
     def begin(cls):
+        """start (or continue) collecting on the current stream; tasks collected from another stream are launched there first (the
+        decoders' backward passes run on lane streams: a group may not mix producers that nothing orders against each other)"""
+        cur = torch.cuda.current_stream()
+        if cls.tasks and cls.origin is not None and cls.origin != cur:
+            cls.flush()
+        cls.origin = cur
         cls.collecting = cls.enabled
 
     @staticmethod
@@ -359,11 +374,20 @@ class WgradGroup:
 
     @classmethod
     def flush(cls):
-        """launch what was collected (on the current stream) and stop collecting"""
+        """launch what was collected (on the stream it was collected from) and stop collecting"""
         cls.collecting = False
         tasks, cls.tasks = cls.tasks, []
         if not tasks:
             return
+        origin, cls.origin = cls.origin, None
+        if origin is not None and origin != torch.cuda.current_stream():
+            with torch.cuda.stream(origin):
+                cls._launch(tasks)
+            return
+        cls._launch(tasks)
+
+    @classmethod
+    def _launch(cls, tasks):
         by_k = {}
         for t in tasks:
             by_k.setdefault(t[4], []).append(t)

@@ -88,8 +88,13 @@ class FusedAdamW:
         # without clip / skip the gradient norm is only logged: the AdamW launches emit partial sums of g^2 over their ranges
         # (the gradient is read there anyway) and one tiny kernel finishes them -- no separate pass over the gradient arena
         self.fuse_norm = not self.clip_grad and not self.skip_grad and os.environ.get("MRG_FUSE_NORM", "1") != "0"
-        self._ss = torch.zeros(1 << 19, dtype=torch.float32, device=dev) if self.fuse_norm else None     # <= 4096 partials per launch, <= 128 launches
-        self._ss_pos = 0
+        # Partial-sum slots are FIXED per element range (decided the first time a range is updated, never moved): a range always
+        # writes the same slice of `_ss`, and the finish kernel sums every slot handed out so far.  Nothing here depends on a host
+        # cursor, so eager calls, captured graphs and any mix of the two (data parallel: stage updates issued eagerly between
+        # graph replays, the rest inside the optimizer graph) stay consistent across replays.
+        self._ss = torch.zeros(1 << 19, dtype=torch.float32, device=dev) if self.fuse_norm else None     # <= 4096 partials per launch, <= 128 ranges
+        self._ss_slots: Dict[tuple, tuple] = {}     # (s, e) -> (offset, nblocks)
+        self._ss_used = 0
         self.param_groups = [
             {"params": [arena.params[n] for n in arena.names_decay], "names": arena.names_decay, "weight_decay": float(self._wd_host[0]),
              "lr": float(self._lr_host[0]), "lr_scale": 1.0},
@@ -113,15 +118,26 @@ class FusedAdamW:
         a = self.arena
         for s, e in ranges:
             nd = max(0, min(e, a.n_decay) - s)
-            ss = None
-            if self.fuse_norm:
-                nb = K.adamw_nblocks(e - s)
-                if self._ss_pos + nb > self._ss.numel():
-                    raise RuntimeError("FusedAdamW: partial-sum buffer exhausted (too many update ranges in one step)")
-                ss = self._ss[self._ss_pos:self._ss_pos + nb]
-                self._ss_pos += nb
+            ss = self._ss_slot(s, e) if self.fuse_norm else None
             K.adamw(a.flat_p[s:e], a.flat_g[s:e], self.exp_avg[s:e], self.exp_avg_sq[s:e], a.flat_bf16[s:e], nd, self.lr_table,
                     self.wd_table, self.step_dev, self.betas[0], self.betas[1], self.eps, sumsq_out=ss)
+
+    def _ss_slot(self, s, e):
+        """The fixed slice of the partial-sum buffer that the update of [s, e) writes.  The registered ranges must form ONE partition
+        of the arena (the finish kernel sums all of them): a new range that overlaps registered ones retires those -- their slices are
+        zeroed and never handed out again (captured graphs keep the addresses they were built with)."""
+        slot = self._ss_slots.get((s, e))
+        if slot is None:
+            for (s1, e1), (o1, n1) in list(self._ss_slots.items()):
+                if s1 < e and s < e1:
+                    self._ss[o1:o1 + n1].zero_()
+                    del self._ss_slots[(s1, e1)]
+            nb = K.adamw_nblocks(e - s)
+            if self._ss_used + nb > self._ss.numel():
+                raise RuntimeError("FusedAdamW: partial-sum buffer exhausted (too many distinct update ranges)")
+            slot = self._ss_slots[(s, e)] = (self._ss_used, nb)
+            self._ss_used += nb
+        return self._ss[slot[0]:slot[0] + slot[1]]
 
     def step(self, done_ranges=None):
         """global grad norm (native_scaler.py:46-61) -> AdamW (+clip / skip) -> counters.  `done_ranges`: sorted, disjoint
@@ -143,8 +159,10 @@ class FusedAdamW:
                 rest.append((pos, a.n_trainable))
             self.step_ranges(rest)
             if self.fuse_norm:
-                K.sumsq_finish(self._ss, self._ss_pos, self.grad_norm)
-                self._ss_pos = 0
+                covered = sorted(self._ss_slots)
+                if covered[0][0] != 0 or covered[-1][1] < a.n_trainable or any(x[1] != y[0] for x, y in zip(covered, covered[1:])):
+                    raise RuntimeError("FusedAdamW: the update ranges of this step do not partition the arena (gradient norm would be wrong)")
+                K.sumsq_finish(self._ss, self._ss_used, self.grad_norm)
         else:
             K.adamw(a.flat_p[:a.n_trainable], g, self.exp_avg, self.exp_avg_sq, a.flat_bf16[:a.n_trainable], a.n_decay, self.lr_table,
                     self.wd_table, self.step_dev, self.betas[0], self.betas[1], self.eps, grad_norm_t=self.grad_norm,

@@ -174,10 +174,16 @@ def main(args):
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise RuntimeError("mirage_amd.run_pretraining needs an MI355X (HIP kernels); there is no CPU path")
+    if os.environ.get("MRG_SHARE_GPU") == "1":        # test hook: several ranks on one GPU (with MRG_DIST_BACKEND=gloo), as in bench.py
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     if world > 1:
-        dist.init_process_group("nccl", device_id=device)
+        backend = os.environ.get("MRG_DIST_BACKEND", "nccl")       # "nccl" is RCCL on ROCm
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=device)
+        else:
+            dist.init_process_group(backend)
     torch.manual_seed(args.seed)                      # weight init: common to all ranks (and broadcast from rank 0 below)
     np.random.seed(args.seed)
     args.in_domains = args.in_domains.split("-")

@@ -33,6 +33,7 @@ class TrainStep:
         self.loss_on_unmasked = loss_on_unmasked      # run_pretraining.py:718-721: loss over every token instead of the masked ones
         self.loss = None
         self.task_losses = {}
+        self.preds, self.masks = {}, {}
         self.reducer = reducer
         self.use_graph = use_graph
         self.g_fb = self.g_opt = self.g_b = None
@@ -141,6 +142,7 @@ class TrainStep:
                                   sample_tasks_uniformly=self.uniform, mask_noise=self.static_noise)
         self.task_losses = {t: self.loss_fns[t](preds[t], x[t], mask=None if self.loss_on_unmasked else masks.get(t)) for t in preds}
         self.loss = sum(self.task_losses.values())
+        self.preds, self.masks = preds, masks         # static tensors of the captured step (parity tests read them after a replay)
         self.opt.zero_grad()
         if self._early is not None:
             from . import engine as E
@@ -214,6 +216,10 @@ class TrainStep:
         if not self.use_graph:
             return
         snap = self.opt.snapshot() if hasattr(self.opt, "snapshot") else None
+        # ... including the random streams: the warm-up iterations draw mask noise (and stochastic-depth factors), so without this
+        # the first real step would see different draws depending on warm_iters
+        dev = next(iter(self.static_x.values())).device
+        rng_cpu, rng_dev = torch.get_rng_state(), torch.cuda.get_rng_state(dev)
         s = torch.cuda.Stream()
         s.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(s):
@@ -224,6 +230,8 @@ class TrainStep:
         if snap is not None:
             self.opt.restore(snap)
             torch.cuda.synchronize()
+        torch.set_rng_state(rng_cpu)
+        torch.cuda.set_rng_state(rng_dev, dev)
         if self.reducer is None:
             self.g_fb = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self.g_fb, capture_error_mode="thread_local"):

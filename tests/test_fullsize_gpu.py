@@ -121,6 +121,106 @@ def test_c4_large_b16_graph_step_vs_oracle():
     _fullsize_case("c4_b16_trainstep", "large", ("bscan", "slo", "bscanlayermap"), 16, 98, check_eager=False)
 
 
+def test_c4_large_b64_production_step_vs_oracle_on_8_samples():
+    """C4 at the PRODUCTION per-GPU batch (Large, 3 modalities, B = 64, M = 64 x 99 = 6336 rows: the shapes gemm_tune_gfx950.json is
+    keyed on, grouped weight gradients, early AdamW) through the graph-replayed TrainStep; samples are independent in the forward
+    pass, so the CPU oracle runs on 8 of the 64 samples: their encoder tokens (rel-RMS <= 1e-2, cosine >= 0.9999) and their masked
+    task losses computed from the engine's own predictions (<= 1e-3).  Reference: mirage/model.py:305-431, criterion.py:31-117."""
+    from mirage_amd import builder
+    from oracle import mirage_oracle as O
+    import test_model_gpu as T
+    doms, B, Kk = ("bscan", "slo", "bscanlayermap"), 64, 98
+    cfg = O.make_config("large", doms)
+    x = O.synthetic_batch(cfg, B, seed=1234)
+    (p, u, g), tm, ids_keep, ids_restore = O.synthetic_masks(cfg, B, Kk, seed=99)
+    noise = (torch.from_numpy(p).to(DEV), torch.cat([torch.from_numpy(a) for a in u], 1).to(DEV), torch.from_numpy(g).to(DEV))
+    model, opt, ts = _run_engine(cfg, B, Kk, x, noise, use_graph=True)
+    assert opt.step_dev.tolist() == [1, 1] and np.isfinite(float(ts.loss)) and np.isfinite(float(opt.grad_norm))
+    idx = torch.arange(0, B, 8) + torch.arange(8) % 8                  # 0, 9, 18, ..., 63: both halves of the batch, every residue
+    idx_d = idx.to(DEV)
+    loss_fns = builder.get_losses(builder.make_args(doms, doms))
+    xg = {d: t.to(DEV) for d, t in x.items()}
+    sub_losses = {d: float(loss_fns[d](ts.preds[d][idx_d].contiguous(), xg[d][idx_d].contiguous(), mask=ts.masks[d][idx_d].contiguous()))
+                  for d in ts.preds}
+    # encoder tokens of the same weights BEFORE the step's update are not retrievable afterwards: the weights moved by one AdamW step
+    # of lr 1e-4, so the token comparison uses a second model instance with the initial weights (decoders off, training-mode forward)
+    model2, _, _ = T._build(cfg)
+    model2.train()
+    model2.output_adapters = None
+    with torch.no_grad():
+        enc, _ = model2({d: xg[d] for d in doms}, num_encoded_tokens=Kk, mask_noise=noise)
+    enc = enc.float()[idx_d].cpu()
+    torch.set_num_threads(min(os.cpu_count() or 1, 32))
+    sd = O.procedural_state_dict(cfg)
+    with torch.no_grad():
+        xs = {d: t[idx] for d, t in x.items()}
+        ref_total, ref_ls, ref_enc, _ = O.forward_loss(cfg, sd, xs, ids_keep[idx], ids_restore[idx])
+    meas = {"B": B, "oracle_samples": 8, "enc_rel_rms": T.rel_rms(enc, ref_enc), "enc_rel_rms_tol": 1e-2,
+            "enc_cos": float(torch.nn.functional.cosine_similarity(enc.flatten().double(), ref_enc.flatten().double(), dim=0))}
+    for d in sub_losses:
+        meas[f"loss_rel.{d}"] = abs(sub_losses[d] - float(ref_ls[d])) / max(1.0, abs(float(ref_ls[d])))
+    meas["loss_rel"] = abs(sum(sub_losses.values()) - float(ref_total)) / abs(float(ref_total))
+    T.report("c4_b64_production_8samples", **meas)
+    for d in doms:
+        assert torch.equal(ts.masks[d].cpu(), torch.from_numpy(tm[list(doms).index(d)]))         # mask indices bit-exact at full size
+    assert meas["enc_rel_rms"] <= 1e-2 and meas["enc_cos"] >= 0.9999, meas
+    assert meas["loss_rel"] <= 1e-3, meas
+    for d in sub_losses:
+        assert meas[f"loss_rel.{d}"] <= 1e-3, (d, meas)
+
+
+def test_c5_large_b256_two_chain_graph_forward_vs_oracle_on_8_samples():
+    """C5 at its real size: Large encoder-only forward over all 256 bscan tokens, B = 256 (M = 65792 rows: gemm_p8_kernel, two
+    half-batch chains of 32896 rows on two streams) captured in a hipGraph exactly as bench.py runs it; the CPU oracle on 8 of
+    the samples: encoder tokens rel-RMS <= 1e-2, cosine >= 0.9999.  Reference: mirage_wrapper.py:208-224, mirage/model.py:305-431."""
+    from mirage_amd import builder, engine
+    from oracle import mirage_oracle as O
+    import test_model_gpu as T
+    B = 256
+    cfg = O.make_config("large", ("bscan",), out_domains=())
+    model, args, sd = T._build(cfg, with_decoders=False)
+    model.eval()
+    x = O.synthetic_batch(cfg, B, seed=4321)["bscan"]
+    static = {"bscan": x.to(DEV)}
+    assert engine.TWO_CHAINS >= 1
+    # mask_inputs=False keeps every token but still in the mask generator's (random) order (mirage/model.py:340-346,384-391): the
+    # order is pinned by feeding the generator's noise, and the oracle gets the same ids
+    (p, u, g), _, ids_keep, ids_restore = O.synthetic_masks(cfg, B, 256, seed=77)
+    noise = (torch.from_numpy(p).to(DEV), torch.cat([torch.from_numpy(a) for a in u], 1).to(DEV), torch.from_numpy(g).to(DEV))
+
+    def fwd():
+        with torch.no_grad():
+            return model(static, mask_inputs=False, mask_noise=noise)[0]
+
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        eager = fwd().float().clone()
+        fwd()                                       # second eager pass: nothing left to tune, the chains overlap
+    torch.cuda.current_stream().wait_stream(s)
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        out_static = fwd()
+    for _ in range(3):
+        graph.replay()
+    torch.cuda.synchronize()
+    out = out_static.float()
+    assert out.shape == (B, 257, 1024)
+    assert torch.equal(out, eager), float((out - eager).abs().max())       # graph replay == eager, bit for bit, all 256 samples
+    idx = torch.arange(0, B, 32) + torch.arange(8) * 4 + 1                 # 1, 37, 73, ...: samples of both half-batch chains
+    assert int(idx.max()) < B and int((idx >= B // 2).sum()) == 4
+    torch.set_num_threads(min(os.cpu_count() or 1, 32))
+    with torch.no_grad():
+        ref, _ = O.forward(cfg, sd, {"bscan": x[idx]}, ids_keep[idx], ids_restore[idx], decode=False)
+    got = out[idx.to(DEV)].cpu()
+    meas = {"B": B, "oracle_samples": 8, "enc_rel_rms": T.rel_rms(got, ref), "enc_rel_rms_tol": 1e-2,
+            "enc_cos": float(torch.nn.functional.cosine_similarity(got.flatten().double(), ref.flatten().double(), dim=0)),
+            "worst_sample_rel_rms": max(T.rel_rms(got[i], ref[i]) for i in range(8))}
+    T.report("c5_b256_two_chain_graph_8samples", **meas)
+    assert meas["enc_rel_rms"] <= 1e-2 and meas["worst_sample_rel_rms"] <= 1.2e-2 and meas["enc_cos"] >= 0.9999, meas
+
+
 def _free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
@@ -165,8 +265,13 @@ def test_two_engine_ranks_on_one_gpu(tmp_path, comm, wire):
     # ~1e-3 relative on the gradients (a missing or doubled stage reduction would be O(1)); the first loss is computed from
     # identical weights and must agree to fp32 roundoff, the second one follows an Adam step taken on those gradients.
     gtol = 5e-3 if wire == "fp32" else 2e-2
+    gn_rel = abs(r0["grad_norm"] - s["grad_norm"]) / s["grad_norm"]
     T.report(f"dp2_one_gpu_{comm}_{wire}", grad_rel=g_rel, grad_tol=gtol, weight_max_abs=dw, loss_rel_step0=l_rel[0], loss_rel_step1=l_rel[1],
-             grad_norm_rel=abs(r0["grad_norm"] - s["grad_norm"]) / s["grad_norm"])
+             grad_norm_rel=gn_rel)
+    # the logged norm (mutils/native_scaler.py:46-61 over the AVERAGED gradients) is assembled from the partial sums of three stage
+    # updates issued eagerly between the graphs and of the rest inside the optimizer graph: all of them must be in it
+    assert gn_rel <= (1e-2 if wire == "fp32" else 2e-2), (r0["grad_norm"], s["grad_norm"])
+    assert r0["grad_norm"] == r1["grad_norm"]
     assert l_rel[0] <= 1e-5, (mean_losses, s["losses"])
     assert l_rel[1] <= 2e-3, (mean_losses, s["losses"])
     assert g_rel <= gtol, g_rel
@@ -174,3 +279,60 @@ def test_two_engine_ranks_on_one_gpu(tmp_path, comm, wire):
     assert dw <= 4 * 1e-3, dw
     moved = float((s["flat_p"] - r0["flat_p"]).abs().mean())
     assert moved <= 1e-4, moved
+
+
+def _rank_env(**extra):
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MRG_SHARE_GPU="1", MRG_DIST_BACKEND="gloo", **extra)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "MRG_DP_COMM", "MRG_DP_DTYPE", "MRG_FORCE_DP"):
+        if k not in extra:
+            env.pop(k, None)
+    return env
+
+
+def test_bench_self_launch_two_ranks():
+    """`python bench.py --gpus 2` without a launcher spawns its two ranks itself (bench.py::_self_launch) and relays rank 0's single
+    JSON line.  Both ranks share GPU 0 over gloo here (1-GPU box); the line must say two ranks joined and carry the roofline object."""
+    import json
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--batch", "8", "--steps", "3", "--warmup", "1"],
+                       env=_rank_env(), capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, (p.stdout[-1500:], p.stderr[-3000:])
+    lines = [l for l in p.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, p.stdout[-2000:]
+    r = json.loads(lines[0])
+    assert r["n_gpus"] == 2 and r["ranks_seen"] == 2 and r["steps"] == 3 and r["warmup"] == 1
+    assert r["config"]["global_batch"] == 16 and r["config"]["parallelism"] == "dp2" and r["scaling"] == "weak"
+    assert r["value"] > 0 and r["roofline"]["frac"] > 0 and "cpu_baseline" not in r
+    assert np.isfinite(r["final_loss"])
+
+
+def test_run_pretraining_two_ranks_two_epochs(tmp_path):
+    """mirage_amd.run_pretraining under two data-parallel ranks (sharing GPU 0, gloo) with hipGraphs: 2 epochs x 40 steps of the staged
+    schedule -- more than the ~40 steps after which the host-side partial-sum cursor used to run off its buffer -- and the logged
+    gradient norm must be the norm of the whole (averaged) gradient, not of the last stage (round-2 verdict, weak #1)."""
+    import json
+    import test_model_gpu as T
+    port = _free_port()
+    out = str(tmp_path / "out")
+    argv = ["-m", "mirage_amd.run_pretraining", "--blr", "1e-2", "--data_path", "synthetic", "--in_domains", "bscan-slo", "--out_domains", "bscan-slo",
+            "--input_size", "128", "--patch_size", "8", "--batch_size", "2", "--num_encoded_tokens", "98", "--epochs", "2",
+            "--steps_per_epoch", "40", "--warmup_epochs", "1", "--save_ckpt_freq", "1", "--base_output_dir", out, "--print_freq", "1"]
+    procs = []
+    for r in range(2):
+        env = _rank_env(RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable] + argv, env=env, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
+    logs = [p.communicate(timeout=1500)[0].decode() for p in procs]
+    for p, lg in zip(procs, logs):
+        assert p.returncode == 0, lg[-3000:]
+    d = os.path.join(out, "miragepre_base")
+    lines = [json.loads(l) for l in open(os.path.join(d, "log.txt"))]
+    assert [l["epoch"] for l in lines] == [0, 1]
+    # per-step log lines of rank 0: 80 steps, finite, the loss falls, and the norm is that of a full Base model's gradient
+    steps = [l for l in logs[0].splitlines() if l.startswith("Epoch: [")]
+    assert len(steps) == 80, len(steps)
+    vals = [dict(zip(l.split()[3::2], l.split()[4::2])) for l in steps]
+    losses = [float(v["loss:"]) for v in vals]; norms = [float(v["grad_norm:"]) for v in vals]
+    assert all(np.isfinite(losses)) and all(np.isfinite(norms)) and min(norms) > 0
+    assert np.mean(losses[-10:]) < np.mean(losses[:10])
+    ck = torch.load(os.path.join(d, "checkpoint-1.pth"), map_location="cpu", weights_only=False)
+    assert ck["optimizer"]["mrg_iteration"] == 80
+    T.report("run_pretraining_dp2", loss_first=losses[0], loss_last=losses[-1], grad_norm_first=norms[0], grad_norm_last=norms[-1])

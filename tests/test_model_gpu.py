@@ -106,11 +106,11 @@ def _case(name, grads=True):
     total = sum(losses.values())
     for d in preds:
         want = float(fx[f"loss.{d}"])
-        tol = max(1e-3, 3.0 * float(fx[f"floor.loss.{d}"]))
+        tol = max(1e-3, 2.5 * float(fx[f"floor.loss.{d}"]))
         meas[f"loss_rel.{d}"] = abs(float(losses[d]) - want) / max(1.0, abs(want)); meas[f"loss_tol.{d}"] = tol
         assert abs(float(losses[d]) - want) <= tol * max(1.0, abs(want)), (d, float(losses[d]), want, tol)
         assert abs(float(preds[d].float().double().norm()) - float(fx[f"pred_norm.{d}"])) <= 1e-2 * float(fx[f"pred_norm.{d}"])
-    tol = max(1e-3, 3.0 * float(fx["floor.loss"]))
+    tol = max(1e-3, 2.5 * float(fx["floor.loss"]))
     meas["loss_rel"] = abs(float(total) - float(fx["loss"])) / abs(float(fx["loss"])); meas["loss_tol"] = tol
     assert abs(float(total) - float(fx["loss"])) <= tol * abs(float(fx["loss"])), (float(total), float(fx["loss"]), tol)
     if not grads:
@@ -121,7 +121,11 @@ def _case(name, grads=True):
     params = dict(model.named_parameters())
     tot2 = 0.0
     worst = (0.0, "")
-    gtol = max(4e-2, 3.0 * float(fx["floor.grad_worst_rel"]))
+    worst_t = (0.0, "")
+    # ~3x the errors measured on MI355X (profiles/r02_parity_measured.md: per-parameter gradient norms within 9.1e-3 on the tiny
+    # models and 4.0e-3 at full size, whole tensors within 9.4e-3 rel-RMS, total norm within 1.7e-3): a regression of that factor
+    # fails.  (Round 2 used max(4e-2, 3 x the reference's own bf16 deviation) = up to 0.147, which a 30x regression passed.)
+    gtol, gtol_t = 1.5e-2, 3e-2
     for n, gn in zip(names, fx["grad_norms"]):
         gr = params[n].grad
         assert gr is not None, n
@@ -135,12 +139,16 @@ def _case(name, grads=True):
             worst = (err, n)
         if f"grad.{n}" in fx:
             ref = torch.from_numpy(fx[f"grad.{n}"]).double()
-            assert float((gr.cpu().double() - ref).norm()) <= gtol * scale + 1e-7, (n, float((gr.cpu().double() - ref).norm()), scale)
-    ttol = max(1e-2, 3.0 * float(fx["floor.grad_total_norm"]))
+            et = float((gr.cpu().double() - ref).norm()) / (scale + 1e-30)
+            if et > worst_t[0]:
+                worst_t = (et, n)
+    ttol = 5e-3
     meas.update(grad_worst_rel=worst[0], grad_worst_name=worst[1], grad_worst_tol=gtol,
+                grad_tensor_worst_rel=worst_t[0], grad_tensor_worst_name=worst_t[1], grad_tensor_worst_tol=gtol_t,
                 grad_total_rel=abs(tot2 ** 0.5 - float(fx["grad_total_norm"])) / float(fx["grad_total_norm"]), grad_total_tol=ttol)
     report(name, **meas)
     assert worst[0] <= gtol, worst
+    assert worst_t[0] <= gtol_t, worst_t
     assert abs(tot2 ** 0.5 - float(fx["grad_total_norm"])) <= ttol * float(fx["grad_total_norm"])
 
 
