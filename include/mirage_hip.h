@@ -26,7 +26,7 @@ extern "C" {
 typedef struct ihipStream_t* hipStream_t;
 #endif
 
-#define MRG_ABI_VERSION 7   /* 7: mrg_wgrad_group, mrg_debug_timestamp; 2: mrg_gemm_desc grew row_scale / defer_reduce, act codes 3, 4, reduce_batch / augment / row_scale entry points; 3: colsum_out, attention colsum_*; 4: step = int[2], mrg_step_inc takes the skip decision; 5: splitk_counters, MRG_GEMM_P8, resize entry points; 6: mrg_adamw_desc.sumsq_out, mrg_sumsq_finish */
+#define MRG_ABI_VERSION 8   /* 8: mrg_gemm_desc.drop_rng / drop_p / drop_stream, mrg_dropout_bwd_bf16; 7: mrg_wgrad_group, mrg_debug_timestamp; 2: mrg_gemm_desc grew row_scale / defer_reduce, act codes 3, 4, reduce_batch / augment / row_scale entry points; 3: colsum_out, attention colsum_*; 4: step = int[2], mrg_step_inc takes the skip decision; 5: splitk_counters, MRG_GEMM_P8, resize entry points; 6: mrg_adamw_desc.sumsq_out, mrg_sumsq_finish */
 
 enum { MRG_DT_BF16 = 0, MRG_DT_F32 = 1 };
 enum { MRG_OP_KCONTIG = 0, MRG_OP_KSTRIDED = 1 };
@@ -96,6 +96,13 @@ typedef struct mrg_gemm_desc {
                                         (deterministic) and applies the epilogue -- no second kernel, the slabs are consumed while
                                         they are still in L2 / Infinity Cache.  Kernel variants without the protocol fall back to
                                         the separate reduction kernel */
+    const void* drop_rng;            /* optional device uint64[2] = {seed, step}: with drop_p > 0 the value (acc + bias) is multiplied by a
+                                        Philox4x32-10 keep mask / (1 - drop_p) before row_scale and resid are applied -- nn.Dropout after
+                                        attn.proj / mlp.fc2 (mirage/utils.py:152,158,172,186-187) fused into the producing GEMM.  Element
+                                        (row, col) uses counter ((row * N + col) >> 2, drop_stream, step), key = seed, draw col & 3; it is
+                                        kept when the draw >= floor(drop_p * 2^32).  act must be NONE, N %% 4 == 0, no split-K.
+                                        mrg_dropout_bwd_bf16 regenerates the same mask for the backward pass. */
+    float drop_p; unsigned drop_stream;
 } mrg_gemm_desc;
 enum { MRG_GEMM_AUTO = 0, MRG_GEMM_GLDS3 = 1, MRG_GEMM_GLDS4 = 2, MRG_GEMM_PIPE128 = 3, MRG_GEMM_PIPE256 = 4, MRG_GEMM_PIPE256X3 = 5, MRG_GEMM_PIPE256SQ = 6, MRG_GEMM_WS256 = 7, MRG_GEMM_GLDS64 = 8, MRG_GEMM_SQP = 9, MRG_GEMM_G256 = 10, MRG_GEMM_P8 = 11 };
 
@@ -277,6 +284,11 @@ int mrg_cast_bf16(const float* src, void* dst_bf16, long n, hipStream_t stream);
 /* dst_bf16[r, :] = src[r, :] * row_scale[r] for an [M, D] fp32 matrix (D % 4 == 0): the gradient entering a stochastic-depth
  * branch (backward of drop_path, mirage/utils.py:103-118). */
 int mrg_row_scale_bf16(const float* src, const float* row_scale, void* dst_bf16, long M, int D, hipStream_t stream);
+/* dst_bf16[r, c] = src[r, c] * keep(r, c) / (1 - drop_p) (* row_scale[r] when given): the gradient entering a branch that ended in
+ * nn.Dropout (mirage/utils.py:158,187), with the mask mrg_gemm applied in the forward pass regenerated from (drop_rng = {seed, step},
+ * drop_stream) -- nothing is stored between the passes.  D % 4 == 0 and D == the N of that GEMM. */
+int mrg_dropout_bwd_bf16(const float* src, const float* row_scale, void* dst_bf16, long M, int D, const void* drop_rng, float drop_p,
+                         unsigned drop_stream, hipStream_t stream);
 
 /* ---- F2: GPU-side pretraining augmentation (mutils/datasets_pretrain.py:18-83, DataAugmentationForMIRAGE.__call__) --------------
  * One fused pass over a batch of uint8 samples [B, H, W]: horizontal flip (:41-42), intensity shift + clip to [0,1] (:43-48;

@@ -31,7 +31,8 @@ class GemmDesc(C.Structure):
                 ("C", vp), ("ldc", ci), ("c_dtype", ci), ("C2", vp), ("ldc2", ci), ("bias", vp),
                 ("resid", vp), ("ldr", ci), ("accumulate", ci), ("act", ci),
                 ("aux_out", vp), ("aux_in", vp), ("ldaux", ci), ("row_map", vp),
-                ("add_tab", vp), ("add_row", vp), ("ldt", ci), ("splitk", ci), ("ws", vp), ("variant", ci), ("ev_start", vp), ("ev_stop", vp), ("row_scale", vp), ("colsum_out", vp), ("defer_reduce", ci), ("splitk_counters", vp)]
+                ("add_tab", vp), ("add_row", vp), ("ldt", ci), ("splitk", ci), ("ws", vp), ("variant", ci), ("ev_start", vp), ("ev_stop", vp), ("row_scale", vp), ("colsum_out", vp), ("defer_reduce", ci), ("splitk_counters", vp),
+                ("drop_rng", vp), ("drop_p", cf), ("drop_stream", C.c_uint)]
 
 
 MRG_WGRAD_GROUP_MAX = 48
@@ -113,6 +114,7 @@ SIGNATURES = {
     "mrg_step_inc": (ci, [vp, vp, C.c_float, C.c_float, vp]),
     "mrg_cast_bf16": (ci, [vp, vp, cl, vp]),
     "mrg_row_scale_bf16": (ci, [vp, vp, vp, cl, ci, vp]),
+    "mrg_dropout_bwd_bf16": (ci, [vp, vp, vp, cl, ci, vp, cf, C.c_uint, vp]),
     "mrg_ln_bwd_partial_rows": (ci, [ci, ci]),
     "mrg_reduce_batch": (ci, [vp, ci, vp]),
     "mrg_augment_image": (ci, [vp, vp, vp, ci, ci, ci, ci, vp]),
@@ -133,7 +135,7 @@ for _name, (_res, _args) in SIGNATURES.items():
     _fn.argtypes = _args
 
 ABI_VERSION = lib.mrg_version()
-EXPECTED_ABI_VERSION = 7       # must match MRG_ABI_VERSION in include/mirage_hip.h: the ctypes structs above mirror that layout
+EXPECTED_ABI_VERSION = 8       # must match MRG_ABI_VERSION in include/mirage_hip.h: the ctypes structs above mirror that layout
 if ABI_VERSION != EXPECTED_ABI_VERSION:
     raise ImportError(f"{LIB_PATH} reports ABI version {ABI_VERSION}, the Python bindings expect {EXPECTED_ABI_VERSION}: rebuild it "
                       "(python -c 'import __graft_entry__ as g; g.build()')")

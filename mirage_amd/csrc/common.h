@@ -66,6 +66,39 @@ __device__ __forceinline__ void gelu_parts(float x, float& cdf, float& pdf) {
 __device__ __forceinline__ float gelu_f(float x) { float c, p; gelu_parts(x, c, p); return x * c; }
 __device__ __forceinline__ float gelu_grad_f(float x) { float c, p; gelu_parts(x, c, p); return c + x * p; }
 
+// ---- dropout (mirage/utils.py:152,158,172,184-187: nn.Dropout after proj / fc2) ------------------------------------------
+// Counter-based masks: Philox4x32-10 (Salmon et al., "Parallel random numbers: as easy as 1, 2, 3", SC'11; the generator behind
+// torch's CUDA dropout as well) keyed by the run's seed, counted by (element quad, launch stream id, step).  One call yields the four
+// 32-bit draws of 4 consecutive columns; an element is KEPT when its draw >= thresh = floor(p * 2^32).  The mask is a pure
+// function of (seed, step, stream, row, col), so the backward pass regenerates it instead of storing M x N bytes, and the CPU
+// oracle restates it bit for bit (oracle/mirage_oracle.py philox4x32_10).
+struct MrgDropout {
+    const unsigned long long* rng;   // device [2]: seed, step (nullptr: no dropout)
+    uint32_t thresh;                 // floor(p * 2^32)
+    float scale;                     // 1 / (1 - p)
+    uint32_t stream;                 // distinguishes the launches of one step (2 * block + branch)
+};
+__device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1, uint32_t (&out)[4]) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+        const uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+        const uint32_t n0 = hi1 ^ c1 ^ k0, n2 = hi0 ^ c3 ^ k1;
+        c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+// multiplies the 4 values of columns col..col+3 (col % 4 == 0) of row `row` of an [*, N] matrix by their mask factor (0 or scale)
+__device__ __forceinline__ void dropout_apply4(const MrgDropout& d, long row, int col, int N, float (&v)[4]) {
+    const unsigned long long seed = d.rng[0], step = d.rng[1];
+    const unsigned long long q = ((unsigned long long)row * (unsigned long long)N + (unsigned long long)col) >> 2;
+    uint32_t r[4];
+    philox4x32_10((uint32_t)q, (uint32_t)(q >> 32), d.stream, (uint32_t)step, (uint32_t)seed, (uint32_t)(seed >> 32), r);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = r[e] >= d.thresh ? v[e] * d.scale : 0.f;
+}
+
 // LDS pointer -> 32-bit LDS byte address
 __device__ __forceinline__ uint32_t lds_addr(const void* p) {
     return (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const void*)p;

@@ -14,6 +14,7 @@
 // double-buffered LDS (one barrier per K tile), XOR-swizzled LDS images (conflict-free ds_read_b128 /
 // tr reads), XCD-aware tile order.
 #include "gemm_common.h"
+#include <math.h>
 
 namespace {
 
@@ -167,7 +168,7 @@ __device__ __forceinline__ void glds_setup(const bf16_t* P, int ld, int row0, in
 // and, per accumulator quad, four CONSECUTIVE columns: the fused epilogue runs straight on the registers and stores 8 B (bf16 x 4) /
 // 16 B (fp32 x 4) per quad -- no fp32 round trip of the tile through LDS (64 ds_write_b32 + 16 ds_read_b128 per lane, at the LDS's
 // ~64-80 B/clk store rate about 1000 cycles per tile) and none of its four barriers.
-template <int AMODE, int BMODE, bool VEC, int OCC, bool CSUM = false, bool KF = false, bool DIRECT = false>
+template <int AMODE, int BMODE, bool VEC, int OCC, bool CSUM = false, bool KF = false, bool DIRECT = false, bool DROP = false>
 __global__ __launch_bounds__(256, OCC) void gemm_glds_kernel(const GemmArgs g) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int nwg = g.tiles_m * g.tiles_n;
@@ -341,6 +342,14 @@ __global__ __launch_bounds__(256, OCC) void gemm_glds_kernel(const GemmArgs g) {
         __syncthreads();
         if (col < g.N) {
             auto row_of = [&](int it, int& rl, int& row) { rl = (tid >> 5) + (it << 3); row = m0 + (rl >> 5) * 64 + pss * 32 + (rl & 31); };
+            if constexpr (DROP) {           // bias -> Philox dropout -> row factor -> residual (the only instantiation that reads g.drop)
+#pragma unroll 1
+                for (int it = 0; it < 8; ++it) {
+                    int rl, row;
+                    row_of(it, rl, row);
+                    if (row < Meff) epi_row_drop<VEC>(g, *reinterpret_cast<const float4*>(ct + rl * BN + cl), bv, row, col, nv);
+                }
+            } else
             if (VEC && !CSUM && (g.side_drain & 2) && ws) MRG_DRAIN8(7, false, ws);
             else if (VEC && (g.side_drain & 1) && g.epi_kind == 4) MRG_DRAIN8(4, CSUM, cs);
             else if (VEC && !CSUM && (g.side_drain & 1) && g.epi_kind == 2) MRG_DRAIN8(2, false, cs);
@@ -1273,6 +1282,20 @@ extern "C" int mrg_gemm(const mrg_gemm_desc* d, hipStream_t stream) {
     g.aux_out = (bf16_t*)d->aux_out; g.aux_in = (const bf16_t*)d->aux_in; g.ldaux = d->ldaux;
     g.row_map = d->row_map; g.add_tab = d->add_tab; g.add_row = d->add_row; g.ldt = d->ldt; g.row_scale = d->row_scale; g.colsum = d->colsum_out;
     g.splitk = splitk; g.ws = d->ws; g.tile_cnt = nullptr;
+    g.drop.rng = nullptr; g.drop.thresh = 0; g.drop.scale = 1.f; g.drop.stream = 0;
+    if (d->drop_rng && d->drop_p > 0.f) {
+        MRG_REQUIRE(d->drop_p < 1.f, MRG_ERR_ARG, "mrg_gemm: drop_p = %g must be in [0, 1)", (double)d->drop_p);
+        MRG_REQUIRE(splitk == 1 && d->N % 4 == 0 && !d->colsum_out && !d->accumulate, MRG_ERR_UNSUPPORTED,
+                    "mrg_gemm: dropout needs N %% 4 == 0 and no split-K / column sums / accumulate");
+        MRG_REQUIRE(d->act == MRG_ACT_NONE && !d->add_tab && !d->row_map && !d->a_map && !d->b_map && !d->m_dev && !d->k_dev &&
+                    d->a_mode == MRG_OP_KCONTIG && d->b_mode == MRG_OP_KCONTIG, MRG_ERR_UNSUPPORTED,
+                    "mrg_gemm: dropout is fused into the forward (+bias)(*row_scale)(+residual) epilogue only");
+        const double t = floor((double)d->drop_p * 4294967296.0);
+        g.drop.rng = (const unsigned long long*)d->drop_rng;
+        g.drop.thresh = (uint32_t)(t > 4294967295.0 ? 4294967295.0 : t);
+        g.drop.scale = 1.f / (1.f - d->drop_p);
+        g.drop.stream = d->drop_stream;
+    }
     MRG_REQUIRE(d->variant >= 0 && d->variant <= MRG_GEMM_P8, MRG_ERR_ARG, "mrg_gemm: bad variant");
     g.tiles_m = cdiv(d->M, BM); g.tiles_n = cdiv(d->N, BN);
     { static const int abl = [] { const char* e = getenv("MRG_GEMM_ABLATE"); return e ? atoi(e) : 0; }(); g.ablate = abl; }
@@ -1280,11 +1303,12 @@ extern "C" int mrg_gemm(const mrg_gemm_desc* d, hipStream_t stream) {
     { static const int xs = [] { const char* e = getenv("MRG_GEMM_XCD_SPLIT"); return e ? atoi(e) : 1; }(); g.xcd_split = xs; }
     { static const int sd = [] { const char* e = getenv("MRG_GEMM_SIDE_DRAIN"); return e ? atoi(e) : 3; }(); g.side_drain = sd; }
     static const int kfast = [] { const char* e = getenv("MRG_GEMM_KFAST"); return e ? atoi(e) : 1; }();
-    static const int epi_direct = [] { const char* e = getenv("MRG_EPI_DIRECT"); return e ? atoi(e) : 0; }();   // register-direct epilogue of the single-stage 128 x 128 kernel: measured SLOWER (12.95 vs 11.02 ms/step at C2)
+    static const int epi_direct_env = [] { const char* e = getenv("MRG_EPI_DIRECT"); return e ? atoi(e) : 0; }();   // register-direct epilogue of the single-stage 128 x 128 kernel: measured SLOWER (12.95 vs 11.02 ms/step at C2)
+    const int epi_direct = epi_direct_env;
     const bool kf = kfast && (d->K % BK == 0) && !d->k_dev && !d->a_map;      // scalar-base loaders
     {   // lean epilogue selection (uniform over the launch)
         static const int lean = [] { const char* e = getenv("MRG_GEMM_LEAN"); return e ? atoi(e) : 1; }();
-        const bool base = splitk == 1 && !d->add_tab && !d->row_map && !d->accumulate && !d->resid && !d->row_scale && !d->C2 && !g.c_f32;
+        const bool base = splitk == 1 && !d->add_tab && !d->row_map && !d->accumulate && !d->resid && !d->row_scale && !d->C2 && !g.c_f32 && !g.drop.rng;
         g.epi_kind = 0;
         if (lean) {
             if (base && d->act == MRG_ACT_NONE) g.epi_kind = 1;
@@ -1292,7 +1316,7 @@ extern "C" int mrg_gemm(const mrg_gemm_desc* d, hipStream_t stream) {
             else if (base && d->act == MRG_ACT_MUL_AUX_F16 && d->aux_in) g.epi_kind = 4;
             else if (base && d->act == MRG_ACT_GELU && !d->aux_out && !d->colsum_out) g.epi_kind = 5;
             else if (splitk == 1 && d->act == MRG_ACT_NONE && d->add_tab && d->add_row && d->row_map && !d->accumulate && !d->resid && !d->row_scale &&
-                     !d->C2 && g.c_f32 && !d->colsum_out) g.epi_kind = 6;
+                     !d->C2 && g.c_f32 && !d->colsum_out && !g.drop.rng) g.epi_kind = 6;
             else if (splitk == 1 && d->act == MRG_ACT_NONE && !d->add_tab && !d->row_map && !d->accumulate && !d->colsum_out && d->resid && g.c_f32) g.epi_kind = 2;
         }
     }
@@ -1311,6 +1335,14 @@ extern "C" int mrg_gemm(const mrg_gemm_desc* d, hipStream_t stream) {
     const bool fast = al && !d->b_map && (!d->a_map || d->a_mode == MRG_OP_KCONTIG);
     const bool mapped = d->a_map != nullptr;                       // gathered A rows: single-/two-stage 128 x 128 kernels, general loader
     if (d->ev_start) (void)hipEventRecord((hipEvent_t)d->ev_start, stream);
+    if (g.drop.rng) {      // nn.Dropout after proj / fc2: the dedicated instantiation of the single-stage 128 x 128 kernel
+        MRG_REQUIRE(fast, MRG_ERR_UNSUPPORTED, "mrg_gemm: dropout needs 16-byte aligned operands with K %% 8 == 0");
+        g.epi_kind = 0;
+        if (vec) hipLaunchKernelGGL((gemm_glds_kernel<0, 0, true, 3, false, false, false, true>), grid, block, (size_t)(2 * TILE_BYTES), stream, g);
+        else hipLaunchKernelGGL((gemm_glds_kernel<0, 0, false, 3, false, false, false, true>), grid, block, (size_t)(2 * TILE_BYTES), stream, g);
+        if (d->ev_stop) (void)hipEventRecord((hipEvent_t)d->ev_stop, stream);
+        return mrg_check_launch("mrg_gemm");
+    }
     // 4 workgroups per CU (<= 128 VGPRs) pay off only when there are enough tiles to fill them (measured: +13..18 % at
     // >= ~1500 tiles, -3..-15 % below and for the wgrad layout)
     // kernel choice (measured, tools/bench_gemm.py): long K loops (>= 24 k-tiles per workgroup) run the pipelined two-stage

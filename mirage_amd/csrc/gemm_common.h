@@ -39,6 +39,8 @@ struct GemmArgs {
     int xcd_split; // MRG_GEMM_XCD_SPLIT (default 1): split-K index slowest in the XCD band order
     int nt;       // MRG_GEMM_NT: 0 plain stores, 1 streaming (nontemporal) stores for C / C2 / aux_out, 2 (default) for aux_out only
     int ablate;   // MRG_GEMM_ABLATE (256x128 kernel only, for roofline analysis): 1 = no DMA, 2 = DMA only, 3 = DMA + LDS reads, no MFMA
+    MrgDropout drop;   // drop.rng != nullptr: (acc + bias) is multiplied by the Philox keep mask / (1 - p) before row_scale / resid --
+                       // only the DROP instantiation of the single-stage kernel reads it (epi_row_drop), the tuned kernels do not
 };
 
 // grouped weight-gradient launch of the 8-phase kernel (gemm8p.hip): per-problem operands, everything else from `base`
@@ -393,6 +395,38 @@ __device__ __forceinline__ void epi_row_resid(const GemmArgs& g, const float4 a4
         if (g.C2) *reinterpret_cast<u32x2*>(g.C2 + (long)row * g.ldc2 + col) = u32x2{pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3])};
     } else {
         for (int e = 0; e < nv; ++e) { v[e] += t[e]; c[e] = v[e]; if (g.C2) g.C2[(long)row * g.ldc2 + col + e] = f2bf(v[e]); }
+    }
+}
+// bias -> dropout -> (stochastic-depth row factor) -> (+ fp32 residual) -> C (fp32 or bf16) (+ bf16 twin): x + drop_path(drop(proj(.)))
+// of Block.forward (mirage/utils.py:158,187,260-261) in one epilogue.  Kept out of the tuned epilogues above on purpose: the Philox
+// rounds inside them cost every hot kernel 25-30 spilled SGPRs although no BASELINE configuration sets a dropout rate.
+template <bool VEC>
+__device__ __forceinline__ void epi_row_drop(const GemmArgs& g, const float4 a4, const float (&bv)[4], int row, int col, int nv) {
+    float v[4] = {a4.x + bv[0], a4.y + bv[1], a4.z + bv[2], a4.w + bv[3]};
+    dropout_apply4(g.drop, row, col, g.N, v);
+    if (g.row_scale) {
+        const float rs = g.row_scale[row];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] *= rs;
+    }
+    if (g.resid) {
+        const float* t = g.resid + (long)row * g.ldr + col;
+        if (VEC) { const float4 t4 = *reinterpret_cast<const float4*>(t); v[0] += t4.x; v[1] += t4.y; v[2] += t4.z; v[3] += t4.w; }
+        else { for (int e = 0; e < nv; ++e) v[e] += t[e]; }
+    }
+    if (g.c_f32) {
+        float* c = reinterpret_cast<float*>(g.C) + (long)row * g.ldc + col;
+        if (VEC) *reinterpret_cast<float4*>(c) = make_float4(v[0], v[1], v[2], v[3]);
+        else { for (int e = 0; e < nv; ++e) c[e] = v[e]; }
+    } else {
+        bf16_t* c = reinterpret_cast<bf16_t*>(g.C) + (long)row * g.ldc + col;
+        if (VEC) *reinterpret_cast<u32x2*>(c) = u32x2{pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3])};
+        else { for (int e = 0; e < nv; ++e) c[e] = f2bf(v[e]); }
+    }
+    if (g.C2) {
+        bf16_t* c = g.C2 + (long)row * g.ldc2 + col;
+        if (VEC) *reinterpret_cast<u32x2*>(c) = u32x2{pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3])};
+        else { for (int e = 0; e < nv; ++e) c[e] = f2bf(v[e]); }
     }
 }
 template <bool VEC>

@@ -5,6 +5,7 @@
 // Hyper-parameters come from device-resident schedule tables indexed by a device step counter, so the whole
 // optimizer step is hipGraph-replayable (run_pretraining.py:683-688 sets lr/wd per step from such arrays).
 #include "common.h"
+#include <math.h>
 #include "mirage_hip.h"
 
 namespace {
@@ -141,6 +142,23 @@ __global__ __launch_bounds__(256) void row_scale_bf16_kernel(const float* __rest
     }
 }
 
+// dst[r, c] = src[r, c] * mask(r, c) / (1 - p) (* scale[r]): the gradient entering a dropped-out branch; mask = the Philox keep mask the
+// forward GEMM epilogue applied (common.h dropout_apply4: same counter, key and threshold)
+__global__ __launch_bounds__(256) void dropout_bwd_bf16_kernel(const float* __restrict__ src, const float* __restrict__ scale,
+                                                               bf16_t* __restrict__ dst, long M, int D, MrgDropout dr) {
+    const int d4 = D >> 2;
+    const long n4 = M * d4;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+        const long row = i / d4;
+        const int col = (int)(i - row * d4) << 2;
+        const float4 t = reinterpret_cast<const float4*>(src)[i];
+        float v[4] = {t.x, t.y, t.z, t.w};
+        dropout_apply4(dr, row, col, D, v);
+        const float s = scale ? scale[row] : 1.f;
+        reinterpret_cast<uint2*>(dst)[i] = make_uint2(pack_bf2(v[0] * s, v[1] * s), pack_bf2(v[2] * s, v[3] * s));
+    }
+}
+
 }  // namespace
 
 extern "C" int mrg_sumsq_nblocks(long n) {
@@ -217,4 +235,22 @@ extern "C" int mrg_row_scale_bf16(const float* src, const float* row_scale, void
     if (nb > 4096) nb = 4096;
     hipLaunchKernelGGL(row_scale_bf16_kernel, dim3((unsigned)nb), dim3(256), 0, stream, src, row_scale, (bf16_t*)dst_bf16, M, D);
     return mrg_check_launch("mrg_row_scale_bf16");
+}
+
+extern "C" int mrg_dropout_bwd_bf16(const float* src, const float* row_scale, void* dst_bf16, long M, int D, const void* drop_rng, float drop_p,
+                                    unsigned drop_stream, hipStream_t stream) {
+    MRG_REQUIRE(src && dst_bf16 && drop_rng && M > 0 && D > 0, MRG_ERR_ARG, "mrg_dropout_bwd_bf16: bad argument");
+    MRG_REQUIRE(D % 4 == 0, MRG_ERR_SHAPE, "mrg_dropout_bwd_bf16: D must be a multiple of 4");
+    MRG_REQUIRE(drop_p > 0.f && drop_p < 1.f, MRG_ERR_ARG, "mrg_dropout_bwd_bf16: drop_p = %g must be in (0, 1)", (double)drop_p);
+    MRG_REQUIRE((((uintptr_t)src & 15) | ((uintptr_t)dst_bf16 & 7) | ((uintptr_t)drop_rng & 7)) == 0, MRG_ERR_ARG, "mrg_dropout_bwd_bf16: misaligned");
+    MrgDropout dr;
+    const double t = floor((double)drop_p * 4294967296.0);
+    dr.rng = (const unsigned long long*)drop_rng;
+    dr.thresh = (uint32_t)(t > 4294967295.0 ? 4294967295.0 : t);
+    dr.scale = 1.f / (1.f - drop_p);
+    dr.stream = drop_stream;
+    long nb = (M * (D / 4) + 255) / 256;
+    if (nb > 4096) nb = 4096;
+    hipLaunchKernelGGL(dropout_bwd_bf16_kernel, dim3((unsigned)nb), dim3(256), 0, stream, src, row_scale, (bf16_t*)dst_bf16, M, D, dr);
+    return mrg_check_launch("mrg_dropout_bwd_bf16");
 }

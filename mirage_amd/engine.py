@@ -163,8 +163,9 @@ def join_side_stream():
 
 # ------------------------------------------------------------------------------------------- linear helpers
 def lin_fwd(x16: torch.Tensor, lin, *, out_dtype=BF16, resid: Optional[torch.Tensor] = None, want_bf16_copy: bool = False,
-            gelu: bool = False, save_pre: bool = False, row_scale: Optional[torch.Tensor] = None):
-    """y = x W^T + b with fused epilogue.  x16: bf16 [..., K].  Returns y (and bf16 copy / pre-activation if asked)."""
+            gelu: bool = False, save_pre: bool = False, row_scale: Optional[torch.Tensor] = None, dropout=None):
+    """y = x W^T + b with fused epilogue.  x16: bf16 [..., K].  Returns y (and bf16 copy / pre-activation if asked).
+    dropout: (rng, p, stream id) -> nn.Dropout(p) on (x W^T + b) before the row factor / residual (kernels.gemm)."""
     W = shadow(lin.weight)
     N = W.shape[0]
     Kin = W.numel() // N
@@ -177,7 +178,7 @@ def lin_fwd(x16: torch.Tensor, lin, *, out_dtype=BF16, resid: Optional[torch.Ten
     pre = K.new(oshape, torch.float16, x16.device) if (gelu and save_pre) else None
     act = L.MRG_ACT_NONE if not gelu else (L.MRG_ACT_GELU_SAVE_GRAD if pre is not None else L.MRG_ACT_GELU)
     K.gemm(x16, W, M, N, Kin, lda=Kin, ldb=Kin, out=out, ldc=N, out2=out2, bias=lin.bias,
-           resid=resid, act=act, aux_out=pre, row_scale=row_scale)
+           resid=resid, act=act, aux_out=pre, row_scale=row_scale, dropout=dropout)
     return out, out2, pre
 
 
@@ -224,11 +225,42 @@ def to_bf16(x32: torch.Tensor) -> torch.Tensor:
     return out
 
 
+# ------------------------------------------------------------------------------------------- dropout state
+class DropoutRNG:
+    """{seed, step} per device for the Philox dropout masks (csrc/common.h dropout_apply4).  `begin_forward` advances the step ON THE
+    DEVICE (an in-place add: hipGraph-replayable, every replay draws new masks) and returns a snapshot tensor; the forward GEMMs and the
+    backward mask kernels of that pass read the snapshot, so a later forward cannot change the masks an earlier backward regenerates."""
+    _state = {}
+
+    @classmethod
+    def state(cls, device) -> torch.Tensor:
+        device = torch.device(device)
+        st = cls._state.get(device)
+        if st is None:
+            st = cls._state[device] = torch.tensor([torch.initial_seed() & 0x7FFFFFFFFFFFFFFF, 0], dtype=torch.int64, device=device)
+        return st
+
+    @classmethod
+    def set(cls, device, seed: int, step: int = 0):
+        """pin the stream (tests, resume): the NEXT forward uses step + 1"""
+        cls.state(device).copy_(torch.tensor([int(seed), int(step)], dtype=torch.int64))
+
+    @classmethod
+    def begin_forward(cls, device) -> torch.Tensor:
+        st = cls.state(device)
+        st[1:2] += 1
+        return st.clone()
+
+
 # ------------------------------------------------------------------------------------------- transformer block
 def block_fwd(blk, x32: torch.Tensor, save: bool, want_bf16_out: bool = False, dp=None):
     """Block.forward (mirage/utils.py:259-262): x + drop_path(attn(norm1(x))); x + drop_path(mlp(norm2(x))).  x32: fp32 [B, N, D].
-    dp = (rows_attn, rows_mlp): per-row stochastic-depth factors floor(keep + u) / keep (mirage/utils.py:103-118), fused into the
-    proj / fc2 epilogues; None when the block's drop_path is Identity (every BASELINE config)."""
+    dp = (rows_attn, rows_mlp[, drop]): per-row stochastic-depth factors floor(keep + u) / keep (mirage/utils.py:103-118) or None, and
+    `drop` = (rng snapshot, p, stream base) for nn.Dropout(p) after proj / fc2 (mirage/utils.py:158,187) or None; all of it is fused
+    into the proj / fc2 epilogues.  dp is None when the block has neither (every BASELINE config)."""
+    drop = dp[2] if (dp is not None and len(dp) > 2) else None
+    d_att = (drop[0], drop[1], drop[2]) if drop is not None else None
+    d_mlp = (drop[0], drop[1], drop[2] + 1) if drop is not None else None
     B, N, D = x32.shape
     H = blk.attn.num_heads
     hd = D // H
@@ -237,11 +269,11 @@ def block_fwd(blk, x32: torch.Tensor, save: bool, want_bf16_out: bool = False, d
     qkv, _, _ = lin_fwd(ln1, blk.attn.qkv)
     st = (N * 3 * D, 3 * D)
     o, lse = K.attn_fwd(qkv[..., :D], qkv[..., D:2 * D], qkv[..., 2 * D:], B, H, N, N, hd, blk.attn.scale, st, st, st, need_lse=save)
-    x_mid, _, _ = lin_fwd(o, blk.attn.proj, out_dtype=F32, resid=x32, row_scale=dp[0] if dp else None)
+    x_mid, _, _ = lin_fwd(o, blk.attn.proj, out_dtype=F32, resid=x32, row_scale=dp[0] if dp else None, dropout=d_att)
     ln2, mean2, rstd2 = K.ln_fwd(x_mid, blk.norm2.weight, blk.norm2.bias, blk.norm2.eps)
     h_act, _, h_pre = lin_fwd(ln2, blk.mlp.fc1, gelu=True, save_pre=save)
     x_out, x_out16, _ = lin_fwd(h_act, blk.mlp.fc2, out_dtype=F32, resid=x_mid, want_bf16_copy=want_bf16_out,
-                                row_scale=dp[1] if dp else None)
+                                row_scale=dp[1] if dp else None, dropout=d_mlp)
     saved = (x32, ln1, mean1, rstd1, qkv, o, lse, x_mid, ln2, mean2, rstd2, h_pre, h_act, dp) if save else None
     return x_out, x_out16, saved
 
@@ -253,10 +285,17 @@ def block_bwd(blk, saved, dx32: torch.Tensor, dx16: Optional[torch.Tensor], rema
     B, N, D = x_in.shape
     H = blk.attn.num_heads
     hd = D // H
+    drop = dp[2] if (dp is not None and len(dp) > 2) else None
+
+    def branch_grad(g32, rows, sid_off):
+        """gradient entering a branch whose output was masked (dropout) and / or scaled per row (stochastic depth) before the add"""
+        if drop is not None:
+            return K.dropout_bwd_bf16(g32, (drop[0], drop[1], drop[2] + sid_off), row_scale=rows)
+        return K.row_scale_bf16(g32, rows)
     if dp is not None:
-        # stochastic depth: the branch sees row_scale * dy, the residual path the unscaled dy; the branch bias gradients are
-        # then column sums of the scaled gradient, not of the residual-stream gradient the LayerNorm kernels sum
-        dxs16 = K.row_scale_bf16(dx32, dp[1])
+        # stochastic depth / dropout: the branch sees mask * row_scale * dy, the residual path the unscaled dy; the branch bias gradients
+        # are then column sums of the scaled gradient, not of the residual-stream gradient the LayerNorm kernels sum
+        dxs16 = branch_grad(dx32, dp[1], 1)
         d_pre, _ = lin_bwd(dxs16, h_act, blk.mlp.fc2, gelu_pre=h_pre, bias_grad=True, dx_colsum=grad_buffer(blk.mlp.fc1.bias))
     else:
         if dx16 is None:
@@ -266,7 +305,7 @@ def block_bwd(blk, saved, dx32: torch.Tensor, dx16: Optional[torch.Tensor], rema
     dx_mid32, dx_mid16 = K.ln_bwd(d_ln2, x_mid, mean2, rstd2, blk.norm2.weight, dx32, grad_buffer(blk.norm2.weight),
                                   grad_buffer(blk.norm2.bias), None if dp is not None else grad_buffer(blk.mlp.fc2.bias))
     if dp is not None:
-        d_o, _ = lin_bwd(K.row_scale_bf16(dx_mid32, dp[0]), o, blk.attn.proj, bias_grad=True)
+        d_o, _ = lin_bwd(branch_grad(dx_mid32, dp[0], 0), o, blk.attn.proj, bias_grad=True)
     else:
         d_o, _ = lin_bwd(dx_mid16, o, blk.attn.proj, bias_grad=False)
     d_qkv = torch.empty_like(qkv)

@@ -256,9 +256,11 @@ def gemm(A: torch.Tensor, B: torch.Tensor, M: int, N: int, K: int, *, a_mode=L.M
          lda: Optional[int] = None, ldb: Optional[int] = None, out: Optional[torch.Tensor] = None, out_dtype=BF16,
          ldc: Optional[int] = None, out2: Optional[torch.Tensor] = None, bias=None, resid=None, accumulate=False,
          act=L.MRG_ACT_NONE, aux_out=None, aux_in=None, row_map=None, add_tab=None, add_row=None, a_map=None, b_map=None,
-         m_dev=None, k_dev=None, splitk: int = 1, tune_split: bool = False, row_scale=None, colsum=None) -> torch.Tensor:
+         m_dev=None, k_dev=None, splitk: int = 1, tune_split: bool = False, row_scale=None, colsum=None, dropout=None) -> torch.Tensor:
     """colsum: optional fp32 [N] destination for the column sums of the values written to `out` (per-tile partial sums in the
-    epilogue + batched reduction): the bias gradient of the layer whose output gradient this GEMM produces."""
+    epilogue + batched reduction): the bias gradient of the layer whose output gradient this GEMM produces.
+    dropout: optional (rng int64[2] = {seed, step} on the device, p, stream id): nn.Dropout(p) on (acc + bias) fused into the epilogue
+    (Philox mask, regenerated by dropout_bwd_bf16 in the backward pass)."""
     _need_cuda(A, "GEMM operand")
     if out is None:
         out = torch.empty((M, N), dtype=out_dtype, device=A.device)
@@ -293,12 +295,18 @@ def gemm(A: torch.Tensor, B: torch.Tensor, M: int, N: int, K: int, *, a_mode=L.M
     if add_tab is not None:
         d.add_tab, d.add_row, d.ldt = add_tab.data_ptr(), add_row.data_ptr(), add_tab.stride(0)
     d.row_scale = _p(row_scale)
+    if dropout is not None:
+        rng, p_drop, sid = dropout
+        if rng.dtype != torch.int64 or rng.numel() != 2 or not rng.is_cuda:
+            raise ValueError("gemm(dropout=...): rng must be an int64[2] device tensor {seed, step}")
+        d.drop_rng, d.drop_p, d.drop_stream = rng.data_ptr(), float(p_drop), int(sid)
     cs_part = None
     if colsum is not None:
         cs_part = torch.empty(((M + 127) // 128, N), dtype=F32, device=A.device)
         d.colsum_out = cs_part.data_ptr()
     variant = L.MRG_GEMM_AUTO
-    tunable = TUNE["enabled"] and a_map is None and b_map is None and m_dev is None and k_dev is None and not accumulate and M * N >= (1 << 16)
+    tunable = (TUNE["enabled"] and a_map is None and b_map is None and m_dev is None and k_dev is None and not accumulate and M * N >= (1 << 16)
+               and dropout is None)
     if tunable:
         key = (a_mode, b_mode, M, N, K, act, resid is not None, out.dtype == F32, tune_split)
         hit = _tune_cache.get(key)
@@ -730,6 +738,18 @@ def step_inc(step: torch.Tensor, grad_norm_t=None, clip_norm=0.0, skip_norm=0.0)
 
 def cast_bf16(src: torch.Tensor, dst: torch.Tensor):
     check(lib.mrg_cast_bf16(src.data_ptr(), dst.data_ptr(), src.numel(), _s()), "mrg_cast_bf16")
+    return dst
+
+
+def dropout_bwd_bf16(src: torch.Tensor, dropout, row_scale: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """bf16(src * keep_mask / (1 - p) (* row_scale[r])) for fp32 src [..., D]: the gradient entering a branch that ended in nn.Dropout;
+    `dropout` = the (rng, p, stream id) triple the forward GEMM was given."""
+    rng, p_drop, sid = dropout
+    D = src.shape[-1]
+    M = src.numel() // D
+    dst = torch.empty(src.shape, dtype=BF16, device=src.device)
+    check(lib.mrg_dropout_bwd_bf16(src.data_ptr(), _p(row_scale), dst.data_ptr(), M, D, rng.data_ptr(), float(p_drop), int(sid), _s()),
+          "mrg_dropout_bwd_bf16")
     return dst
 
 

@@ -52,6 +52,8 @@ class MIRAGEModel(nn.Module):
         self.encoder = nn.Sequential(*[
             Block(dim=dim_tokens, num_heads=num_heads, mlp_ratio=mlp_ratio, qkv_bias=qkv_bias, drop=drop_rate,
                   attn_drop=attn_drop_rate, drop_path=dpr[i], norm_layer=norm_layer) for i in range(depth)])
+        for i, blk in enumerate(self.encoder):
+            blk.drop_stream = 2 * i          # Philox mask streams of block i: 2i (after attn.proj), 2i + 1 (after mlp.fc2)
         # initialisation: same calls in the same order as mirage/model.py:95-121 (same RNG stream -> same weights)
         self.apply(self._init_weights)
         for name, m in self.named_modules():
@@ -283,6 +285,15 @@ class MIRAGEModel(nn.Module):
             dps = [None] * len(blocks)
             for j, i in enumerate(act):
                 dps[i] = blocks[i].drop_path_rows(B, x0.shape[1], device, u[j])
+        if self.training and any(getattr(b, "drop_prob", 0.0) > 0.0 for b in blocks):
+            # nn.Dropout after proj / fc2 (drop_rate, mirage/model.py:54,87): one Philox step per forward pass, one mask stream per
+            # (block, branch); the snapshot keeps forward and backward of THIS pass on the same masks
+            snap = E.DropoutRNG.begin_forward(device)
+            dps = dps if dps is not None else [None] * len(blocks)
+            for i, b in enumerate(blocks):
+                drop = b.dropout_args(snap)
+                if drop is not None:
+                    dps[i] = (dps[i][0], dps[i][1], drop) if dps[i] is not None else (None, None, drop)
         split = getattr(self, "_mrg_split_at", None)
         cuts = [split] if isinstance(split, int) else list(split or [])
         cuts = [c for c in cuts if 0 < c < len(blocks)]

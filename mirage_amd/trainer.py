@@ -220,6 +220,8 @@ class TrainStep:
         # the first real step would see different draws depending on warm_iters
         dev = next(iter(self.static_x.values())).device
         rng_cpu, rng_dev = torch.get_rng_state(), torch.cuda.get_rng_state(dev)
+        from .engine import DropoutRNG
+        drop_state = DropoutRNG.state(dev).clone()
         s = torch.cuda.Stream()
         s.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(s):
@@ -232,6 +234,7 @@ class TrainStep:
             torch.cuda.synchronize()
         torch.set_rng_state(rng_cpu)
         torch.cuda.set_rng_state(rng_dev, dev)
+        DropoutRNG.state(dev).copy_(drop_state)
         if self.reducer is None:
             self.g_fb = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self.g_fb, capture_error_mode="thread_local"):

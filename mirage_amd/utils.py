@@ -90,6 +90,11 @@ def _check_no_dropout(p, what):
         raise NotImplementedError(f"mirage_amd: {what} > 0 is not implemented on the HIP path (the pretraining configs use 0)")
 
 
+def _check_prob(p, what):
+    if p is None or not (0.0 <= float(p) < 1.0):
+        raise ValueError(f"mirage_amd: {what} = {p!r} must be in [0, 1)")
+
+
 # ------------------------------------------------------------------------- generic stand-alone ops (autograd)
 class _LinearFn(torch.autograd.Function):
     @staticmethod
@@ -168,13 +173,17 @@ class _MlpFn(torch.autograd.Function):
 class Mlp(nn.Module):
     """fc1 -> exact-erf GELU -> fc2 (mirage/utils.py:137-159); GELU is fused into the fc1 epilogue."""
 
-    def __init__(self, in_features, hidden_features=None, out_features=None, act_layer=nn.GELU, drop=0.0):
+    def __init__(self, in_features, hidden_features=None, out_features=None, act_layer=nn.GELU, drop=0.0, _in_block=False):
         super().__init__()
         out_features = out_features or in_features
         hidden_features = hidden_features or in_features
         if act_layer is not nn.GELU:
             raise NotImplementedError("mirage_amd.Mlp: only the exact-erf nn.GELU of the reference is fused")
-        _check_no_dropout(drop, "Mlp drop")
+        # dropout after fc2 is fused into the fc2 epilogue of a Block (engine.block_fwd); a stand-alone Mlp has no such epilogue
+        if _in_block:
+            _check_prob(drop, "Mlp drop")
+        else:
+            _check_no_dropout(drop, "Mlp drop (outside a Block)")
         self.fc1 = Linear(in_features, hidden_features)
         self.act = act_layer()
         self.fc2 = Linear(hidden_features, out_features)
@@ -219,10 +228,15 @@ class _AttentionFn(torch.autograd.Function):
 class Attention(nn.Module):
     """Fused-QKV self attention (mirage/utils.py:162-188)."""
 
-    def __init__(self, dim, num_heads=8, qkv_bias=False, attn_drop=0.0, proj_drop=0.0):
+    def __init__(self, dim, num_heads=8, qkv_bias=False, attn_drop=0.0, proj_drop=0.0, _in_block=False):
         super().__init__()
-        _check_no_dropout(attn_drop, "attn_drop")
-        _check_no_dropout(proj_drop, "proj_drop")
+        # dropout on the attention PROBABILITIES (F.scaled_dot_product_attention(dropout_p=...), mirage/utils.py:181-185) is not built:
+        # it would have to live inside the attention kernels' softmax; refuse it loudly rather than train without it
+        _check_no_dropout(attn_drop, "attn_drop (dropout on attention probabilities)")
+        if _in_block:
+            _check_prob(proj_drop, "proj_drop")
+        else:
+            _check_no_dropout(proj_drop, "proj_drop (outside a Block)")
         self.num_heads = num_heads
         head_dim = dim // num_heads
         if head_dim not in (32, 64):
@@ -305,13 +319,18 @@ class Block(nn.Module):
                  attn_drop: float = 0.0, drop_path: float = 0.0, act_layer: Callable = nn.GELU, norm_layer: Callable = LayerNorm):
         super().__init__()
         self.norm1 = norm_layer(dim)
-        self.attn = Attention(dim, num_heads=num_heads, qkv_bias=qkv_bias, attn_drop=attn_drop, proj_drop=drop)
+        self.attn = Attention(dim, num_heads=num_heads, qkv_bias=qkv_bias, attn_drop=attn_drop, proj_drop=drop, _in_block=True)
         self.drop_path = DropPath(drop_path) if drop_path > 0.0 else nn.Identity()
         self.norm2 = norm_layer(dim)
-        self.mlp = Mlp(in_features=dim, hidden_features=int(dim * mlp_ratio), act_layer=act_layer, drop=drop)
+        self.mlp = Mlp(in_features=dim, hidden_features=int(dim * mlp_ratio), act_layer=act_layer, drop=drop, _in_block=True)
         if not (qkv_bias and isinstance(self.norm1, nn.LayerNorm)):
             raise NotImplementedError("mirage_amd.Block: needs qkv_bias=True and a LayerNorm norm_layer (the reference's defaults)")
         self.drop_path_prob = float(drop_path)
+        # nn.Dropout(drop) after attn.proj and after mlp.fc2 (mirage/utils.py:158,187): Philox masks fused into those GEMMs' epilogues.
+        # drop_stream: even id that tells this block's two mask streams (id, id + 1) from every other block's within one step; the
+        # owning model numbers its blocks (MIRAGEModel: 2 * index), a stand-alone Block keeps 0
+        self.drop_prob = float(drop)
+        self.drop_stream = 0
 
     def _params(self):
         return (self.norm1.weight, self.norm1.bias, self.attn.qkv.weight, self.attn.qkv.bias, self.attn.proj.weight, self.attn.proj.bias,
@@ -327,6 +346,15 @@ class Block(nn.Module):
         f = drop_path_factor(u.to(device), self.drop_path_prob)
         return (f[0].repeat_interleave(N).contiguous(), f[1].repeat_interleave(N).contiguous())
 
+    def dropout_args(self, rng_snapshot: Optional[torch.Tensor]):
+        """(rng snapshot, p, stream id) for engine.block_fwd, or None when dropout is inactive (p = 0 or eval mode)"""
+        if self.drop_prob == 0.0 or not self.training or rng_snapshot is None:
+            return None
+        return (rng_snapshot, self.drop_prob, self.drop_stream)
+
     def forward(self, x, drop_path_noise: Optional[torch.Tensor] = None):
         dp = self.drop_path_rows(x.shape[0], x.shape[1], x.device, drop_path_noise)
+        if self.drop_prob > 0.0 and self.training:
+            drop = self.dropout_args(E.DropoutRNG.begin_forward(x.device))
+            dp = (dp[0], dp[1], drop) if dp is not None else (None, None, drop)
         return E.BlockFn.apply(x, self, torch.is_grad_enabled(), dp, *self._params())

@@ -32,8 +32,9 @@ def _build(cfg, with_decoders=True):
                              layermap_patch=dom[lm]["patch"] if lm else 8, decoder_dim=cfg["decoder_dim"],
                              decoder_depth=cfg["decoder_depth"], decoder_num_heads=cfg["decoder_heads"],
                              drop_path=cfg.get("drop_path_rate", 0.0))
+    extra = {"drop_rate": cfg["drop_rate"]} if cfg.get("drop_rate", 0.0) > 0.0 else {}
     model = builder.get_model(args, with_decoders=with_decoders and bool(cfg["out_domains"]), dim_tokens=cfg["dim"], depth=cfg["depth"],
-                              num_heads=cfg["heads"])
+                              num_heads=cfg["heads"], **extra)
     sd = O.procedural_state_dict(cfg)
     missing = model.load_state_dict(sd, strict=True)
     return model.to(DEV), args, sd
@@ -255,6 +256,134 @@ def test_drop_path_training_parity():
         p_eval2, _ = model({d: x[d] for d in doms}, num_encoded_tokens=Kk, mask_noise=noise, drop_path_noise=dpn)
     for d in p_eval:
         assert torch.equal(p_eval[d], p_eval2[d])
+
+
+def test_dropout_mask_is_the_oracles_philox_mask_bit_for_bit():
+    """The fused epilogue (mrg_gemm drop_rng / drop_p / drop_stream) and the backward mask kernel (mrg_dropout_bwd_bf16) both apply
+    exactly the oracle's keep pattern: zero operands + unit bias make the GEMM output the mask factor itself."""
+    from mirage_amd import kernels as K
+    from oracle import mirage_oracle as O
+    seed, step = 0x1234ABCD5678, 7
+    rng = torch.tensor([seed, step], dtype=torch.int64, device=DEV)
+    for (M, N, Kd, p, sid) in ((774, 128, 64, 0.1, 0), (516, 768, 128, 0.25, 5), (130, 260, 64, 0.5, 1000003)):
+        want = O.dropout_factor(M, N, p, seed, step, sid)
+        A = torch.zeros(M, Kd, dtype=torch.bfloat16, device=DEV)
+        W = torch.zeros(N, Kd, dtype=torch.bfloat16, device=DEV)
+        out = torch.empty(M, N, dtype=torch.float32, device=DEV)
+        K.gemm(A, W, M, N, Kd, out=out, bias=torch.ones(N, device=DEV), dropout=(rng, p, sid))
+        assert torch.equal(out.cpu(), want), (M, N, p)
+        # + residual, per-row factor and the bf16 twin, as the proj / fc2 epilogues of a Block use it
+        res = torch.randn(M, N, device=DEV); rows = torch.rand(M, device=DEV) + 0.5
+        out2 = torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
+        K.gemm(A, W, M, N, Kd, out=out, out2=out2, bias=torch.ones(N, device=DEV), resid=res, row_scale=rows, dropout=(rng, p, sid))
+        ref = res.cpu() + want * rows.cpu()[:, None]
+        assert torch.allclose(out.cpu(), ref, rtol=1e-6, atol=1e-6) and torch.equal(out2.float(), out.bfloat16().float())
+        g = torch.ones(M, N, device=DEV)
+        back = K.dropout_bwd_bf16(g, (rng, p, sid)).float().cpu()
+        assert torch.equal(back > 0, want > 0) and torch.allclose(back, want, rtol=4e-3)
+        back2 = K.dropout_bwd_bf16(g, (rng, p, sid), row_scale=rows).float().cpu()
+        assert torch.allclose(back2, want * rows.cpu()[:, None], rtol=8e-3)
+    # another step / stream / seed -> another mask
+    a = K.dropout_bwd_bf16(torch.ones(256, 256, device=DEV), (rng, 0.3, 0))
+    rng2 = torch.tensor([seed, step + 1], dtype=torch.int64, device=DEV)
+    assert not torch.equal(a, K.dropout_bwd_bf16(torch.ones(256, 256, device=DEV), (rng2, 0.3, 0)))
+    assert not torch.equal(a, K.dropout_bwd_bf16(torch.ones(256, 256, device=DEV), (rng, 0.3, 1)))
+
+
+def test_dropout_training_parity():
+    """A16: nn.Dropout(drop_rate) after attn.proj / mlp.fc2 fused into the GEMM epilogues (forward) and regenerated for the backward
+    pass, against the REFERENCE model run with the same Philox masks (tests/golden/tiny3_dropout.npz; mirage/utils.py:152,158,172,
+    186-187, mirage/model.py:54,87).  Also: eval mode ignores it, every training forward draws new masks (device-side step counter,
+    also under hipGraph replay), attn_drop_rate > 0 is refused loudly."""
+    from mirage_amd import builder, engine as E
+    from oracle import mirage_oracle as O
+    fx, meta = load_golden("tiny3_dropout")
+    cfg, B, Kk = meta["cfg"], meta["B"], meta["K"]
+    model, args, sd = _build(cfg)
+    model.train()
+    assert all(b.drop_prob == pytest.approx(0.1) and b.drop_stream == 2 * i for i, b in enumerate(model.encoder))
+    x = {d: t.to(DEV) for d, t in O.synthetic_batch(cfg, B, seed=meta["data_seed"]).items()}
+    doms = cfg["in_domains"]
+    noise = (torch.from_numpy(fx["p"]).to(DEV), torch.cat([torch.from_numpy(fx[f"u.{d}"]) for d in doms], 1).to(DEV),
+             torch.from_numpy(fx["g"]).to(DEV))
+    oa = model.output_adapters
+    model.output_adapters = None
+    E.DropoutRNG.set(DEV, meta["drop_seed"], meta["drop_step"] - 1)            # the next forward runs at the fixture's step
+    with torch.no_grad():
+        enc, _ = model({d: x[d] for d in doms}, num_encoded_tokens=Kk, mask_noise=noise)
+    model.output_adapters = oa
+    ref = torch.from_numpy(fx["enc_tokens"])
+    meas = {"enc_rel_rms": rel_rms(enc.float().cpu(), ref)}
+    assert meas["enc_rel_rms"] <= 1e-2
+    loss_fns = builder.get_losses(args)
+    E.DropoutRNG.set(DEV, meta["drop_seed"], meta["drop_step"] - 1)
+    preds, masks = model({d: x[d] for d in doms}, num_encoded_tokens=Kk, mask_noise=noise)
+    total = sum(loss_fns[d](preds[d], x[d], mask=masks.get(d)) for d in preds)
+    meas["loss_rel"] = abs(float(total) - float(fx["loss"])) / abs(float(fx["loss"]))
+    meas["loss_rel_if_dropout_were_off"] = abs(float(fx["loss_without_dropout"]) - float(fx["loss"])) / abs(float(fx["loss"]))
+    assert meas["loss_rel"] <= 3e-3 and meas["loss_rel"] < 0.5 * meas["loss_rel_if_dropout_were_off"], meas
+    total.backward()
+    params = dict(model.named_parameters())
+    tot = float(fx["grad_total_norm"])
+    worst = 0.0
+    for n, gn in zip(fx["grad_names"], fx["grad_norms"]):
+        mine = float(params[str(n)].grad.double().norm())
+        worst = max(worst, abs(mine - gn) / max(gn, 1e-3 * tot))
+    worst_t = 0.0
+    for key in fx:
+        if key.startswith("grad."):
+            r = torch.from_numpy(fx[key]).double()
+            worst_t = max(worst_t, float((params[key[5:]].grad.cpu().double() - r).norm() / max(float(r.norm()), 1e-3 * tot)))
+    meas.update(grad_worst_rel=worst, grad_tensor_worst_rel=worst_t)
+    report("tiny3_dropout", **meas)
+    assert worst <= 1.5e-2 and worst_t <= 3e-2, meas
+    # every training forward advances the device-side step: new masks, different output; eval mode has no dropout at all
+    with torch.no_grad():
+        e1, _ = model({d: x[d] for d in doms}, num_encoded_tokens=Kk, mask_noise=noise)
+        e2, _ = model({d: x[d] for d in doms}, num_encoded_tokens=Kk, mask_noise=noise)
+        assert not torch.equal(e1[d0 := list(e1)[0]], e2[d0])
+        model.eval()
+        v1, _ = model({d: x[d] for d in doms}, num_encoded_tokens=Kk, mask_noise=noise)
+        v2, _ = model({d: x[d] for d in doms}, num_encoded_tokens=Kk, mask_noise=noise)
+        assert torch.equal(v1[d0], v2[d0])
+    # dropout on the attention probabilities is not built: the constructor must say so instead of silently training without it
+    with pytest.raises(NotImplementedError, match="attn_drop"):
+        builder.get_model(args, dim_tokens=cfg["dim"], depth=1, num_heads=cfg["heads"], attn_drop_rate=0.1)
+
+
+def test_dropout_graph_replay_draws_new_masks_and_matches_eager():
+    """TrainStep with drop_rate > 0: the Philox step lives on the device and is advanced inside the captured graph, so replays draw fresh
+    masks, and a graph-replayed run equals the eager run step for step (same seed): losses bit-identical over 4 steps."""
+    from mirage_amd import builder, optim, engine as E
+    from mirage_amd.trainer import TrainStep
+    from oracle import mirage_oracle as O
+    fx, meta = load_golden("tiny3_dropout")
+    cfg, B, Kk = meta["cfg"], meta["B"], meta["K"]
+    doms = cfg["in_domains"]
+    x = {d: t.to(DEV) for d, t in O.synthetic_batch(cfg, B, seed=meta["data_seed"]).items()}
+    noise = (torch.from_numpy(fx["p"]).to(DEV), torch.cat([torch.from_numpy(fx[f"u.{d}"]) for d in doms], 1).to(DEV),
+             torch.from_numpy(fx["g"]).to(DEV))
+
+    def run(use_graph):
+        model, args, _ = _build(cfg)
+        model.train()
+        opt = optim.FusedAdamW(model, [1e-3] * 8, [0.05] * 8)
+        ts = TrainStep(model, builder.get_losses(args), opt, x, Kk, use_graph=use_graph, feed_mask_noise=True)
+        ts.load(x)
+        for dst, src in zip(ts.static_noise, noise):
+            dst.copy_(src)
+        E.DropoutRNG.set(DEV, 4242, 0)
+        ts.warmup_and_capture(warm_iters=1)
+        losses = []
+        for _ in range(4):
+            ts.step(x, noise=noise)
+            losses.append(float(ts.loss))
+        return losses, int(E.DropoutRNG.state(DEV)[1])
+    eager, st_e = run(False)
+    graph, st_g = run(True)
+    assert eager == graph, (eager, graph)
+    assert st_e == st_g == 4                       # warm-up left no trace in the step counter; one step per optimizer step
+    assert len(set(eager)) == 4
 
 
 def test_mixed_token_grids_raise_like_the_reference():

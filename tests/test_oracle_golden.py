@@ -256,3 +256,45 @@ def test_drop_path_training_mode_matches_reference():
     with torch.no_grad():
         l0, _, _, _ = O.forward_loss(cfg, sd, x, _t(fx["ids_keep"]), _t(fx["ids_restore"]))
     assert abs(float(l0) - float(fx["loss"])) > 1e-3
+
+
+def test_philox_known_answer_vectors():
+    """The dropout masks are Philox4x32-10 draws (oracle.philox4x32_10 = csrc/common.h philox4x32_10).  Known-answer vectors of the
+    published generator (Random123 kat_vectors, philox4x32 with 10 rounds): zero, all-ones and the pi-digits counter / key."""
+    kat = [((0, 0, 0, 0), (0, 0), (0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8)),
+           ((0xffffffff,) * 4, (0xffffffff,) * 2, (0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd)),
+           ((0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344), (0xa4093822, 0x299f31d0), (0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1))]
+    for ctr, key, want in kat:
+        got = O.philox4x32_10(np.array(ctr, dtype=np.uint32), np.array(key, dtype=np.uint32))
+        assert tuple(int(v) for v in got) == want
+    # batched evaluation == one at a time; the mask rate follows p; different streams / steps give different masks
+    ctrs = np.array([k[0] for k in kat], dtype=np.uint32)
+    keys = np.array([k[1] for k in kat], dtype=np.uint32)
+    assert np.array_equal(O.philox4x32_10(ctrs, keys), np.array([k[2] for k in kat], dtype=np.uint32))
+    f = O.dropout_factor(256, 128, 0.1, 99, 1, 0)
+    assert abs(float((f == 0).float().mean()) - 0.1) < 0.01 and float(f.max()) == pytest.approx(1 / 0.9)
+    assert not torch.equal(f, O.dropout_factor(256, 128, 0.1, 99, 1, 1)) and not torch.equal(f, O.dropout_factor(256, 128, 0.1, 99, 2, 0))
+
+
+def test_dropout_training_mode_matches_reference():
+    """nn.Dropout(0.1) after attn.proj / mlp.fc2 of the encoder blocks (A16; mirage/utils.py:152,158,172,186-187): the fixture is the
+    reference model with its Dropout modules fed the Philox masks (tools/gen_golden.py run_dropout_case); the oracle must reproduce its
+    encoder tokens, loss and every gradient norm, and must differ when the masks are left out."""
+    fx, meta = load_golden("tiny3_dropout")
+    cfg, B, K = meta["cfg"], meta["B"], meta["K"]
+    assert cfg["drop_rate"] == pytest.approx(0.1)
+    state = (meta["drop_seed"], meta["drop_step"])
+    sd = {k: v.clone().requires_grad_(O.param_shapes(cfg)[k][1]) for k, v in O.procedural_state_dict(cfg).items()}
+    x = O.synthetic_batch(cfg, B, seed=meta["data_seed"])
+    loss, ls, enc, _ = O.forward_loss(cfg, sd, x, _t(fx["ids_keep"]), _t(fx["ids_restore"]), drop_state=state)
+    np.testing.assert_allclose(enc.detach().numpy(), fx["enc_tokens"], rtol=2e-5, atol=5e-5)
+    assert abs(float(loss) - float(fx["loss"])) <= 1e-5 * abs(float(fx["loss"]))
+    loss.backward()
+    for n, gn in zip(fx["grad_names"], fx["grad_norms"]):
+        g = sd[str(n)].grad
+        assert g is not None, n
+        assert abs(float(g.double().norm()) - gn) <= 2e-4 * max(gn, 1e-3 * float(fx["grad_total_norm"])), (str(n), float(g.double().norm()), gn)
+    with torch.no_grad():
+        l0, _, _, _ = O.forward_loss(cfg, sd, x, _t(fx["ids_keep"]), _t(fx["ids_restore"]))
+    assert abs(float(l0) - float(fx["loss_without_dropout"])) <= 1e-5 * abs(float(l0))
+    assert abs(float(l0) - float(fx["loss"])) > 1e-3 * abs(float(l0))

@@ -41,7 +41,7 @@ with contextlib.redirect_stdout(io.StringIO()):
 OUT = os.path.join(ROOT, "tests", "golden")
 
 
-def build_reference(cfg, drop_path_rate=0.0):
+def build_reference(cfg, drop_path_rate=0.0, drop_rate=0.0):
     """Adapters exactly as run_pretraining.py:380-403 builds them, model as mirage/model.py:43."""
     args = types.SimpleNamespace()
     args.input_size = {d: (c["image"], c["image"]) for d, c in cfg["domains"].items()}
@@ -64,7 +64,7 @@ def build_reference(cfg, drop_path_rate=0.0):
                                      image_size=(c["image"], c["image"]))
     model = MIRAGEModel(args, input_adapters=ia, output_adapters=oa if cfg["out_domains"] else None,
                         num_global_tokens=cfg["num_global_tokens"], dim_tokens=cfg["dim"], depth=cfg["depth"],
-                        num_heads=cfg["heads"], drop_path_rate=drop_path_rate)
+                        num_heads=cfg["heads"], drop_path_rate=drop_path_rate, drop_rate=drop_rate)
     return model
 
 
@@ -234,6 +234,98 @@ def run_droppath_case(name, cfg, B, K, data_seed, mask_seed):
           [(torch.floor(1 - r + dp[j]) == 0).sum().item() for j, r in enumerate([r for r in rates if r > 0.0])])
     assert err < 1e-4 and abs(float(ol) - loss.item()) < 1e-5 * abs(loss.item())
     fx["meta"] = np.array(json.dumps(dict(cfg=cfg, B=B, K=K, data_seed=data_seed, mask_seed=mask_seed)))
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **fx)
+
+
+class ReplayedDropout(torch.nn.Module):
+    """Stand-in for the reference's nn.Dropout modules (mirage/utils.py:152,172): same place in the graph, same semantics (zero with
+    probability p, survivors scaled by 1 / (1 - p)), but the mask comes from the engine's counter-based definition
+    (oracle.dropout_factor: Philox4x32-10 over (seed, step, stream, row, col)) instead of torch's unreplayable generator."""
+
+    def __init__(self, p, seed, step, stream):
+        super().__init__()
+        self.p, self.seed, self.step, self.stream = p, seed, step, stream
+
+    def forward(self, x):
+        B, N, D = x.shape
+        return x * O.dropout_factor(B * N, D, self.p, self.seed, self.step, self.stream).reshape(B, N, D).to(x.dtype)
+
+
+def run_dropout_case(name, cfg, B, K, data_seed, mask_seed, drop_seed, drop_step):
+    """nn.Dropout(drop_rate) after attn.proj and mlp.fc2 of every encoder block (mirage/model.py:54,87 -> mirage/utils.py:158,187) in
+    training mode: the REFERENCE model, forward + losses + backward, with its Dropout modules replaced by ReplayedDropout."""
+    p_drop = cfg["drop_rate"]
+    print(f"== {name}: B={B} K={K} drop_rate={p_drop}")
+    with contextlib.redirect_stdout(io.StringIO()):
+        model = build_reference(cfg, drop_rate=p_drop)
+    model.load_state_dict(O.procedural_state_dict(cfg), strict=True)
+    model.train()
+    n_swapped = 0
+    for i, blk in enumerate(model.encoder):
+        assert isinstance(blk.attn.proj_drop, torch.nn.Dropout) and blk.attn.proj_drop.p == p_drop
+        assert isinstance(blk.mlp.drop, torch.nn.Dropout) and blk.mlp.drop.p == p_drop
+        blk.attn.proj_drop = ReplayedDropout(p_drop, drop_seed, drop_step, 2 * i)
+        blk.mlp.drop = ReplayedDropout(p_drop, drop_seed, drop_step, 2 * i + 1)
+        n_swapped += 2
+    left = [n for n, m in model.named_modules() if isinstance(m, torch.nn.Dropout) and m.p > 0]
+    assert not left, left                                       # every active Dropout of the model is replayed
+    x = O.synthetic_batch(cfg, B, seed=data_seed)
+    x_in = {d: x[d] for d in cfg["in_domains"]}
+    p, u, g = replay_mask_noise(cfg, B, mask_seed)
+    fx = {"p": p, "g": g}
+    for d, ud in zip(cfg["in_domains"], u):
+        fx[f"u.{d}"] = ud
+    captured = {}
+    first = cfg["out_domains"][0]
+    orig = model.output_adapters[first].forward
+
+    def spy(encoder_tokens, input_info, ids_keep, ids_restore):
+        captured["enc"] = encoder_tokens
+        captured["ids_keep"], captured["ids_restore"] = ids_keep, ids_restore
+        return orig(encoder_tokens=encoder_tokens, input_info=input_info, ids_keep=ids_keep, ids_restore=ids_restore)
+    model.output_adapters[first].forward = spy
+    torch.manual_seed(mask_seed)
+    with contextlib.redirect_stdout(io.StringIO()):
+        preds, task_masks = model(x_in, num_encoded_tokens=K, alphas=1.0, sample_tasks_uniformly=False)
+    fx["ids_keep"], fx["ids_restore"] = captured["ids_keep"].numpy(), captured["ids_restore"].numpy()
+    fx["enc_tokens"] = captured["enc"].detach().numpy()
+    loss_fns = reference_losses(cfg)
+    task_losses = {d: loss_fns[d](preds[d].float(), x[d], mask=task_masks.get(d)) for d in preds}
+    loss = sum(task_losses.values())
+    for d in preds:
+        fx[f"loss.{d}"] = np.float64(task_losses[d].item())
+    fx["loss"] = np.float64(loss.item())
+    loss.backward()
+    names, norms = [], []
+    for n_, p_ in model.named_parameters():
+        if p_.grad is not None:
+            names.append(n_); norms.append(p_.grad.double().norm().item())
+    fx["grad_names"] = np.array(names)
+    fx["grad_norms"] = np.array(norms, dtype=np.float64)
+    fx["grad_total_norm"] = np.float64(get_grad_norm_(model.parameters()).item())
+    for n_ in ("encoder.0.attn.proj.weight", f"encoder.{cfg['depth'] - 1}.mlp.fc2.bias", "encoder.1.mlp.fc1.weight", "global_tokens"):
+        fx[f"grad.{n_}"] = dict(model.named_parameters())[n_].grad.detach().numpy()
+    # the same pass without dropout: how much the masks matter (a test that passes with dropout silently off would be worthless)
+    with contextlib.redirect_stdout(io.StringIO()):
+        ref0 = build_reference(cfg, drop_rate=0.0)
+    ref0.load_state_dict(O.procedural_state_dict(cfg), strict=True)
+    ref0.train()
+    torch.manual_seed(mask_seed)
+    with contextlib.redirect_stdout(io.StringIO()):
+        preds0, tm0 = ref0(x_in, num_encoded_tokens=K, alphas=1.0, sample_tasks_uniformly=False)
+    loss0 = sum(loss_fns[d](preds0[d].float(), x[d], mask=tm0.get(d)) for d in preds0)
+    fx["loss_without_dropout"] = np.float64(loss0.item())
+    # the oracle must reproduce the reference
+    ik, ir = torch.from_numpy(fx["ids_keep"]), torch.from_numpy(fx["ids_restore"])
+    sd = {k: v.clone().requires_grad_(False) for k, v in O.procedural_state_dict(cfg).items()}
+    with torch.no_grad():
+        ol, _, oenc, _ = O.forward_loss(cfg, sd, x, ik, ir, drop_state=(drop_seed, drop_step))
+    err = (oenc - captured["enc"].detach()).abs().max().item()
+    print(f"   oracle vs reference: enc max abs err {err:.3e}, loss {float(ol):.6f} vs {loss.item():.6f} (without dropout {loss0.item():.6f}); "
+          f"{n_swapped} Dropout modules replayed")
+    assert err < 1e-4 and abs(float(ol) - loss.item()) < 1e-5 * abs(loss.item())
+    assert abs(loss0.item() - loss.item()) > 1e-3 * abs(loss.item())
+    fx["meta"] = np.array(json.dumps(dict(cfg=cfg, B=B, K=K, data_seed=data_seed, mask_seed=mask_seed, drop_seed=drop_seed, drop_step=drop_step)))
     np.savez_compressed(os.path.join(OUT, name + ".npz"), **fx)
 
 
@@ -493,6 +585,10 @@ def main():
         "tiny3_curve": lambda: run_train_curve("tiny3_curve", tiny_cfg(three), B=4, K=24, steps=5),
         "harness": lambda: run_harness_fixtures(tiny_cfg(three)),
         "tiny3_optstate": lambda: run_optstate_case("tiny3_optstate", tiny_cfg(three), B=4, K=24, steps=4),
+        "tiny3_dropout": lambda: run_dropout_case("tiny3_dropout", dict(O.make_config(model="tiny", in_domains=three, input_size=64, patch_size=8,
+                                                  layermap_size=16, layermap_patch=2, decoder_dim=64, decoder_depth=2, decoder_heads=2,
+                                                  dim=128, depth=4, heads=2), drop_rate=0.1), B=6, K=24, data_seed=17, mask_seed=29,
+                                                  drop_seed=0x1234ABCD5678, drop_step=3),
         "tiny3_droppath": lambda: run_droppath_case("tiny3_droppath", dict(O.make_config(model="tiny", in_domains=three, input_size=64, patch_size=8,
                                                     layermap_size=16, layermap_patch=2, decoder_dim=64, decoder_depth=2, decoder_heads=2,
                                                     dim=128, depth=4, heads=2, drop_path_rate=0.4)), B=6, K=24, data_seed=13, mask_seed=23),
