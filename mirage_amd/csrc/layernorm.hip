@@ -179,6 +179,175 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const void* __restrict__ dy
     }
 }
 
+
+// ---- rows of at most 256 elements (the 256-wide output adapters, mirage/output_adapters.py:279-280 and their decoder blocks) -------
+// A wave per row leaves 48 of 64 lanes with one float4 and makes every row pay two 6-step cross-lane reductions: 13.9 us for a
+// 16384 x 256 forward whose traffic is worth 5 us, and no faster for a third of the rows.  Here 16 lanes own a row (NV float4 each),
+// a wave works on 4 rows at once and the reductions are 4 DPP steps inside the 16-lane row (quad swaps, half mirror, row mirror).
+__device__ __forceinline__ float row16_sum(float v) {
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));    // quad_perm [1,0,3,2]
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));    // quad_perm [2,3,0,1]
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true));   // row_half_mirror
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xF, 0xF, true));   // row_mirror
+    return v;
+}
+
+template <int NV>
+__global__ __launch_bounds__(256) void ln_fwd_small_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                           const float* __restrict__ beta, bf16_t* __restrict__ y,
+                                                           float* __restrict__ y32, float* __restrict__ mean,
+                                                           float* __restrict__ rstd, int M, int D, float eps) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int sub = lane & 15;                       // lane within the row
+    const int row = (blockIdx.x * 4 + wave) * 4 + (lane >> 4);
+    const int nv = D >> 2;
+    const float invD = 1.f / (float)D;
+    const int rr = row < M ? row : M - 1;            // clamped: every lane takes part in the DPP reductions
+    const float4* xr = reinterpret_cast<const float4*>(x + (long)rr * D);
+    const float4* g4 = reinterpret_cast<const float4*>(gamma);
+    const float4* b4 = reinterpret_cast<const float4*>(beta);
+    float4 v[NV], gv[NV], bv[NV];
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+        const int c = sub + 16 * j;
+        if (c < nv) { v[j] = xr[c]; gv[j] = g4[c]; bv[j] = b4[c]; }
+        else v[j] = gv[j] = bv[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < NV; ++j) s += (v[j].x + v[j].y) + (v[j].z + v[j].w);
+    const float mu = row16_sum(s) * invD;
+    float q = 0.f;
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+        if (sub + 16 * j < nv) {
+            const float a = v[j].x - mu, b = v[j].y - mu, c2 = v[j].z - mu, d = v[j].w - mu;
+            q += (a * a + b * b) + (c2 * c2 + d * d);
+        }
+    }
+    const float rs = rsqrtf(row16_sum(q) * invD + eps);
+    if (row >= M) return;
+    if (sub == 0) { mean[row] = mu; rstd[row] = rs; }
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+        const int c = sub + 16 * j;
+        if (c < nv) {
+            const float4 g = gv[j], b = bv[j];
+            const float o0 = (v[j].x - mu) * rs * g.x + b.x, o1 = (v[j].y - mu) * rs * g.y + b.y;
+            const float o2 = (v[j].z - mu) * rs * g.z + b.z, o3 = (v[j].w - mu) * rs * g.w + b.w;
+            if (y) reinterpret_cast<uint2*>(y + (long)row * D)[c] = make_uint2(pack_bf2(o0, o1), pack_bf2(o2, o3));
+            if (y32) reinterpret_cast<float4*>(y32 + (long)row * D)[c] = make_float4(o0, o1, o2, o3);
+        }
+    }
+}
+
+// backward for rows of at most 256 elements: same contract as ln_bwd_kernel (partials [gridDim.x][3][D]); 16 lanes per row, a wave
+// walks 4 rows per step with the next step's operands requested before this step's reductions.
+template <int NV, bool DY16, bool HAS_RES>
+__global__ __launch_bounds__(256) void ln_bwd_small_kernel(const void* __restrict__ dyp, const float* __restrict__ x,
+                                                           const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                           const float* __restrict__ gamma, const float* __restrict__ dres,
+                                                           float* __restrict__ dx32, bf16_t* __restrict__ dx16,
+                                                           float* __restrict__ partials, int M, int D) {
+    __shared__ __attribute__((aligned(16))) float buf[16][NV * 64];         // [wave * 4 + row group][D <= 256]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int sub = lane & 15, grp = lane >> 4;
+    const int nv = D >> 2;
+    const float invD = 1.f / (float)D;
+    float4 ag[NV], ab[NV], ar[NV], gm[NV];
+    const float4* g4 = reinterpret_cast<const float4*>(gamma);
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+        ag[j] = ab[j] = ar[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+        const int c = sub + 16 * j;
+        gm[j] = c < nv ? g4[c] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    const bf16_t* dy16 = reinterpret_cast<const bf16_t*>(dyp);
+    const float* dy32 = reinterpret_cast<const float*>(dyp);
+    float4 xn[NV], dn[NV], rn[NV];
+    float mun = 0.f, rsn = 0.f;
+    auto fetch = [&](int row) {
+        const int r = row < M ? row : M - 1;
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+            const int c = sub + 16 * j;
+            const int cc = c < nv ? c : 0;
+            xn[j] = reinterpret_cast<const float4*>(x + (long)r * D)[cc];
+            if (DY16) { const uint2 u = reinterpret_cast<const uint2*>(dy16 + (long)r * D)[cc]; dn[j].x = __uint_as_float(u.x); dn[j].y = __uint_as_float(u.y); }
+            else dn[j] = reinterpret_cast<const float4*>(dy32 + (long)r * D)[cc];
+            if (HAS_RES) rn[j] = reinterpret_cast<const float4*>(dres + (long)r * D)[cc];
+        }
+        mun = mean[r]; rsn = rstd[r];
+    };
+    const int row0 = (blockIdx.x * 4 + wave) * 4 + grp, rstep = gridDim.x * 16;
+    const int base0 = (blockIdx.x * 4 + wave) * 4;          // wave-uniform loop bound: all four row groups run the same trip count
+    if (base0 < M) fetch(row0);
+    for (int base = base0, row = row0; base < M; base += rstep, row += rstep) {
+        const bool live = row < M;
+        float4 xv[NV], dyv[NV], rv[NV];
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+            const bool ok = live && (sub + 16 * j) < nv;
+            xv[j] = xn[j];
+            if (DY16) dyv[j] = bf4_to_f4(make_uint2(__float_as_uint(dn[j].x), __float_as_uint(dn[j].y)));
+            else dyv[j] = dn[j];
+            if (HAS_RES) rv[j] = rn[j];
+            if (!ok) { xv[j] = dyv[j] = make_float4(0.f, 0.f, 0.f, 0.f); if (HAS_RES) rv[j] = xv[j]; }
+        }
+        const float mu = mun, rs = rsn;
+        if (base + rstep < M) fetch(row + rstep);
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+            const bool ok = live && (sub + 16 * j) < nv;
+            float4 xh = make_float4((xv[j].x - mu) * rs, (xv[j].y - mu) * rs, (xv[j].z - mu) * rs, (xv[j].w - mu) * rs);
+            if (!ok) xh = make_float4(0.f, 0.f, 0.f, 0.f);
+            xv[j] = xh;
+            const float4 d = dyv[j];
+            const float w0 = d.x * gm[j].x, w1 = d.y * gm[j].y, w2 = d.z * gm[j].z, w3 = d.w * gm[j].w;
+            s1 += (w0 + w1) + (w2 + w3);
+            s2 += (w0 * xh.x + w1 * xh.y) + (w2 * xh.z + w3 * xh.w);
+            ag[j].x += d.x * xh.x; ag[j].y += d.y * xh.y; ag[j].z += d.z * xh.z; ag[j].w += d.w * xh.w;
+            ab[j].x += d.x; ab[j].y += d.y; ab[j].z += d.z; ab[j].w += d.w;
+        }
+        const float m1 = row16_sum(s1) * invD, m2 = row16_sum(s2) * invD;
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+            const int c = sub + 16 * j;
+            if (live && c < nv) {
+                float4 o;
+                o.x = rs * (dyv[j].x * gm[j].x - m1 - xv[j].x * m2);
+                o.y = rs * (dyv[j].y * gm[j].y - m1 - xv[j].y * m2);
+                o.z = rs * (dyv[j].z * gm[j].z - m1 - xv[j].z * m2);
+                o.w = rs * (dyv[j].w * gm[j].w - m1 - xv[j].w * m2);
+                if (HAS_RES) {
+                    o.x += rv[j].x; o.y += rv[j].y; o.z += rv[j].z; o.w += rv[j].w;
+                    ar[j].x += rv[j].x; ar[j].y += rv[j].y; ar[j].z += rv[j].z; ar[j].w += rv[j].w;
+                }
+                if (dx32) reinterpret_cast<float4*>(dx32 + (long)row * D)[c] = o;
+                if (dx16) reinterpret_cast<uint2*>(dx16 + (long)row * D)[c] = make_uint2(pack_bf2(o.x, o.y), pack_bf2(o.z, o.w));
+            }
+        }
+    }
+    float* outp = partials + (long)blockIdx.x * 3 * D;
+#pragma unroll
+    for (int qn = 0; qn < 3; ++qn) {
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+            const int c = sub + 16 * j;
+            if (c < nv) reinterpret_cast<float4*>(&buf[wave * 4 + grp][0])[c] = qn == 0 ? ag[j] : (qn == 1 ? ab[j] : ar[j]);
+        }
+        __syncthreads();
+        for (int c = threadIdx.x; c < D; c += 256) {
+            float t = 0.f;
+#pragma unroll
+            for (int w = 0; w < 16; ++w) t += buf[w][c];
+            outp[qn * D + c] = t;
+        }
+        __syncthreads();
+    }
+}
+
 // out_q[c] = sum_b partials[b][q][c]; grid (ceil(D/64), nq), 1024 threads: lane = column, 16 waves split the rows
 __global__ __launch_bounds__(1024) void colsum_partials_kernel(const float* __restrict__ partials, int nblocks, int nq, int D,
                                                                float* o0, float* o1, float* o2) {
@@ -342,6 +511,15 @@ extern "C" int mrg_ln_fwd(const float* x, const float* gamma, const float* beta,
     MRG_REQUIRE(x && gamma && beta && mean && rstd && (y_bf16 || y_f32), MRG_ERR_ARG, "mrg_ln_fwd: null pointer");
     MRG_REQUIRE(M > 0 && D > 0 && D % 4 == 0 && D <= 1024, MRG_ERR_SHAPE, "mrg_ln_fwd: need D %% 4 == 0 and D <= 1024 (D=%d)", D);
     static const int band = [] { const char* e = getenv("MRG_LN_BAND"); return e ? atoi(e) : 1; }();   // same box: C2 9.527 -> 9.500 ms (3 of 3 pairs), C4 within noise
+    static const int small = [] { const char* e = getenv("MRG_LN_SMALL"); return e ? atoi(e) : 1; }();  // A/B: 0 = wave per row also for D <= 256
+    if (small && D <= 256) {
+        const dim3 grid(cdiv(M, 16)), block(256);
+        const int nvr = cdiv(D, 64);
+#define MRG_LNF(NV_) hipLaunchKernelGGL((ln_fwd_small_kernel<NV_>), grid, block, 0, stream, x, gamma, beta, (bf16_t*)y_bf16, y_f32, mean, rstd, M, D, eps)
+        if (nvr == 1) MRG_LNF(1); else if (nvr == 2) MRG_LNF(2); else if (nvr == 3) MRG_LNF(3); else MRG_LNF(4);
+#undef MRG_LNF
+        return mrg_check_launch("mrg_ln_fwd");
+    }
     hipLaunchKernelGGL(ln_fwd_kernel, dim3(cdiv(M, 4)), dim3(256), 0, stream, x, gamma, beta, (bf16_t*)y_bf16, y_f32, mean, rstd, M,
                        D, eps, band);
     return mrg_check_launch("mrg_ln_fwd");
@@ -377,6 +555,17 @@ extern "C" int mrg_ln_bwd(const void* dy_bf16, const float* dy_f32, const float*
                                                    gamma, dres, dx_f32, (bf16_t*)dx_bf16, partials, M, D)
 #define MRG_LNB2(NV_) do { if (dy_bf16) { if (dres) MRG_LNB(NV_, true, true); else MRG_LNB(NV_, true, false); } \
                            else { if (dres) MRG_LNB(NV_, false, true); else MRG_LNB(NV_, false, false); } } while (0)
+    static const int small = [] { const char* e = getenv("MRG_LN_SMALL"); return e ? atoi(e) : 1; }();
+    if (small && D <= 256) {
+        const int nvs = cdiv(D, 64);
+#define MRG_LNS(NV_, D16, RES) hipLaunchKernelGGL((ln_bwd_small_kernel<NV_, D16, RES>), dim3(nb), dim3(256), 0, stream, dyp, x, mean, rstd, \
+                                                   gamma, dres, dx_f32, (bf16_t*)dx_bf16, partials, M, D)
+#define MRG_LNS2(NV_) do { if (dy_bf16) { if (dres) MRG_LNS(NV_, true, true); else MRG_LNS(NV_, true, false); } \
+                           else { if (dres) MRG_LNS(NV_, false, true); else MRG_LNS(NV_, false, false); } } while (0)
+        if (nvs == 1) MRG_LNS2(1); else if (nvs == 2) MRG_LNS2(2); else if (nvs == 3) MRG_LNS2(3); else MRG_LNS2(4);
+#undef MRG_LNS2
+#undef MRG_LNS
+    } else
     if (NVr == 1) MRG_LNB2(1); else if (NVr == 2) MRG_LNB2(2); else if (NVr == 3) MRG_LNB2(3); else MRG_LNB2(4);
 #undef MRG_LNB2
 #undef MRG_LNB
