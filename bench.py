@@ -211,8 +211,11 @@ def measure(a, cfg_name, steps, warmup, batch, rank, world, dev, force_dp, ranks
         # exclusively (profiles/r01_c2_timeline.md), whereas a fully pre-queued eager step would overlap the two streams
         # maximally and inflate every per-launch duration
         from mirage_amd import engine as _E
-        side_was = _E._Side.enabled
+        side_was, chains_was = _E._Side.enabled, _E.TWO_CHAINS
         _E._Side.enabled = False
+        # ... and the forward runs as ONE chain of full-batch launches (production: two half-batch chains on two streams, whose
+        # launches overlap pairwise and therefore have no exclusive duration to divide the flops by)
+        _E.TWO_CHAINS = 0
         try:
             if train:
                 # forward + losses + backward only, with the reducer detached: rank 0 runs this step alone, so nothing in it
@@ -230,7 +233,7 @@ def measure(a, cfg_name, steps, warmup, batch, rank, world, dev, force_dp, ranks
                 fwd()
         finally:
             K.TIMING["on"] = False
-            _E._Side.enabled = side_was
+            _E._Side.enabled, _E.TWO_CHAINS = side_was, chains_was
         torch.cuda.synchronize()
         vname = {0: "auto", 1: "gemm_glds_kernel", 2: "gemm_glds_kernel", 3: "gemm_pipe_kernel", 4: "gemm_pipe256_kernel",
                  5: "gemm_pipe256_kernel", 6: "gemm_pipe256sq_kernel", 7: "gemm_ws256_kernel", 8: "gemm_glds64_kernel",
@@ -283,6 +286,7 @@ def measure(a, cfg_name, steps, warmup, batch, rank, world, dev, force_dp, ranks
             "config": {"workload": f"{cfg_name}: {model_name} 512/32 {'+'.join(doms)}, per-GPU batch {B}, {Kk} of {256 * len(doms)} tokens encoded, "
                                    f"{'fwd+loss+bwd+AdamW' if train else 'encoder forward only'}",
                        "global_batch": B * world, "parallelism": f"dp{world}", "hipgraph": not a.no_graph,
+                       "forward_chains": 2 if (_E.TWO_CHAINS == 2 or (_E.TWO_CHAINS == 1 and not train)) else 1,
                        "gflop_per_image": round(fpi / 1e9, 2)},
             "mfma_frac_of_peak": round(value / world * fpi / MFMA_BF16_PEAK, 4),
             "roofline": roofline,

@@ -88,6 +88,27 @@ __device__ __forceinline__ bf16x8 frag_cols_tr(uint32_t lds_base, int row0, int 
     return f;
 }
 
+// the same two with the row index clamped to `rmax` (the zero row of a compactly stored tile: rows N .. 32 * ceil(N / 32) - 1 of a
+// padded tile do not exist in LDS, they all alias one zero row -- 132 instead of 160 rows at N = 129)
+template <int HD, int SWZ>
+__device__ __forceinline__ bf16x8 frag_rows_cl(const char* lds, int row0, int kk, int lane, int rmax) {
+    const int r = min(row0 + (lane & 31), rmax);
+    return *reinterpret_cast<const bf16x8*>(lds + tile_off<HD, SWZ>(r, kk * 2 + (lane >> 5)));
+}
+template <int HD, int SWZ>
+__device__ __forceinline__ bf16x8 frag_cols_tr_cl(uint32_t lds_base, int row0, int mf, int dj, int lane, int rmax) {
+    const int i = lane & 15;
+    const int d = dj * 32 + (lane & 16) + ((i & 3) << 2);
+    const int r0u = row0 + 16 * mf + 4 * (lane >> 5) + (i >> 2);
+    const int r0 = min(r0u, rmax), r1 = min(r0u + 8, rmax);
+    const s16x4 lo = lds_read_tr16(lds_base + tile_off<HD, SWZ>(r0, d >> 3) + ((d & 4) << 1));
+    const s16x4 hi = lds_read_tr16(lds_base + tile_off<HD, SWZ>(r1, d >> 3) + ((d & 4) << 1));
+    bf16x8 f;
+    f[0] = lo[0]; f[1] = lo[1]; f[2] = lo[2]; f[3] = lo[3];
+    f[4] = hi[0]; f[5] = hi[1]; f[6] = hi[2]; f[7] = hi[3];
+    return f;
+}
+
 __device__ __forceinline__ bf16x8 pack8(const f32x16& s, int mf) {
     bf16x8 f;
     const int b = mf * 8;
@@ -113,6 +134,8 @@ struct AttnArgs {
     bf16_t* dq; bf16_t* dk; bf16_t* dv;
     long dq_bs, dq_rs, dk_bs, dk_rs, dv_bs, dv_rs;
     int chunk_rows;
+    int rmax;         // forward, resident K / V stored compactly: index of the zero row every out-of-range key row is clamped to (else INT_MAX)
+    int stage_tail;   // forward: rows of the LAST wave's staging tile when it was allocated short (0: every wave has 32 rows)
     float* cs_q; float* cs_k; float* cs_v; long cs_bs;   // optional per-(batch, head) column sums of dQ / dK / dV (bias gradients)
 };
 
@@ -124,8 +147,9 @@ struct AttnArgs {
 // store 2 bytes at a time.
 constexpr int FUSED_SP = 144;                     // staging pitch (bytes) of a 64-column bf16 row: 16-B aligned, 36 banks
 template <int DJ>
-__device__ __forceinline__ void fused_stage(char* stg, const f32x16 (&acc)[DJ], int lane) {
+__device__ __forceinline__ void fused_stage(char* stg, const f32x16 (&acc)[DJ], int lane, int nrows = 32) {
     const int rr = lane & 31, hf = lane >> 5;
+    if (rr >= nrows) return;                      // a short staging tile (the row tail of the last query tile) holds only nrows rows
 #pragma unroll
     for (int dj = 0; dj < DJ; ++dj)
 #pragma unroll
@@ -149,8 +173,8 @@ __device__ __forceinline__ void fused_flush(const char* stg, bf16_t* __restrict_
 #pragma unroll
     for (int j = 0; j < 32 / RPI; ++j) {
         const int rr = lane / CPR + RPI * j, c = lane % CPR;
-        const uint4 v = *reinterpret_cast<const uint4*>(stg + rr * FUSED_SP + c * 16);
         if (row0 + rr < N) {
+            const uint4 v = *reinterpret_cast<const uint4*>(stg + rr * FUSED_SP + c * 16);
             *reinterpret_cast<uint4*>(dst + (long)(row0 + rr) * rs + c * 8) = v;
             if (CS) {
                 const uint32_t w[4] = {v.x, v.y, v.z, v.w};
@@ -239,10 +263,10 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_kernel(const AttnArgs a) {
             for (int kb = 0; kb < CB; ++kb) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) s[kb][r] = 0.f;
-                if (kb * 32 < kvalid) {
+                if (kb * 32 < kvalid) {                // rows past the last key alias the zero row of a compactly stored tile (a.rmax)
 #pragma unroll
                     for (int kk = 0; kk < KS; ++kk)
-                        s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows<HD, SWZ_ROW>(ldsK, lbase + kb * 32, kk, lane), qf[kk], s[kb], 0, 0, 0);
+                        s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows_cl<HD, SWZ_ROW>(ldsK, lbase + kb * 32, kk, lane, a.rmax), qf[kk], s[kb], 0, 0, 0);
                 }
                 if (kb * 32 + 32 > kvalid) {         // only the last, partial key block needs the key-range test
 #pragma unroll
@@ -281,7 +305,7 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_kernel(const AttnArgs a) {
                         const bf16x8 pa = pack8(s[kb], mf);
 #pragma unroll
                         for (int dj = 0; dj < DJ; ++dj)
-                            o[dj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_cols_tr<HD, SWZ_TR>(ldsV_u, lbase + kb * 32, mf, dj, lane), pa, o[dj], 0, 0, 0);
+                            o[dj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_cols_tr_cl<HD, SWZ_TR>(ldsV_u, lbase + kb * 32, mf, dj, lane, a.rmax), pa, o[dj], 0, 0, 0);
                     }
                 }
             }
@@ -296,7 +320,7 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_kernel(const AttnArgs a) {
         if (STAGE) {
             char* stg = smem + 2 * lds_rows * HD * 2 + wave * (32 * FUSED_SP);
             float unused[8];
-            fused_stage<DJ>(stg, o, lane);
+            fused_stage<DJ>(stg, o, lane, (a.stage_tail && qt == nqt - 1) ? a.stage_tail : 32);
             fused_flush<DJ, false>(stg, op, a.o_rs, q0, a.Nq, lane, unused);
         } else {
             const int qr = q0 + (lane & 31);
@@ -878,12 +902,23 @@ int launch_fwd(const AttnArgs& a0, hipStream_t stream) {
     const int nkb = (a.Nk + 31) / 32;
     dim3 grid(a.H, a.B), block(64 * waves_for((a.Nq + 31) / 32));
     // K and V of the whole row stay in LDS when that leaves room for two workgroups per CU (<= 80 KiB)
+    // Resident K / V are stored compactly: rows N .. (padded to 32) alias ONE zero row (index rmax), and the last wave's staging tile holds
+    // only its valid rows -- at N = 129 that is 132 instead of 160 rows per tile and 52.8 instead of 63 KiB per workgroup: three
+    // workgroups per CU instead of two, i.e. the 768 (batch, head) pairs of C2 in ONE round instead of two (19.4 -> ~14 us);
+    // N = 99 (C4): 40 instead of 50 KiB, four per CU instead of three (1024 pairs in one round).
+    static const int compact = [] { const char* e = getenv("MRG_ATTN_COMPACT"); return e ? atoi(e) : 1; }();
 #define MRG_FWD(CB_) do { const bool fits = (size_t)2 * nkb * 32 * HD * 2 <= 80 * 1024; \
         a.chunk_rows = fits ? nkb * 32 : CB_ * 32; \
         if (a.chunk_rows < CB_ * 32) a.chunk_rows = CB_ * 32; \
+        a.rmax = 0x7fffffff; a.stage_tail = 0; \
+        const int nwav = block.x / 64, nqt_ = (a.Nq + 31) / 32; \
+        if (compact && fits && (a.Nk & 31) && CB_ == 1) { a.chunk_rows = ((a.Nk + 1 + 3) / 4) * 4; a.rmax = a.chunk_rows - 1; } \
         const size_t kv = (size_t)2 * a.chunk_rows * HD * 2; \
-        const size_t stg = (size_t)(block.x / 64) * 32 * FUSED_SP; \
+        size_t stg = (size_t)nwav * 32 * FUSED_SP; \
+        if (compact && nqt_ == nwav && (a.Nq & 31) && (a.Nq & 31) <= 16) { a.stage_tail = (((a.Nq & 31) + 3) / 4) * 4; \
+                                                                          stg = (size_t)(nwav - 1) * 32 * FUSED_SP + (size_t)a.stage_tail * FUSED_SP; } \
         const bool stage = kv + stg <= 80 * 1024;        /* staging must not cost the second workgroup per CU */ \
+        if (!stage) a.stage_tail = 0; \
         const size_t sh = stage ? kv + stg : kv; \
         if (stage) { if (sh > 65536) (void)hipFuncSetAttribute((const void*)attn_fwd_kernel<HD, CB_, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
                      hipLaunchKernelGGL((attn_fwd_kernel<HD, CB_, true>), grid, block, sh, stream, a); } \
@@ -919,7 +954,7 @@ void fill(AttnArgs& a, const mrg_attn_desc* d) {
     a.d_o = (const bf16_t*)d->d_o; a.do_bs = d->do_bs; a.do_rs = d->do_rs; a.dsum = d->dsum;
     a.dq = (bf16_t*)d->dq; a.dk = (bf16_t*)d->dk; a.dv = (bf16_t*)d->dv;
     a.dq_bs = d->dq_bs; a.dq_rs = d->dq_rs; a.dk_bs = d->dk_bs; a.dk_rs = d->dk_rs; a.dv_bs = d->dv_bs; a.dv_rs = d->dv_rs;
-    a.chunk_rows = 0;
+    a.chunk_rows = 0; a.rmax = 0x7fffffff; a.stage_tail = 0;
 }
 
 }  // namespace

@@ -1408,7 +1408,8 @@ extern "C" int mrg_gemm(const mrg_gemm_desc* d, hipStream_t stream) {
         else { if (vec) MRG_G256(1, 1, true); else MRG_G256(1, 1, false); }
 #undef MRG_G256
         if (d->ev_stop) (void)hipEventRecord((hipEvent_t)d->ev_stop, stream);
-        return mrg_check_launch("mrg_gemm");
+        int rcg = mrg_check_launch("mrg_gemm");
+        return rcg ? rcg : finish_splitk();       // split-K slabs of this variant are reduced by the separate kernel (or left to the caller: defer_reduce)
     }
     if (fast && !mapped && d->variant == MRG_GEMM_GLDS64 && d->a_mode == MRG_OP_KCONTIG && splitk == 1 && !d->colsum_out) {
         const dim3 g64(cdiv(d->M, 64) * g.tiles_n);

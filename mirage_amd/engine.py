@@ -345,10 +345,11 @@ class BlockFn(torch.autograd.Function):
 # fill each other's tails and phase gaps (profiles/r02_experiments.md: encoder forward -7.6 % at C2).  The activations the backward
 # pass needs are full-batch tensors: chain A allocates them and works on the first halves, chain B on the second (kernels.Halves),
 # so the backward pass (full batch, weight gradients over all rows in one GEMM) is unchanged.
-# MRG_TWO_CHAINS: 0 off; 1 (default) forward-only passes (feature extraction, C5: -3 %); 2 also the training forward (C2 / C4: -0.7 %
-# same box -- left off by default because two overlapping half-size launches have no exclusive duration, which would blur the
-# per-launch roofline accounting of bench.py and of the rocprof traces for a gain inside the box-to-box noise).
-TWO_CHAINS = int(os.environ.get("MRG_TWO_CHAINS", "1"))
+# MRG_TWO_CHAINS: 0 off; 1 forward-only passes only (feature extraction, C5: -3 %); 2 (default since round 3) also the training forward:
+# same box, 30 steps, two repetitions: C2 9.71 / 9.75 -> 9.60 / 9.59 ms (-1.3 %), C4 21.05 / 21.06 -> 20.58 / 20.55 ms (-2.3 %).
+# Two overlapping half-size launches have no exclusive duration, so bench.py's instrumented roofline step (and the rocprof traces it is
+# compared with) run ONE chain -- the per-launch numbers describe the full-batch kernels, the step time the production schedule.
+TWO_CHAINS = int(os.environ.get("MRG_TWO_CHAINS", "2"))
 TWO_CHAINS_MIN_ROWS = int(os.environ.get("MRG_TWO_CHAINS_MIN_ROWS", "16"))
 _CHAIN_STREAM = {}
 
