@@ -258,7 +258,7 @@ def measure(a, cfg_name, steps, warmup, batch, rank, world, dev, force_dp, ranks
         # HBM bytes per launch of the dominant kernel come from a separate rocprofv3 --pmc pass (counters cannot be read from
         # inside the process): the committed summary of that pass is quoted and its file named in `traffic_source`
         traffic, traffic_src = None, None
-        for tname in ("r02_c2_pmc_traffic.json", "r01_c2_pmc_traffic.json"):
+        for tname in ("r03_c2_pmc_traffic.json", "r02_c2_pmc_traffic.json", "r01_c2_pmc_traffic.json"):
             tfile = os.path.join(ROOT, "profiles", tname)
             if cfg_name == "c2" and os.path.exists(tfile):
                 tj = json.load(open(tfile))
