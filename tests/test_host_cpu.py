@@ -1,11 +1,15 @@
 """Host-side logic that needs no GPU: module surface / state_dict layout / init stream / schedules / parameter groups
 against fixtures captured from the reference (tools/gen_golden.py)."""
 import json
+import os
 
 import numpy as np
+import pytest
 import torch
 
 from conftest import load_golden
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def _tiny_model(seed=None):
@@ -129,3 +133,37 @@ def test_half_batch_placement_and_weight_gradient_collector_rules():
     assert ok()
     assert not ok(accumulate=True) and not ok(bias=torch.zeros(256)) and not ok(a_map=torch.zeros(4, dtype=torch.int32))
     assert not ok(K=100) and not ok(M=128) and not ok(out=out.bfloat16()) and not ok(K=K.WgradGroup.max_k + 64)
+
+
+def test_bench_refuses_more_ranks_than_gpus():
+    """`python bench.py --gpus 2` on a box without two GPUs must refuse (exit code 2, message on stderr, nothing on stdout) instead of
+    running fewer ranks or hanging in a rendezvous (bench.py::_self_launch)."""
+    import subprocess, sys
+    env = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MRG_SHARE_GPU"):
+        env.pop(k, None)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"], env=env,
+                       capture_output=True, text=True, timeout=300)
+    if torch.cuda.device_count() >= 2:
+        pytest.skip("two GPUs visible")
+    assert p.returncode == 2 and "only" in p.stderr and p.stdout.strip() == ""
+
+
+def test_wrapper_inference_geometry():
+    """mirage_wrapper._inference_args: modalities -> per-modality image / patch / grid tables (layer maps keep 128 / 8 whatever the image
+    size; `grid_size` is the image grid for every modality, as mirage_wrapper.py:66-82 builds it), the pooling table and the registry."""
+    import types
+    from mirage_amd import mirage_wrapper as W
+    ck = types.SimpleNamespace(model="miragepre_base", out_domains="bscan-slo", decoder_dim=256, decoder_depth=2, decoder_num_heads=8)
+    a = W._inference_args(ck, "bscan-bscanlayermap", 512, 32)
+    assert a.in_domains == ["bscan", "bscanlayermap"] and a.out_domains == ["bscan", "slo"]
+    assert a.input_size == {"bscan": (512, 512), "bscanlayermap": (128, 128)} and a.patch_size == {"bscan": (32, 32), "bscanlayermap": (8, 8)}
+    assert a.grid_size == {"bscan": [16, 16], "bscanlayermap": [16, 16]} and a.grid_sizes == {"bscan": [16, 16], "bscanlayermap": [16, 16]}
+    assert a.num_global_tokens == 1 and a.drop_path == 0.0 and ck.out_domains == "bscan-slo"          # the checkpoint's namespace is not mutated
+    b = W._inference_args(ck, "slo", (256, 128), 16)
+    assert b.input_size["slo"] == (256, 128) and b.grid_size["slo"] == [16, 8]
+    assert set(W.miragecls_factory) == {"global", "cls", "token_mix"}
+    assert W.miragecls_factory["token_mix"] is W.MIRAGEClsTokenMix and issubclass(W.MIRAGEClsCLS, W.MIRAGEClsGlobal)
+    x = torch.arange(2 * 5 * 4, dtype=torch.float32).reshape(2, 5, 4)
+    g = W._token_groups(x, 1)
+    assert g["patch"].shape == (2, 4, 4) and g["global"].shape == (2, 1, 4) and torch.equal(g["global"][:, 0], x[:, -1])
