@@ -245,6 +245,14 @@ def main(args):
                 step.load(batch)
                 step.warmup_and_capture(warm_iters=1)
                 optimizer.set_iteration(epoch * steps_per_epoch)
+                if rank == 0:
+                    # which GEMM variant table this run is on: shapes served from the committed table vs tuned during the warm-up step
+                    # (a per-GPU batch the table was not measured at falls back to first-use autotuning)
+                    from . import kernels as _K
+                    tuned = [f"{k[2]}x{k[3]}x{k[4]}" for k, _, _ in _K.TUNE["log"]]
+                    print(f"GEMM table {os.path.basename(_K._TUNE_FILE)}: {_K.TUNE['table_entries']} entries, {len(_K.TUNE['table_used'])} shapes of this run "
+                          f"served from it, {len(tuned)} tuned at warm-up" + (f" ({', '.join(tuned[:12])}{' ...' if len(tuned) > 12 else ''})" if tuned else ""),
+                          flush=True)
             step.step(batch)
             if it % args.print_freq == 0 or it == steps_per_epoch - 1:
                 vals = {"loss": all_reduce_scalar_mean(step.loss.detach().clone().reshape(1))}
