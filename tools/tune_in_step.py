@@ -14,16 +14,41 @@ model_name, doms, B, Kk, train = Bn.CONFIGS[cfg]
 dev = torch.device("cuda", 0)
 args = builder.make_args(doms, doms)
 torch.manual_seed(0)
-model = builder.get_model(args, model_name).to(dev).train()
+if not train:
+    args = builder.make_args(doms, ())
+model = builder.get_model(args, model_name, with_decoders=train).to(dev).train(train)
 pool = Bn.synth_batches(doms, B, 2, 1234, dev)
-lrs = optim.cosine_scheduler(1e-4, 0.0, 1, 4096, warmup_epochs=1, warmup_steps=100)
-wds = optim.cosine_scheduler(0.05, 0.05, 1, 4096)
-opt = optim.FusedAdamW(model, lrs, wds, betas=(0.9, 0.95), eps=1e-8)
-opt.arena.refresh_shadow(force=True)
-loss_fns = builder.get_losses(args)
+if train:
+    lrs = optim.cosine_scheduler(1e-4, 0.0, 1, 4096, warmup_epochs=1, warmup_steps=100)
+    wds = optim.cosine_scheduler(0.05, 0.05, 1, 4096)
+    opt = optim.FusedAdamW(model, lrs, wds, betas=(0.9, 0.95), eps=1e-8)
+    opt.arena.refresh_shadow(force=True)
+    loss_fns = builder.get_losses(args)
+
+
+def measure_forward(reps=3, steps=6):
+    """encoder-only forward (C5) replayed from a hipGraph, as bench.py runs it"""
+    static = {d: pool[0][d].clone() for d in doms}
+    fwd = lambda: model(static, mask_inputs=False)[0]
+    with torch.no_grad():
+        fwd(); fwd()
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            fwd()
+    best = 1e9
+    for _ in range(reps):
+        g.replay()
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        for _ in range(steps): g.replay()
+        torch.cuda.synchronize(); best = min(best, (time.perf_counter() - t0) / steps * 1e3)
+    del g; gc.collect(); torch.cuda.empty_cache()
+    return best
 
 
 def measure(reps=3, steps=15):
+    if not train:
+        return measure_forward(reps, max(4, steps // 3))
     ts = TrainStep(model, loss_fns, opt, pool[0], Kk, use_graph=True)
     ts.load(pool[0]); ts.warmup_and_capture(1)
     best = 1e9
