@@ -50,6 +50,39 @@ def get_parameter_groups(model, weight_decay=1e-5, skip_list=()):
     return list(groups.values())
 
 
+class PartialSumSlots:
+    """Host-side map from an update range [s, e) of the arena to its FIXED slice of a partial-sum buffer (pure bookkeeping, no device
+    state): a range is given a slice the first time it is seen and keeps it for ever, so that nothing about the placement changes from
+    step to step -- eager launches, captured graphs and their mix (data parallel: stage updates issued eagerly between graph replays,
+    the rest inside the optimizer graph) write and sum the same addresses on every replay.  The registered ranges are meant to form ONE
+    partition of [0, n): a new range that overlaps registered ones retires those (the caller zeroes their slices; they are never
+    handed out again, because captured graphs keep the addresses they were built with)."""
+
+    def __init__(self, capacity: int):
+        self.capacity, self.used = int(capacity), 0
+        self.slots: Dict[tuple, tuple] = {}          # (s, e) -> (offset, length)
+
+    def get(self, s: int, e: int, length: int):
+        """-> (offset, length, retired): the slice of [s, e) and the (offset, length) slices that this registration retired"""
+        slot = self.slots.get((s, e))
+        retired = []
+        if slot is None:
+            for (s1, e1), sl in list(self.slots.items()):
+                if s1 < e and s < e1:
+                    retired.append(sl)
+                    del self.slots[(s1, e1)]
+            if self.used + length > self.capacity:
+                raise RuntimeError("FusedAdamW: partial-sum buffer exhausted (too many distinct update ranges)")
+            slot = self.slots[(s, e)] = (self.used, int(length))
+            self.used += int(length)
+        return slot[0], slot[1], retired
+
+    def is_partition(self, n: int) -> bool:
+        """do the registered ranges tile [0, n) without gap or overlap (the last range may run past n: alignment padding)?"""
+        cov = sorted(self.slots)
+        return bool(cov) and cov[0][0] == 0 and cov[-1][1] >= n and all(x[1] == y[0] for x, y in zip(cov, cov[1:]))
+
+
 class FusedAdamW:
     """AdamW over the model's flat arenas: one gradient-norm reduction + one update launch per step; the update also
     refreshes the bf16 shadow weights.  lr / weight-decay come from device-resident per-step tables indexed by a device
@@ -93,8 +126,7 @@ class FusedAdamW:
         # cursor, so eager calls, captured graphs and any mix of the two (data parallel: stage updates issued eagerly between
         # graph replays, the rest inside the optimizer graph) stay consistent across replays.
         self._ss = torch.zeros(1 << 19, dtype=torch.float32, device=dev) if self.fuse_norm else None     # <= 4096 partials per launch, <= 128 ranges
-        self._ss_slots: Dict[tuple, tuple] = {}     # (s, e) -> (offset, nblocks)
-        self._ss_used = 0
+        self._slots = PartialSumSlots(1 << 19)
         self.param_groups = [
             {"params": [arena.params[n] for n in arena.names_decay], "names": arena.names_decay, "weight_decay": float(self._wd_host[0]),
              "lr": float(self._lr_host[0]), "lr_scale": 1.0},
@@ -123,21 +155,12 @@ class FusedAdamW:
                     self.wd_table, self.step_dev, self.betas[0], self.betas[1], self.eps, sumsq_out=ss)
 
     def _ss_slot(self, s, e):
-        """The fixed slice of the partial-sum buffer that the update of [s, e) writes.  The registered ranges must form ONE partition
-        of the arena (the finish kernel sums all of them): a new range that overlaps registered ones retires those -- their slices are
-        zeroed and never handed out again (captured graphs keep the addresses they were built with)."""
-        slot = self._ss_slots.get((s, e))
-        if slot is None:
-            for (s1, e1), (o1, n1) in list(self._ss_slots.items()):
-                if s1 < e and s < e1:
-                    self._ss[o1:o1 + n1].zero_()
-                    del self._ss_slots[(s1, e1)]
-            nb = K.adamw_nblocks(e - s)
-            if self._ss_used + nb > self._ss.numel():
-                raise RuntimeError("FusedAdamW: partial-sum buffer exhausted (too many distinct update ranges)")
-            slot = self._ss_slots[(s, e)] = (self._ss_used, nb)
-            self._ss_used += nb
-        return self._ss[slot[0]:slot[0] + slot[1]]
+        """The fixed slice of the partial-sum buffer that the update of [s, e) writes (PartialSumSlots); slices of ranges this one
+        supersedes are zeroed so that the finish kernel, which sums every slice ever handed out, does not count them."""
+        off, n, retired = self._slots.get(s, e, K.adamw_nblocks(e - s))
+        for o1, n1 in retired:
+            self._ss[o1:o1 + n1].zero_()
+        return self._ss[off:off + n]
 
     def step(self, done_ranges=None):
         """global grad norm (native_scaler.py:46-61) -> AdamW (+clip / skip) -> counters.  `done_ranges`: sorted, disjoint
@@ -159,10 +182,9 @@ class FusedAdamW:
                 rest.append((pos, a.n_trainable))
             self.step_ranges(rest)
             if self.fuse_norm:
-                covered = sorted(self._ss_slots)
-                if covered[0][0] != 0 or covered[-1][1] < a.n_trainable or any(x[1] != y[0] for x, y in zip(covered, covered[1:])):
+                if not self._slots.is_partition(a.n_trainable):
                     raise RuntimeError("FusedAdamW: the update ranges of this step do not partition the arena (gradient norm would be wrong)")
-                K.sumsq_finish(self._ss, self._ss_used, self.grad_norm)
+                K.sumsq_finish(self._ss, self._slots.used, self.grad_norm)
         else:
             K.adamw(a.flat_p[:a.n_trainable], g, self.exp_avg, self.exp_avg_sq, a.flat_bf16[:a.n_trainable], a.n_decay, self.lr_table,
                     self.wd_table, self.step_dev, self.betas[0], self.betas[1], self.eps, grad_norm_t=self.grad_norm,

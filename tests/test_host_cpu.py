@@ -167,3 +167,26 @@ def test_wrapper_inference_geometry():
     x = torch.arange(2 * 5 * 4, dtype=torch.float32).reshape(2, 5, 4)
     g = W._token_groups(x, 1)
     assert g["patch"].shape == (2, 4, 4) and g["global"].shape == (2, 1, 4) and torch.equal(g["global"][:, 0], x[:, -1])
+
+
+def test_partial_sum_slots_are_replay_safe():
+    """optim.PartialSumSlots (the bookkeeping behind the fused gradient norm; round-2 defect: a host cursor that a captured step() never
+    reset): a range keeps its slice for ever, repeated steps hand out nothing new, a repartition retires what it overlaps, and only a
+    gap-free tiling of the arena is accepted."""
+    from mirage_amd.optim import PartialSumSlots
+    sl = PartialSumSlots(capacity=100)
+    step1 = [sl.get(s, e, n)[:2] for s, e, n in ((512, 1024, 7), (256, 512, 5), (0, 256, 3))]          # backward order: last stage first
+    assert step1 == [(0, 7), (7, 5), (12, 3)] and sl.used == 15 and sl.is_partition(1000)
+    for _ in range(1000):                                                                            # 1000 further steps: same slices, no growth
+        assert [sl.get(s, e, n)[:2] for s, e, n in ((512, 1024, 7), (256, 512, 5), (0, 256, 3))] == step1
+    assert sl.used == 15
+    # a different partition of the same arena (single launch) retires all three and gets a fresh slice; the old ones are reported for zeroing
+    off, n, retired = sl.get(0, 1024, 9)
+    assert (off, n) == (15, 9) and sorted(retired) == [(0, 7), (7, 5), (12, 3)] and sl.is_partition(1000) and sl.used == 24
+    # back to stages: the single range is retired again, slices are NEW ones (captured graphs may still hold the old addresses)
+    a = sl.get(512, 1024, 7)
+    assert a[0] == 24 and a[2] == [(15, 9)] and not sl.is_partition(1000)                            # [0, 512) not covered yet
+    sl.get(0, 512, 8)
+    assert sl.is_partition(1000) and not sl.is_partition(2000)
+    with pytest.raises(RuntimeError, match="exhausted"):
+        PartialSumSlots(capacity=4).get(0, 64, 5)
