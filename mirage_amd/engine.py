@@ -781,6 +781,10 @@ class DecodersFn(torch.autograd.Function):
             if _Side.enabled:
                 _Side.finished.append("decoders")
             else:
+                # side stream off: the adapters' weight gradients may still sit in the group collector (two decoder blocks per adapter
+                # never reach the flush cadence) -- launch them before the update that consumes them.  (Found in round 3: without a
+                # warm-up iteration the early update read zero gradients; with one, the previous iteration's.)
+                K.WgradGroup.flush()
                 _Side.early_opt(["decoders"])
         if not ctx.defer_join:
             _Side.join()

@@ -388,9 +388,11 @@ class WgradGroup:
         if not tasks:
             return
         origin, cls.origin = cls.origin, None
-        if origin is not None and origin != torch.cuda.current_stream():
+        cur = torch.cuda.current_stream()
+        if origin is not None and origin != cur:
             with torch.cuda.stream(origin):
                 cls._launch(tasks)
+            cur.wait_stream(origin)         # whoever flushes goes on to read the gradients (reductions, optimizer): order it behind them
             return
         cls._launch(tasks)
 
