@@ -43,10 +43,16 @@ def _run_engine(cfg, B, Kk, x, noise, use_graph):
     opt = optim.FusedAdamW(model, [1e-4] * 8, [0.05] * 8, betas=(0.9, 0.95), eps=1e-8)
     xg = {d: t.to(DEV) for d, t in x.items()}
     ts = TrainStep(model, loss_fns, opt, xg, Kk, use_graph=use_graph, feed_mask_noise=True)
-    ts.load(xg)
-    for dst, src in zip(ts.static_noise, noise):
-        dst.copy_(src)
     if use_graph:
+        # the warm-up iteration and the capture run on OTHER data than the measured replay: a mis-ordered kernel that reads what an
+        # earlier iteration left behind cannot hide behind identical stale values (tests/test_train_gpu.py::test_graph_step_does_not_...)
+        from oracle import mirage_oracle as O
+        xw = {d: t.to(DEV) for d, t in O.synthetic_batch(cfg, B, seed=4321).items()}
+        (pw, uw, gw), _, _, _ = O.synthetic_masks(cfg, B, Kk, seed=77)
+        nw = (torch.from_numpy(pw).to(DEV), torch.cat([torch.from_numpy(a_) for a_ in uw], 1).to(DEV), torch.from_numpy(gw).to(DEV))
+        ts.load(xw)
+        for dst, src in zip(ts.static_noise, nw):
+            dst.copy_(src)
         ts.warmup_and_capture(warm_iters=1)
         assert ts.g_fb is not None and ts._early is not None        # one graph, early block-wise AdamW on (the bench configuration)
     ts.step(xg, noise=noise)

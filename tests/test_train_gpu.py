@@ -499,3 +499,41 @@ def test_side_stream_off_is_the_same_step(monkeypatch):
         assert float((got[1] - ref[1]).norm() / ref[1].norm()) <= 1e-6                      # same gradients (reduction order only)
         assert float((got[2] - ref[2]).abs().max()) <= 2e-6, (side, graph)                   # same update: no parameter left behind by a whole lr
         assert abs(got[3] - ref[3]) <= 1e-5 * ref[3]
+
+
+@pytest.mark.parametrize("doms", [("bscan", "slo", "bscanlayermap"), ("bscan", "slo")])
+def test_graph_step_does_not_depend_on_warmup_data(doms):
+    """A captured step whose kernels were mis-ordered would read buffers a previous iteration left behind; when the warm-up iteration runs on
+    the SAME batch those stale values equal the right ones and every eager == graph comparison passes anyway.  Here the warm-up (and the
+    capture) see batch A with noise A, the measured replay sees batch B with noise B, and the result must equal -- bit for bit: loss, every
+    gradient, every weight, the logged norm -- a fresh eager step on batch B that never saw A."""
+    from mirage_amd import builder, optim
+    from mirage_amd.trainer import TrainStep
+    from oracle import mirage_oracle as O
+    import test_model_gpu as T
+    cfg = O.make_config(model="tiny", in_domains=doms, input_size=64, patch_size=8, layermap_size=16, layermap_patch=2, decoder_dim=64,
+                        decoder_depth=2, decoder_heads=2, dim=128, depth=4, heads=2)
+    B, Kk = 6, 24
+
+    def data(seed):
+        x = {d: t.to(DEV) for d, t in O.synthetic_batch(cfg, B, seed=seed).items()}
+        (p, u, g), _, _, _ = O.synthetic_masks(cfg, B, Kk, seed=seed + 1)
+        return x, (torch.from_numpy(p).to(DEV), torch.cat([torch.from_numpy(a) for a in u], 1).to(DEV), torch.from_numpy(g).to(DEV))
+    (xa, na), (xb, nb) = data(100), data(200)
+
+    def run(graph):
+        model, args, _ = T._build(cfg)
+        model.train()
+        opt = optim.FusedAdamW(model, [1e-3] * 8, [0.05] * 8)
+        ts = TrainStep(model, builder.get_losses(args), opt, xa, Kk, use_graph=graph, feed_mask_noise=True)
+        if graph:
+            ts.load(xa)
+            for dst, src in zip(ts.static_noise, na):
+                dst.copy_(src)
+            ts.warmup_and_capture(warm_iters=2)
+        ts.step(xb, noise=nb)
+        torch.cuda.synchronize()
+        return float(ts.loss), opt.arena.flat_g.clone(), opt.arena.flat_p.clone(), float(opt.grad_norm), opt.exp_avg.clone()
+    e, g = run(False), run(True)
+    assert e[0] == g[0] and e[3] == g[3]
+    assert torch.equal(e[1], g[1]) and torch.equal(e[2], g[2]) and torch.equal(e[4], g[4])
