@@ -479,6 +479,8 @@ def test_side_stream_off_is_the_same_step(monkeypatch):
     cfg = meta["cfg"]
     x = {d: t.to(DEV) for d, t in O.synthetic_batch(cfg, 4, seed=9).items()}
 
+    monkeypatch.setenv("MRG_EARLY_OPT", "1")                     # the path under test: per-block / per-adapter updates behind their gradients
+
     def run(side, graph):
         monkeypatch.setattr(E._Side, "enabled", side)
         model, args, _ = T._build(cfg)
