@@ -154,7 +154,9 @@ def measure(a, cfg_name, steps, warmup, batch, rank, world, dev, force_dp, ranks
         def run_step(i):
             ts.step(pool[i % len(pool)])
     else:
+        from mirage_amd import kernels as _Kn
         static = {d: torch.empty_like(pool[0][d]) for d in doms}
+        slots = _Kn.InputSlots(static)          # the captured forward reads each pool batch in place (include/mirage_hip.h "Input slots")
         graph = None
 
         def fwd():
@@ -171,8 +173,7 @@ def measure(a, cfg_name, steps, warmup, batch, rank, world, dev, force_dp, ranks
                 out_static = fwd()
 
         def run_step(i):
-            for d in doms:
-                static[d].copy_(pool[i % len(pool)][d], non_blocking=True)
+            slots.bind(pool[i % len(pool)])
             if graph is not None:
                 graph.replay()
             else:

@@ -26,7 +26,7 @@ extern "C" {
 typedef struct ihipStream_t* hipStream_t;
 #endif
 
-#define MRG_ABI_VERSION 8   /* 8: mrg_gemm_desc.drop_rng / drop_p / drop_stream, mrg_dropout_bwd_bf16; 7: mrg_wgrad_group, mrg_debug_timestamp; 2: mrg_gemm_desc grew row_scale / defer_reduce, act codes 3, 4, reduce_batch / augment / row_scale entry points; 3: colsum_out, attention colsum_*; 4: step = int[2], mrg_step_inc takes the skip decision; 5: splitk_counters, MRG_GEMM_P8, resize entry points; 6: mrg_adamw_desc.sumsq_out, mrg_sumsq_finish */
+#define MRG_ABI_VERSION 9   /* 9: mrg_maskgen_rng, input slots (mrg_set_slots, *_slot parameters, mrg_loss_desc.target_slot); 8: mrg_gemm_desc.drop_rng / drop_p / drop_stream, mrg_dropout_bwd_bf16; 7: mrg_wgrad_group, mrg_debug_timestamp; 2: mrg_gemm_desc grew row_scale / defer_reduce, act codes 3, 4, reduce_batch / augment / row_scale entry points; 3: colsum_out, attention colsum_*; 4: step = int[2], mrg_step_inc takes the skip decision; 5: splitk_counters, MRG_GEMM_P8, resize entry points; 6: mrg_adamw_desc.sumsq_out, mrg_sumsq_finish */
 
 enum { MRG_DT_BF16 = 0, MRG_DT_F32 = 1 };
 enum { MRG_OP_KCONTIG = 0, MRG_OP_KSTRIDED = 1 };
@@ -190,6 +190,12 @@ int mrg_attn_bwd(const mrg_attn_desc* d, hipStream_t stream);
  *   mrg_fill_global     x[b*N + K + g] = global_tokens[g]
  * The projection itself is mrg_gemm with m_dev = &counts[d], row_map = rows, add_tab/add_row = posemb/toks.
  */
+/* Input slots.  The kernels that read a raw input batch -- the patch packers, the class-embedding gradient and the masked losses (their
+ * targets ARE the inputs) -- take, next to the plain pointer, an optional SLOT: a device location holding the batch's base address,
+ * read by the kernel when it runs.  A captured step (hipGraph) thereby consumes each new batch where the data pipeline left it: the
+ * host stores the addresses with mrg_set_slots (one launch, values passed by value) and replays; no copy into a staging buffer.
+ * With a slot the plain pointer may be NULL; the address stored must satisfy the plain pointer's alignment rule (16 B). */
+int mrg_set_slots(const void** slots_dev, const void* const* values_host, int n, hipStream_t stream);   /* n <= 8 */
 int mrg_embed_plan(const long* ids_keep, int B, int K, int N, int ndom, const int* dom_start_host, int* rows, int* toks,
                    int* srcb, int* counts, hipStream_t stream);
 /* dst bf16 [cap, D] = rows map[0 .. *count_dev) of src bf16 (row stride src_ld elements), zero beyond the count: the gradient rows of
@@ -198,12 +204,14 @@ int mrg_embed_plan(const long* ids_keep, int B, int K, int N, int ndom, const in
 int mrg_gather_rows_bf16(const void* src_bf16, long src_ld, const int* map, const int* count_dev, int cap, int D, void* dst_bf16,
                          hipStream_t stream);
 int mrg_im2col_image(const float* img, const int* srcb, const int* toks, const int* count_dev, int cap, int C, int H, int W,
-                     int P, void* out_bf16, hipStream_t stream);
+                     int P, void* out_bf16, const void* const* img_slot, hipStream_t stream);
 int mrg_im2col_layermap(const long* labels, const float* class_emb, const int* srcb, const int* toks, const int* count_dev,
-                        int cap, int ncls, int E, int Hs, int Ws, int P, void* out_bf16, hipStream_t stream);
+                        int cap, int ncls, int E, int Hs, int Ws, int P, void* out_bf16, const void* const* labels_slot,
+                        hipStream_t stream);
 int mrg_class_emb_grad_slices(void);   /* rows of the `partials` workspace: fp32 [slices][ncls][E] */
 int mrg_class_emb_grad(const void* dA_bf16, const long* labels, const int* srcb, const int* toks, const int* count_dev,
-                       int ncls, int E, int Hs, int Ws, int P, float* partials, float* out, hipStream_t stream);
+                       int ncls, int E, int Hs, int Ws, int P, float* partials, float* out, const void* const* labels_slot,
+                       hipStream_t stream);
 int mrg_fill_global(float* x, const float* global_tokens, int B, int N, int K, int ng, int D, hipStream_t stream);
 
 /* ---------------------------------------------------------------------------------------------------
@@ -240,6 +248,7 @@ typedef struct mrg_loss_desc {
     int B, C, H, W, P;
     float* partial; float* loss; float* coef; float* per_sample;
     const float* gout; void* dpred;
+    const void* const* target_slot;   /* input slot of the target (see "Input slots"); NULL: `target` is read */
 } mrg_loss_desc;
 int mrg_loss_partial_floats(int B);
 int mrg_masked_loss_fwd(const mrg_loss_desc* d, hipStream_t stream);
@@ -252,6 +261,14 @@ int mrg_patch_rearrange(const void* src, void* dst, int dtype, int to_image, int
  */
 int mrg_maskgen(const float* p, const float* u, const float* g, int B, int T, int K, int ndom, const int* dom_start_host,
                 long* task_mask, long* ids_keep, long* ids_restore, hipStream_t stream);
+/* Same masks with the noise drawn inside the launch (the production path: replaces the reference's Dirichlet draw + two torch.rand
+ * calls, mirage/model.py:205-207,216,225): conc fp32 [B,ndom] Dirichlet concentrations; rng = device uint64[3] {seed, step, 0}: the
+ * launch reads seed and step, and advances step by one when its last workgroup retires (hipGraph-replayable: every replay draws new
+ * masks).  u, g = 24-bit uniforms of Philox4x32-10 streams 0 / 1 over (sample, token quad), p = normalised Gamma(conc) draws of
+ * stream 2.  p_out [B,ndom] / u_out / g_out [B,T] (each may be NULL) receive the noise that was drawn: mrg_maskgen fed with them
+ * returns the same masks. */
+int mrg_maskgen_rng(const float* conc, unsigned long long* rng, int B, int T, int K, int ndom, const int* dom_start_host,
+                    long* task_mask, long* ids_keep, long* ids_restore, float* p_out, float* u_out, float* g_out, hipStream_t stream);
 
 /* ---------------------------------------------------------------------------------------------------
  * Step boundary on flat arenas: global grad L2 norm (mutils/native_scaler.py:46-61), AdamW with decoupled decay on

@@ -67,7 +67,8 @@ class DecAssembleDesc(C.Structure):
 class LossDesc(C.Structure):
     _fields_ = [("kind", ci), ("pred", vp), ("pred_dtype", ci), ("target", vp), ("mask", vp),
                 ("B", ci), ("C", ci), ("H", ci), ("W", ci), ("P", ci),
-                ("partial", vp), ("loss", vp), ("coef", vp), ("per_sample", vp), ("gout", vp), ("dpred", vp)]
+                ("partial", vp), ("loss", vp), ("coef", vp), ("per_sample", vp), ("gout", vp), ("dpred", vp),
+                ("target_slot", vp)]
 
 
 class AdamWDesc(C.Structure):
@@ -93,10 +94,11 @@ SIGNATURES = {
     "mrg_attn_bwd": (ci, [C.POINTER(AttnDesc), vp]),
     "mrg_embed_plan": (ci, [vp, ci, ci, ci, ci, C.POINTER(ci), vp, vp, vp, vp, vp]),
     "mrg_gather_rows_bf16": (ci, [vp, cl, vp, vp, ci, ci, vp, vp]),
-    "mrg_im2col_image": (ci, [vp, vp, vp, vp, ci, ci, ci, ci, ci, vp, vp]),
-    "mrg_im2col_layermap": (ci, [vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, vp, vp]),
+    "mrg_set_slots": (ci, [vp, C.POINTER(vp), ci, vp]),
+    "mrg_im2col_image": (ci, [vp, vp, vp, vp, ci, ci, ci, ci, ci, vp, vp, vp]),
+    "mrg_im2col_layermap": (ci, [vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, vp, vp, vp]),
     "mrg_class_emb_grad_slices": (ci, []),
-    "mrg_class_emb_grad": (ci, [vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, vp, vp, vp]),
+    "mrg_class_emb_grad": (ci, [vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, vp, vp, vp, vp]),
     "mrg_fill_global": (ci, [vp, vp, ci, ci, ci, ci, ci, vp]),
     "mrg_dec_assemble_fwd": (ci, [C.POINTER(DecAssembleDesc), vp]),
     "mrg_dec_assemble_bwd_nblocks": (ci, [ci, ci, ci]),
@@ -106,6 +108,7 @@ SIGNATURES = {
     "mrg_masked_loss_bwd": (ci, [C.POINTER(LossDesc), vp]),
     "mrg_patch_rearrange": (ci, [vp, vp, ci, ci, ci, ci, ci, ci, vp]),
     "mrg_maskgen": (ci, [vp, vp, vp, ci, ci, ci, ci, C.POINTER(ci), vp, vp, vp, vp]),
+    "mrg_maskgen_rng": (ci, [vp, vp, ci, ci, ci, ci, C.POINTER(ci), vp, vp, vp, vp, vp, vp, vp]),
     "mrg_sumsq_nblocks": (ci, [cl]),
     "mrg_grad_norm": (ci, [vp, cl, vp, vp, vp]),
     "mrg_adamw": (ci, [C.POINTER(AdamWDesc), vp]),
@@ -135,7 +138,7 @@ for _name, (_res, _args) in SIGNATURES.items():
     _fn.argtypes = _args
 
 ABI_VERSION = lib.mrg_version()
-EXPECTED_ABI_VERSION = 8       # must match MRG_ABI_VERSION in include/mirage_hip.h: the ctypes structs above mirror that layout
+EXPECTED_ABI_VERSION = 9       # must match MRG_ABI_VERSION in include/mirage_hip.h: the ctypes structs above mirror that layout
 if ABI_VERSION != EXPECTED_ABI_VERSION:
     raise ImportError(f"{LIB_PATH} reports ABI version {ABI_VERSION}, the Python bindings expect {EXPECTED_ABI_VERSION}: rebuild it "
                       "(python -c 'import __graft_entry__ as g; g.build()')")

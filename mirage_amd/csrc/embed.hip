@@ -32,59 +32,90 @@ __device__ __forceinline__ int find_dom(const int* dom_start, int ndom, int t) {
     return d;
 }
 
-// single block, 1024 threads: deterministic (flat (b,k) order) compaction per modality
+// single block of 16 waves: deterministic (flat (b, k) order) compaction per modality.  The flat list is cut into chunks of 64
+// entries; a round covers 16 waves x PLAN_IT chunks = 8192 entries whose ids every lane requests up front (one memory round trip,
+// kept in registers for both passes).  A chunk's per-modality counts and every entry's position inside its chunk are wave ballots,
+// the chunk bases one 128-wide exclusive scan: three barriers per round.  (The version this replaces -- per-thread counts, a
+// 10-step Hillis-Steele scan, two dependent passes over global memory -- took 17 us at the head of every step.)
+constexpr int PLAN_IT = 8, PLAN_CHUNKS = 16 * PLAN_IT;
+
 __global__ __launch_bounds__(1024) void embed_plan_kernel(const PlanArgs a) {
-    __shared__ int cnt[MAXDOM][1024];
-    const int tid = threadIdx.x;
-    const int total = a.B * a.K;
-    const int per = (total + 1023) / 1024;
-    const int beg = min(total, tid * per), end = min(total, beg + per);
-    int c[MAXDOM];
+    __shared__ int cnt[MAXDOM][PLAN_CHUNKS];      // chunk counts, then exclusive chunk bases
+    __shared__ int wave_tot[MAXDOM][2];
+    __shared__ int carry[MAXDOM];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int total = a.B * a.K, cap = total;
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    if (tid < MAXDOM) carry[tid] = 0;
+    for (int round0 = 0; round0 < total; round0 += PLAN_CHUNKS * 64) {
+        int tok[PLAN_IT], dom[PLAN_IT];
 #pragma unroll
-    for (int d = 0; d < MAXDOM; ++d) c[d] = 0;
-    for (int i = beg; i < end; ++i) {
-        const int dm = find_dom(a.dom_start, a.ndom, (int)a.ids_keep[i]);
+        for (int it = 0; it < PLAN_IT; ++it) {
+            const int i = round0 + (wave + 16 * it) * 64 + lane;
+            tok[it] = i < total ? (int)a.ids_keep[i] : -1;
+        }
+        __syncthreads();                              // the previous round is done with cnt / wave_tot; carry is visible
+        // (1) per-chunk counts
 #pragma unroll
-        for (int d = 0; d < MAXDOM; ++d) c[d] += (dm == d) ? 1 : 0;
+        for (int it = 0; it < PLAN_IT; ++it) {
+            dom[it] = tok[it] >= 0 ? find_dom(a.dom_start, a.ndom, tok[it]) : -1;
+#pragma unroll
+            for (int d = 0; d < MAXDOM; ++d) {
+                const unsigned long long m = __ballot(dom[it] == d);
+                if (lane == 0) cnt[d][wave + 16 * it] = __popcll(m);
+            }
+        }
+        __syncthreads();
+        // (2) exclusive scan over the 128 chunks by the first two waves
+        int mine[MAXDOM], incl[MAXDOM];
+        if (tid < PLAN_CHUNKS) {
+#pragma unroll
+            for (int d = 0; d < MAXDOM; ++d) {
+                mine[d] = cnt[d][tid];
+                int v = mine[d];
+#pragma unroll
+                for (int o = 1; o < 64; o <<= 1) { const int up = __shfl_up(v, o, 64); if (lane >= o) v += up; }
+                incl[d] = v;
+                if (lane == 63) wave_tot[d][wave] = v;
+            }
+        }
+        __syncthreads();
+        if (tid < PLAN_CHUNKS) {
+#pragma unroll
+            for (int d = 0; d < MAXDOM; ++d) cnt[d][tid] = carry[d] + (wave == 1 ? wave_tot[d][0] : 0) + incl[d] - mine[d];
+        }
+        __syncthreads();
+        // (3) positions
+#pragma unroll
+        for (int it = 0; it < PLAN_IT; ++it) {
+            const int c = wave + 16 * it;
+            int p = 0;
+#pragma unroll
+            for (int d = 0; d < MAXDOM; ++d) {
+                const unsigned long long m = __ballot(dom[it] == d);
+                if (dom[it] == d) p = cnt[d][c] + __popcll(m & lt);
+            }
+            if (dom[it] >= 0) {
+                const int i = round0 + c * 64 + lane;
+                const int b = i / a.K, k = i - b * a.K, dm = dom[it];
+                a.rows[dm * cap + p] = b * a.N + k;
+                a.toks[dm * cap + p] = tok[it] - a.dom_start[dm];
+                a.srcb[dm * cap + p] = b;
+            }
+        }
+        __syncthreads();
+        if (tid < MAXDOM) carry[tid] += wave_tot[tid][0] + wave_tot[tid][1];
     }
-#pragma unroll
-    for (int d = 0; d < MAXDOM; ++d) cnt[d][tid] = c[d];
     __syncthreads();
-    // inclusive Hillis-Steele scan per modality
-    for (int off = 1; off < 1024; off <<= 1) {
-        int v[MAXDOM];
-#pragma unroll
-        for (int d = 0; d < MAXDOM; ++d) v[d] = tid >= off ? cnt[d][tid - off] : 0;
-        __syncthreads();
-#pragma unroll
-        for (int d = 0; d < MAXDOM; ++d) cnt[d][tid] += v[d];
-        __syncthreads();
-    }
-    int pos[MAXDOM];
-#pragma unroll
-    for (int d = 0; d < MAXDOM; ++d) pos[d] = cnt[d][tid] - c[d];
-    if (tid == 1023) {
-#pragma unroll
-        for (int d = 0; d < MAXDOM; ++d) if (d < a.ndom) a.counts[d] = cnt[d][1023];
-    }
-    const int cap = total;
-    for (int i = beg; i < end; ++i) {
-        const int t = (int)a.ids_keep[i];
-        const int dm = find_dom(a.dom_start, a.ndom, t);
-        const int b = i / a.K, k = i - b * a.K;
-        int p = 0;
-#pragma unroll
-        for (int d = 0; d < MAXDOM; ++d) if (dm == d) { p = pos[d]; pos[d] += 1; }
-        a.rows[dm * cap + p] = b * a.N + k;
-        a.toks[dm * cap + p] = t - a.dom_start[dm];
-        a.srcb[dm * cap + p] = b;
-    }
+    if (tid < a.ndom) a.counts[tid] = carry[tid];
 }
 
 // image patches: img fp32 [B, C, H, W]; row i = patch (srcb[i], toks[i]) flattened (c, ph, pw) -> bf16 [cap, C*P*P]
-__global__ __launch_bounds__(256) void im2col_image_kernel(const float* __restrict__ img, const int* __restrict__ srcb,
+__global__ __launch_bounds__(256) void im2col_image_kernel(const float* __restrict__ img, const void* const* __restrict__ slot,
+                                                           const int* __restrict__ srcb,
                                                            const int* __restrict__ toks, const int* __restrict__ count,
                                                            int C, int H, int W, int P, int G, bf16_t* __restrict__ out) {
+    if (slot) img = static_cast<const float*>(*slot);        // input slot: the batch is read where it lies (mirage_hip.h, "Input slots")
     const int lane = threadIdx.x & 63;
     const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (i >= *count) return;
@@ -101,10 +132,12 @@ __global__ __launch_bounds__(256) void im2col_image_kernel(const float* __restri
 }
 
 // layer-map patches: labels int64 [B, Hs, Ws]; out[i][ch*PP + ph*P + pw] = class_emb[label][ch]
-__global__ __launch_bounds__(256) void im2col_layermap_kernel(const long* __restrict__ labels, const float* __restrict__ class_emb,
+__global__ __launch_bounds__(256) void im2col_layermap_kernel(const long* __restrict__ labels, const void* const* __restrict__ slot,
+                                                              const float* __restrict__ class_emb,
                                                               const int* __restrict__ srcb, const int* __restrict__ toks,
                                                               const int* __restrict__ count, int ncls, int E, int Hs, int Ws,
                                                               int P, int G, bf16_t* __restrict__ out) {
+    if (slot) labels = static_cast<const long*>(*slot);
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* emb = reinterpret_cast<float*>(smem);           // [ncls][E]
     int* lab = reinterpret_cast<int*>(emb + ncls * E);     // [P*P]
@@ -133,9 +166,11 @@ __global__ __launch_bounds__(256) void im2col_layermap_kernel(const long* __rest
 // grid = (E, nslices): one block per (embedding channel, slice of the kept rows); deterministic tree reduction per block into
 // partials[slice][c][ch], summed over slices by class_emb_grad_finish_kernel.
 __global__ __launch_bounds__(256) void class_emb_grad_kernel(const bf16_t* __restrict__ dA, const long* __restrict__ labels,
+                                                             const void* const* __restrict__ slot,
                                                              const int* __restrict__ srcb, const int* __restrict__ toks,
                                                              const int* __restrict__ count, int ncls, int E, int Hs, int Ws,
                                                              int P, int G, float* __restrict__ out_all) {
+    if (slot) labels = static_cast<const long*>(*slot);
     __shared__ float red[256];
     const int ch = blockIdx.x;
     const int PP = P * P;
@@ -236,24 +271,44 @@ extern "C" int mrg_embed_plan(const long* ids_keep, int B, int K, int N, int ndo
     return mrg_check_launch("mrg_embed_plan");
 }
 
+namespace {
+struct SlotValues { const void* v[8]; };
+__global__ void set_slots_kernel(const void** slots, const SlotValues vals, int n) {
+    if ((int)threadIdx.x < n) slots[threadIdx.x] = vals.v[threadIdx.x];
+}
+}  // namespace
+
+extern "C" int mrg_set_slots(const void** slots_dev, const void* const* values_host, int n, hipStream_t stream) {
+    MRG_REQUIRE(slots_dev && values_host, MRG_ERR_ARG, "mrg_set_slots: null pointer");
+    MRG_REQUIRE(n >= 1 && n <= 8, MRG_ERR_SHAPE, "mrg_set_slots: 1 <= n <= 8");
+    SlotValues vals = {};
+    for (int i = 0; i < n; ++i) {
+        MRG_REQUIRE(values_host[i] && ((uintptr_t)values_host[i] & 15) == 0, MRG_ERR_ARG, "mrg_set_slots: address %d is null or not 16-B aligned", i);
+        vals.v[i] = values_host[i];
+    }
+    hipLaunchKernelGGL(set_slots_kernel, dim3(1), dim3(64), 0, stream, slots_dev, vals, n);
+    return mrg_check_launch("mrg_set_slots");
+}
+
 extern "C" int mrg_im2col_image(const float* img, const int* srcb, const int* toks, const int* count_dev, int cap, int C, int H,
-                                int W, int P, void* out_bf16, hipStream_t stream) {
-    MRG_REQUIRE(img && srcb && toks && count_dev && out_bf16, MRG_ERR_ARG, "mrg_im2col_image: null pointer");
+                                int W, int P, void* out_bf16, const void* const* img_slot, hipStream_t stream) {
+    MRG_REQUIRE((img || img_slot) && srcb && toks && count_dev && out_bf16, MRG_ERR_ARG, "mrg_im2col_image: null pointer");
     MRG_REQUIRE(P > 0 && H % P == 0 && W % P == 0 && P % 4 == 0 && W % 4 == 0, MRG_ERR_SHAPE,
                 "mrg_im2col_image: need H,W divisible by P and P %% 4 == 0 (H=%d W=%d P=%d)", H, W, P);
-    MRG_REQUIRE(((uintptr_t)img & 15) == 0, MRG_ERR_ARG, "mrg_im2col_image: image must be 16-B aligned");
-    hipLaunchKernelGGL(im2col_image_kernel, dim3(cdiv(cap, 4)), dim3(256), 0, stream, img, srcb, toks, count_dev, C, H, W, P, W / P,
+    MRG_REQUIRE(((uintptr_t)img & 15) == 0, MRG_ERR_ARG, "mrg_im2col_image: image must be 16-B aligned");   // a slot's target: the caller's promise
+    hipLaunchKernelGGL(im2col_image_kernel, dim3(cdiv(cap, 4)), dim3(256), 0, stream, img, img_slot, srcb, toks, count_dev, C, H, W, P, W / P,
                        (bf16_t*)out_bf16);
     return mrg_check_launch("mrg_im2col_image");
 }
 
 extern "C" int mrg_im2col_layermap(const long* labels, const float* class_emb, const int* srcb, const int* toks, const int* count_dev,
-                                   int cap, int ncls, int E, int Hs, int Ws, int P, void* out_bf16, hipStream_t stream) {
-    MRG_REQUIRE(labels && class_emb && srcb && toks && count_dev && out_bf16, MRG_ERR_ARG, "mrg_im2col_layermap: null pointer");
+                                   int cap, int ncls, int E, int Hs, int Ws, int P, void* out_bf16, const void* const* labels_slot,
+                                   hipStream_t stream) {
+    MRG_REQUIRE((labels || labels_slot) && class_emb && srcb && toks && count_dev && out_bf16, MRG_ERR_ARG, "mrg_im2col_layermap: null pointer");
     MRG_REQUIRE(P > 0 && Hs % P == 0 && Ws % P == 0 && (P * P) % 4 == 0, MRG_ERR_SHAPE, "mrg_im2col_layermap: bad patch geometry");
     MRG_REQUIRE(ncls <= 16, MRG_ERR_UNSUPPORTED, "mrg_im2col_layermap: at most 16 classes");
     const size_t sh = (size_t)ncls * E * 4 + (size_t)P * P * 4;
-    hipLaunchKernelGGL(im2col_layermap_kernel, dim3(cap), dim3(256), sh, stream, labels, class_emb, srcb, toks, count_dev, ncls, E, Hs,
+    hipLaunchKernelGGL(im2col_layermap_kernel, dim3(cap), dim3(256), sh, stream, labels, labels_slot, class_emb, srcb, toks, count_dev, ncls, E, Hs,
                        Ws, P, Ws / P, (bf16_t*)out_bf16);
     return mrg_check_launch("mrg_im2col_layermap");
 }
@@ -261,12 +316,13 @@ extern "C" int mrg_im2col_layermap(const long* labels, const float* class_emb, c
 extern "C" int mrg_class_emb_grad_slices(void) { return 16; }
 
 extern "C" int mrg_class_emb_grad(const void* dA_bf16, const long* labels, const int* srcb, const int* toks, const int* count_dev,
-                                  int ncls, int E, int Hs, int Ws, int P, float* partials, float* out, hipStream_t stream) {
-    MRG_REQUIRE(dA_bf16 && labels && srcb && toks && count_dev && partials && out, MRG_ERR_ARG, "mrg_class_emb_grad: null pointer");
+                                  int ncls, int E, int Hs, int Ws, int P, float* partials, float* out, const void* const* labels_slot,
+                                  hipStream_t stream) {
+    MRG_REQUIRE(dA_bf16 && (labels || labels_slot) && srcb && toks && count_dev && partials && out, MRG_ERR_ARG, "mrg_class_emb_grad: null pointer");
     MRG_REQUIRE(ncls <= 16 && P * P <= 256 && 256 % (P * P) == 0, MRG_ERR_UNSUPPORTED,
                 "mrg_class_emb_grad: need <= 16 classes and P*P dividing 256");
     const int ns = mrg_class_emb_grad_slices();
-    hipLaunchKernelGGL(class_emb_grad_kernel, dim3(E, ns), dim3(256), 0, stream, (const bf16_t*)dA_bf16, labels, srcb, toks, count_dev,
+    hipLaunchKernelGGL(class_emb_grad_kernel, dim3(E, ns), dim3(256), 0, stream, (const bf16_t*)dA_bf16, labels, labels_slot, srcb, toks, count_dev,
                        ncls, E, Hs, Ws, P, Ws / P, partials);
     int rc = mrg_check_launch("mrg_class_emb_grad");
     if (rc) return rc;

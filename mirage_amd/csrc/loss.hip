@@ -34,8 +34,10 @@ __device__ __forceinline__ float block_sum(float v, float* red) {
 // grid (LOSS_CHUNKS, B); partial [B][LOSS_CHUNKS][2] = (sum of masked per-pixel loss, masked pixel count)
 template <typename T, bool CE>
 __global__ __launch_bounds__(256) void loss_fwd_kernel(const T* __restrict__ pred, const void* __restrict__ target,
+                                                       const void* const* __restrict__ tslot,
                                                        const long* __restrict__ mask, int B, int C, int H, int W, int P,
                                                        float* __restrict__ partial) {
+    if (tslot) target = *tslot;                              // input slot: the batch is read where it lies (mirage_hip.h, "Input slots")
     __shared__ float red[4];
     const int b = blockIdx.y, chunk = blockIdx.x;
     const int nw = W / P;
@@ -113,9 +115,11 @@ __global__ void loss_finish_kernel(const float* __restrict__ partial, int B, flo
 
 template <typename T, bool CE>
 __global__ __launch_bounds__(256) void loss_bwd_kernel(const T* __restrict__ pred, const void* __restrict__ target,
+                                                       const void* const* __restrict__ tslot,
                                                        const long* __restrict__ mask, const float* __restrict__ coef,
                                                        const float* __restrict__ gout, int B, int C, int H, int W, int P,
                                                        T* __restrict__ dpred) {
+    if (tslot) target = *tslot;
     const long HW = (long)H * W;
     const long total = (long)B * HW;
     const int nw = W / P;
@@ -150,8 +154,10 @@ __global__ __launch_bounds__(256) void loss_bwd_kernel(const T* __restrict__ pre
 
 // ---- single-channel bf16 MSE fast path: 8 consecutive pixels (16 B of predictions, 32 B of targets) per thread
 __global__ __launch_bounds__(256) void mse1_fwd_vec_kernel(const bf16_t* __restrict__ pred, const float* __restrict__ target,
+                                                           const void* const* __restrict__ tslot,
                                                            const long* __restrict__ mask, int B, int H, int W, int P,
                                                            float* __restrict__ partial) {
+    if (tslot) target = static_cast<const float*>(*tslot);
     __shared__ float red[4];
     const int b = blockIdx.y, chunk = blockIdx.x;
     const int nw = W / P;
@@ -181,9 +187,11 @@ __global__ __launch_bounds__(256) void mse1_fwd_vec_kernel(const bf16_t* __restr
 }
 
 __global__ __launch_bounds__(256) void mse1_bwd_vec_kernel(const bf16_t* __restrict__ pred, const float* __restrict__ target,
+                                                           const void* const* __restrict__ tslot,
                                                            const long* __restrict__ mask, const float* __restrict__ coef,
                                                            const float* __restrict__ gout, int B, int H, int W, int P,
                                                            bf16_t* __restrict__ dpred) {
+    if (tslot) target = static_cast<const float*>(*tslot);
     const long HW = (long)H * W;
     const long total8 = (long)B * HW / 8;
     const int nw = W / P;
@@ -231,7 +239,7 @@ __global__ void patch_rearrange_kernel(const T* __restrict__ src, T* __restrict_
 
 int check(const mrg_loss_desc* d, const char* who) {
     MRG_REQUIRE(d != nullptr, MRG_ERR_ARG, "%s: null descriptor", who);
-    MRG_REQUIRE(d->pred && d->target && d->partial && d->coef, MRG_ERR_ARG, "%s: null pointer", who);
+    MRG_REQUIRE(d->pred && (d->target || d->target_slot) && d->partial && d->coef, MRG_ERR_ARG, "%s: null pointer", who);
     MRG_REQUIRE(d->kind == MRG_LOSS_MSE || d->kind == MRG_LOSS_CE, MRG_ERR_ARG, "%s: bad kind", who);
     MRG_REQUIRE(d->B > 0 && d->C > 0 && d->P > 0 && d->H % d->P == 0 && d->W % d->P == 0, MRG_ERR_SHAPE, "%s: bad geometry", who);
     MRG_REQUIRE(d->pred_dtype == MRG_DT_BF16 || d->pred_dtype == MRG_DT_F32, MRG_ERR_ARG, "%s: bad dtype", who);
@@ -250,10 +258,10 @@ extern "C" int mrg_masked_loss_fwd(const mrg_loss_desc* d, hipStream_t stream) {
     const bool vec_mse = d->kind == MRG_LOSS_MSE && d->C == 1 && d->pred_dtype == MRG_DT_BF16 && d->P % 8 == 0 && d->W % 8 == 0 &&
                          (((uintptr_t)d->pred | (uintptr_t)d->target) & 15) == 0;
     if (vec_mse) {
-        hipLaunchKernelGGL(mse1_fwd_vec_kernel, grid, block, 0, stream, (const bf16_t*)d->pred, (const float*)d->target, d->mask, d->B, d->H,
+        hipLaunchKernelGGL(mse1_fwd_vec_kernel, grid, block, 0, stream, (const bf16_t*)d->pred, (const float*)d->target, d->target_slot, d->mask, d->B, d->H,
                            d->W, d->P, d->partial);
     } else {
-#define MRG_L(T, CE) hipLaunchKernelGGL((loss_fwd_kernel<T, CE>), grid, block, 0, stream, (const T*)d->pred, d->target, d->mask, d->B, d->C, d->H, d->W, d->P, d->partial)
+#define MRG_L(T, CE) hipLaunchKernelGGL((loss_fwd_kernel<T, CE>), grid, block, 0, stream, (const T*)d->pred, d->target, d->target_slot, d->mask, d->B, d->C, d->H, d->W, d->P, d->partial)
     if (d->pred_dtype == MRG_DT_BF16) { if (d->kind == MRG_LOSS_CE) MRG_L(bf16_t, true); else MRG_L(bf16_t, false); }
     else { if (d->kind == MRG_LOSS_CE) MRG_L(float, true); else MRG_L(float, false); }
 #undef MRG_L
@@ -274,10 +282,10 @@ extern "C" int mrg_masked_loss_bwd(const mrg_loss_desc* d, hipStream_t stream) {
                          (((uintptr_t)d->pred | (uintptr_t)d->target | (uintptr_t)d->dpred) & 15) == 0;
     if (vec_mse) {
         hipLaunchKernelGGL(mse1_bwd_vec_kernel, dim3((unsigned)((total / 8 + 255) / 256 < 4096 ? (total / 8 + 255) / 256 : 4096)), block, 0, stream,
-                           (const bf16_t*)d->pred, (const float*)d->target, d->mask, d->coef, d->gout, d->B, d->H, d->W, d->P, (bf16_t*)d->dpred);
+                           (const bf16_t*)d->pred, (const float*)d->target, d->target_slot, d->mask, d->coef, d->gout, d->B, d->H, d->W, d->P, (bf16_t*)d->dpred);
         return mrg_check_launch("mrg_masked_loss_bwd");
     }
-#define MRG_L(T, CE) hipLaunchKernelGGL((loss_bwd_kernel<T, CE>), grid, block, 0, stream, (const T*)d->pred, d->target, d->mask, d->coef, d->gout, d->B, d->C, d->H, d->W, d->P, (T*)d->dpred)
+#define MRG_L(T, CE) hipLaunchKernelGGL((loss_bwd_kernel<T, CE>), grid, block, 0, stream, (const T*)d->pred, d->target, d->target_slot, d->mask, d->coef, d->gout, d->B, d->C, d->H, d->W, d->P, (T*)d->dpred)
     if (d->pred_dtype == MRG_DT_BF16) { if (d->kind == MRG_LOSS_CE) MRG_L(bf16_t, true); else MRG_L(bf16_t, false); }
     else { if (d->kind == MRG_LOSS_CE) MRG_L(float, true); else MRG_L(float, false); }
 #undef MRG_L

@@ -22,6 +22,7 @@ BF16, F32 = torch.bfloat16, torch.float32
 KS = L.MRG_OP_KSTRIDED
 FUSE_EPI_COLSUM = True    # bias gradient of the producing layer from the dgrad GEMM's epilogue (column sums of dx per tile)
 EMBED_WGRAD_GATHER = True # patch-embedding weight gradient: compact the gradient rows, then a plain k-strided GEMM (A/B: MRG_EMBED_GATHER=0)
+EMBED_LANES = os.environ.get("MRG_EMBED_LANES", "0") != "0"   # the modalities' patch projections side by side on lane streams: measured neutral (C2 9.52 / 9.54 vs 9.54 / 9.51 ms, C4 20.46 vs 20.53), the two cross-stream edges cost what the shared round saves
 FUSE_ATTN_BIAS = True     # q / k / v bias gradients from inside the attention-backward kernels (else: a column-sum pass over d_qkv)
 
 
@@ -506,8 +507,7 @@ def embed_fwd(model, x: Dict[str, torch.Tensor], ids_keep: torch.Tensor, save: b
     rows, toks, srcb, counts = K.embed_plan(ids_keep, N, dom_start)
     cap = B * Kk
     x0 = torch.empty((B, N, D), dtype=F32, device=dev)
-    saved = []
-    for d, dom in enumerate(doms):
+    def embed_one(d, dom):
         ad = model.input_adapters[dom]
         inp = x[dom]
         if ad.kind == "semseg":
@@ -518,7 +518,11 @@ def embed_fwd(model, x: Dict[str, torch.Tensor], ids_keep: torch.Tensor, save: b
         Kp = A.shape[1]
         K.gemm(A, W, cap, D, Kp, lda=Kp, ldb=Kp, out=x0, ldc=D, bias=ad.proj.bias, row_map=rows[d], add_tab=_pos_tokens(ad),
                add_row=toks[d], m_dev=counts[d:d + 1])
-        saved.append(A if save else None)
+        return A if save else None
+    # the modalities' patch projections are independent (disjoint rows of x0) and each fills about 1 / ndom of its capacity-sized
+    # grid: MRG_EMBED_LANES=1 runs them side by side on lane streams (one shared round of the chip instead of one each)
+    saved = _Lanes.run_all([(lambda d=d, dom=dom: embed_one(d, dom)) for d, dom in enumerate(doms)], dev,
+                           enabled=_Lanes.enabled and EMBED_LANES)
     K.fill_global(x0, model.global_tokens, B, N, Kk)
     plan = (rows, toks, srcb, counts)
     return x0, (plan, saved, {k: x[k] for k in doms}) if save else None

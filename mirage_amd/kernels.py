@@ -6,7 +6,8 @@ libmirage_hip.so, and returns torch tensors.  No computation happens in torch.
 import ctypes as C
 import json
 import os
-from typing import Optional, Sequence
+import weakref
+from typing import Dict, Optional, Sequence
 
 import torch
 
@@ -588,11 +589,79 @@ def embed_plan(ids_keep: torch.Tensor, N: int, dom_start: Sequence[int]):
     return rows, toks, srcb, counts
 
 
+# ------------------------------------------------------------------------------------------- input slots
+_SLOT_OF_PTR: Dict[int, int] = {}      # data_ptr of a placeholder tensor -> address of its slot (see InputSlots)
+
+
+def slot_of(t: Optional[torch.Tensor]) -> Optional[int]:
+    """Address of the input slot a placeholder tensor stands for, or None: the wrappers of the kernels that read raw input batches
+    (patch packers, class-embedding gradient, masked losses) pass it along, and the kernel then reads the batch at the address the
+    slot holds when it RUNS instead of at t.data_ptr()."""
+    return _SLOT_OF_PTR.get(t.data_ptr()) if (t is not None and _SLOT_OF_PTR) else None
+
+
+class InputSlots:
+    """Device table of input-batch base addresses (include/mirage_hip.h "Input slots").  `placeholders` {name: tensor} fix shape,
+    dtype and device of each input and stand for "whatever batch is bound" wherever the engine meets them (their data_ptr is the
+    registry key, so views / .contiguous() of a placeholder resolve too); `bind` points the slots at a batch without copying it.  A
+    captured step therefore reads every new batch in place.  The bound batch is kept alive until the next bind."""
+
+    def __init__(self, placeholders: Dict[str, torch.Tensor]):
+        self.names = list(placeholders)
+        if not 1 <= len(self.names) <= 8:
+            raise ValueError("InputSlots: 1 to 8 inputs")
+        self.placeholders = dict(placeholders)
+        dev = next(iter(placeholders.values())).device
+        for k, t in placeholders.items():
+            _need_cuda(t, f"input placeholder {k}")
+            if not t.is_contiguous() or t.device != dev:
+                raise ValueError(f"InputSlots: placeholder {k} must be contiguous and on {dev}")
+        self.table = torch.zeros(len(self.names), dtype=torch.int64, device=dev)
+        self._bound_ptrs, self._held = None, None
+        self._keys = []
+        for i, k in enumerate(self.names):
+            key = placeholders[k].data_ptr()
+            if key in _SLOT_OF_PTR:
+                raise RuntimeError(f"InputSlots: placeholder {k} already stands for another slot")
+            _SLOT_OF_PTR[key] = self.table.data_ptr() + 8 * i
+            self._keys.append(key)
+        weakref.finalize(self, InputSlots._release, list(self._keys))
+        self.bind(self.placeholders)
+
+    @staticmethod
+    def _release(keys):
+        for k in keys:
+            _SLOT_OF_PTR.pop(k, None)
+
+    def close(self):
+        InputSlots._release(self._keys)
+
+    def bind(self, batch: Dict[str, torch.Tensor]):
+        ptrs = []
+        for k in self.names:
+            t, ref = batch[k], self.placeholders[k]
+            if t.shape != ref.shape or t.dtype != ref.dtype or t.device != ref.device or not t.is_contiguous():
+                raise ValueError(f"InputSlots.bind: {k} must be a contiguous {tuple(ref.shape)} {ref.dtype} tensor on {ref.device}, "
+                                 f"got {tuple(t.shape)} {t.dtype} on {t.device}" + ("" if t.is_contiguous() else " (not contiguous)"))
+            if t.data_ptr() % 16:
+                raise ValueError(f"InputSlots.bind: {k} is not 16-byte aligned")
+            ptrs.append(t.data_ptr())
+        if ptrs != self._bound_ptrs:
+            arr = (C.c_void_p * len(ptrs))(*ptrs)
+            check(lib.mrg_set_slots(self.table.data_ptr(), arr, len(ptrs), _s()), "mrg_set_slots")
+            self._bound_ptrs = ptrs
+        cur = torch.cuda.current_stream()
+        for k in self.names:
+            if batch[k] is not self.placeholders[k]:
+                batch[k].record_stream(cur)        # produced on a loader's stream: its memory must outlive this stream's reads
+        self._held = {k: batch[k] for k in self.names}
+
+
 def im2col_image(img: torch.Tensor, srcb, toks, count, cap: int, P: int) -> torch.Tensor:
     B, Cc, H, W = img.shape
     out = torch.empty((cap, Cc * P * P), dtype=BF16, device=img.device)
-    check(lib.mrg_im2col_image(img.data_ptr(), srcb.data_ptr(), toks.data_ptr(), count.data_ptr(), cap, Cc, H, W, P, out.data_ptr(), _s()),
-          "mrg_im2col_image")
+    check(lib.mrg_im2col_image(img.data_ptr(), srcb.data_ptr(), toks.data_ptr(), count.data_ptr(), cap, Cc, H, W, P, out.data_ptr(),
+                               slot_of(img), _s()), "mrg_im2col_image")
     return out
 
 
@@ -601,7 +670,7 @@ def im2col_layermap(labels: torch.Tensor, class_emb: torch.Tensor, srcb, toks, c
     ncls, E = class_emb.shape
     out = torch.empty((cap, E * P * P), dtype=BF16, device=labels.device)
     check(lib.mrg_im2col_layermap(labels.data_ptr(), class_emb.data_ptr(), srcb.data_ptr(), toks.data_ptr(), count.data_ptr(), cap, ncls,
-                                  E, Hs, Ws, P, out.data_ptr(), _s()), "mrg_im2col_layermap")
+                                  E, Hs, Ws, P, out.data_ptr(), slot_of(labels), _s()), "mrg_im2col_layermap")
     return out
 
 
@@ -609,7 +678,7 @@ def class_emb_grad(dA: torch.Tensor, labels, srcb, toks, count, ncls: int, E: in
     B, Hs, Ws = labels.shape
     partials = torch.empty(lib.mrg_class_emb_grad_slices() * ncls * E, dtype=F32, device=dA.device)
     check(lib.mrg_class_emb_grad(dA.data_ptr(), labels.data_ptr(), srcb.data_ptr(), toks.data_ptr(), count.data_ptr(), ncls, E, Hs, Ws, P,
-                                 partials.data_ptr(), out.data_ptr(), _s()), "mrg_class_emb_grad")
+                                 partials.data_ptr(), out.data_ptr(), slot_of(labels), _s()), "mrg_class_emb_grad")
     return out
 
 
@@ -660,7 +729,7 @@ def loss_desc(kind, pred, target, mask, P):
     d = L.LossDesc()
     B, Cc, H, W = pred.shape
     d.kind, d.pred, d.pred_dtype = kind, pred.data_ptr(), (L.MRG_DT_BF16 if pred.dtype == BF16 else L.MRG_DT_F32)
-    d.target, d.mask = target.data_ptr(), _p(mask)
+    d.target, d.mask, d.target_slot = target.data_ptr(), _p(mask), slot_of(target)
     d.B, d.C, d.H, d.W, d.P = B, Cc, H, W, P
     d._refs = (pred, target, mask)
     return d
@@ -701,6 +770,27 @@ def maskgen(p: torch.Tensor, u: torch.Tensor, g: torch.Tensor, K: int, dom_start
     check(lib.mrg_maskgen(p.data_ptr(), u.data_ptr(), g.data_ptr(), B, T, K, len(dom_start) - 1, _int_array(list(dom_start)),
                           task_mask.data_ptr(), ids_keep.data_ptr(), ids_restore.data_ptr(), _s()), "mrg_maskgen")
     return task_mask, ids_keep, ids_restore
+
+
+def maskgen_rng(conc: torch.Tensor, rng: torch.Tensor, K: int, T: int, dom_start: Sequence[int], return_noise: bool = False):
+    """The masks of `maskgen` with the noise drawn inside the launch (csrc/maskgen.hip): conc fp32 [B, ndom]; rng int64 [3] on the
+    device = {seed, step, 0}, advanced by the launch itself.  return_noise: also (p, u, g) as drawn (tests)."""
+    _need_cuda(conc, "Dirichlet concentrations")
+    if rng.dtype != torch.int64 or rng.numel() != 3 or rng.device != conc.device or not rng.is_contiguous():
+        raise ValueError("maskgen_rng: rng must be a contiguous int64[3] tensor {seed, step, 0} on the masks' device")
+    if conc.dtype != F32 or not conc.is_contiguous():
+        raise ValueError("maskgen_rng: conc must be contiguous fp32 [B, ndom]")
+    B, ndom = conc.shape
+    dev = conc.device
+    task_mask = torch.empty((B, T), dtype=torch.int64, device=dev)
+    ids_keep = torch.empty((B, K), dtype=torch.int64, device=dev)
+    ids_restore = torch.empty((B, T), dtype=torch.int64, device=dev)
+    noise = (torch.empty((B, ndom), dtype=F32, device=dev), torch.empty((B, T), dtype=F32, device=dev),
+             torch.empty((B, T), dtype=F32, device=dev)) if return_noise else (None, None, None)
+    check(lib.mrg_maskgen_rng(conc.data_ptr(), rng.data_ptr(), B, T, K, ndom, _int_array(list(dom_start)), task_mask.data_ptr(),
+                              ids_keep.data_ptr(), ids_restore.data_ptr(), *[(t.data_ptr() if t is not None else None) for t in noise],
+                              _s()), "mrg_maskgen_rng")
+    return (task_mask, ids_keep, ids_restore) + ((noise,) if return_noise else ())
 
 
 # ------------------------------------------------------------------------------------------- optimizer

@@ -175,10 +175,31 @@ class MIRAGEModel(nn.Module):
             al = tuple(float(a) for a in alphas)
             conc = self._const(("conc", al, B, str(device)),
                                lambda: torch.tensor(al, dtype=torch.float32, device=device).expand(B, n).contiguous())
-        p = torch._sample_dirichlet(conc)                      # model.py:205-207 (device-side draw)
-        u = torch.rand(B, T, device=device)                     # model.py:216 (one draw covering all tasks)
-        g = torch.rand(B, T, device=device)                     # model.py:225
-        return self.generate_random_masks_from_noise(p, u, g, num_encoded_tokens, doms)
+        # the Dirichlet shares (model.py:205-207) and the two uniform draws (model.py:216,225) are drawn inside the mask launch
+        dom_start = self._dom_start(doms)
+        tm, ids_keep, ids_restore = K.maskgen_rng(conc, self.mask_rng(device), num_encoded_tokens, T, dom_start)
+        return {d: tm[:, dom_start[i]:dom_start[i + 1]] for i, d in enumerate(doms)}, ids_keep, ids_restore
+
+    def mask_rng(self, device) -> Tensor:
+        """Device state {seed, step, 0} (int64[3]) of the mask generator's Philox streams; the mask launch advances `step` itself, so a
+        captured step draws new masks at every replay.  Seeded from `torch.initial_seed()` on first use and again whenever that seed
+        has changed since (i.e. after `torch.manual_seed(other)`; not inside a stream capture); `seed_masks` pins it explicitly."""
+        device = torch.device(device)
+        states = self.__dict__.setdefault("_mask_rng_states", {})
+        src = torch.initial_seed()
+        st = states.get(device)
+        if st is None:
+            st = states[device] = [torch.tensor([src & 0x7FFFFFFFFFFFFFFF, 0, 0], dtype=torch.int64, device=device), src]
+        elif st[1] != src and not (device.type == "cuda" and torch.cuda.is_current_stream_capturing()):
+            st[0].copy_(torch.tensor([src & 0x7FFFFFFFFFFFFFFF, 0, 0], dtype=torch.int64))
+            st[1] = src
+        return st[0]
+
+    def seed_masks(self, seed: int, step: int = 0, device=None):
+        """Pin the mask stream (tests, resume): the next forward pass draws the masks of (seed, step)."""
+        device = device if device is not None else next(self.parameters()).device
+        st = self.mask_rng(device)
+        st.copy_(torch.tensor([int(seed) & 0x7FFFFFFFFFFFFFFF, int(step), 0], dtype=torch.int64))
 
     @staticmethod
     def make_mask(N_H, N_W, xy_idxs, full_tasks=[], indicate_visible=True, flatten=True, device="cuda"):

@@ -20,7 +20,11 @@ class TrainStep:
                  feed_mask_noise: bool = False):
         self.model, self.loss_fns, self.opt = model, loss_fns, optimizer
         self.K, self.alphas, self.uniform = num_encoded_tokens, alphas, sample_tasks_uniformly
-        self.static_x = {k: torch.empty_like(v) for k, v in batch_example.items()}
+        # the step reads its inputs through input slots (kernels.InputSlots): `static_x` are the placeholders the captured launches
+        # were recorded with AND the staging buffers of load(); step(batch) re-points the slots at the batch itself -- no copy
+        self.static_x = {k: torch.empty_like(v.contiguous()) for k, v in batch_example.items()}
+        from . import kernels as _K
+        self.slots = _K.InputSlots(self.static_x)
         self.in_domains = list(model.input_adapters.keys())
         # parity runs: the three random inputs of the mask generator (Dirichlet shares p [B, n], per-task
         # noise u [B, T], tie-break noise g [B, T]) come from static buffers filled by step(noise=...) instead of the device RNG
@@ -222,6 +226,7 @@ class TrainStep:
         rng_cpu, rng_dev = torch.get_rng_state(), torch.cuda.get_rng_state(dev)
         from .engine import DropoutRNG
         drop_state = DropoutRNG.state(dev).clone()
+        mask_state = self.model.mask_rng(dev).clone() if hasattr(self.model, "mask_rng") else None
         s = torch.cuda.Stream()
         s.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(s):
@@ -235,6 +240,8 @@ class TrainStep:
         torch.set_rng_state(rng_cpu)
         torch.cuda.set_rng_state(rng_dev, dev)
         DropoutRNG.state(dev).copy_(drop_state)
+        if mask_state is not None:
+            self.model.mask_rng(dev).copy_(mask_state)
         if self.reducer is None:
             self.g_fb = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self.g_fb, capture_error_mode="thread_local"):
@@ -265,12 +272,20 @@ class TrainStep:
         self.opt.arena.mark_fresh()
 
     def load(self, batch: Dict[str, torch.Tensor]):
+        """copy a batch into the staging buffers and read the next steps from there"""
         for k, v in batch.items():
             self.static_x[k].copy_(v, non_blocking=True)
+        self.slots.bind(self.static_x)
 
     def step(self, batch: Optional[Dict[str, torch.Tensor]] = None, noise=None):
+        """One training step.  `batch` (device tensors shaped like the example batch, contiguous) is read IN PLACE: the input slots are
+        pointed at it (one tiny launch) and it is kept alive until the next step; the caller must not overwrite it on another stream
+        before this step has run.  Without `batch` the step re-reads what is bound (after load(): the staging buffers)."""
         if batch is not None:
-            self.load(batch)
+            try:
+                self.slots.bind(batch)
+            except ValueError:
+                self.load(batch)                       # other dtype / layout / device: converted by the staging copy
         if noise is not None:
             if self.static_noise is None:
                 raise RuntimeError("TrainStep.step(noise=...): construct the TrainStep with feed_mask_noise=True")

@@ -628,6 +628,136 @@ def test_maskgen_full_size_properties(K):
     assert torch.equal(torch.gather(ir, 1, ik), torch.arange(Kk, device=dev())[None].expand(B, -1))
 
 
+def test_maskgen_rng_noise_is_the_oracle_philox_and_masks_are_the_explicit_path(K):
+    """The production launch draws its noise itself: u, g bit-equal to the oracle's Philox restatement, p to ~1e-5 (fast device log /
+    cos), the masks bit-equal to the explicit-noise launch and to the oracle fed with the drawn noise; the launch advances the step."""
+    from oracle import mirage_oracle as O
+    B, T, Kk, ds = 64, 768, 98, [0, 256, 512, 768]
+    seed, step = 0x1234_5678_9ABC, 41
+    conc = torch.ones(B, 3, device=dev())
+    st = torch.tensor([seed, step, 0], dtype=torch.int64, device=dev())
+    tm, ik, ir, (p, u, g) = K.maskgen_rng(conc, st, Kk, T, ds, return_noise=True)
+    assert st.tolist() == [seed, step + 1, 0]
+    ou, og = O.mask_noise_philox(B, T, seed, step)
+    assert np.array_equal(u.cpu().numpy(), ou) and np.array_equal(g.cpu().numpy(), og)
+    op = O.mask_shares_philox(np.ones((B, 3), np.float32), seed, step)
+    np.testing.assert_allclose(p.cpu().numpy(), op, rtol=2e-4, atol=1e-6)
+    tm2, ik2, ir2 = K.maskgen(p, u, g, Kk, ds)
+    assert torch.equal(tm, tm2) and torch.equal(ik, ik2) and torch.equal(ir, ir2)
+    pn, un, gn = p.cpu().numpy(), u.cpu().numpy(), g.cpu().numpy()
+    rtm, rik, rir = O.generate_masks_from_noise(pn, [un[:, :256], un[:, 256:512], un[:, 512:]], gn, Kk)
+    assert np.array_equal(ik.cpu().numpy(), rik) and np.array_equal(ir.cpu().numpy(), rir)
+    assert np.array_equal(tm.cpu().numpy(), np.concatenate(rtm, 1))
+    # next step: other masks; the same (seed, step) again: the same masks
+    tm3, ik3, _ = K.maskgen_rng(conc, st, Kk, T, ds)
+    assert st.tolist() == [seed, step + 2, 0] and not torch.equal(ik3, ik)
+    st.copy_(torch.tensor([seed, step, 0]))
+    tm4, ik4, ir4 = K.maskgen_rng(conc, st, Kk, T, ds)
+    assert torch.equal(ik4, ik) and torch.equal(ir4, ir) and torch.equal(tm4, tm)
+    # awkward geometry: token counts that are not multiples of 4, one modality, K = T
+    st2 = torch.tensor([7, 0, 0], dtype=torch.int64, device=dev())
+    for (Tn, dsn, Kn) in ((7, [0, 3, 7], 2), (130, [0, 130], 130), (2048, [0, 1000, 2048], 300)):
+        cn = torch.full((3, len(dsn) - 1), 0.7, device=dev())
+        a, b_, c, (pp, uu, gg) = K.maskgen_rng(cn, st2, Kn, Tn, dsn, return_noise=True)
+        a2, b2, c2 = K.maskgen(pp, uu, gg, Kn, dsn)
+        assert torch.equal(a, a2) and torch.equal(b_, b2) and torch.equal(c, c2)
+        assert ((a == 0).sum(1) == Kn).all()
+        uo, go = O.mask_noise_philox(3, Tn, 7, int(st2[1]) - 1)
+        assert np.array_equal(uu.cpu().numpy(), uo) and np.array_equal(gg.cpu().numpy(), go)
+
+
+def test_maskgen_rng_statistics(K):
+    """Dirichlet(1, 1) shares are uniform, Dirichlet(a, b) has the Beta moments, a vanishing concentration gets (almost) nothing, and
+    every token of a modality is equally likely to be kept."""
+    B, T, Kk, ds = 8192, 128, 32, [0, 64, 128]
+    st = torch.tensor([99, 0, 0], dtype=torch.int64, device=dev())
+    tm, ik, ir, (p, u, g) = K.maskgen_rng(torch.ones(B, 2, device=dev()), st, Kk, T, ds, return_noise=True)
+    p0 = p[:, 0].double().cpu().numpy()
+    assert abs(p0.mean() - 0.5) < 0.012 and abs(p0.var() - 1 / 12) < 0.004
+    hist = np.histogram(p0, bins=10, range=(0, 1))[0] / B
+    assert np.abs(hist - 0.1).max() < 0.015
+    assert abs(float(u.mean()) - 0.5) < 2e-3 and abs(float(g.var()) - 1 / 12) < 2e-3
+    keep_freq = (tm == 0).double().mean(0).cpu().numpy()                 # expected K / T for every token
+    assert np.abs(keep_freq - Kk / T).max() < 0.025
+    conc = torch.tensor([[2.5, 0.6]], device=dev()).expand(B, 2).contiguous()
+    _, _, _, (p, _, _) = K.maskgen_rng(conc, st, Kk, T, ds, return_noise=True)
+    p0 = p[:, 0].double().cpu().numpy()
+    a, b = 2.5, 0.6
+    assert abs(p0.mean() - a / (a + b)) < 0.01 and abs(p0.var() - a * b / ((a + b) ** 2 * (a + b + 1))) < 0.004
+    conc = torch.tensor([[1e-5, 1.0 + 1e-5]], device=dev()).expand(B, 2).contiguous()      # sample_alphas: a task that was not chosen
+    tm, _, _, (p, _, _) = K.maskgen_rng(conc, st, Kk, T, ds, return_noise=True)
+    assert float(p[:, 0].max()) < 1e-3 and int((tm[:, :64] == 0).sum()) == 0 and ((tm == 0).sum(1) == Kk).all()
+    assert torch.isfinite(p).all()
+
+
+def test_input_slots_redirect_the_batch_readers(K):
+    """Every kernel that reads a raw input batch (image / layer-map patch packers, class-embedding gradient, both masked losses forward
+    and backward) follows its input slot: launched on the PLACEHOLDER (filled with garbage) with the slots bound to the real batch, the
+    results equal those of a direct launch on the real batch; re-binding re-directs without another launch-site change."""
+    torch.manual_seed(0)
+    B, Kk, dom_start, T = 4, 40, [0, 64, 128], 128
+    ids = torch.stack([torch.randperm(T)[:Kk] for _ in range(B)]).to(dev())
+    rows, toks, srcb, counts = K.embed_plan(ids, Kk + 1, dom_start)
+    cap = B * Kk
+    real = {"img": torch.rand(B, 1, 64, 64, device=dev()), "lab": torch.randint(0, 13, (B, 16, 16), device=dev())}
+    other = {"img": torch.rand(B, 1, 64, 64, device=dev()), "lab": torch.randint(0, 13, (B, 16, 16), device=dev())}
+    ph = {"img": torch.full((B, 1, 64, 64), float("nan"), device=dev()), "lab": torch.full((B, 16, 16), 99, dtype=torch.int64, device=dev())}
+    emb = torch.randn(13, 64, device=dev()) * 0.05
+    dA = (torch.randn(cap, 256, device=dev()) * 0.1).to(BF16)
+    pred = (torch.randn(B, 1, 64, 64, device=dev())).to(BF16)
+    logits = torch.randn(B, 13, 16, 16, device=dev())
+    mask = (torch.rand(B, 64, device=dev()) < 0.7).long()
+
+    def everything(x):
+        out = [K.im2col_image(x["img"], srcb[0], toks[0], counts[0:1], cap, 8),
+               K.im2col_layermap(x["lab"], emb, srcb[1], toks[1], counts[1:2], cap, 2),
+               K.class_emb_grad(dA, x["lab"], srcb[1], toks[1], counts[1:2], 13, 64, 2, torch.empty(13, 64, device=dev())).clone()]
+        for kind, p_, t_, P in ((K.L.MRG_LOSS_MSE, pred, x["img"], 8), (K.L.MRG_LOSS_CE, logits, x["lab"], 2)):
+            d = K.loss_desc(kind, p_, t_, mask, P)
+            loss, coef, partial = K.masked_loss_fwd(d, p_.device)
+            out += [loss.clone(), K.masked_loss_bwd(d, coef, partial, None, p_)]
+        c0, c1 = int(counts[0]), int(counts[1])
+        out[0], out[1] = out[0][:c0].clone(), out[1][:c1].clone()
+        return out
+    direct, direct_other = everything(real), everything(other)
+    slots = K.InputSlots(ph)
+    assert K.slot_of(ph["img"]) is not None and K.slot_of(real["img"]) is None
+    slots.bind(real)
+    via = everything(ph)
+    for a, b in zip(direct, via):
+        assert torch.equal(a, b)
+    slots.bind(other)
+    for a, b in zip(direct_other, everything(ph)):
+        assert torch.equal(a, b)
+    with pytest.raises(ValueError):
+        slots.bind({"img": real["img"][:, :, ::2], "lab": real["lab"]})
+    with pytest.raises(ValueError):
+        slots.bind({"img": real["img"].double(), "lab": real["lab"]})
+    slots.close()
+    assert K.slot_of(ph["img"]) is None
+
+
+def test_embed_plan_long_lists_and_ragged_chunks(K):
+    """The plan kernel walks lists of more than 131072 kept tokens in rounds; counts and order are those of a flat (b, k) scan."""
+    g = torch.Generator().manual_seed(3)
+    for (B, Kk, dom_start) in ((600, 256, [0, 100, 356, 400, 1024]), (3, 7, [0, 5, 9]), (64, 128, [0, 256, 512]), (257, 129, [0, 512])):
+        T = dom_start[-1]
+        ids = torch.stack([torch.randperm(T, generator=g)[:Kk] for _ in range(B)])
+        N = Kk + 1
+        rows, toks, srcb, counts = K.embed_plan(ids.to(dev()), N, dom_start)
+        flat = ids.reshape(-1)
+        dm = torch.bucketize(flat, torch.tensor(dom_start[1:-1]), right=True) if len(dom_start) > 2 else torch.zeros_like(flat)
+        bb = torch.arange(B).repeat_interleave(Kk)
+        kk = torch.arange(Kk).repeat(B)
+        for d in range(len(dom_start) - 1):
+            sel = dm == d
+            c = int(counts[d])
+            assert c == int(sel.sum())
+            assert torch.equal(rows[d, :c].cpu().long(), (bb * N + kk)[sel])
+            assert torch.equal(toks[d, :c].cpu().long(), flat[sel] - dom_start[d])
+            assert torch.equal(srcb[d, :c].cpu().long(), bb[sel])
+
+
 # ------------------------------------------------------------------------------------------- optimizer
 def test_adamw_gradnorm_cast(K):
     from oracle import mirage_oracle as O

@@ -539,3 +539,57 @@ def test_graph_step_does_not_depend_on_warmup_data(doms):
     e, g = run(False), run(True)
     assert e[0] == g[0] and e[3] == g[3]
     assert torch.equal(e[1], g[1]) and torch.equal(e[2], g[2]) and torch.equal(e[4], g[4])
+
+
+def test_step_reads_batches_in_place_through_input_slots():
+    """TrainStep.step(batch) points the input slots at the batch (no staging copy): three captured steps over three different batches
+    equal -- bit for bit -- the same steps fed through load() (the copying path), the staging buffers are left alone, and a batch the
+    slots cannot take (non-contiguous) silently goes through the copy."""
+    from mirage_amd import builder, optim, kernels as K
+    from mirage_amd.trainer import TrainStep
+    from oracle import mirage_oracle as O
+    import test_model_gpu as T
+    doms = ["bscan", "slo", "bscanlayermap"]
+    cfg = O.make_config(model="tiny", in_domains=doms, input_size=64, patch_size=8, layermap_size=16, layermap_patch=2, decoder_dim=64,
+                        decoder_depth=2, decoder_heads=2, dim=128, depth=4, heads=2)
+    B, Kk = 6, 24
+
+    def data(seed):
+        x = {d: t.to(DEV) for d, t in O.synthetic_batch(cfg, B, seed=seed).items()}
+        (p, u, g), _, _, _ = O.synthetic_masks(cfg, B, Kk, seed=seed + 1)
+        return x, (torch.from_numpy(p).to(DEV), torch.cat([torch.from_numpy(a) for a in u], 1).to(DEV), torch.from_numpy(g).to(DEV))
+    batches = [data(300 + 10 * i) for i in range(3)]
+
+    def run(in_place):
+        model, args, _ = T._build(cfg)
+        model.train()
+        opt = optim.FusedAdamW(model, [1e-3] * 8, [0.05] * 8)
+        ts = TrainStep(model, builder.get_losses(args), opt, batches[0][0], Kk, use_graph=True, feed_mask_noise=True)
+        ts.load(batches[0][0])
+        for dst, src in zip(ts.static_noise, batches[0][1]):
+            dst.copy_(src)
+        ts.warmup_and_capture(warm_iters=1)
+        staged = {k: v.clone() for k, v in ts.static_x.items()}
+        losses = []
+        for i, (x, n) in enumerate(batches):
+            if in_place:
+                if i == 2:       # a layout the slots refuse: the step falls back to the staging copy
+                    x = dict(x, bscan=x["bscan"].transpose(2, 3).contiguous().transpose(2, 3))
+                    assert not x["bscan"].is_contiguous()
+                ts.step(x, noise=n)
+                if i < 2:
+                    assert all(torch.equal(ts.static_x[k], staged[k]) for k in staged)
+                    assert ts.slots._bound_ptrs == [x[k].data_ptr() for k in ts.slots.names]
+            else:
+                ts.load(x)
+                ts.step(noise=n)
+            losses.append(float(ts.loss))
+        torch.cuda.synchronize()
+        return losses, opt.arena.flat_p.clone(), opt.exp_avg_sq.clone(), float(opt.grad_norm)
+    a, b = run(True), run(False)
+    assert a[0] == b[0] and a[3] == b[3] and len(set(a[0])) == 3
+    assert torch.equal(a[1], b[1]) and torch.equal(a[2], b[2])
+    # the registry does not outlive its TrainStep
+    import gc
+    gc.collect()
+    assert not K._SLOT_OF_PTR
