@@ -249,6 +249,8 @@ typedef struct mrg_loss_desc {
     float* partial; float* loss; float* coef; float* per_sample;
     const float* gout; void* dpred;
     const void* const* target_slot;   /* input slot of the target (see "Input slots"); NULL: `target` is read */
+    int pred_tokens;                  /* != 0: pred / dpred are in the decoder's token layout [B,(H/P)*(W/P),C*P*P] (inner order c, ph, pw):
+                                         the loss reads the out_proj output as it is and mrg_patch_rearrange is not needed */
 } mrg_loss_desc;
 int mrg_loss_partial_floats(int B);
 int mrg_masked_loss_fwd(const mrg_loss_desc* d, hipStream_t stream);

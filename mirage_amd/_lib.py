@@ -68,7 +68,7 @@ class LossDesc(C.Structure):
     _fields_ = [("kind", ci), ("pred", vp), ("pred_dtype", ci), ("target", vp), ("mask", vp),
                 ("B", ci), ("C", ci), ("H", ci), ("W", ci), ("P", ci),
                 ("partial", vp), ("loss", vp), ("coef", vp), ("per_sample", vp), ("gout", vp), ("dpred", vp),
-                ("target_slot", vp)]
+                ("target_slot", vp), ("pred_tokens", ci)]
 
 
 class AdamWDesc(C.Structure):

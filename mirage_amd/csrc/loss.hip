@@ -20,6 +20,14 @@ template <typename T> __device__ __forceinline__ void stf(T* p, long i, float v)
 template <> __device__ __forceinline__ void stf<float>(float* p, long i, float v) { p[i] = v; }
 template <> __device__ __forceinline__ void stf<bf16_t>(bf16_t* p, long i, float v) { p[i] = f2bf(v); }
 
+// element (b, c, y, x) of the predictions: image layout [B, C, H, W], or (tok != 0) the decoder's own token layout
+// [B, (H/P)*(W/P), C*P*P] with (c, ph, pw) inside a token (mirage/output_adapters.py:291-294 is then never materialised)
+__device__ __forceinline__ long pred_index(int tok, int b, int c, int y, int x, int C, int H, int W, int P) {
+    if (!tok) return (((long)b * C + c) * H + y) * W + x;
+    const int nw = W / P, ty = y / P, tx = x / P;
+    return (((long)b * (H / P) + ty) * nw + tx) * ((long)C * P * P) + (long)c * P * P + (y - ty * P) * P + (x - tx * P);
+}
+
 __device__ __forceinline__ float block_sum(float v, float* red) {
     v = wave_sum(v);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -35,7 +43,7 @@ __device__ __forceinline__ float block_sum(float v, float* red) {
 template <typename T, bool CE>
 __global__ __launch_bounds__(256) void loss_fwd_kernel(const T* __restrict__ pred, const void* __restrict__ target,
                                                        const void* const* __restrict__ tslot,
-                                                       const long* __restrict__ mask, int B, int C, int H, int W, int P,
+                                                       const long* __restrict__ mask, int B, int C, int H, int W, int P, int tok,
                                                        float* __restrict__ partial) {
     if (tslot) target = *tslot;                              // input slot: the batch is read where it lies (mirage_hip.h, "Input slots")
     __shared__ float red[4];
@@ -51,14 +59,14 @@ __global__ __launch_bounds__(256) void loss_fwd_kernel(const T* __restrict__ pre
         if (CE) {
             const int t = (int)reinterpret_cast<const long*>(target)[(long)b * HW + px];
             float mx = -INFINITY, zt = 0.f;
-            for (int c = 0; c < C; ++c) { const float z = ldf<T>(pred, ((long)b * C + c) * HW + px); mx = fmaxf(mx, z); zt = (c == t) ? z : zt; }
+            for (int c = 0; c < C; ++c) { const float z = ldf<T>(pred, pred_index(tok, b, c, y, x, C, H, W, P)); mx = fmaxf(mx, z); zt = (c == t) ? z : zt; }
             float se = 0.f;
-            for (int c = 0; c < C; ++c) se += __expf(ldf<T>(pred, ((long)b * C + c) * HW + px) - mx);
+            for (int c = 0; c < C; ++c) se += __expf(ldf<T>(pred, pred_index(tok, b, c, y, x, C, H, W, P)) - mx);
             l = mx + __logf(se) - zt;
         } else {
             float q = 0.f;
             for (int c = 0; c < C; ++c) {
-                const float d = ldf<T>(pred, ((long)b * C + c) * HW + px) - reinterpret_cast<const float*>(target)[((long)b * C + c) * HW + px];
+                const float d = ldf<T>(pred, pred_index(tok, b, c, y, x, C, H, W, P)) - reinterpret_cast<const float*>(target)[((long)b * C + c) * HW + px];
                 q += d * d;
             }
             l = q / (float)C;
@@ -117,7 +125,7 @@ template <typename T, bool CE>
 __global__ __launch_bounds__(256) void loss_bwd_kernel(const T* __restrict__ pred, const void* __restrict__ target,
                                                        const void* const* __restrict__ tslot,
                                                        const long* __restrict__ mask, const float* __restrict__ coef,
-                                                       const float* __restrict__ gout, int B, int C, int H, int W, int P,
+                                                       const float* __restrict__ gout, int B, int C, int H, int W, int P, int tok,
                                                        T* __restrict__ dpred) {
     if (tslot) target = *tslot;
     const long HW = (long)H * W;
@@ -131,22 +139,23 @@ __global__ __launch_bounds__(256) void loss_bwd_kernel(const T* __restrict__ pre
         const float m = mask ? (float)mask[(long)b * (H / P) * nw + (y / P) * nw + x / P] : 1.f;
         const float k = go * coef[b] * m;
         if (CE) {
-            if (k == 0.f) { for (int c = 0; c < C; ++c) stf<T>(dpred, ((long)b * C + c) * HW + px, 0.f); continue; }
+            if (k == 0.f) { for (int c = 0; c < C; ++c) stf<T>(dpred, pred_index(tok, b, c, y, x, C, H, W, P), 0.f); continue; }
             const int t = (int)reinterpret_cast<const long*>(target)[(long)b * HW + px];
             float mx = -INFINITY;
-            for (int c = 0; c < C; ++c) mx = fmaxf(mx, ldf<T>(pred, ((long)b * C + c) * HW + px));
+            for (int c = 0; c < C; ++c) mx = fmaxf(mx, ldf<T>(pred, pred_index(tok, b, c, y, x, C, H, W, P)));
             float se = 0.f;
-            for (int c = 0; c < C; ++c) se += __expf(ldf<T>(pred, ((long)b * C + c) * HW + px) - mx);
+            for (int c = 0; c < C; ++c) se += __expf(ldf<T>(pred, pred_index(tok, b, c, y, x, C, H, W, P)) - mx);
             const float inv = 1.f / se;
             for (int c = 0; c < C; ++c) {
-                const float p = __expf(ldf<T>(pred, ((long)b * C + c) * HW + px) - mx) * inv;
-                stf<T>(dpred, ((long)b * C + c) * HW + px, k * (p - (c == t ? 1.f : 0.f)));
+                const long j = pred_index(tok, b, c, y, x, C, H, W, P);
+                const float p = __expf(ldf<T>(pred, j) - mx) * inv;
+                stf<T>(dpred, j, k * (p - (c == t ? 1.f : 0.f)));
             }
         } else {
             const float kk = k * 2.f / (float)C;
             for (int c = 0; c < C; ++c) {
-                const long j = ((long)b * C + c) * HW + px;
-                stf<T>(dpred, j, kk * (ldf<T>(pred, j) - reinterpret_cast<const float*>(target)[j]));
+                const long j = ((long)b * C + c) * HW + px, jp = pred_index(tok, b, c, y, x, C, H, W, P);
+                stf<T>(dpred, jp, kk * (ldf<T>(pred, jp) - reinterpret_cast<const float*>(target)[j]));
             }
         }
     }
@@ -155,7 +164,7 @@ __global__ __launch_bounds__(256) void loss_bwd_kernel(const T* __restrict__ pre
 // ---- single-channel bf16 MSE fast path: 8 consecutive pixels (16 B of predictions, 32 B of targets) per thread
 __global__ __launch_bounds__(256) void mse1_fwd_vec_kernel(const bf16_t* __restrict__ pred, const float* __restrict__ target,
                                                            const void* const* __restrict__ tslot,
-                                                           const long* __restrict__ mask, int B, int H, int W, int P,
+                                                           const long* __restrict__ mask, int B, int H, int W, int P, int tok,
                                                            float* __restrict__ partial) {
     if (tslot) target = static_cast<const float*>(*tslot);
     __shared__ float red[4];
@@ -168,7 +177,7 @@ __global__ __launch_bounds__(256) void mse1_fwd_vec_kernel(const bf16_t* __restr
         const int y = (int)(px / W), x = (int)(px - (long)y * W);
         const float m = mask ? (float)mask[(long)b * (H / P) * nw + (y / P) * nw + x / P] : 1.f;
         if (m == 0.f) continue;
-        const uint4 p = *reinterpret_cast<const uint4*>(pred + (long)b * H * W + px);
+        const uint4 p = *reinterpret_cast<const uint4*>(pred + pred_index(tok, b, 0, y, x, 1, H, W, P));     // P % 8 == 0: 8 pixels stay inside a patch row
         const float4 t0 = *reinterpret_cast<const float4*>(target + (long)b * H * W + px);
         const float4 t1 = *reinterpret_cast<const float4*>(target + (long)b * H * W + px + 4);
         const float d0 = __uint_as_float(p.x << 16) - t0.x, d1 = __uint_as_float(p.x & 0xffff0000u) - t0.y;
@@ -189,7 +198,7 @@ __global__ __launch_bounds__(256) void mse1_fwd_vec_kernel(const bf16_t* __restr
 __global__ __launch_bounds__(256) void mse1_bwd_vec_kernel(const bf16_t* __restrict__ pred, const float* __restrict__ target,
                                                            const void* const* __restrict__ tslot,
                                                            const long* __restrict__ mask, const float* __restrict__ coef,
-                                                           const float* __restrict__ gout, int B, int H, int W, int P,
+                                                           const float* __restrict__ gout, int B, int H, int W, int P, int tok,
                                                            bf16_t* __restrict__ dpred) {
     if (tslot) target = static_cast<const float*>(*tslot);
     const long HW = (long)H * W;
@@ -204,8 +213,9 @@ __global__ __launch_bounds__(256) void mse1_bwd_vec_kernel(const bf16_t* __restr
         const float m = mask ? (float)mask[(long)b * (H / P) * nw + (y / P) * nw + x / P] : 1.f;
         const float k = 2.f * go * coef[b] * m;
         uint4 o = make_uint4(0, 0, 0, 0);
+        const long ip = pred_index(tok, b, 0, y, x, 1, H, W, P);
         if (k != 0.f) {
-            const uint4 p = *reinterpret_cast<const uint4*>(pred + i);
+            const uint4 p = *reinterpret_cast<const uint4*>(pred + ip);
             const float4 t0 = *reinterpret_cast<const float4*>(target + i);
             const float4 t1 = *reinterpret_cast<const float4*>(target + i + 4);
             o.x = pack_bf2(k * (__uint_as_float(p.x << 16) - t0.x), k * (__uint_as_float(p.x & 0xffff0000u) - t0.y));
@@ -213,7 +223,7 @@ __global__ __launch_bounds__(256) void mse1_bwd_vec_kernel(const bf16_t* __restr
             o.z = pack_bf2(k * (__uint_as_float(p.z << 16) - t1.x), k * (__uint_as_float(p.z & 0xffff0000u) - t1.y));
             o.w = pack_bf2(k * (__uint_as_float(p.w << 16) - t1.z), k * (__uint_as_float(p.w & 0xffff0000u) - t1.w));
         }
-        *reinterpret_cast<uint4*>(dpred + i) = o;
+        *reinterpret_cast<uint4*>(dpred + ip) = o;
     }
 }
 
@@ -259,9 +269,9 @@ extern "C" int mrg_masked_loss_fwd(const mrg_loss_desc* d, hipStream_t stream) {
                          (((uintptr_t)d->pred | (uintptr_t)d->target) & 15) == 0;
     if (vec_mse) {
         hipLaunchKernelGGL(mse1_fwd_vec_kernel, grid, block, 0, stream, (const bf16_t*)d->pred, (const float*)d->target, d->target_slot, d->mask, d->B, d->H,
-                           d->W, d->P, d->partial);
+                           d->W, d->P, d->pred_tokens, d->partial);
     } else {
-#define MRG_L(T, CE) hipLaunchKernelGGL((loss_fwd_kernel<T, CE>), grid, block, 0, stream, (const T*)d->pred, d->target, d->target_slot, d->mask, d->B, d->C, d->H, d->W, d->P, d->partial)
+#define MRG_L(T, CE) hipLaunchKernelGGL((loss_fwd_kernel<T, CE>), grid, block, 0, stream, (const T*)d->pred, d->target, d->target_slot, d->mask, d->B, d->C, d->H, d->W, d->P, d->pred_tokens, d->partial)
     if (d->pred_dtype == MRG_DT_BF16) { if (d->kind == MRG_LOSS_CE) MRG_L(bf16_t, true); else MRG_L(bf16_t, false); }
     else { if (d->kind == MRG_LOSS_CE) MRG_L(float, true); else MRG_L(float, false); }
 #undef MRG_L
@@ -282,10 +292,10 @@ extern "C" int mrg_masked_loss_bwd(const mrg_loss_desc* d, hipStream_t stream) {
                          (((uintptr_t)d->pred | (uintptr_t)d->target | (uintptr_t)d->dpred) & 15) == 0;
     if (vec_mse) {
         hipLaunchKernelGGL(mse1_bwd_vec_kernel, dim3((unsigned)((total / 8 + 255) / 256 < 4096 ? (total / 8 + 255) / 256 : 4096)), block, 0, stream,
-                           (const bf16_t*)d->pred, (const float*)d->target, d->target_slot, d->mask, d->coef, d->gout, d->B, d->H, d->W, d->P, (bf16_t*)d->dpred);
+                           (const bf16_t*)d->pred, (const float*)d->target, d->target_slot, d->mask, d->coef, d->gout, d->B, d->H, d->W, d->P, d->pred_tokens, (bf16_t*)d->dpred);
         return mrg_check_launch("mrg_masked_loss_bwd");
     }
-#define MRG_L(T, CE) hipLaunchKernelGGL((loss_bwd_kernel<T, CE>), grid, block, 0, stream, (const T*)d->pred, d->target, d->target_slot, d->mask, d->coef, d->gout, d->B, d->C, d->H, d->W, d->P, (T*)d->dpred)
+#define MRG_L(T, CE) hipLaunchKernelGGL((loss_bwd_kernel<T, CE>), grid, block, 0, stream, (const T*)d->pred, d->target, d->target_slot, d->mask, d->coef, d->gout, d->B, d->C, d->H, d->W, d->P, d->pred_tokens, (T*)d->dpred)
     if (d->pred_dtype == MRG_DT_BF16) { if (d->kind == MRG_LOSS_CE) MRG_L(bf16_t, true); else MRG_L(bf16_t, false); }
     else { if (d->kind == MRG_LOSS_CE) MRG_L(float, true); else MRG_L(float, false); }
 #undef MRG_L

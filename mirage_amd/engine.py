@@ -633,7 +633,10 @@ def decoder_fwd(ad, enc32: torch.Tensor, enc16: torch.Tensor, ids_keep, ids_rest
         blk_saved.append(sv)
     y, _, _ = lin_fwd(x16, ad.out_proj)                                                  # :288
     g = ad.image_size[0] // (ad.stride_level * ad.P_H)
-    img = K.patch_rearrange(y.view(B, Tq, -1), True, B, ad.num_channels, g, ad.P_H)      # :291-294
+    if PredLayout.tokens:
+        img = y.view(B, Tq, -1)              # the masked losses read (and differentiate) the token layout directly: no image copy
+    else:
+        img = K.patch_rearrange(y.view(B, Tq, -1), True, B, ad.num_channels, g, ad.P_H)  # :291-294
     K.timestamp(f"dec_fwd_end.{ad.task}")
     saved = None
     if save:
@@ -650,7 +653,10 @@ def decoder_bwd(ad, saved, d_img: torch.Tensor):
     dev = d_img.device
     K.timestamp(f"dec_bwd_start.{ad.task}")
     blocks = list(ad.decoder_transformer) if isinstance(ad.decoder_transformer, torch.nn.Sequential) else []
-    d_y = K.patch_rearrange(d_img.contiguous(), False, B, ad.num_channels, g, ad.P_H).view(B * Tq, -1)
+    if d_img.dim() == 3:                     # PredLayout.tokens: the loss gradient arrives in the token layout already
+        d_y = d_img.contiguous().view(B * Tq, -1)
+    else:
+        d_y = K.patch_rearrange(d_img.contiguous(), False, B, ad.num_channels, g, ad.P_H).view(B * Tq, -1)
     if d_y.dtype != BF16:
         d_y = to_bf16(d_y)
     dx32, dx16 = lin_bwd(d_y, x16, ad.out_proj, dx_dtype=F32, dx_bf16_copy=True)
@@ -698,6 +704,21 @@ def decoder_bwd_finish(ad, d_ctx16: torch.Tensor, d_enc32: torch.Tensor, first: 
     B, N, Dd = d_ctx16.shape
     D = d_enc32.shape[-1]
     K.gemm(d_ctx16, shadow(ad.proj_context.weight), B * N, D, Dd, b_mode=KS, lda=Dd, ldb=D, out=d_enc32, ldc=D, accumulate=not first)
+
+
+class PredLayout:
+    """What the output adapters return.  Default: images [B, C, H, W] (the reference's contract, mirage/output_adapters.py:291-294).
+    `tokens = True` (set by trainer.TrainStep around its forward pass): the out_proj output [B, tokens, C*P*P] as it is -- the masked
+    losses index it in place (mrg_loss_desc.pred_tokens) and write their gradient in the same layout, so the two rearrangement passes
+    per task and direction disappear from the step.  `to_images` converts such a prediction for callers that want the picture."""
+    tokens = False
+
+    @staticmethod
+    def to_images(pred: torch.Tensor, ad) -> torch.Tensor:
+        if pred.dim() != 3:
+            return pred
+        g = ad.image_size[0] // (ad.stride_level * ad.P_H)
+        return K.patch_rearrange(pred.contiguous(), True, pred.shape[0], ad.num_channels, g, ad.P_H)
 
 
 class _Lanes:

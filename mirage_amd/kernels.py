@@ -727,7 +727,16 @@ def dec_assemble_bwd(d: "L.DecAssembleDesc", d_queries, d_context, d_task_embs, 
 def loss_desc(kind, pred, target, mask, P):
     _need_cuda(pred, "loss input")
     d = L.LossDesc()
-    B, Cc, H, W = pred.shape
+    if pred.dim() == 3:
+        # predictions in the decoder's token layout [B, tokens, C*P*P] (engine.DecodersFn with token_layout): geometry from the target
+        H, W = target.shape[-2:]
+        B, ntok, inner = pred.shape
+        Cc = inner // (P * P)
+        if ntok != (H // P) * (W // P) or Cc * P * P != inner or (kind == L.MRG_LOSS_MSE and target.shape[1] != Cc):
+            raise ValueError(f"loss_desc: token-layout predictions {tuple(pred.shape)} do not match target {tuple(target.shape)} at patch {P}")
+        d.pred_tokens = 1
+    else:
+        B, Cc, H, W = pred.shape
     d.kind, d.pred, d.pred_dtype = kind, pred.data_ptr(), (L.MRG_DT_BF16 if pred.dtype == BF16 else L.MRG_DT_F32)
     d.target, d.mask, d.target_slot = target.data_ptr(), _p(mask), slot_of(target)
     d.B, d.C, d.H, d.W, d.P = B, Cc, H, W, P

@@ -10,7 +10,11 @@ from typing import Dict, Optional
 
 import torch
 
+import os
+
 from .dp import GradReducer
+
+TOKEN_PREDS = os.environ.get("MRG_TOKEN_PREDS", "1") != "0"   # predictions stay in the decoders' token layout inside the step (engine.PredLayout)
 
 
 class TrainStep:
@@ -138,12 +142,27 @@ class TrainStep:
             self._early_seen += len([b for b in blks if key(b) in self._early])
 
     # -- pieces ----------------------------------------------------------------------------------------
+    def _forward(self, x):
+        """model forward with the predictions left in the decoders' token layout when every loss can read it (engine.PredLayout)"""
+        from . import engine as E
+        from .criterion import MaskedCrossEntropyLoss, MaskedMSELoss
+        E.PredLayout.tokens = TOKEN_PREDS and all(isinstance(f, (MaskedMSELoss, MaskedCrossEntropyLoss)) for f in self.loss_fns.values())
+        try:
+            return self.model({d: x[d] for d in self.in_domains}, num_encoded_tokens=self.K, alphas=self.alphas,
+                              sample_tasks_uniformly=self.uniform, mask_noise=self.static_noise)
+        finally:
+            E.PredLayout.tokens = False
+
+    def pred_images(self) -> Dict[str, torch.Tensor]:
+        """the last step's predictions as images [B, C, H, W] (self.preds holds what the step itself produced)"""
+        from . import engine as E
+        return {t: E.PredLayout.to_images(p, self.model.output_adapters[t]) for t, p in self.preds.items()}
+
     def _fwd_bwd(self):
         from . import kernels as _K
         _K.timestamp("step_start")
         x = self.static_x
-        preds, masks = self.model({d: x[d] for d in self.in_domains}, num_encoded_tokens=self.K, alphas=self.alphas,
-                                  sample_tasks_uniformly=self.uniform, mask_noise=self.static_noise)
+        preds, masks = self._forward(x)
         self.task_losses = {t: self.loss_fns[t](preds[t], x[t], mask=None if self.loss_on_unmasked else masks.get(t)) for t in preds}
         self.loss = sum(self.task_losses.values())
         self.preds, self.masks = preds, masks         # static tensors of the captured step (parity tests read them after a replay)
@@ -165,8 +184,7 @@ class TrainStep:
         """forward + losses + backward down to the activation at the encoder cut; the gradients above the cut are final on return."""
         from . import engine as E
         x = self.static_x
-        preds, masks = self.model({d: x[d] for d in self.in_domains}, num_encoded_tokens=self.K, alphas=self.alphas,
-                                  sample_tasks_uniformly=self.uniform, mask_noise=self.static_noise)
+        preds, masks = self._forward(x)
         self.task_losses = {t: self.loss_fns[t](preds[t], x[t], mask=None if self.loss_on_unmasked else masks.get(t)) for t in preds}
         self.loss = sum(self.task_losses.values())
         self.opt.zero_grad()

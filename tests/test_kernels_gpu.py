@@ -737,6 +737,31 @@ def test_input_slots_redirect_the_batch_readers(K):
     assert K.slot_of(ph["img"]) is None
 
 
+def test_masked_losses_on_token_layout_predictions(K):
+    """mrg_loss_desc.pred_tokens: the losses read the decoder's [B, tokens, C*P*P] output in place and write their gradient in the same
+    layout; loss and gradient equal -- bit for bit -- the image-layout launch on the rearranged tensors."""
+    torch.manual_seed(3)
+    B = 3
+    cases = [(K.L.MRG_LOSS_MSE, 1, 64, 8, BF16), (K.L.MRG_LOSS_MSE, 3, 32, 4, torch.float32), (K.L.MRG_LOSS_MSE, 1, 64, 8, torch.float32),
+             (K.L.MRG_LOSS_CE, 13, 16, 2, torch.float32), (K.L.MRG_LOSS_CE, 13, 32, 8, BF16)]
+    for kind, Cc, H, P, dt in cases:
+        g = H // P
+        tok = torch.randn(B, g * g, Cc * P * P, device=dev()).to(dt)
+        img = K.patch_rearrange(tok, True, B, Cc, g, P)
+        target = torch.randint(0, 13, (B, H, H), device=dev()) if kind == K.L.MRG_LOSS_CE else torch.rand(B, Cc, H, H, device=dev())
+        for mask in (None, (torch.rand(B, g * g, device=dev()) < 0.6).long()):
+            out = []
+            for pred in (img, tok):
+                d = K.loss_desc(kind, pred, target, mask, P)
+                loss, coef, partial = K.masked_loss_fwd(d, pred.device)
+                out.append((loss.clone(), K.masked_loss_bwd(d, coef, partial, None, pred)))
+            (li, di), (lt, dtk) = out
+            assert torch.equal(li, lt) and dtk.shape == tok.shape
+            assert torch.equal(K.patch_rearrange(dtk, True, B, Cc, g, P), di)
+    with pytest.raises(ValueError):
+        K.loss_desc(K.L.MRG_LOSS_MSE, torch.zeros(B, 60, 64, device=dev()), torch.zeros(B, 1, 64, 64, device=dev()), None, 8)
+
+
 def test_embed_plan_long_lists_and_ragged_chunks(K):
     """The plan kernel walks lists of more than 131072 kept tokens in rounds; counts and order are those of a flat (b, k) scan."""
     g = torch.Generator().manual_seed(3)

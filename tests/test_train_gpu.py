@@ -593,3 +593,38 @@ def test_step_reads_batches_in_place_through_input_slots():
     import gc
     gc.collect()
     assert not K._SLOT_OF_PTR
+
+
+def test_token_layout_predictions_are_the_same_step(monkeypatch):
+    """Inside TrainStep the output adapters hand their out_proj output to the losses as it is (engine.PredLayout); with MRG_TOKEN_PREDS=0
+    the reference's image tensors are built and differentiated instead.  Same arithmetic, same summation order: losses, gradients and
+    weights agree bit for bit, and pred_images() gives the picture either way."""
+    from mirage_amd import builder, optim, trainer
+    from oracle import mirage_oracle as O
+    import test_model_gpu as T
+    doms = ["bscan", "slo", "bscanlayermap"]
+    cfg = O.make_config(model="tiny", in_domains=doms, input_size=64, patch_size=8, layermap_size=16, layermap_patch=2, decoder_dim=64,
+                        decoder_depth=2, decoder_heads=2, dim=128, depth=4, heads=2)
+    B, Kk = 6, 24
+    x = {d: t.to(DEV) for d, t in O.synthetic_batch(cfg, B, seed=77).items()}
+    noise, _, _ = _noise_dev(cfg, B, Kk, 78)
+
+    def run(tokens):
+        monkeypatch.setattr(trainer, "TOKEN_PREDS", tokens)
+        model, args, _ = T._build(cfg)
+        model.train()
+        opt = optim.FusedAdamW(model, [1e-3] * 8, [0.05] * 8)
+        ts = trainer.TrainStep(model, builder.get_losses(args), opt, x, Kk, use_graph=True, feed_mask_noise=True)
+        ts.load(x)
+        for dst, src in zip(ts.static_noise, noise):
+            dst.copy_(src)
+        ts.warmup_and_capture(warm_iters=1)
+        ts.step(noise=noise)
+        ts.step(noise=noise)
+        torch.cuda.synchronize()
+        assert all(p.dim() == (3 if tokens else 4) for p in ts.preds.values())
+        return float(ts.loss), opt.arena.flat_g.clone(), opt.arena.flat_p.clone(), {k: v.clone() for k, v in ts.pred_images().items()}
+    a, b = run(True), run(False)
+    assert a[0] == b[0] and torch.equal(a[1], b[1]) and torch.equal(a[2], b[2])
+    for k in a[3]:
+        assert a[3][k].dim() == 4 and torch.equal(a[3][k], b[3][k])
