@@ -23,6 +23,7 @@ KS = L.MRG_OP_KSTRIDED
 FUSE_EPI_COLSUM = True    # bias gradient of the producing layer from the dgrad GEMM's epilogue (column sums of dx per tile)
 EMBED_WGRAD_GATHER = True # patch-embedding weight gradient: compact the gradient rows, then a plain k-strided GEMM (A/B: MRG_EMBED_GATHER=0)
 EMBED_LANES = os.environ.get("MRG_EMBED_LANES", "0") != "0"   # the modalities' patch projections side by side on lane streams: measured neutral (C2 9.52 / 9.54 vs 9.54 / 9.51 ms, C4 20.46 vs 20.53), the two cross-stream edges cost what the shared round saves
+CHAIN_END_FLUSH = os.environ.get("MRG_CHAIN_END_FLUSH", "0") != "0"   # experiment: side-stream fork at the end of the encoder's dgrad chain (neutral)
 FUSE_ATTN_BIAS = True     # q / k / v bias gradients from inside the attention-backward kernels (else: a column-sum pass over d_qkv)
 
 
@@ -78,8 +79,10 @@ class _Side:
         ev = torch.cuda.Event()
         ev.record(main)
         jobs, cls.queue = cls.queue, []
+        tag = K.timestamp_seq("side_flush")
         with torch.cuda.stream(cls.stream):
             cls.stream.wait_event(ev)
+            K.timestamp(f"{tag}.start")
             K.WgradGroup.begin()                 # the plain weight gradients of this flush go out as ONE grouped launch without split-K
             try:
                 for fn in jobs:
@@ -88,6 +91,7 @@ class _Side:
                 K.WgradGroup.collecting, K.WgradGroup.tasks = False, []
                 raise
             K.WgradGroup.flush()
+            K.timestamp(f"{tag}.wgrad_end")
             if cls.reduce_early:
                 # finish the split-K slabs / column-sum partials produced so far (the event above covers the LayerNorm partials of
                 # the calling stream): only the last group's reductions are then left for the tail of the step
@@ -95,6 +99,7 @@ class _Side:
                 if cls.early_opt is not None and cls.finished:
                     done, cls.finished = cls.finished, []
                     cls.early_opt(done)          # their gradients are final now: AdamW for these blocks overlaps the rest of backward
+            K.timestamp(f"{tag}.end")
         cls.pending = True
 
     @classmethod
@@ -458,8 +463,12 @@ class EncoderFn(torch.autograd.Function):
         n = len(ctx.blocks)
         for i, (blk, sv) in enumerate(zip(reversed(ctx.blocks), reversed(ctx.saved))):
             dx32, dx16 = block_bwd(blk, sv, dx32, dx16, remaining=(n - 1 - i) if _Side.taper else None)
+            K.timestamp(f"enc_bwd_block_end.{n - 1 - i}")
         ctx.saved = None
         K.timestamp("enc_bwd_chain_end")
+        # (forking what the last blocks queued HERE instead of at the embedding backward's join was measured neutral: section 3.3)
+        if CHAIN_END_FLUSH:
+            _Side.flush()
         # hand the bf16 twin of the returned gradient to the embedding backward: keyed by the tensor OBJECT (identity
         # is checked on lookup, so a recycled address can never alias); at most one entry is alive
         _TWINS.clear()

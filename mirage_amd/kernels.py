@@ -909,10 +909,20 @@ def resize_label(x: torch.Tensor, size) -> torch.Tensor:
 TS = {"buf": None, "names": [], "on": os.environ.get("MRG_TS") == "1"}
 
 
+def timestamp_seq(prefix: str) -> str:
+    """MRG_TS=1: a name unique within the step for a point that is reached several times (numbered in call order since step_start)"""
+    if not TS["on"]:
+        return prefix
+    TS["seq"] = TS.get("seq", 0) + 1
+    return f"{prefix}{TS['seq']}"
+
+
 def timestamp(name: str):
     """MRG_TS=1: record the device wall clock when the current stream reaches this point (graph-capturable); tools/step_phases.py"""
     if not TS["on"]:
         return
+    if name == "step_start":
+        TS["seq"] = 0
     if TS["buf"] is None:
         TS["buf"] = torch.zeros(256, dtype=torch.int64, device="cuda")
     if name not in TS["names"]:
