@@ -14,6 +14,7 @@ import os
 
 from .dp import GradReducer
 
+IN_PLACE_INPUTS = os.environ.get("MRG_INPUT_SLOTS", "1") != "0"   # step(batch) re-points the input slots at the batch (0: staging copy, as load())
 TOKEN_PREDS = os.environ.get("MRG_TOKEN_PREDS", "1") != "0"   # predictions stay in the decoders' token layout inside the step (engine.PredLayout)
 
 
@@ -300,10 +301,13 @@ class TrainStep:
         pointed at it (one tiny launch) and it is kept alive until the next step; the caller must not overwrite it on another stream
         before this step has run.  Without `batch` the step re-reads what is bound (after load(): the staging buffers)."""
         if batch is not None:
-            try:
-                self.slots.bind(batch)
-            except ValueError:
-                self.load(batch)                       # other dtype / layout / device: converted by the staging copy
+            if not IN_PLACE_INPUTS:
+                self.load(batch)
+            else:
+                try:
+                    self.slots.bind(batch)
+                except ValueError:
+                    self.load(batch)                   # other dtype / layout / device: converted by the staging copy
         if noise is not None:
             if self.static_noise is None:
                 raise RuntimeError("TrainStep.step(noise=...): construct the TrainStep with feed_mask_noise=True")

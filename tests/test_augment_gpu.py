@@ -102,6 +102,35 @@ def test_driver_trains_from_npy_folder_with_gpu_augmentation(tmp_path):
     assert len(lines) == 2 and all(np.isfinite(l["[Epoch] loss"]) for l in lines)
 
 
+def test_graph_training_from_the_loader_reads_batches_in_place(tmp_path, monkeypatch):
+    """The captured step consumes the loader's batches where its augmentation kernel wrote them (input slots; the tensors are
+    allocated on the loader's copy stream and handed over with record_stream): 3 epochs x 4 steps from a .npy folder with hipGraphs give
+    exactly the log of the same run through the staging copy (MRG_INPUT_SLOTS=0)."""
+    import json, os
+    from mirage_amd import run_pretraining as R, trainer
+    rng = np.random.default_rng(1)
+    root = tmp_path / "data"
+    for d, (hw, hi) in {"bscan": (128, 256), "slo": (128, 256), "bscanlayermap": (128, 13)}.items():
+        os.makedirs(root / d)
+        for i in range(16):
+            np.save(root / d / f"s{i:03d}.npy", rng.integers(0, hi, (hw, hw), dtype=np.uint8))
+
+    def run(tag, in_place):
+        monkeypatch.setattr(trainer, "IN_PLACE_INPUTS", in_place)
+        out = str(tmp_path / tag)
+        argv = ["--data_path", str(root), "--in_domains", "bscan-slo-bscanlayermap", "--out_domains", "bscan-slo-bscanlayermap",
+                "--input_size", "128", "--patch_size", "8", "--batch_size", "4", "--num_encoded_tokens", "98", "--epochs", "3",
+                "--warmup_epochs", "1", "--save_ckpt_freq", "3", "--base_output_dir", out, "--print_freq", "1", "--seed", "5",
+                "--hflip", "0.5", "--intensity_shift", "0.1", "--affine"]
+        R.main(R.get_args(argv))
+        return [json.loads(l) for l in open(os.path.join(out, "miragepre_base", "log.txt"))]
+    a, b = run("slots", True), run("copy", False)
+    assert len(a) == 3 and all(np.isfinite(l["[Epoch] loss"]) for l in a)
+    keys = [k for k in a[0] if "loss" in k or "grad_norm" in k]
+    assert keys and all(la[k] == lb[k] for la, lb in zip(a, b) for k in keys), (a, b)
+    assert a[-1]["[Epoch] loss"] < a[0]["[Epoch] loss"]
+
+
 def test_resize_branch_matches_aten():
     """TF.resize branch (mutils/datasets_pretrain.py:66-81): torchvision resizes tensors through aten's interpolate -- bilinear with
     antialias=True for images, nearest for label maps.  The HIP kernels against torch's CPU kernels of the same ops, down- and
