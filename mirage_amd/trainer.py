@@ -1,6 +1,7 @@
 """One optimizer step of the pretraining loop (run_pretraining.py:683-742 train_one_epoch body) as a replayable unit.
 
-TrainStep owns static input buffers and, on one GPU, captures masks -> forward -> masked losses -> backward ->
+TrainStep owns the input slots (device addresses of the batch to read; step(batch) consumes the batch in place) plus staging buffers for
+load(), and, on one GPU, captures masks -> forward -> masked losses -> backward ->
 grad-norm -> AdamW into a single hipGraph (torch.cuda.CUDAGraph): ~600 kernel launches become one graph launch and
 no host synchronisation is left in the step (the reference has 5+ `.item()` syncs per step).  With several ranks the
 collective stays outside the graphs: graph A (forward+backward), bucketed RCCL all-reduce on a side stream, graph B
