@@ -216,6 +216,10 @@ def main(args):
     steps_per_epoch = len(data)
     total_batch = args.batch_size * world
     args.lr = args.blr * total_batch / 256
+    if args.warmup_epochs > args.epochs:
+        # the reference's scheduler (mutils/native_scaler.py:64-88) fails its length assertion here; say why
+        raise ValueError(f"--warmup_epochs ({args.warmup_epochs}) exceeds --epochs ({args.epochs}): the per-iteration schedule would be "
+                         f"longer than the run")
     lrs = optim.cosine_scheduler(args.lr, args.min_lr, args.epochs, steps_per_epoch, warmup_epochs=args.warmup_epochs,
                                  warmup_steps=args.warmup_steps)
     wd_end = args.weight_decay if args.weight_decay_end is None else args.weight_decay_end
