@@ -294,6 +294,10 @@ class TrainStep:
     def load(self, batch: Dict[str, torch.Tensor]):
         """copy a batch into the staging buffers and read the next steps from there"""
         for k, v in batch.items():
+            if k not in self.static_x:
+                continue
+            if tuple(v.shape) != tuple(self.static_x[k].shape):          # copy_ would broadcast silently
+                raise ValueError(f"TrainStep.load: {k} has shape {tuple(v.shape)}, the step was built for {tuple(self.static_x[k].shape)}")
             self.static_x[k].copy_(v, non_blocking=True)
         self.slots.bind(self.static_x)
 

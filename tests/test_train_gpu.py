@@ -585,7 +585,10 @@ def test_step_reads_batches_in_place_through_input_slots():
                 ts.step(noise=n)
             losses.append(float(ts.loss))
         torch.cuda.synchronize()
-        return losses, opt.arena.flat_p.clone(), opt.exp_avg_sq.clone(), float(opt.grad_norm)
+        out = losses, opt.arena.flat_p.clone(), opt.exp_avg_sq.clone(), float(opt.grad_norm)
+        with pytest.raises(ValueError):                  # another batch size is an error on both paths, never a silent broadcast
+            (ts.step if in_place else ts.load)({k: v[:3].contiguous() for k, v in batches[0][0].items()})
+        return out
     a, b = run(True), run(False)
     assert a[0] == b[0] and a[3] == b[3] and len(set(a[0])) == 3
     assert torch.equal(a[1], b[1]) and torch.equal(a[2], b[2])
