@@ -666,6 +666,23 @@ def test_maskgen_rng_noise_is_the_oracle_philox_and_masks_are_the_explicit_path(
         assert np.array_equal(uu.cpu().numpy(), uo) and np.array_equal(gg.cpu().numpy(), go)
 
 
+def test_maskgen_rng_four_modalities_single_sample_and_all_tokens_kept(K):
+    """Corner geometry of the production launch: the maximum of four modalities with unequal token counts, one sample, K = 1 and K = T;
+    always equal to the explicit-noise launch on the noise it drew, and exactly K tokens kept."""
+    st = torch.tensor([11, 5, 0], dtype=torch.int64, device=dev())
+    ds = [0, 16, 80, 81, 200]
+    for B in (1, 5):
+        for Kn in (1, 77, 199, 200):
+            conc = torch.tensor([[0.3, 1.0, 2.0, 5.0]], device=dev()).expand(B, 4).contiguous()
+            tm, ik, ir, (p, u, g) = K.maskgen_rng(conc, st, Kn, 200, ds, return_noise=True)
+            tm2, ik2, ir2 = K.maskgen(p, u, g, Kn, ds)
+            assert torch.equal(tm, tm2) and torch.equal(ik, ik2) and torch.equal(ir, ir2)
+            assert ((tm == 0).sum(1) == Kn).all() and ik.shape == (B, Kn)
+            assert torch.equal(torch.sort(ir, 1).values, torch.arange(200, device=dev())[None].expand(B, -1))
+            assert float((p.sum(1) - 1).abs().max()) < 1e-5 and float(p.min()) >= 0
+    assert int(st[1]) == 5 + 8 and int(st[2]) == 0
+
+
 def test_maskgen_rng_statistics(K):
     """Dirichlet(1, 1) shares are uniform, Dirichlet(a, b) has the Beta moments, a vanishing concentration gets (almost) nothing, and
     every token of a modality is equally likely to be kept."""
