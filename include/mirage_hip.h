@@ -26,7 +26,7 @@ extern "C" {
 typedef struct ihipStream_t* hipStream_t;
 #endif
 
-#define MRG_ABI_VERSION 9   /* 9: mrg_maskgen_rng, input slots (mrg_set_slots, *_slot parameters, mrg_loss_desc.target_slot); 8: mrg_gemm_desc.drop_rng / drop_p / drop_stream, mrg_dropout_bwd_bf16; 7: mrg_wgrad_group, mrg_debug_timestamp; 2: mrg_gemm_desc grew row_scale / defer_reduce, act codes 3, 4, reduce_batch / augment / row_scale entry points; 3: colsum_out, attention colsum_*; 4: step = int[2], mrg_step_inc takes the skip decision; 5: splitk_counters, MRG_GEMM_P8, resize entry points; 6: mrg_adamw_desc.sumsq_out, mrg_sumsq_finish */
+#define MRG_ABI_VERSION 10   /* 10: MRG_GEMM_P8SK (stream-K schedule of the 8-phase kernel), mrg_gemm_desc.sk_grid, mrg_wgrad_group_desc.streamk / counters / sk_grid, mrg_streamk_ws_bytes; 9: mrg_maskgen_rng, input slots (mrg_set_slots, *_slot parameters, mrg_loss_desc.target_slot); 8: mrg_gemm_desc.drop_rng / drop_p / drop_stream, mrg_dropout_bwd_bf16; 7: mrg_wgrad_group, mrg_debug_timestamp; 2: mrg_gemm_desc grew row_scale / defer_reduce, act codes 3, 4, reduce_batch / augment / row_scale entry points; 3: colsum_out, attention colsum_*; 4: step = int[2], mrg_step_inc takes the skip decision; 5: splitk_counters, MRG_GEMM_P8, resize entry points; 6: mrg_adamw_desc.sumsq_out, mrg_sumsq_finish */
 
 enum { MRG_DT_BF16 = 0, MRG_DT_F32 = 1 };
 enum { MRG_OP_KCONTIG = 0, MRG_OP_KSTRIDED = 1 };
@@ -61,7 +61,7 @@ const char* mrg_last_error_string(void);
  *   splitk  >1: partial sums to ws [splitk][M][N] fp32, then reduced (bias/accumulate epilogue only)
  *   variant kernel variant for aligned, map-free problems: single-stage LDS-DMA kernel at 3 or 4 workgroups/CU,
  *           two-stage pipelined 128x128 kernel, two- / three-stage pipelined 256x128 kernel (8 waves), two-stage 256x256 kernel, warp-specialised 256x128 kernel (8 compute + 4 loader waves, 3-stage ring), single-stage 64x128 kernel (A k-contiguous only), (9 reserved: a persistent 256x256 kernel that was measured and dropped), single-stage 256x128 kernel with 4 waves x (128x64) (K a multiple of 64);
- *           0 picks by shape
+ *           0 picks by shape; MRG_GEMM_P8 / MRG_GEMM_P8SK = the 256 x 256 8-phase kernel, one tile per workgroup / stream-K (see sk_grid)
  */
 typedef struct mrg_gemm_desc {
     const void* A; const void* B;
@@ -103,8 +103,16 @@ typedef struct mrg_gemm_desc {
                                         kept when the draw >= floor(drop_p * 2^32).  act must be NONE, N %% 4 == 0, no split-K.
                                         mrg_dropout_bwd_bf16 regenerates the same mask for the backward pass. */
     float drop_p; unsigned drop_stream;
+    int sk_grid;                     /* variant MRG_GEMM_P8SK only: number of persistent workgroups (0 = one per CU).  That variant runs the
+                                        256 x 256 8-phase kernel on a stream-K schedule: the (tile, k-tile) iteration space is cut into
+                                        sk_grid equal ranges, tiles shared by several ranges are finished by their last arriver inside the
+                                        launch (any epilogue).  It needs splitk <= 1, ws = mrg_streamk_ws_bytes(sk_grid) bytes of scratch
+                                        (partial accumulator images) and splitk_counters = ceil(M/256) * ceil(N/256) ints, ZERO on entry and
+                                        left zero on exit.  The result is a deterministic function of the operands and sk_grid. */
 } mrg_gemm_desc;
-enum { MRG_GEMM_AUTO = 0, MRG_GEMM_GLDS3 = 1, MRG_GEMM_GLDS4 = 2, MRG_GEMM_PIPE128 = 3, MRG_GEMM_PIPE256 = 4, MRG_GEMM_PIPE256X3 = 5, MRG_GEMM_PIPE256SQ = 6, MRG_GEMM_WS256 = 7, MRG_GEMM_GLDS64 = 8, MRG_GEMM_SQP = 9, MRG_GEMM_G256 = 10, MRG_GEMM_P8 = 11 };
+enum { MRG_GEMM_AUTO = 0, MRG_GEMM_GLDS3 = 1, MRG_GEMM_GLDS4 = 2, MRG_GEMM_PIPE128 = 3, MRG_GEMM_PIPE256 = 4, MRG_GEMM_PIPE256X3 = 5, MRG_GEMM_PIPE256SQ = 6, MRG_GEMM_WS256 = 7, MRG_GEMM_GLDS64 = 8, MRG_GEMM_SQP = 9, MRG_GEMM_G256 = 10, MRG_GEMM_P8 = 11, MRG_GEMM_P8SK = 12 };
+/* bytes of `ws` a stream-K launch with sk_grid workgroups needs (sk_grid <= 0: one workgroup per CU of the current device) */
+long mrg_streamk_ws_bytes(int sk_grid);
 
 int mrg_gemm(const mrg_gemm_desc* d, hipStream_t stream);
 
@@ -123,6 +131,9 @@ typedef struct mrg_wgrad_group_desc {
     int M[MRG_WGRAD_GROUP_MAX], N[MRG_WGRAD_GROUP_MAX], lda[MRG_WGRAD_GROUP_MAX], ldb[MRG_WGRAD_GROUP_MAX], ldc[MRG_WGRAD_GROUP_MAX];
     void* ev_start; void* ev_stop;
     int splitk; float* ws;
+    int streamk;       /* != 0: stream-K schedule over the concatenated tile lists (splitk must be <= 1): ws = mrg_streamk_ws_bytes(sk_grid)
+                          bytes of scratch, counters = one int per 256 x 256 tile of the whole group, ZERO on entry and left zero */
+    int* counters; int sk_grid;
 } mrg_wgrad_group_desc;
 int mrg_wgrad_group(const mrg_wgrad_group_desc* d, hipStream_t stream);
 
@@ -326,6 +337,9 @@ int mrg_resize_label(const long* src, long* dst, int B, int Hi, int Wi, int Ho, 
 
 /* Profiling aid: *slot = wall_clock64() (constant 100 MHz counter) when `stream` reaches this point; capturable into a hipGraph. */
 int mrg_debug_timestamp(unsigned long long* slot, hipStream_t stream);
+/* Profiling aid: while buf != NULL every stream-K launch records per-workgroup phase timestamps into buf[workgroup * 32 ..] (u64, 100 MHz);
+ * NULL switches it off.  Process-global, for tools only. */
+int mrg_debug_sk_trace(unsigned long long* buf);
 
 #ifdef __cplusplus
 }

@@ -1296,7 +1296,7 @@ extern "C" int mrg_gemm(const mrg_gemm_desc* d, hipStream_t stream) {
         g.drop.scale = 1.f / (1.f - d->drop_p);
         g.drop.stream = d->drop_stream;
     }
-    MRG_REQUIRE(d->variant >= 0 && d->variant <= MRG_GEMM_P8, MRG_ERR_ARG, "mrg_gemm: bad variant");
+    MRG_REQUIRE(d->variant >= 0 && d->variant <= MRG_GEMM_P8SK, MRG_ERR_ARG, "mrg_gemm: bad variant");
     g.tiles_m = cdiv(d->M, BM); g.tiles_n = cdiv(d->N, BN);
     { static const int abl = [] { const char* e = getenv("MRG_GEMM_ABLATE"); return e ? atoi(e) : 0; }(); g.ablate = abl; }
     { static const int nt = [] { const char* e = getenv("MRG_GEMM_NT"); return e ? atoi(e) : 2; }(); g.nt = nt; }
@@ -1318,6 +1318,8 @@ extern "C" int mrg_gemm(const mrg_gemm_desc* d, hipStream_t stream) {
             else if (splitk == 1 && d->act == MRG_ACT_NONE && d->add_tab && d->add_row && d->row_map && !d->accumulate && !d->resid && !d->row_scale &&
                      !d->C2 && g.c_f32 && !d->colsum_out && !g.drop.rng) g.epi_kind = 6;
             else if (splitk == 1 && d->act == MRG_ACT_NONE && !d->add_tab && !d->row_map && !d->accumulate && !d->colsum_out && d->resid && g.c_f32) g.epi_kind = 2;
+            else if (splitk == 1 && d->act == MRG_ACT_NONE && !d->add_tab && !d->row_map && !d->accumulate && !d->colsum_out && !d->resid && !d->row_scale &&
+                     !d->C2 && !d->bias && g.c_f32 && !g.drop.rng && (d->variant == MRG_GEMM_P8 || d->variant == MRG_GEMM_P8SK)) g.epi_kind = 7;
         }
     }
     dim3 grid(g.tiles_m * g.tiles_n, splitk), block(256);
@@ -1392,6 +1394,18 @@ extern "C" int mrg_gemm(const mrg_gemm_desc* d, hipStream_t stream) {
     const bool will_g256 = fast && d->variant == MRG_GEMM_G256 && kf && !d->colsum_out && d->M > 128;
     inkernel = splitk > 1 && d->splitk_counters && !d->defer_reduce && !d->colsum_out && !will_sq && !will_g256 && !(use_big && !will_ws);
     g.tile_cnt = inkernel ? d->splitk_counters : nullptr;
+    if (d->variant == MRG_GEMM_P8SK) {     // stream-K schedule of the 8-phase kernel: an explicit request, so an unmet precondition is an error
+        MRG_REQUIRE(fast && !mapped && !d->colsum_out && splitk == 1 && d->K % BK == 0 && !d->m_dev && !d->k_dev, MRG_ERR_UNSUPPORTED,
+                    "mrg_gemm: MRG_GEMM_P8SK needs aligned unmapped operands, K %% 64 == 0, no split-K / column sums / device counts");
+        MRG_REQUIRE(d->ws && d->splitk_counters && (((uintptr_t)d->ws) & 15) == 0, MRG_ERR_ARG,
+                    "mrg_gemm: MRG_GEMM_P8SK needs ws (mrg_streamk_ws_bytes) and zeroed splitk_counters");
+        MRG_REQUIRE(d->sk_grid >= 0 && d->sk_grid <= 4096, MRG_ERR_ARG, "mrg_gemm: bad sk_grid %d", d->sk_grid);
+        g.tile_cnt = nullptr; g.ws = nullptr;
+        MRG_REQUIRE(mrg_gemm8p_sk_launch(g, d->a_mode, d->b_mode, vec, d->ws, d->splitk_counters, d->sk_grid, stream), MRG_ERR_UNSUPPORTED,
+                    "mrg_gemm: MRG_GEMM_P8SK cannot run this operand layout");
+        if (d->ev_stop) (void)hipEventRecord((hipEvent_t)d->ev_stop, stream);
+        return mrg_check_launch("mrg_gemm");
+    }
     if (fast && !mapped && d->variant == MRG_GEMM_P8 && !d->colsum_out && d->M > 128 && d->N > 128 &&
         mrg_gemm8p_launch(g, d->a_mode, d->b_mode, vec, splitk, stream)) {
         if (d->ev_stop) (void)hipEventRecord((hipEvent_t)d->ev_stop, stream);
@@ -1479,7 +1493,7 @@ extern "C" int mrg_wgrad_group(const mrg_wgrad_group_desc* d, hipStream_t stream
     const int splitk = d->splitk > 1 ? d->splitk : 1;
     MRG_REQUIRE(splitk == 1 || d->ws, MRG_ERR_ARG, "mrg_wgrad_group: split-K needs a workspace");
     MRG_REQUIRE(splitk <= (d->K / BK), MRG_ERR_SHAPE, "mrg_wgrad_group: split-K factor %d exceeds the %d k-tiles", splitk, d->K / BK);
-    g.c_f32 = 1; g.splitk = splitk; g.ws = d->ws; g.epi_kind = 0; g.act = MRG_ACT_NONE; g.xcd_split = 1;
+    g.c_f32 = 1; g.splitk = splitk; g.ws = d->ws; g.epi_kind = splitk == 1 ? 7 : 0; g.act = MRG_ACT_NONE; g.xcd_split = 1;
     { static const int nt = [] { const char* e = getenv("MRG_GEMM_NT"); return e ? atoi(e) : 2; }(); g.nt = nt; }
     { static const int sd = [] { const char* e = getenv("MRG_GEMM_SIDE_DRAIN"); return e ? atoi(e) : 3; }(); g.side_drain = sd; }
     ga.nprob = d->count;
@@ -1504,8 +1518,23 @@ extern "C" int mrg_wgrad_group(const mrg_wgrad_group_desc* d, hipStream_t stream
     for (int p = d->count; p <= P8_GROUP_MAX; ++p) ga.tile_start[p] = tiles;
     for (int p = d->count; p < P8_GROUP_MAX; ++p) { ga.A[p] = nullptr; ga.B[p] = nullptr; ga.C[p] = nullptr; ga.M[p] = ga.N[p] = ga.lda[p] = ga.ldb[p] = ga.ldc[p] = 0; ga.ws_off[p] = 0; }
     if (splitk > 1) vec = vec && (((uintptr_t)d->ws) % 16 == 0);
+    if (d->streamk) {
+        MRG_REQUIRE(splitk == 1 && d->ws && d->counters && (((uintptr_t)d->ws) & 15) == 0, MRG_ERR_ARG,
+                    "mrg_wgrad_group: stream-K needs splitk <= 1, ws (mrg_streamk_ws_bytes) and zeroed counters");
+        MRG_REQUIRE(d->sk_grid >= 0 && d->sk_grid <= 4096, MRG_ERR_ARG, "mrg_wgrad_group: bad sk_grid %d", d->sk_grid);
+        g.ws = nullptr;
+        if (d->ev_start) (void)hipEventRecord((hipEvent_t)d->ev_start, stream);
+        MRG_REQUIRE(mrg_gemm8p_sk_group_launch(ga, vec, d->ws, d->counters, d->sk_grid, stream), MRG_ERR_SHAPE, "mrg_wgrad_group: nothing to launch");
+        if (d->ev_stop) (void)hipEventRecord((hipEvent_t)d->ev_stop, stream);
+        return mrg_check_launch("mrg_wgrad_group");
+    }
     if (d->ev_start) (void)hipEventRecord((hipEvent_t)d->ev_start, stream);
     MRG_REQUIRE(mrg_gemm8p_group_launch(ga, vec, stream), MRG_ERR_SHAPE, "mrg_wgrad_group: nothing to launch");
     if (d->ev_stop) (void)hipEventRecord((hipEvent_t)d->ev_stop, stream);
     return mrg_check_launch("mrg_wgrad_group");
+}
+
+extern "C" long mrg_streamk_ws_bytes(int sk_grid) {
+    const long P = sk_grid > 0 ? sk_grid : mrg_num_cus();
+    return P * 2 * 256 * 256 * (long)sizeof(float);
 }

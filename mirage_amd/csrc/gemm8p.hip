@@ -95,34 +95,28 @@ struct P8Frag {
     }
 };
 
-// one 256 x 256 output tile (tile `bid` of the problem in grouped row-major order, k-range `ksplit` of g.splitk)
-template <int AMODE, int BMODE, bool VEC, int PHASES>
-__device__ __forceinline__ void p8_tile(const GemmArgs& g, const int bid, const int ksplit, char* smem) {
+// (row, column) origin of tile `bid` of the problem in grouped row-major order (GROUP_M row tiles share a B panel walk)
+__device__ __forceinline__ void p8_tile_origin(const GemmArgs& g, const int bid, int& m0, int& n0) {
     const int tiles_m = (g.M + 255) / 256, tiles_n = (g.N + 255) / 256;
     constexpr int GROUP_M = 4;
-    int tm, tn;
-    {
-        const int per_group = GROUP_M * tiles_n;
-        const int grp = fast_udiv(bid, per_group), in_grp = bid - grp * per_group;
-        const int first = grp * GROUP_M;
-        const int rows = min(GROUP_M, tiles_m - first);
-        tn = fast_udiv(in_grp, rows);
-        tm = first + in_grp - tn * rows;
-    }
-    const int m0 = tm * 256, n0 = tn * 256;
+    const int per_group = GROUP_M * tiles_n;
+    const int grp = fast_udiv(bid, per_group), in_grp = bid - grp * per_group;
+    const int first = grp * GROUP_M;
+    const int rows = min(GROUP_M, tiles_m - first);
+    const int tn = fast_udiv(in_grp, rows);
+    const int tm = first + in_grp - tn * rows;
+    m0 = tm * 256; n0 = tn * 256;
+}
+
+// main loop of one 256 x 256 tile at (m0, n0) over the k-tiles [t0, t0 + nt): acc = A[m0.., k] B[n0.., k]^T (accumulators zeroed here).
+// On return both wave groups are aligned again and no LDS read or LDS-DMA of this call is outstanding.
+template <int AMODE, int BMODE, int PHASES>
+__device__ __forceinline__ void p8_mainloop(const GemmArgs& g, const int m0, const int n0, const int t0, const int nt,
+                                            f32x16 (&acc)[4][2], char* smem, const int tid) {
     const int Meff = g.M;
-    const int tid = threadIdx.x, lane = tid & 63;
+    const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 2, wn = wave & 3;             // rows wm*128.., cols wn*64..
-    const int ntiles = g.K / BK;
-    int t0 = 0, t1 = ntiles;
-    if (g.splitk > 1) {
-        const int per = (ntiles + g.splitk - 1) / g.splitk;
-        t0 = ksplit * per;
-        t1 = min(ntiles, t0 + per);
-    }
-    const int nt = t1 - t0;
-    f32x16 acc[4][2];
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -282,56 +276,105 @@ __device__ __forceinline__ void p8_tile(const GemmArgs& g, const int bid, const 
 #undef P8_MFMA
         if (wm == 0 && !(abl & 16)) __builtin_amdgcn_s_barrier();               // re-align the two halves
     }
-    // ---- epilogue: four 64-row x 256-col slabs through a 64 KiB fp32 staging tile
+}
+
+// bias values of this thread's four output columns (requested before the main loop: the load's latency would otherwise open the epilogue)
+__device__ __forceinline__ void p8_bias(const GemmArgs& g, const int n0, bool want, float (&bv)[4], const int tid) {
+    const int col = n0 + ((tid & 63) << 2);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) bv[e] = (want && g.bias && col + e < g.N) ? g.bias[col + e] : 0.f;
+}
+
+// Epilogue of one tile: two passes of 128 rows (64 of each M-half, so that all eight waves stage at once) through a 128 KiB fp32 staging
+// tile -- the whole operand ring, idle by now -- drained as 16-B row segments in batches of eight (side operands of a batch are
+// requested before the first is consumed).  One workgroup per CU means nothing hides this phase: at K = 768 it is as long as the main
+// loop (profiles/r04_streamk.md), hence two barriers per pass instead of four half-used ones and no dependent global round trip per row.
+// ws != nullptr: split-K slab stores instead.
+template <bool VEC, int ps>
+__device__ __forceinline__ void p8_epilogue_pass(const GemmArgs& g, const int m0, const int n0, f32x16 (&acc)[4][2], char* smem, float* ws,
+                                                 const float (&bv)[4], unsigned long long* etr, const int tid) {
+    const int Meff = g.M;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 2, wn = wave & 3;
     float* ct = reinterpret_cast<float*>(smem);
     const int cl = (tid & 63) << 2;
     const int col = n0 + cl;
     const int nv = min(4, g.N - col);
-    float* ws = g.splitk > 1 ? g.ws + (long)ksplit * g.M * g.N : nullptr;
-    float bv[4] = {0.f, 0.f, 0.f, 0.f};
-    if (g.bias && !ws && col < g.N) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) if (e < nv) bv[e] = g.bias[col + e];
-    }
-#pragma unroll
-    for (int sl = 0; sl < 4; ++sl) {
+    {
         __syncthreads();
-        if (wm == (sl >> 1)) {
+        if (etr && tid == 0) etr[3 * ps] = wall_clock64();
 #pragma unroll
-            for (int ii = 0; ii < 2; ++ii)
+        for (int ii = 0; ii < 2; ++ii)
 #pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    const int c2 = wn * 64 + j * 32 + (lane & 31);
+            for (int j = 0; j < 2; ++j) {
+                const int c2 = wn * 64 + j * 32 + (lane & 31);
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int rl = ii * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                        ct[rl * 256 + c2] = acc[2 * (sl & 1) + ii][j][r];
-                    }
+                for (int r = 0; r < 16; ++r) {
+                    const int rl = wm * 64 + ii * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                    ct[rl * 256 + c2] = acc[2 * ps + ii][j][r];
                 }
-        }
+            }
         __syncthreads();
+        if (etr && tid == 0) etr[3 * ps + 1] = wall_clock64();
         if (col < g.N) {
-            auto row_of = [&](int it, int& rl, int& row) { rl = (tid >> 6) + (it << 3); row = m0 + sl * 64 + rl; };
-            if (VEC && (g.side_drain & 2) && ws) { MRG_DRAIN8_W(7, false, ws, 256); }
-            else if (VEC && (g.side_drain & 1) && g.epi_kind == 2) { MRG_DRAIN8_W(2, false, nullptr, 256); }
-            else if (VEC && (g.side_drain & 1) && g.epi_kind == 4) { MRG_DRAIN8_W(4, false, nullptr, 256); }
-            else if (VEC && (g.side_drain & 1) && g.epi_kind == 1) { MRG_DRAIN8_W(1, false, nullptr, 256); }
-            else if (VEC && (g.side_drain & 1) && g.epi_kind == 3) { MRG_DRAIN8_W(3, false, nullptr, 256); }
-            else if (VEC && (g.side_drain & 1) && g.epi_kind == 5) { MRG_DRAIN8_W(5, false, nullptr, 256); }
+            // staging row rl (0..127) = M-half (rl >> 6), row (rl & 63) of this pass's 64-row band of that half
+            auto row_of = [&](int it, int& rl, int& row) { rl = (tid >> 6) + (it << 3); row = m0 + ((rl >> 6) << 7) + ps * 64 + (rl & 63); };
+#define P8_DRAIN16(KIND_, CSP_) do { \
+            drain_side<KIND_, false, 8, 256>(g, ct, cl, col, bv, Meff, [&](int it, int& rl, int& row) { row_of(it, rl, row); }, CSP_); \
+            drain_side<KIND_, false, 8, 256>(g, ct, cl, col, bv, Meff, [&](int it, int& rl, int& row) { row_of(it + 8, rl, row); }, CSP_); } while (0)
+            if (VEC && (g.side_drain & 2) && ws) { P8_DRAIN16(7, ws); }
+            else if (VEC && (g.side_drain & 1) && g.epi_kind == 2) { P8_DRAIN16(2, nullptr); }
+            else if (VEC && (g.side_drain & 1) && g.epi_kind == 4) { P8_DRAIN16(4, nullptr); }
+            else if (VEC && (g.side_drain & 1) && g.epi_kind == 1) { P8_DRAIN16(1, nullptr); }
+            else if (VEC && (g.side_drain & 1) && g.epi_kind == 3) { P8_DRAIN16(3, nullptr); }
+            else if (VEC && (g.side_drain & 1) && g.epi_kind == 5) { P8_DRAIN16(5, nullptr); }
+            else if (VEC && (g.side_drain & 1) && g.epi_kind == 7) { P8_DRAIN16(8, nullptr); }
             else {
 #pragma unroll 1
-                for (int it = 0; it < 8; ++it) {
-                    const int rl = (tid >> 6) + (it << 3);                  // 0..63
-                    const int row = m0 + sl * 64 + rl;
+                for (int it = 0; it < 16; ++it) {
+                    int rl, row;
+                    row_of(it, rl, row);
                     if (row < Meff) {
                         const float4 a4 = *reinterpret_cast<const float4*>(ct + rl * 256 + cl);
                         epi_any<VEC>(g, a4, bv, ws, row, col, nv);
                     }
                 }
             }
+#undef P8_DRAIN16
         }
+        if (etr && tid == 0) etr[3 * ps + 2] = wall_clock64();
     }
-    if (ws && g.tile_cnt) splitk_finish<VEC>(g, bid, m0, n0, 256, 256, Meff, smem, tid, 512);
+}
+
+template <bool VEC>
+__device__ __forceinline__ void p8_epilogue(const GemmArgs& g, const int m0, const int n0, f32x16 (&acc)[4][2], char* smem, float* ws,
+                                            const float (&bv)[4], const int tid, unsigned long long* etr = nullptr) {
+    // two calls with a compile-time pass index: inside a loop the accumulator array is indexed at run time and moves to scratch memory
+    p8_epilogue_pass<VEC, 0>(g, m0, n0, acc, smem, ws, bv, etr, tid);
+    p8_epilogue_pass<VEC, 1>(g, m0, n0, acc, smem, ws, bv, etr, tid);
+}
+
+// one 256 x 256 output tile (tile `bid` of the problem in grouped row-major order, k-range `ksplit` of g.splitk)
+template <int AMODE, int BMODE, bool VEC, int PHASES>
+__device__ __forceinline__ void p8_tile(const GemmArgs& g, const int bid, const int ksplit, char* smem) {
+    int m0, n0;
+    p8_tile_origin(g, bid, m0, n0);
+    const int ntiles = g.K / BK;
+    int t0 = 0, t1 = ntiles;
+    if (g.splitk > 1) {
+        const int per = (ntiles + g.splitk - 1) / g.splitk;
+        t0 = ksplit * per;
+        t1 = min(ntiles, t0 + per);
+    }
+    const int tid = threadIdx.x;
+    float bv[4];
+    p8_bias(g, n0, g.splitk <= 1, bv, tid);
+    f32x16 acc[4][2];
+    p8_mainloop<AMODE, BMODE, PHASES>(g, m0, n0, t0, t1 - t0, acc, smem, tid);
+    float* ws = g.splitk > 1 ? g.ws + (long)ksplit * g.M * g.N : nullptr;
+    p8_epilogue<VEC>(g, m0, n0, acc, smem, ws, bv, tid);
+    if (ws && g.tile_cnt) splitk_finish<VEC>(g, bid, m0, n0, 256, 256, g.M, smem, threadIdx.x, 512);
 }
 
 template <int AMODE, int BMODE, bool VEC, int PHASES>
@@ -366,6 +409,175 @@ __global__ __launch_bounds__(512) void gemm_p8_group_kernel(const P8GroupArgs ga
     p8_tile<MRG_OP_KSTRIDED, MRG_OP_KSTRIDED, VEC, PHASES>(g, bid - ga.tile_start[p], ksplit, smem);
 }
 
+
+// ------------------------------------------------------------------------------------------------------------------------------
+// Stream-K schedule of the same tile code (Osama et al., "Stream-K: work-centric parallel decomposition for dense matrix-matrix
+// multiplication on the GPU", PPoPP'23, restated for one persistent workgroup per CU).  The launch has P workgroups; the iteration
+// space (tile, k-tile) of all `tiles` output tiles, tile-major, is cut into P equal contiguous ranges, so every CU performs the same
+// number of MAC iterations whatever tiles / P is (C2 fc1 forward: 396 tiles = 1.55 rounds of 256 CUs -> 18.6 k-tiles per CU).
+// A range covers the tail of one tile, whole tiles, and the head of another; a tile whose k-range is shared by s workgroups
+// (s <= 3 when a range is at least half a tile) is finished by its LAST ARRIVER, which keeps its own partial sums in registers:
+//   contributor:  peek the tile's arrival counter -- if the s - 1 others have arrived it is the finisher and stores nothing;
+//                 otherwise store the 256 KiB accumulator image (fragment order, 16 B per lane, write-through), drain, take a ticket
+//                 (the ticket may still make it the finisher: it then reads back nothing of its own either);
+//   finisher:     agent-scope acquire, sum the s partial images in SLICE order (its own slice from registers), fused epilogue, reset
+//                 the counter (zero on entry, zero on exit: graph-replayable without a memset).
+// Nobody waits for anybody, so the result and termination are independent of dispatch order, residency and the number of launches
+// sharing the chip; the sum order is fixed, so the result is a pure function of (operands, P).  A range walks its LAST tile first
+// and its FIRST tile last: the head part of a tile (owned by the lower workgroup) is published at the start of a launch and its
+// tail owner arrives at the end, i.e. in the common case exactly one image per split point travels (P - 1 per launch).
+// Workgroup -> range uses the XCD band order (consecutive ranges share an L2).
+struct P8SkArgs { float* slabs; int* cnt; int tiles; int nk; unsigned long long* trace; };
+// mrg_debug_sk_trace: per workgroup 32 x u64 = {start, then per segment: main loop end, exchange end, role (0 whole tile, 1 stored,
+// 2 finisher without a store, 3 finisher after storing) << 32 | tile, epilogue end} in wall_clock64 ticks (100 MHz)
+#define SK_TRACE(slot, val) do { if (sk.trace && tid == 0) sk.trace[(long)blockIdx.x * 32 + (slot)] = (val); } while (0)
+constexpr int P8_SLAB_FLOATS = 256 * 256;
+
+__device__ __forceinline__ int sk_owner(long x, int P, long I) { return (int)(((x + 1) * P - 1) / I); }   // workgroup whose range holds iteration x
+
+template <int AMODE, int BMODE, bool VEC, int PHASES, typename ProblemOf>
+__device__ __forceinline__ void p8_streamk(const P8SkArgs& sk, char* smem, ProblemOf problem_of) {
+    const int P = gridDim.x;
+    int lin;
+    {
+        const int b = blockIdx.x, q = P >> 3, r = P & 7, xcd = b & 7, idx = b >> 3;
+        lin = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int nk = sk.nk;
+    const long I = (long)sk.tiles * nk;
+    const int S = (int)((long)lin * I / P), E = (int)((long)(lin + 1) * I / P);
+    if (S >= E) return;
+    const int tf = S / nk, tl = (E - 1) / nk;
+    const int nseg = tl - tf + 1;
+    volatile int* flag = reinterpret_cast<volatile int*>(smem);
+    { const int tid = threadIdx.x; SK_TRACE(0, wall_clock64()); }
+    for (int si = 0; si < nseg; ++si) {
+        // the lane id is made opaque per segment: everything per-lane below (loader offsets, fragment addresses, epilogue columns,
+        // partial-image offsets) would otherwise be loop-invariant, hoisted out of this loop and kept in registers across the main loop
+        int tid = threadIdx.x;
+        asm volatile("" : "+v"(tid));
+        const int lane = tid & 63;
+        const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+        const int t = nseg == 1 ? tf : (si == 0 ? tl : (si == nseg - 1 ? tf : tf + si));
+        const int k0 = max(S, t * nk) - t * nk, k1 = min(E, (t + 1) * nk) - t * nk;
+        GemmArgs gl;
+        int bid;
+        const GemmArgs& g = problem_of(t, gl, bid);
+        int m0, n0;
+        p8_tile_origin(g, bid, m0, n0);
+        float bv[4];
+        p8_bias(g, n0, true, bv, tid);
+        f32x16 acc[4][2];
+        p8_mainloop<AMODE, BMODE, PHASES>(g, m0, n0, k0, k1 - k0, acc, smem, tid);
+        if (si < 7) SK_TRACE(1 + 4 * si, wall_clock64());
+        bool finish = true;
+        int role = 0;
+        if (k1 - k0 < nk) {
+            const int w0 = sk_owner((long)t * nk, P, I), w1 = sk_owner((long)(t + 1) * nk - 1, P, I);
+            const int s = w1 - w0 + 1, z = lin - w0;
+            auto slab_of = [&](int w) -> float* {
+                const int tfw = (int)((long)w * I / P) / nk;
+                return sk.slabs + ((long)w * 2 + (tfw == t ? 0 : 1)) * P8_SLAB_FLOATS;
+            };
+            int* cnt = sk.cnt + t;
+            if (tid == 0) *flag = (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == s - 1) ? 1 : 0;
+            __syncthreads();
+            bool last = *flag != 0;
+            __syncthreads();
+            if (!last) {
+                float* mine = slab_of(lin) + ((long)wave * 32 * 64 + lane) * 4;
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+#pragma unroll
+                        for (int q4 = 0; q4 < 4; ++q4)
+                            st_slab(mine + ((i * 2 + j) * 4 + q4) * 256,
+                                    make_float4(acc[i][j][4 * q4], acc[i][j][4 * q4 + 1], acc[i][j][4 * q4 + 2], acc[i][j][4 * q4 + 3]), true);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
+                if (tid == 0) *flag = (__hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == s - 1) ? 1 : 0;
+                __syncthreads();
+                last = *flag != 0;
+                __syncthreads();
+                role = last ? 3 : 1;
+            } else role = 2;
+            finish = last;
+            if (last) {
+                if (tid == 0) {
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                    __hip_atomic_store(cnt, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                __syncthreads();
+                const long lane_off = ((long)wave * 32 * 64 + lane) * 4;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    // row tile i of the accumulators: 8 x 16 B per lane.  Canonical order ((p_0 + p_1) + ...) + p_{s-1} with the own
+                    // slice taken from registers at position z.
+                    float4 pre[8];
+                    for (int zz = 0; zz < z; ++zz) {
+                        const float* p = slab_of(w0 + zz) + lane_off + i * 8 * 256;
+                        float4 ld[8];
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) ld[e] = *reinterpret_cast<const float4*>(p + e * 256);
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) {
+                            if (zz == 0) pre[e] = ld[e];
+                            else { pre[e].x += ld[e].x; pre[e].y += ld[e].y; pre[e].z += ld[e].z; pre[e].w += ld[e].w; }
+                        }
+                    }
+                    if (z > 0) {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) {
+                            f32x16& a = acc[i][e >> 2];
+                            const int b4 = (e & 3) * 4;
+                            a[b4] = pre[e].x + a[b4]; a[b4 + 1] = pre[e].y + a[b4 + 1]; a[b4 + 2] = pre[e].z + a[b4 + 2]; a[b4 + 3] = pre[e].w + a[b4 + 3];
+                        }
+                    }
+                    for (int zz = z + 1; zz < s; ++zz) {
+                        const float* p = slab_of(w0 + zz) + lane_off + i * 8 * 256;
+                        float4 ld[8];
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) ld[e] = *reinterpret_cast<const float4*>(p + e * 256);
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) {
+                            f32x16& a = acc[i][e >> 2];
+                            const int b4 = (e & 3) * 4;
+                            a[b4] += ld[e].x; a[b4 + 1] += ld[e].y; a[b4 + 2] += ld[e].z; a[b4 + 3] += ld[e].w;
+                        }
+                    }
+                }
+            }
+        }
+        if (si < 7) { SK_TRACE(2 + 4 * si, wall_clock64()); SK_TRACE(3 + 4 * si, ((unsigned long long)role << 32) | (unsigned)t | ((unsigned long long)(k1 - k0) << 48)); }
+        if (finish) p8_epilogue<VEC>(g, m0, n0, acc, smem, nullptr, bv, tid, (sk.trace && si == nseg - 1 && nseg <= 4) ? sk.trace + (long)blockIdx.x * 32 + 20 : nullptr);
+        __syncthreads();                         // the staging tile is the next segment's operand ring
+        if (si < 7) SK_TRACE(4 + 4 * si, wall_clock64());
+    }
+}
+
+template <int AMODE, int BMODE, bool VEC, int PHASES>
+__global__ __launch_bounds__(512) void gemm_p8sk_kernel(const GemmArgs g, const P8SkArgs sk) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    p8_streamk<AMODE, BMODE, VEC, PHASES>(sk, smem, [&](int t, GemmArgs&, int& bid) -> const GemmArgs& { bid = t; return g; });
+}
+
+// grouped weight gradients (gemm_p8_group_kernel's problem list) on the stream-K schedule: the concatenated tile lists of all problems
+// form one iteration space (K is common), so a group of 432 tiles is 1.69 "rounds" of work per CU instead of two rounds
+template <bool VEC, int PHASES>
+__global__ __launch_bounds__(512) void gemm_p8sk_group_kernel(const P8GroupArgs ga, const P8SkArgs sk) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    p8_streamk<MRG_OP_KSTRIDED, MRG_OP_KSTRIDED, VEC, PHASES>(sk, smem, [&](int t, GemmArgs& gl, int& bid) -> const GemmArgs& {
+        int p = 0;
+        while (p + 1 < ga.nprob && t >= ga.tile_start[p + 1]) ++p;
+        gl = ga.base;
+        gl.A = ga.A[p]; gl.B = ga.B[p]; gl.C = ga.C[p];
+        gl.M = ga.M[p]; gl.N = ga.N[p]; gl.lda = ga.lda[p]; gl.ldb = ga.ldb[p]; gl.ldc = ga.ldc[p];
+        bid = t - ga.tile_start[p];
+        return gl;
+    });
+}
+
 }  // namespace
 
 bool mrg_gemm8p_group_launch(const mrg_detail::P8GroupArgs& ga, bool vec, hipStream_t stream) {
@@ -398,5 +610,61 @@ bool mrg_gemm8p_launch(const mrg_detail::GemmArgs& g, int a_mode, int b_mode, bo
     else return false;
 #undef MRG_P8
 #undef MRG_P8_
+    return true;
+}
+
+static unsigned long long* g_sk_trace = nullptr;
+extern "C" int mrg_debug_sk_trace(unsigned long long* buf) { g_sk_trace = buf; return 0; }
+
+int mrg_num_cus() {
+    static const int n = [] {
+        int dev = 0, cus = 256;
+        if (hipGetDevice(&dev) != hipSuccess) return 256;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) return 256;
+        return cus;
+    }();
+    return n;
+}
+
+// stream-K launch: grid workgroups (0: one per CU), slabs = grid * 2 * 256 KiB of fp32 workspace, cnt = one zero int per 256 x 256 tile
+bool mrg_gemm8p_sk_launch(const mrg_detail::GemmArgs& g, int a_mode, int b_mode, bool vec, float* slabs, int* cnt, int grid, hipStream_t stream) {
+    if (g.K % BK != 0 || g.a_map || g.b_map || g.m_dev || g.k_dev || g.colsum || g.splitk > 1) return false;
+    if (!g.a_aligned || !g.b_aligned || !slabs || !cnt) return false;
+    if (a_mode == MRG_OP_KSTRIDED && (g.M % 8 != 0)) return false;
+    if (b_mode == MRG_OP_KSTRIDED && (g.N % 8 != 0)) return false;
+    P8SkArgs sk;
+    sk.slabs = slabs; sk.cnt = cnt; sk.tiles = cdiv(g.M, 256) * cdiv(g.N, 256); sk.nk = g.K / BK; sk.trace = g_sk_trace;
+    const long iters = (long)sk.tiles * sk.nk;
+    int P = grid > 0 ? grid : mrg_num_cus();
+    if (P > iters) P = (int)iters;
+    static const int phases = [] { const char* e = getenv("MRG_P8_PHASES"); return e ? atoi(e) : 2; }();
+#define MRG_P8SK_(AM, BM_, V, PH) do { const void* fn = (const void*)gemm_p8sk_kernel<AM, BM_, V, PH>; \
+        (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, P8_LDS); \
+        hipLaunchKernelGGL((gemm_p8sk_kernel<AM, BM_, V, PH>), dim3(P), dim3(512), (size_t)P8_LDS, stream, g, sk); } while (0)
+#define MRG_P8SK(AM, BM_, V) do { if (phases == 4) MRG_P8SK_(AM, BM_, V, 4); else MRG_P8SK_(AM, BM_, V, 2); } while (0)
+    if (a_mode == MRG_OP_KCONTIG && b_mode == MRG_OP_KCONTIG) { if (vec) MRG_P8SK(0, 0, true); else MRG_P8SK(0, 0, false); }
+    else if (a_mode == MRG_OP_KCONTIG && b_mode == MRG_OP_KSTRIDED) { if (vec) MRG_P8SK(0, 1, true); else MRG_P8SK(0, 1, false); }
+    else if (a_mode == MRG_OP_KSTRIDED && b_mode == MRG_OP_KSTRIDED) { if (vec) MRG_P8SK(1, 1, true); else MRG_P8SK(1, 1, false); }
+    else return false;
+#undef MRG_P8SK
+#undef MRG_P8SK_
+    return true;
+}
+
+bool mrg_gemm8p_sk_group_launch(const mrg_detail::P8GroupArgs& ga, bool vec, float* slabs, int* cnt, int grid, hipStream_t stream) {
+    const int total = ga.tile_start[ga.nprob];
+    if (total <= 0 || !slabs || !cnt || ga.base.splitk > 1) return false;
+    P8SkArgs sk;
+    sk.slabs = slabs; sk.cnt = cnt; sk.tiles = total; sk.nk = ga.base.K / BK; sk.trace = g_sk_trace;
+    const long iters = (long)sk.tiles * sk.nk;
+    int P = grid > 0 ? grid : mrg_num_cus();
+    if (P > iters) P = (int)iters;
+    static const int phases = [] { const char* e = getenv("MRG_P8_PHASES"); return e ? atoi(e) : 2; }();
+#define MRG_P8SKG(V, PH) do { const void* fn = (const void*)gemm_p8sk_group_kernel<V, PH>; \
+        (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, P8_LDS); \
+        hipLaunchKernelGGL((gemm_p8sk_group_kernel<V, PH>), dim3(P), dim3(512), (size_t)P8_LDS, stream, ga, sk); } while (0)
+    if (vec) { if (phases == 4) MRG_P8SKG(true, 4); else MRG_P8SKG(true, 2); }
+    else { if (phases == 4) MRG_P8SKG(false, 4); else MRG_P8SKG(false, 2); }
+#undef MRG_P8SKG
     return true;
 }

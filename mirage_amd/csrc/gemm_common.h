@@ -34,7 +34,8 @@ struct GemmArgs {
     int tiles_m, tiles_n;
     int epi_kind;  // 0 generic epilogue; lean paths: 1 (+bias) -> bf16 C; 2 (+bias)(*row_scale) + fp32 residual -> fp32 C (+ bf16 twin);
                    // 3 bias + GELU with fp16 GELU' side output; 4 multiply by the fp16 side input -> bf16 C (1 and 4 also with column sums);
-                   // 5 bias + GELU -> bf16 C; 6 bias + table row -> fp32 C at a mapped row (patch embedding)
+                   // 5 bias + GELU -> bf16 C; 6 bias + table row -> fp32 C at a mapped row (patch embedding); 7 plain fp32 C (weight gradients:
+                   // 8-phase kernel only, the other kernels take the generic path for it)
     int side_drain; // MRG_GEMM_SIDE_DRAIN (bit 0: batched drain of the lean epilogues, bit 1: of the split-K slab stores; default 3)
     int xcd_split; // MRG_GEMM_XCD_SPLIT (default 1): split-K index slowest in the XCD band order
     int nt;       // MRG_GEMM_NT: 0 plain stores, 1 streaming (nontemporal) stores for C / C2 / aux_out, 2 (default) for aux_out only
@@ -60,6 +61,11 @@ using namespace mrg_detail;
 // launcher of the 256 x 256 8-phase kernel (gemm8p.hip); returns false when the problem is outside its domain
 bool mrg_gemm8p_launch(const mrg_detail::GemmArgs& g, int a_mode, int b_mode, bool vec, int splitk, hipStream_t stream);
 bool mrg_gemm8p_group_launch(const mrg_detail::P8GroupArgs& ga, bool vec, hipStream_t stream);
+// stream-K schedule of the same kernel (gemm8p.hip): persistent grid (0 = one workgroup per CU), slabs = grid * 2 * 256 KiB fp32, cnt = zeroed
+// int per 256 x 256 tile (left zero)
+bool mrg_gemm8p_sk_launch(const mrg_detail::GemmArgs& g, int a_mode, int b_mode, bool vec, float* slabs, int* cnt, int grid, hipStream_t stream);
+bool mrg_gemm8p_sk_group_launch(const mrg_detail::P8GroupArgs& ga, bool vec, float* slabs, int* cnt, int grid, hipStream_t stream);
+int mrg_num_cus();
 
 namespace {
 
@@ -437,7 +443,7 @@ __device__ __forceinline__ void epi_any(const GemmArgs& g, const float4 a4, cons
     else if (g.epi_kind == 4) epi_row_mulaux<VEC>(g, a4, bv, row, col, nv);
     else if (g.epi_kind == 5) epi_row_gelu<VEC>(g, a4, bv, row, col, nv);
     else if (g.epi_kind == 6) epi_row_embed<VEC>(g, a4, bv, row, col, nv);
-    else epi_row<VEC>(g, a4, bv, ws, row, col, nv);
+    else epi_row<VEC>(g, a4, bv, ws, row, col, nv);      // kinds 0 and 7
 }
 template <bool VEC>
 __device__ __forceinline__ void epi_any_cs(const GemmArgs& g, const float4 a4, const float (&bv)[4], float* ws, int row, int col, int nv, float* cs) {
@@ -476,6 +482,7 @@ __device__ __forceinline__ void drain_side(const GemmArgs& g, const float* ct, i
         const int row = rows[it];
         if (row < Meff) {
             if (KIND == 7) { st_slab(cs + (long)row * g.N + col, a[it], g.tile_cnt != nullptr); continue; }      // split-K slab (cs = slab base)
+            if (KIND == 8) { *reinterpret_cast<float4*>(reinterpret_cast<float*>(g.C) + (long)row * g.ldc + col) = a[it]; continue; }   // plain fp32 tile (weight gradients)
             if (KIND == 1) { epi_row_bf16<true, CS>(g, a[it], bv, row, col, 4, cs); continue; }
             if (KIND == 3) { epi_row_gelu_save<true>(g, a[it], bv, row, col, 4); continue; }
             if (KIND == 5) { epi_row_gelu<true>(g, a[it], bv, row, col, 4); continue; }

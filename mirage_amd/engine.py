@@ -135,8 +135,12 @@ class _Side:
 
     @classmethod
     def join(cls):
-        cls.flush()
-        K.WgradGroup.flush()                     # side stream off: what the last blocks queued
+        K.WgradGroup.exposed = True              # the caller waits for this group: it may take the whole chip (stream-K schedule)
+        try:
+            cls.flush()
+            K.WgradGroup.flush()                 # side stream off: what the last blocks queued
+        finally:
+            K.WgradGroup.exposed = False
         cls._blocks = 0
         if K.Deferred.tasks:
             main = torch.cuda.current_stream()

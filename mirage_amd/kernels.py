@@ -185,11 +185,28 @@ def _splitk_counters(ntiles: int, device):
     return buf.data_ptr() + 4 * pos
 
 
+# Stream-K launches (MRG_GEMM_P8SK, mrg_wgrad_group streamk): persistent grid of SK_GRID workgroups (0 = one per CU); the scratch for the
+# partial accumulator images is the per-stream workspace, the per-tile arrival counters come from the zero ring above
+SK_GRID = int(os.environ.get("MRG_SK_GRID", "0"))
+STREAMK = os.environ.get("MRG_STREAMK", "1") != "0"          # A/B: 0 keeps the stream-K variant out of the tuner and the groups
+
+
+def _streamk_scratch(d, tiles256: int, dev):
+    d.ws = _workspace(lib.mrg_streamk_ws_bytes(SK_GRID), dev).data_ptr()
+    d.sk_grid = SK_GRID
+    return _splitk_counters(tiles256, dev)
+
+
 def _gemm_launch(d, splitk, variant, dev, defer_out=None):
     d.splitk = splitk
     d.variant = variant
     d.defer_reduce = 0
     d.splitk_counters = None
+    if variant == L.MRG_GEMM_P8SK:
+        d.splitk = 1
+        d.splitk_counters = _streamk_scratch(d, ((d.M + 255) // 256) * ((d.N + 255) // 256), dev)
+        check(lib.mrg_gemm(C.byref(d), _s()), "mrg_gemm")
+        return
     if splitk > 1:
         if (SPLITK_INKERNEL and not d.colsum_out and splitk <= SPLITK_INKERNEL_MAX
                 and ((d.M + 127) // 128) * ((d.N + 127) // 128) >= SPLITK_INKERNEL_MIN_TILES):
@@ -234,6 +251,8 @@ def _autotune(d, key, splitk, allow_split, dev):
         for s_ in splits:
             if t8 * s_ >= 192:
                 cands.append((L.MRG_GEMM_P8, s_))
+        if STREAMK and t8 * (d.K // 64) >= 1024:                   # stream-K: at least ~4 k-tiles per CU
+            cands.append((L.MRG_GEMM_P8SK, 1))
     best, best_t = (L.MRG_GEMM_AUTO, splitk), float("inf")
     for v, s_ in cands:
         _gemm_launch(d, s_, v, dev)
@@ -354,6 +373,14 @@ class WgradGroup:
     split_below = int(os.environ.get("MRG_WGRAD_GROUP_SPLIT_BELOW", "0"))
     split_max_k = int(os.environ.get("MRG_WGRAD_GROUP_SPLIT_MAX_K", "12288"))
     max_k = int(os.environ.get("MRG_WGRAD_GROUP_MAX_K", "16384"))
+    # groups on the stream-K schedule: 0 (default) never, 1 always, 2 only the groups launched from a join (engine._Side.join sets
+    # `exposed`: the calling stream waits for those, nothing else wants the CUs).  Measured same box (profiles/r04_streamk.md): all groups
+    # C2 9.53 -> 10.04 ms, C4 20.58 -> 22.41 (a persistent launch holds every CU until its last range ends and starves the dgrad chain
+    # beside it); exposed groups only C2 9.42 -> 9.55, C4 20.44 -> 20.46: isolated, 432 tiles take 456 us as two rounds of tiles and
+    # 538 us as 1.69 rounds of work -- the second round of a one-tile-per-workgroup launch runs on a two-thirds empty chip at a higher
+    # rate, while every stream-K range pays a partial-image store, a read and a split main loop
+    streamk_mode = int(os.environ.get("MRG_WGRAD_GROUP_STREAMK", "0"))
+    exposed = False
     collecting = False
     tasks = []
     origin = None      # stream the queued tasks' operands (dy, x) were produced on: the grouped launch must go out on THAT stream
@@ -419,12 +446,21 @@ class WgradGroup:
                 wgrad_group(chunk, K_, sk)
 
 
-def wgrad_group(ts, K: int, splitk: int = 1):
+def wgrad_group(ts, K: int, splitk: int = 1, streamk: Optional[bool] = None):
     """one mrg_wgrad_group launch: ts = [(A, B, M, N, K, lda, ldb, out, ldc, _)], out_p[M_p, N_p] = A_p^T B_p (fp32, overwritten);
-    splitk > 1: slabs + deferred batched reduction (only inside a backward pass: Deferred.active)"""
+    splitk > 1: slabs + deferred batched reduction (only inside a backward pass: Deferred.active); streamk (default: on for groups
+    that do not fill a whole number of rounds): the concatenated tile lists on the stream-K schedule"""
     d = L.WgradGroupDesc()
     d.count, d.K = len(ts), K
     fl = 0.0
+    tiles_all = sum(((t[2] + 255) // 256) * ((t[3] + 255) // 256) for t in ts)
+    if streamk is None:
+        streamk = STREAMK and (WgradGroup.streamk_mode == 1 or (WgradGroup.streamk_mode == 2 and WgradGroup.exposed))
+    if streamk and splitk == 1:
+        d.streamk = 1
+        d.ws = _workspace(lib.mrg_streamk_ws_bytes(SK_GRID), ts[0][0].device).data_ptr()
+        d.sk_grid = SK_GRID
+        d.counters = _splitk_counters(tiles_all, ts[0][0].device)
     if splitk > 1:
         ws = torch.empty(splitk * sum(t[2] * t[3] for t in ts), dtype=F32, device=ts[0][0].device)
         d.splitk, d.ws = splitk, ws.data_ptr()

@@ -1,0 +1,116 @@
+#!/usr/bin/env python3
+"""Stream-K schedule of the 8-phase kernel (variant 12) against the one-tile-per-workgroup 8-phase kernel (11), the tuned table entry
+and the vendor BLAS on the encoder shapes of C2 / C4 / C5 WITH the production epilogues (bias -> bf16, bias + fp32 residual,
+bias + GELU + fp16 GELU' side output, multiply by the GELU' side input).  Every variant is timed as a captured graph of `reps`
+launches that rotate through `nrot` operand / output sets (cold-ish operands as inside the step), interleaved rounds, median.
+
+usage: bench_sk.py [c2|c4|c5|all] [grid ...]      grid: stream-K grids to try (0 = one workgroup per CU)"""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from mirage_amd import kernels as K, _lib as L
+
+dev = "cuda:0"
+KS = L.MRG_OP_KSTRIDED
+BF16, F32 = torch.bfloat16, torch.float32
+
+
+def graph_of(fn, reps):
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        for i in range(2):
+            fn(i)
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=s):
+            for i in range(reps):
+                fn(i)
+    torch.cuda.synchronize()
+    return g
+
+
+def time_graph(g, reps):
+    st, en = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    g.replay()
+    st.record(); g.replay(); en.record()
+    torch.cuda.synchronize()
+    return st.elapsed_time(en) * 1e3 / reps
+
+
+def case(tag, mode, epi, M, N, Kd, grids, reps=16, nrot=4, rounds=5):
+    torch.manual_seed(0)
+    sets = []
+    for r in range(nrot):
+        if mode == "fwd":
+            A = torch.randn(M, Kd, device=dev).bfloat16(); B = (torch.randn(N, Kd, device=dev) * 0.05).bfloat16()
+            kw = {}
+        else:
+            A = torch.randn(M, Kd, device=dev).bfloat16(); B = (torch.randn(Kd, N, device=dev) * 0.05).bfloat16()
+            kw = dict(b_mode=KS)
+        if epi == "bias":
+            kw.update(bias=torch.randn(N, device=dev), out=torch.empty(M, N, dtype=BF16, device=dev))
+        elif epi == "plain":
+            kw.update(out=torch.empty(M, N, dtype=BF16, device=dev))
+        elif epi == "resid":
+            kw.update(bias=torch.randn(N, device=dev), out=torch.empty(M, N, dtype=F32, device=dev), resid=torch.randn(M, N, device=dev))
+        elif epi == "gelu":
+            kw.update(bias=torch.randn(N, device=dev), out=torch.empty(M, N, dtype=BF16, device=dev), act=L.MRG_ACT_GELU_SAVE_GRAD,
+                      aux_out=torch.empty(M, N, dtype=torch.float16, device=dev))
+        elif epi == "mulaux":
+            kw.update(out=torch.empty(M, N, dtype=BF16, device=dev), act=L.MRG_ACT_MUL_AUX_F16,
+                      aux_in=torch.rand(M, N, device=dev).half())
+        sets.append((A, B, kw))
+
+    def runner(variant, grid=0):
+        def f(i):
+            A, B, kw = sets[i % nrot]
+            if variant == "vendor":
+                torch.mm(A, B.t() if mode == "fwd" else B)
+                return
+            K.TUNE["force"] = variant
+            K.SK_GRID = grid
+            try:
+                K.gemm(A, B, M, N, Kd, **kw)
+            finally:
+                K.TUNE["force"] = None
+                K.SK_GRID = 0
+        return f
+
+    fns = {"vendor": runner("vendor"), "tuned": runner(None), "p8": runner(L.MRG_GEMM_P8)}
+    for gr in grids:
+        fns[f"sk{gr}"] = runner(L.MRG_GEMM_P8SK, gr)
+    graphs = {k: graph_of(f, reps) for k, f in fns.items()}
+    res = {k: [] for k in fns}
+    for _ in range(rounds):
+        for k, g in graphs.items():
+            res[k].append(time_graph(g, reps))
+    fl = 2.0 * M * N * Kd
+    line = f"{tag:10s} {mode:5s} {epi:6s} {M:6d}x{N:5d}x{Kd:5d} "
+    for k, v in res.items():
+        v = sorted(v)
+        m = v[len(v) // 2]
+        line += f"| {k} {m:6.1f} us {fl / m / 1e6:5.0f} TF "
+    print(line, flush=True)
+
+
+def shapes(M, D):
+    H = 4 * D
+    return [("qkv", "fwd", "bias", M, 3 * D, D), ("proj", "fwd", "resid", M, D, D), ("fc1", "fwd", "gelu", M, H, D),
+            ("fc2", "fwd", "resid", M, D, H), ("fc2", "dgrad", "mulaux", M, H, D), ("fc1", "dgrad", "plain", M, D, H),
+            ("proj", "dgrad", "plain", M, D, D), ("qkv", "dgrad", "plain", M, D, 3 * D)]
+
+
+if __name__ == "__main__":
+    which = sys.argv[1] if len(sys.argv) > 1 else "all"
+    grids = [int(x) for x in sys.argv[2:]] or [0]
+    if which in ("all", "c2"):
+        for (nm, mode, epi, M, N, Kd) in shapes(8256, 768):
+            case("c2 " + nm, mode, epi, M, N, Kd, grids)
+        for (nm, mode, epi, M, N, Kd) in shapes(4128, 768)[:4]:
+            case("c2h " + nm, mode, epi, M, N, Kd, grids)
+    if which in ("all", "c4"):
+        for (nm, mode, epi, M, N, Kd) in shapes(6336, 1024):
+            case("c4 " + nm, mode, epi, M, N, Kd, grids)
+    if which in ("all", "c5"):
+        for (nm, mode, epi, M, N, Kd) in shapes(65792 // 2, 1024)[:4]:
+            case("c5h " + nm, mode, epi, M, N, Kd, grids, reps=6, nrot=2)
