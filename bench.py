@@ -185,17 +185,36 @@ def measure(a, cfg_name, steps, warmup, batch, rank, world, dev, force_dp, ranks
     if multi:
         dist.barrier()
     torch.cuda.synchronize()
+    if multi and train and reducer is not None:
+        reducer.exposed = []
+        reducer.timing = True
     t0 = time.perf_counter()
     for i in range(steps):
         run_step(warmup + i)
     torch.cuda.synchronize()
+    own = time.perf_counter() - t0              # this rank's own clock, before it waits for the slowest
     if multi:
         dist.barrier()
     elapsed = time.perf_counter() - t0
+    dp_info = None
     if multi:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+        # per-rank detail for the first real multi-GPU run: every rank's own step time and the part of it the compute stream spent
+        # blocked on the gradient exchange (event pair around GradReducer.wait()), next to the exchange format that produced it
+        exposed = 0.0
+        if train and reducer is not None:
+            reducer.timing = False
+            exposed = reducer.exposed_ms() / steps
+        mine = torch.tensor([1e3 * own / steps, exposed], device=dev, dtype=torch.float64)
+        allr = [torch.zeros_like(mine) for _ in range(dist.get_world_size())]
+        dist.all_gather(allr, mine)
+        dp_info = {"ranks_ms_per_step": [round(float(x[0]), 3) for x in allr],
+                   "exposed_comm_ms_per_step": [round(float(x[1]), 3) for x in allr]}
+        if train and reducer is not None:
+            dp_info.update(reducer.describe())
+            dp_info.update({"overlap": bool(ts.split), "encoder_cuts": list(ts.cuts), "early_adamw_per_stage": bool(ts._stage_merged)})
     ms_per_step = 1e3 * elapsed / steps
     value = B * world * steps / elapsed
     fpi = flops_per_image(model_name, doms, Kk, train)
@@ -294,6 +313,8 @@ def measure(a, cfg_name, steps, warmup, batch, rank, world, dev, force_dp, ranks
         }
         if train:
             result["final_loss"] = round(float(ts.loss), 5)
+        if dp_info is not None:
+            result["dp"] = dp_info
         if os.environ.get("MRG_TUNE_LOG") == "1":
             names = {1: "glds3", 2: "glds4", 3: "pipe128", 4: "pipe256", 5: "pipe256x3", 6: "pipe256sq", 7: "ws256", 8: "glds64", 10: "g256", 11: "p8"}
             for key, (v, sk), us in K.TUNE["log"]:
@@ -458,6 +479,7 @@ def _run(real_stdout: int):
                     r = measure(a, name, st, wu, None, rank, world, dev, False, ranks_seen)
                 except Exception as exc:          # the headline must survive a failure here; the failure is reported, not hidden
                     others[name] = {"error": f"{type(exc).__name__}: {exc}"[:300]}
+                    print(f"bench.py: other_configs[{name}] FAILED: {type(exc).__name__}: {exc}", file=sys.stderr)
                     continue
                 rf = r["roofline"]
                 others[name] = {"workload": r["config"]["workload"], "value": r["value"], "unit": r["unit"], "steps": st, "warmup": wu,

@@ -49,6 +49,8 @@ class GradReducer:
         self.backend = dist.get_backend(process_group) if dist.is_initialized() else None
         self.side = torch.cuda.Stream(device=flat_grad.device) if flat_grad.is_cuda else None
         self._done = None
+        self.timing = False        # bench.py: record an event pair around every wait() -- the time the compute stream is blocked on the
+        self.exposed = []          # exchange, i.e. the communication the backward pass did not hide
         self.comm = os.environ.get("MRG_DP_COMM", "allreduce")
         self.wire = os.environ.get("MRG_DP_DTYPE", "fp32")
         if self.comm not in ("allreduce", "rs_ag") or self.wire not in ("fp32", "bf16"):
@@ -162,8 +164,26 @@ class GradReducer:
 
     def wait(self):
         if self._done is not None:
-            torch.cuda.current_stream(self.flat.device).wait_event(self._done)
+            cur = torch.cuda.current_stream(self.flat.device)
+            if self.timing:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record(cur)
+                cur.wait_event(self._done)
+                e1.record(cur)
+                self.exposed.append((e0, e1))
+            else:
+                cur.wait_event(self._done)
             self._done = None
+
+    def exposed_ms(self) -> float:
+        """sum of the blocked intervals recorded since `timing` was switched on (call after a synchronize); clears the record"""
+        t = sum(a.elapsed_time(b) for a, b in self.exposed)
+        self.exposed = []
+        return t
+
+    def describe(self) -> dict:
+        return {"backend": self.backend, "comm": self.comm, "wire_dtype": self.wire, "bucket_mib": self.bucket_elems * 4 / 2 ** 20,
+                "buckets": len(self.ranges), "avg_op": bool(self.use_avg), "bytes_per_step": int(self.flat.numel()) * (2 if self.wire == "bf16" else 4)}
 
     def reduce(self):
         self.reduce_async()

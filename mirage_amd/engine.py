@@ -241,19 +241,30 @@ class DropoutRNG:
     DEVICE (an in-place add: hipGraph-replayable, every replay draws new masks) and returns a snapshot tensor; the forward GEMMs and the
     backward mask kernels of that pass read the snapshot, so a later forward cannot change the masks an earlier backward regenerates."""
     _state = {}
+    _seeded_from = {}      # device -> the torch.initial_seed() the state was derived from (None after an explicit set())
 
     @classmethod
     def state(cls, device) -> torch.Tensor:
+        """Seeded from torch.initial_seed() on first use and again whenever that seed has changed since (torch.manual_seed(other); not
+        inside a stream capture), like the mask stream (model.mask_rng): two runs in one process after the same manual_seed calls
+        draw the same masks.  Process-wide (one stream per device, shared by all models); `set` pins it and checkpoints may store it."""
         device = torch.device(device)
+        src = torch.initial_seed()
         st = cls._state.get(device)
         if st is None:
-            st = cls._state[device] = torch.tensor([torch.initial_seed() & 0x7FFFFFFFFFFFFFFF, 0], dtype=torch.int64, device=device)
+            st = cls._state[device] = torch.tensor([src & 0x7FFFFFFFFFFFFFFF, 0], dtype=torch.int64, device=device)
+            cls._seeded_from[device] = src
+        elif (cls._seeded_from.get(device) is not None and cls._seeded_from[device] != src
+              and not (device.type == "cuda" and torch.cuda.is_current_stream_capturing())):
+            st.copy_(torch.tensor([src & 0x7FFFFFFFFFFFFFFF, 0], dtype=torch.int64))
+            cls._seeded_from[device] = src
         return st
 
     @classmethod
     def set(cls, device, seed: int, step: int = 0):
-        """pin the stream (tests, resume): the NEXT forward uses step + 1"""
+        """pin the stream (tests, resume): the NEXT forward uses step + 1; a later torch.manual_seed no longer reseeds it"""
         cls.state(device).copy_(torch.tensor([int(seed), int(step)], dtype=torch.int64))
+        cls._seeded_from[torch.device(device)] = None
 
     @classmethod
     def begin_forward(cls, device) -> torch.Tensor:
@@ -361,6 +372,7 @@ class BlockFn(torch.autograd.Function):
 # compared with) run ONE chain -- the per-launch numbers describe the full-batch kernels, the step time the production schedule.
 TWO_CHAINS = int(os.environ.get("MRG_TWO_CHAINS", "2"))
 TWO_CHAINS_MIN_ROWS = int(os.environ.get("MRG_TWO_CHAINS_MIN_ROWS", "16"))
+TWO_CHAINS_GUARD = os.environ.get("MRG_TWO_CHAINS_GUARD", "1") != "0"      # s2 waits for chain A of block i - 2 before chain B of block i
 _CHAIN_STREAM = {}
 
 
@@ -394,6 +406,7 @@ def _encoder_fwd_two_chains(x: torch.Tensor, blocks, save: bool, want_bf16: bool
     x_in_full = x
     xa16 = None
     keep = []                                   # (end-of-block event on s2, that block's full-batch tensors), oldest first
+    ev_a = []                                   # end of chain A's block i on the main stream
     for i, blk in enumerate(blocks):
         last = want_bf16 and i == n - 1
         if len(keep) >= 2:                      # block i - 2 is finished on BOTH streams from here on: its tensors may be recycled
@@ -406,6 +419,15 @@ def _encoder_fwd_two_chains(x: torch.Tensor, blocks, save: bool, want_bf16: bool
         finally:
             K.Halves.end()
         fulls_i = list(K.Halves.fulls)
+        if TWO_CHAINS_GUARD:
+            # the opposite direction of the same lag: the full tensors of block i may sit in memory that block i - 2's unsaved tensors
+            # just gave back, and chain B writes their second halves from s2 -- it must not overtake chain A's (main stream) reads of
+            # block i - 2.  The edge is satisfied long before it is reached (chain A runs ahead); it only closes the window.
+            e = torch.cuda.Event()
+            e.record(main)
+            ev_a.append(e)
+            if i >= 2:
+                s2.wait_event(ev_a[i - 2])
         if sync_blocks:
             main.synchronize()
         K.Halves.begin(2)

@@ -28,7 +28,11 @@ class TrainStep:
         self.K, self.alphas, self.uniform = num_encoded_tokens, alphas, sample_tasks_uniformly
         # the step reads its inputs through input slots (kernels.InputSlots): `static_x` are the placeholders the captured launches
         # were recorded with AND the staging buffers of load(); step(batch) re-points the slots at the batch itself -- no copy
-        self.static_x = {k: torch.empty_like(v.contiguous()) for k, v in batch_example.items()}
+        # The placeholders have the dtype the batch-reading kernels take (fp32 images, int64 label maps), whatever the example batch
+        # holds: a placeholder of another dtype would be cast by the engine into a NEW tensor that no slot stands for, and every step
+        # would silently train on the staging buffer.  Batches of another dtype are converted by the staging copy (step -> load).
+        self.static_x = {k: torch.empty(v.shape, dtype=torch.float32 if v.is_floating_point() else torch.int64, device=v.device)
+                         for k, v in batch_example.items()}
         from . import kernels as _K
         self.slots = _K.InputSlots(self.static_x)
         self.in_domains = list(model.input_adapters.keys())
@@ -293,12 +297,15 @@ class TrainStep:
 
     def load(self, batch: Dict[str, torch.Tensor]):
         """copy a batch into the staging buffers and read the next steps from there"""
-        for k, v in batch.items():
-            if k not in self.static_x:
-                continue
-            if tuple(v.shape) != tuple(self.static_x[k].shape):          # copy_ would broadcast silently
-                raise ValueError(f"TrainStep.load: {k} has shape {tuple(v.shape)}, the step was built for {tuple(self.static_x[k].shape)}")
-            self.static_x[k].copy_(v, non_blocking=True)
+        held = self.slots._held or {}
+        for k, dst in self.static_x.items():
+            if k in batch:
+                v = batch[k]
+                if tuple(v.shape) != tuple(dst.shape):                       # copy_ would broadcast silently
+                    raise ValueError(f"TrainStep.load: {k} has shape {tuple(v.shape)}, the step was built for {tuple(dst.shape)}")
+                dst.copy_(v, non_blocking=True)
+            elif k in held and held[k] is not dst:
+                dst.copy_(held[k], non_blocking=True)                        # an input bound in place earlier and not named now stays what it was
         self.slots.bind(self.static_x)
 
     def step(self, batch: Optional[Dict[str, torch.Tensor]] = None, noise=None):
@@ -306,11 +313,18 @@ class TrainStep:
         pointed at it (one tiny launch) and it is kept alive until the next step; the caller must not overwrite it on another stream
         before this step has run.  Without `batch` the step re-reads what is bound (after load(): the staging buffers)."""
         if batch is not None:
+            unknown = [k for k in batch if k not in self.static_x]
+            if not any(k in self.static_x for k in batch):
+                raise ValueError(f"TrainStep.step: the batch has none of the inputs the step was built for ({sorted(self.static_x)}); got {sorted(batch)}")
+            del unknown                               # extra keys (targets of other tasks, metadata) are ignored, as load() does
             if not IN_PLACE_INPUTS:
                 self.load(batch)
             else:
+                # a batch that names only some inputs re-points those and leaves the others bound as they are (load() semantics)
+                held = self.slots._held or self.static_x
+                full = {k: batch.get(k, held[k]) for k in self.slots.names}
                 try:
-                    self.slots.bind(batch)
+                    self.slots.bind(full)
                 except ValueError:
                     self.load(batch)                   # other dtype / layout / device: converted by the staging copy
         if noise is not None:

@@ -115,6 +115,70 @@ def _fullsize_case(tag, kind, doms, B, Kk, check_eager=True):
         assert meas["eager_equals_graph"]
 
 
+@pytest.mark.parametrize("kind,doms,B,Kk,chains", [("base", ("bscan", "slo"), 64, 128, 1), ("base", ("bscan", "slo"), 64, 128, 2),
+                                                     ("large", ("bscan", "slo", "bscanlayermap"), 16, 98, 1),
+                                                     ("large", ("bscan", "slo", "bscanlayermap"), 16, 98, 2)])
+def test_poisoned_workspaces_leave_every_gradient_unchanged(kind, doms, B, Kk, chains, monkeypatch):
+    """Every float buffer the step allocates (activations, split-K slabs, LayerNorm / column-sum / attention partial rows, stream-K
+    scratch) and the cached GEMM workspaces are filled with NaN before a kernel sees them: a reduction that sums a partial row nobody
+    wrote, or a kernel that reads a workspace it did not fill, turns a gradient into NaN (the unexplained NaN of the
+    reverted two-chain backward went through this shared machinery -- kernels.Deferred, reduce_batch, the colsum / LayerNorm
+    partials).  The poisoned eager step must reproduce the clean step bit for bit, with one and with two forward chains."""
+    from mirage_amd import builder, optim, engine as E, kernels as K
+    from mirage_amd.trainer import TrainStep
+    from oracle import mirage_oracle as O
+    import test_model_gpu as T
+    cfg = O.make_config(kind, doms)
+    if kind == "large":
+        cfg = O.make_config(kind, doms, depth=6)              # the shapes of C4 at B = 16; six blocks keep the four cases short
+    x = {d: t.to(DEV) for d, t in O.synthetic_batch(cfg, B, seed=1234).items()}
+    (p, u, g), _, _, _ = O.synthetic_masks(cfg, B, Kk, seed=99)
+    noise = (torch.from_numpy(p).to(DEV), torch.cat([torch.from_numpy(a) for a in u], 1).to(DEV), torch.from_numpy(g).to(DEV))
+    monkeypatch.setattr(E, "TWO_CHAINS", 2 if chains == 2 else 0)
+
+    def run(poison):
+        model, args, _ = T._build(cfg)
+        model.train()
+        opt = optim.FusedAdamW(model, [1e-4] * 8, [0.05] * 8, betas=(0.9, 0.95), eps=1e-8)
+        ts = TrainStep(model, builder.get_losses(args), opt, x, Kk, use_graph=False, feed_mask_noise=True)
+        ts.load(x)
+        for dst, src in zip(ts.static_noise, noise):
+            dst.copy_(src)
+        ts._fwd_bwd(); E.join_side_stream()                   # first pass: autotuning, allocator warm-up
+        torch.cuda.synchronize()
+        real_empty, real_like = torch.empty, torch.empty_like
+        if poison:
+            def empty(*a, **kw):
+                t = real_empty(*a, **kw)
+                if t.is_cuda and t.is_floating_point():
+                    t.fill_(float("nan"))
+                return t
+
+            def empty_like(*a, **kw):
+                t = real_like(*a, **kw)
+                if t.is_cuda and t.is_floating_point():
+                    t.fill_(float("nan"))
+                return t
+            monkeypatch.setattr(torch, "empty", empty)
+            monkeypatch.setattr(torch, "empty_like", empty_like)
+            for ws in K._ws_cache.values():
+                ws.fill_(float("nan"))
+        try:
+            ts._fwd_bwd(); E.join_side_stream()
+            torch.cuda.synchronize()
+        finally:
+            monkeypatch.setattr(torch, "empty", real_empty)
+            monkeypatch.setattr(torch, "empty_like", real_like)
+        return float(ts.loss), opt.arena.flat_g[:opt.arena.n_trainable].clone()
+    clean_loss, clean = run(False)
+    loss, grads = run(True)
+    bad = int((~torch.isfinite(grads)).sum())
+    T.report(f"poison_{kind}_b{B}_chains{chains}", nonfinite_gradient_elements=bad, loss_equal=bool(loss == clean_loss),
+             gradients_bit_equal=bool(torch.equal(grads, clean)))
+    assert bad == 0, f"{bad} non-finite gradient elements with poisoned workspaces"
+    assert loss == clean_loss and torch.equal(grads, clean)
+
+
 def test_c2_base_b64_graph_step_vs_oracle():
     _fullsize_case("c2_b64_trainstep", "base", ("bscan", "slo"), 64, 128)
 
@@ -309,6 +373,47 @@ def test_bench_self_launch_two_ranks():
     assert r["config"]["global_batch"] == 16 and r["config"]["parallelism"] == "dp2" and r["scaling"] == "weak"
     assert r["value"] > 0 and r["roofline"]["frac"] > 0 and "cpu_baseline" not in r
     assert np.isfinite(r["final_loss"])
+    # per-rank detail for the first real multi-GPU run (VERDICT r03 #8): every rank's own step time, the time its compute stream was
+    # blocked on the gradient exchange, and the exchange format that produced the numbers
+    dp = r["dp"]
+    assert len(dp["ranks_ms_per_step"]) == 2 and all(t > 0 for t in dp["ranks_ms_per_step"])
+    assert len(dp["exposed_comm_ms_per_step"]) == 2 and all(0 <= t < r["ms_per_step"] * 1.05 for t in dp["exposed_comm_ms_per_step"])
+    assert max(dp["ranks_ms_per_step"]) <= r["ms_per_step"] * 1.05
+    assert dp["comm"] in ("allreduce", "rs_ag") and dp["wire_dtype"] in ("fp32", "bf16") and dp["backend"] == "gloo"
+    assert dp["bucket_mib"] == 64 and dp["buckets"] >= 1 and dp["bytes_per_step"] > 0 and isinstance(dp["encoder_cuts"], list)
+
+
+def test_two_ranks_over_rccl_on_one_gpu_or_recorded_refusal():
+    """World size 2 over the nccl (= RCCL) backend with both ranks on GPU 0 (the boxes of this pool have one GPU): either the
+    collectives and GradReducer's two exchange formats work, or RCCL refuses two ranks per device -- then the refusal is recorded
+    (gpurun_out/parity_measured.jsonl) and the gloo tests above remain the multi-rank coverage (VERDICT r03 #8)."""
+    import json
+    port = _free_port()
+    procs = []
+    for r in range(2):
+        env = _rank_env(RANK=str(r), LOCAL_RANK="0", WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.pop("MRG_DIST_BACKEND", None)
+        env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tools", "debug", "rccl_two_ranks_one_gpu.py")], env=env, cwd=ROOT,
+                                      stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = []
+    for p in procs:
+        try:
+            outs.append(p.communicate(timeout=240) + (p.returncode,))
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            outs.append(("", "timeout: a rank never joined the RCCL communicator", 3))
+    rcs = [o[2] for o in outs]
+    rec = {"test": "rccl_two_ranks_one_gpu", "exit_codes": rcs, "stderr": [o[1][-300:] for o in outs]}
+    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+    with open(os.path.join(ROOT, "gpurun_out", "parity_measured.jsonl"), "a") as f:
+        f.write(json.dumps(rec) + "\n")
+    if all(rc == 0 for rc in rcs):
+        return
+    if all(rc in (0, 3) for rc in rcs):
+        pytest.skip("RCCL refuses two ranks on one device on this pool: " + " | ".join(o[1].strip()[-200:] for o in outs if o[2] == 3))
+    raise AssertionError(outs)
 
 
 def test_run_pretraining_two_ranks_two_epochs(tmp_path):

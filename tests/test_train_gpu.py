@@ -598,6 +598,54 @@ def test_step_reads_batches_in_place_through_input_slots():
     assert not K._SLOT_OF_PTR
 
 
+def test_half_precision_and_partial_batches_go_through_the_staging_copy():
+    """Inputs of a dtype the batch readers do not take (fp16 images, int32 label maps) -- also as the EXAMPLE batch -- are converted by
+    the staging copy instead of being bound in place (a non-fp32 placeholder would be cast into a tensor no slot stands
+    for and every step would train on stale data); a batch naming only some inputs re-points those and keeps the others."""
+    from mirage_amd import builder, optim
+    from mirage_amd.trainer import TrainStep
+    from oracle import mirage_oracle as O
+    import test_model_gpu as T
+    doms = ["bscan", "slo", "bscanlayermap"]
+    cfg = O.make_config(model="tiny", in_domains=doms, input_size=64, patch_size=8, layermap_size=16, layermap_patch=2, decoder_dim=64,
+                        decoder_depth=2, decoder_heads=2, dim=128, depth=4, heads=2)
+    B, Kk = 4, 24
+
+    def data(seed):
+        x = {d: t.to(DEV) for d, t in O.synthetic_batch(cfg, B, seed=seed).items()}
+        x = {d: (t.half().float() if t.is_floating_point() else t) for d, t in x.items()}       # values exactly representable in fp16
+        (p, u, g), _, _, _ = O.synthetic_masks(cfg, B, Kk, seed=seed + 1)
+        return x, (torch.from_numpy(p).to(DEV), torch.cat([torch.from_numpy(a) for a in u], 1).to(DEV), torch.from_numpy(g).to(DEV))
+    batches = [data(500 + 10 * i) for i in range(3)]
+    low = lambda x: {d: (t.half() if t.is_floating_point() else t.int()) for d, t in x.items()}
+
+    def run(convert):
+        model, args, _ = T._build(cfg)
+        model.train()
+        opt = optim.FusedAdamW(model, [1e-3] * 8, [0.05] * 8)
+        ex = convert(batches[0][0])
+        ts = TrainStep(model, builder.get_losses(args), opt, ex, Kk, use_graph=True, feed_mask_noise=True)
+        assert all(v.dtype in (torch.float32, torch.int64) for v in ts.static_x.values())
+        ts.load(ex)
+        for dst, src in zip(ts.static_noise, batches[0][1]):
+            dst.copy_(src)
+        ts.warmup_and_capture(warm_iters=1)
+        losses = []
+        for x, n in batches:
+            ts.step(convert(x), noise=n)
+            losses.append(float(ts.loss))
+        # partial batch: only the bscan of batch 0 changes, slo / layer map stay those of batch 2
+        ts.step({"bscan": convert(batches[0][0])["bscan"]}, noise=batches[0][1])
+        losses.append(float(ts.loss))
+        with pytest.raises(ValueError):
+            ts.step({"not_an_input": batches[0][0]["bscan"]})
+        torch.cuda.synchronize()
+        return losses, opt.arena.flat_p.clone()
+    a, b = run(lambda x: x), run(low)
+    assert a[0] == b[0] and len(set(a[0])) == 4, (a[0], b[0])
+    assert torch.equal(a[1], b[1])
+
+
 def test_token_layout_predictions_are_the_same_step(monkeypatch):
     """Inside TrainStep the output adapters hand their out_proj output to the losses as it is (engine.PredLayout); with MRG_TOKEN_PREDS=0
     the reference's image tensors are built and differentiated instead.  Same arithmetic, same summation order: losses, gradients and
