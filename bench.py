@@ -257,7 +257,7 @@ def measure(a, cfg_name, steps, warmup, batch, rank, world, dev, force_dp, ranks
         torch.cuda.synchronize()
         vname = {0: "auto", 1: "gemm_glds_kernel", 2: "gemm_glds_kernel", 3: "gemm_pipe_kernel", 4: "gemm_pipe256_kernel",
                  5: "gemm_pipe256_kernel", 6: "gemm_pipe256sq_kernel", 7: "gemm_ws256_kernel", 8: "gemm_glds64_kernel",
-                 10: "gemm_g256_kernel", 11: "gemm_p8_kernel", 12: "gemm_p8_group_kernel"}
+                 10: "gemm_g256_kernel", 11: "gemm_p8_kernel", 12: "gemm_p8sk_kernel", 13: "gemm_p8_group_kernel"}
         mname = {(0, 0): "forward x*W^T", (0, 1): "dgrad dy*W", (1, 1): "wgrad dy^T*x"}
         groups = {}
         shapes = {}
@@ -278,7 +278,7 @@ def measure(a, cfg_name, steps, warmup, batch, rank, world, dev, force_dp, ranks
         # HBM bytes per launch of the dominant kernel come from a separate rocprofv3 --pmc pass (counters cannot be read from
         # inside the process): the committed summary of that pass is quoted and its file named in `traffic_source`
         traffic, traffic_src = None, None
-        for tname in ("r03_c2_pmc_traffic.json", "r02_c2_pmc_traffic.json", "r01_c2_pmc_traffic.json"):
+        for tname in ("r04_c2_pmc_traffic.json", "r03_c2_pmc_traffic.json", "r02_c2_pmc_traffic.json", "r01_c2_pmc_traffic.json"):
             tfile = os.path.join(ROOT, "profiles", tname)
             if cfg_name == "c2" and os.path.exists(tfile):
                 tj = json.load(open(tfile))
@@ -316,7 +316,7 @@ def measure(a, cfg_name, steps, warmup, batch, rank, world, dev, force_dp, ranks
         if dp_info is not None:
             result["dp"] = dp_info
         if os.environ.get("MRG_TUNE_LOG") == "1":
-            names = {1: "glds3", 2: "glds4", 3: "pipe128", 4: "pipe256", 5: "pipe256x3", 6: "pipe256sq", 7: "ws256", 8: "glds64", 10: "g256", 11: "p8"}
+            names = {1: "glds3", 2: "glds4", 3: "pipe128", 4: "pipe256", 5: "pipe256x3", 6: "pipe256sq", 7: "ws256", 8: "glds64", 10: "g256", 11: "p8", 12: "p8sk"}
             for key, (v, sk), us in K.TUNE["log"]:
                 am, bm, M_, N_, K_ = key[:5]
                 print(f"tune mode=({am},{bm}) {M_}x{N_}x{K_} act={key[5]} -> {names.get(v, v)} splitk={sk} {us:.1f} us {2.0 * M_ * N_ * K_ / us / 1e6:.0f} TF/s",

@@ -86,6 +86,8 @@ for key in used:
             t = measure(reps=2, steps=12)
         except Exception as e:
             print("  failed", key, ch, e); continue
+        if os.environ.get("MRG_TUNE_VERBOSE"):
+            print(f"    trial {key[:5]} act={key[5]} {ch}: {t:.3f} ms (current {cur:.3f})", flush=True)
         if t < best_t * 0.997:
             best_choice, best_t = ch, t
     K._tune_cache[key] = best_choice
