@@ -763,6 +763,18 @@ class PredLayout:
         return K.patch_rearrange(pred.contiguous(), True, pred.shape[0], ad.num_channels, g, ad.P_H)
 
 
+class LaneLosses:
+    """Masked losses computed ON the output adapters' lane streams (set by trainer.TrainStep around its forward pass).  The reference
+    computes the task losses after the model call (run_pretraining.py:713-721); as separate autograd nodes they run one after the other
+    on the calling stream between the join of the decoders' forward lanes and the fork of their backward lanes -- 150 us (C2) / 300 us
+    (C4) of serial small launches.  With `spec` = {task: (kind, patch, target, use_mask)} model.forward hands each adapter its loss:
+    the lane that ran the adapter runs the loss forward right behind out_proj, DecodersFn returns the loss scalars, and its backward
+    starts every lane with that task's loss backward.  Same kernels on the same data: bit-identical to the separate nodes
+    (MRG_LANE_LOSSES=0).  `preds` keeps the (detached) predictions of the last pass for callers that read them (parity tests)."""
+    spec = None
+    preds = {}
+
+
 class _Lanes:
     """Independent output adapters run on their own HIP streams (fork from / join into the calling stream): each adapter is a
     chain of ~25 short launches on [B*256, 256]-sized problems that cannot fill 256 CUs on its own."""
@@ -820,26 +832,49 @@ class DecodersFn(torch.autograd.Function):
     """One or more output adapters in one node: their proj_context dgrads accumulate straight into one d_enc buffer."""
 
     @staticmethod
-    def forward(ctx, enc32, enc16, adapters, dom_names, dom_start, ng, ids_keep, ids_restore, save, defer_join, *params):
+    def forward(ctx, enc32, enc16, adapters, dom_names, dom_start, ng, ids_keep, ids_restore, save, defer_join, loss_spec, *params):
+        """loss_spec: None, or one (kind, patch, target, mask or None) per adapter (LaneLosses): the node then returns the task LOSSES"""
         ctx.defer_join = defer_join
         enc32 = enc32.contiguous().float()
         if enc16 is None:
             enc16 = to_bf16(enc32)
         doms_l, start_l = list(dom_names), list(dom_start)
-        jobs = [(lambda ad=ad: decoder_fwd(ad, enc32, enc16, ids_keep, ids_restore, doms_l, start_l, ng, save)) for ad in adapters]
+
+        def job(i, ad):
+            img, sv = decoder_fwd(ad, enc32, enc16, ids_keep, ids_restore, doms_l, start_l, ng, save)
+            if loss_spec is None:
+                return img, sv, None
+            kind, patch, target, mask = loss_spec[i]
+            d = K.loss_desc(kind, img, target, mask, patch)
+            loss, coef, partial = K.masked_loss_fwd(d, img.device)
+            return loss, sv, (d, coef, partial, img)
+        jobs = [(lambda i=i, ad=ad: job(i, ad)) for i, ad in enumerate(adapters)]
         res = _Lanes.run_all(jobs, enc32.device, enabled=_Lanes.enabled and _Lanes.fwd)
-        imgs = [r[0] for r in res]
+        outs = [r[0] for r in res]
         saved = [r[1] for r in res]
         ctx.adapters, ctx.saved, ctx.shape = adapters, saved, enc32.shape
-        return tuple(imgs)
+        ctx.loss_saved = [r[2] for r in res] if loss_spec is not None else None
+        if loss_spec is not None:
+            LaneLosses.preds = {ad.task: r[2][3] for ad, r in zip(adapters, res)}
+        return tuple(outs)
 
     @staticmethod
     def backward(ctx, *d_imgs):
         _Side.begin_backward()
         dev = next(d for d in d_imgs if d is not None).device
         d_enc = torch.empty(ctx.shape, dtype=F32, device=dev)
-        todo = [(ad, sv, d_img) for ad, sv, d_img in zip(ctx.adapters, ctx.saved, d_imgs) if d_img is not None]
-        jobs = [(lambda ad=ad, sv=sv, d_img=d_img: decoder_bwd(ad, sv, d_img)) for ad, sv, d_img in todo]
+        if ctx.loss_saved is not None:
+            # d_imgs are the gradients of the task LOSSES (scalars): every lane opens with its loss backward
+            todo = [(ad, sv, (g, ls)) for ad, sv, g, ls in zip(ctx.adapters, ctx.saved, d_imgs, ctx.loss_saved) if g is not None]
+
+            def bwd(ad, sv, gl):
+                g, (d, coef, partial, img) = gl
+                return decoder_bwd(ad, sv, K.masked_loss_bwd(d, coef, partial, g.contiguous().float(), img))
+            jobs = [(lambda ad=ad, sv=sv, gl=gl: bwd(ad, sv, gl)) for ad, sv, gl in todo]
+            ctx.loss_saved = None
+        else:
+            todo = [(ad, sv, d_img) for ad, sv, d_img in zip(ctx.adapters, ctx.saved, d_imgs) if d_img is not None]
+            jobs = [(lambda ad=ad, sv=sv, d_img=d_img: decoder_bwd(ad, sv, d_img)) for ad, sv, d_img in todo]
         d_ctxs = _Lanes.run_all(jobs, dev, enabled=_Lanes.enabled and _Lanes.bwd)
         for i, ((ad, _, _), d_ctx16) in enumerate(zip(todo, d_ctxs)):
             decoder_bwd_finish(ad, d_ctx16, d_enc, i == 0)

@@ -345,8 +345,17 @@ class MIRAGEModel(nn.Module):
             return enc32, task_masks
 
         ads = list(self.output_adapters.values())
+        loss_spec = None
+        if E.LaneLosses.spec is not None and save:
+            # trainer.TrainStep: the masked losses run on the adapters' lanes; what comes back under each task's name is its LOSS
+            loss_spec = []
+            for name in self.output_adapters.keys():
+                kind, patch, target, use_mask = E.LaneLosses.spec[name]
+                m = task_masks.get(name) if use_mask else None
+                loss_spec.append((kind, patch, target.contiguous() if kind != E.L.MRG_LOSS_MSE else target.contiguous().float(),
+                                  m.contiguous().long() if m is not None else None))
         imgs = E.DecodersFn.apply(enc32, enc16, ads, doms, dom_start, self.num_global_tokens, ids_keep.contiguous(),
-                                  ids_restore.contiguous(), save, True, *self._decoder_params())
+                                  ids_restore.contiguous(), save, True, loss_spec, *self._decoder_params())
         preds = {name: img for name, img in zip(self.output_adapters.keys(), imgs)}
         return preds, task_masks
 

@@ -87,5 +87,5 @@ class SpatialOutputAdapter(nn.Module):
         if ng < 1:
             raise NotImplementedError("mirage_amd: decoding without global tokens is not implemented")
         (img,) = E.DecodersFn.apply(encoder_tokens, None, [self], names, dom_start, ng, ids_keep.contiguous(), ids_restore.contiguous(),
-                                    torch.is_grad_enabled(), False, *[p for p in self.parameters()])
+                                    torch.is_grad_enabled(), False, None, *[p for p in self.parameters()])
         return img

@@ -16,6 +16,7 @@ import os
 from .dp import GradReducer
 
 IN_PLACE_INPUTS = os.environ.get("MRG_INPUT_SLOTS", "1") != "0"   # step(batch) re-points the input slots at the batch (0: staging copy, as load())
+LANE_LOSSES = os.environ.get("MRG_LANE_LOSSES", "1") != "0"   # the masked losses run on the output adapters' lane streams (engine.LaneLosses)
 TOKEN_PREDS = os.environ.get("MRG_TOKEN_PREDS", "1") != "0"   # predictions stay in the decoders' token layout inside the step (engine.PredLayout)
 
 
@@ -152,12 +153,29 @@ class TrainStep:
         """model forward with the predictions left in the decoders' token layout when every loss can read it (engine.PredLayout)"""
         from . import engine as E
         from .criterion import MaskedCrossEntropyLoss, MaskedMSELoss
-        E.PredLayout.tokens = TOKEN_PREDS and all(isinstance(f, (MaskedMSELoss, MaskedCrossEntropyLoss)) for f in self.loss_fns.values())
+        ours = all(isinstance(f, (MaskedMSELoss, MaskedCrossEntropyLoss)) for f in self.loss_fns.values())
+        E.PredLayout.tokens = TOKEN_PREDS and ours
+        self._lane_losses = bool(LANE_LOSSES and E.PredLayout.tokens and getattr(self.model, "output_adapters", None) is not None
+                                 and set(self.model.output_adapters.keys()) <= set(self.loss_fns) and all(t in x for t in self.model.output_adapters.keys()))
+        if self._lane_losses:
+            from . import _lib as L
+            E.LaneLosses.spec = {t: (L.MRG_LOSS_MSE if isinstance(self.loss_fns[t], MaskedMSELoss) else L.MRG_LOSS_CE, self.loss_fns[t].scale_factor,
+                                     x[t], not self.loss_on_unmasked) for t in self.model.output_adapters.keys()}
         try:
             return self.model({d: x[d] for d in self.in_domains}, num_encoded_tokens=self.K, alphas=self.alphas,
                               sample_tasks_uniformly=self.uniform, mask_noise=self.static_noise)
         finally:
             E.PredLayout.tokens = False
+            E.LaneLosses.spec = None
+
+    def _losses(self, preds, masks, x):
+        """task losses of a forward pass: computed by the adapters' lanes already (engine.LaneLosses) or here, as the reference does"""
+        if self._lane_losses:
+            from . import engine as E
+            self.preds = dict(E.LaneLosses.preds)
+            return dict(preds)
+        self.preds = preds
+        return {t: self.loss_fns[t](preds[t], x[t], mask=None if self.loss_on_unmasked else masks.get(t)) for t in preds}
 
     def pred_images(self) -> Dict[str, torch.Tensor]:
         """the last step's predictions as images [B, C, H, W] (self.preds holds what the step itself produced)"""
@@ -169,9 +187,9 @@ class TrainStep:
         _K.timestamp("step_start")
         x = self.static_x
         preds, masks = self._forward(x)
-        self.task_losses = {t: self.loss_fns[t](preds[t], x[t], mask=None if self.loss_on_unmasked else masks.get(t)) for t in preds}
+        self.task_losses = self._losses(preds, masks, x)
         self.loss = sum(self.task_losses.values())
-        self.preds, self.masks = preds, masks         # static tensors of the captured step (parity tests read them after a replay)
+        self.masks = masks                            # static tensors of the captured step (parity tests read them and self.preds after a replay)
         self.opt.zero_grad()
         if self._early is not None:
             from . import engine as E
@@ -191,7 +209,7 @@ class TrainStep:
         from . import engine as E
         x = self.static_x
         preds, masks = self._forward(x)
-        self.task_losses = {t: self.loss_fns[t](preds[t], x[t], mask=None if self.loss_on_unmasked else masks.get(t)) for t in preds}
+        self.task_losses = self._losses(preds, masks, x)
         self.loss = sum(self.task_losses.values())
         self.opt.zero_grad()
         self._hs = list(self.model._mrg_h_cuts)

@@ -405,14 +405,15 @@ def test_two_ranks_over_rccl_on_one_gpu_or_recorded_refusal():
                 q.kill()
             outs.append(("", "timeout: a rank never joined the RCCL communicator", 3))
     rcs = [o[2] for o in outs]
-    rec = {"test": "rccl_two_ranks_one_gpu", "exit_codes": rcs, "stderr": [o[1][-300:] for o in outs]}
+    why = [next((l for l in o[1].splitlines() if "RCCL refused" in l), o[1].strip()[-300:])[:500] for o in outs]
+    rec = {"test": "rccl_two_ranks_one_gpu", "exit_codes": rcs, "stderr": why}
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
     with open(os.path.join(ROOT, "gpurun_out", "parity_measured.jsonl"), "a") as f:
         f.write(json.dumps(rec) + "\n")
     if all(rc == 0 for rc in rcs):
         return
     if all(rc in (0, 3) for rc in rcs):
-        pytest.skip("RCCL refuses two ranks on one device on this pool: " + " | ".join(o[1].strip()[-200:] for o in outs if o[2] == 3))
+        pytest.skip("RCCL refuses two ranks on one device on this pool: " + " | ".join(w for w, o in zip(why, outs) if o[2] == 3))
     raise AssertionError(outs)
 
 

@@ -679,3 +679,42 @@ def test_token_layout_predictions_are_the_same_step(monkeypatch):
     assert a[0] == b[0] and torch.equal(a[1], b[1]) and torch.equal(a[2], b[2])
     for k in a[3]:
         assert a[3][k].dim() == 4 and torch.equal(a[3][k], b[3][k])
+
+
+def test_losses_on_the_adapter_lanes_are_the_same_step(monkeypatch):
+    """Inside TrainStep every masked loss runs on the lane stream of its output adapter (engine.LaneLosses: loss forward behind out_proj,
+    loss backward in front of the adapter's backward); with MRG_LANE_LOSSES=0 they are the reference's separate calls after the model
+    (run_pretraining.py:713-721).  Same kernels on the same data: task losses, gradients, weights and predictions agree bit for bit,
+    with masked and with unmasked losses, captured and eager."""
+    from mirage_amd import builder, optim, trainer
+    from oracle import mirage_oracle as O
+    import test_model_gpu as T
+    doms = ["bscan", "slo", "bscanlayermap"]
+    cfg = O.make_config(model="tiny", in_domains=doms, input_size=64, patch_size=8, layermap_size=16, layermap_patch=2, decoder_dim=64,
+                        decoder_depth=2, decoder_heads=2, dim=128, depth=4, heads=2)
+    B, Kk = 6, 24
+    x = {d: t.to(DEV) for d, t in O.synthetic_batch(cfg, B, seed=177).items()}
+    noise, _, _ = _noise_dev(cfg, B, Kk, 178)
+
+    def run(lanes, graph, unmasked):
+        monkeypatch.setattr(trainer, "LANE_LOSSES", lanes)
+        model, args, _ = T._build(cfg)
+        model.train()
+        opt = optim.FusedAdamW(model, [1e-3] * 8, [0.05] * 8)
+        ts = trainer.TrainStep(model, builder.get_losses(args), opt, x, Kk, use_graph=graph, feed_mask_noise=True, loss_on_unmasked=unmasked)
+        ts.load(x)
+        for dst, src in zip(ts.static_noise, noise):
+            dst.copy_(src)
+        ts.warmup_and_capture(warm_iters=1)
+        ts.step(noise=noise)
+        ts.step(noise=noise)
+        torch.cuda.synchronize()
+        assert ts._lane_losses == lanes
+        return (float(ts.loss), {k: float(v) for k, v in ts.task_losses.items()}, opt.arena.flat_g.clone(), opt.arena.flat_p.clone(),
+                {k: v.clone() for k, v in ts.pred_images().items()})
+    for graph, unmasked in ((True, False), (False, False), (True, True)):
+        a, b = run(True, graph, unmasked), run(False, graph, unmasked)
+        assert a[0] == b[0] and a[1] == b[1], (graph, unmasked, a[1], b[1])
+        assert torch.equal(a[2], b[2]) and torch.equal(a[3], b[3])
+        for k in a[4]:
+            assert torch.equal(a[4][k], b[4][k])

@@ -18,7 +18,12 @@ def make(nblocks):
     ts = []
     for b in range(nblocks):
         for (M, N) in ((3 * D, D), (D, D), (4 * D, D), (D, 4 * D)):
-            A = torch.randn(T, M, device=dev).bfloat16(); B = torch.randn(T, N, device=dev).bfloat16()
+            A = torch.randn(T, M, device=dev); B = torch.randn(T, N, device=dev)
+            fill = os.environ.get("MRG_BENCH_DATA", "randn")      # randn | small (x 0.02) | zeros | sign (|randn|): what bounds the launch? (DVFS)
+            if fill == "zeros": A.zero_(); B.zero_()
+            elif fill == "small": A *= 0.02; B *= 0.02
+            elif fill == "sign": A.abs_(); B.abs_()
+            A = A.bfloat16(); B = B.bfloat16()
             ts.append((A, B, M, N, T, M, N, torch.empty(M, N, device=dev), N, 1))
     return ts
 

@@ -8,8 +8,7 @@ from mirage_amd import kernels as K, _lib as L
 M, N, Kd, v = (int(x) for x in sys.argv[1:5])
 am, bm = (int(x) for x in sys.argv[5:7]) if len(sys.argv) > 6 else (0, 0)
 K.TUNE["enabled"] = False
-_orig = K._gemm_launch
-K._gemm_launch = lambda d, splitk, variant, dev_: _orig(d, splitk, v, dev_)
+K.TUNE["force"] = v
 dev = "cuda:0"
 a = torch.randn((M, Kd) if am == 0 else (Kd, M), device=dev).bfloat16()
 b = torch.randn((N, Kd) if bm == 0 else (Kd, N), device=dev).bfloat16()
