@@ -36,7 +36,9 @@ def main():
     dev = torch.device("cuda", 0)
     if world > 1:
         os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=port)
-        dist.init_process_group("gloo", rank=rank, world_size=world)
+        import datetime
+        # a peer that died during start-up must surface within minutes, not after gloo's default half hour
+        dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=240))
     from mirage_amd import builder, optim
     from mirage_amd.dp import GradReducer, broadcast_params
     from mirage_amd.trainer import TrainStep

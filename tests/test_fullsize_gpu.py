@@ -299,12 +299,40 @@ def _free_port():
     return p
 
 
+def _wait_ranks(procs, timeout):
+    """wait for every child; on a hang abort them all (faulthandler prints where each one stood) and fail with their output instead
+    of leaving stuck ranks on the GPU behind a bare TimeoutExpired"""
+    import signal
+    import time
+    deadline = time.time() + timeout
+    logs = [None] * len(procs)
+    try:
+        for i, p in enumerate(procs):
+            logs[i] = p.communicate(timeout=max(1.0, deadline - time.time()))[0]
+    except subprocess.TimeoutExpired:
+        for p in procs:
+            if p.poll() is None:
+                p.send_signal(signal.SIGABRT)
+        time.sleep(2.0)
+        tails = []
+        for i, p in enumerate(procs):
+            if p.poll() is None:
+                p.kill()
+            try:
+                out = p.communicate(timeout=20)[0]
+            except Exception:
+                out = b""
+            tails.append((logs[i] or out or b"").decode(errors="replace")[-2500:])
+        raise AssertionError(f"ranks did not finish within {timeout} s; output tails: {tails}")
+    return [(lg or b"").decode(errors="replace") if isinstance(lg, bytes) else (lg or "") for lg in logs]
+
+
 def _spawn(rank, world, port, out, *extra):
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "MRG_DP_COMM", "MRG_DP_DTYPE"):
         env.pop(k, None)
-    return subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "_dp_engine_worker.py"), str(rank), str(world), str(port), out, *extra],
-                            env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+    return subprocess.Popen([sys.executable, "-X", "faulthandler", os.path.join(ROOT, "tests", "_dp_engine_worker.py"), str(rank), str(world),
+                             str(port), out, *extra], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
 
 
 @pytest.mark.parametrize("comm,wire", [("allreduce", "fp32"), ("rs_ag", "bf16")])
@@ -317,11 +345,11 @@ def test_two_engine_ranks_on_one_gpu(tmp_path, comm, wire):
     outs = [str(tmp_path / f"r{r}.pt") for r in range(2)]
     single = str(tmp_path / "single.pt")
     procs = [_spawn(r, 2, port, outs[r], comm, wire) for r in range(2)]
-    logs = [p.communicate(timeout=600)[0].decode() for p in procs]
+    logs = _wait_ranks(procs, 300)
     for p, lg in zip(procs, logs):
         assert p.returncode == 0, lg[-3000:]
     ps = _spawn(0, 1, port, single)
-    lg = ps.communicate(timeout=600)[0].decode()
+    (lg,) = _wait_ranks([ps], 300)
     assert ps.returncode == 0, lg[-3000:]
     r0, r1, s = (torch.load(f, weights_only=False) for f in (outs[0], outs[1], single))
     assert r0["n_graphs"] == 4 and r0["cuts"] == [1, 2] and s["n_graphs"] == 1          # upper / middle / lower / optimizer
@@ -432,7 +460,7 @@ def test_run_pretraining_two_ranks_two_epochs(tmp_path):
     for r in range(2):
         env = _rank_env(RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
         procs.append(subprocess.Popen([sys.executable] + argv, env=env, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
-    logs = [p.communicate(timeout=1500)[0].decode() for p in procs]
+    logs = _wait_ranks(procs, 900)
     for p, lg in zip(procs, logs):
         assert p.returncode == 0, lg[-3000:]
     d = os.path.join(out, "miragepre_base")
