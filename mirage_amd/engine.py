@@ -773,6 +773,11 @@ class LaneLosses:
     (MRG_LANE_LOSSES=0).  `preds` keeps the (detached) predictions of the last pass for callers that read them (parity tests)."""
     spec = None
     preds = {}
+    # defer_join (set with `spec` by TrainStep on one GPU): the decoders' forward lanes are not joined into the calling stream; every lane
+    # runs straight on from its loss forward into its loss backward when DecodersFn.backward forks again, and that backward's join covers
+    # both passes.  The caller seeds the backward with the constant gradient of each task loss (d sum / d loss_t = 1) instead of
+    # differentiating the sum, and reads the loss scalars only after the backward pass.
+    defer_join = False
 
 
 class _Lanes:
@@ -794,8 +799,10 @@ class _Lanes:
     all_lanes = False
 
     @classmethod
-    def run_all(cls, jobs, device, enabled=None):
-        """jobs: list of zero-arg callables; job 0 runs on the current stream, the others on lane streams."""
+    def run_all(cls, jobs, device, enabled=None, join=True):
+        """jobs: list of zero-arg callables; job 0 runs on the current stream, the others on lane streams.  join=False leaves the lanes
+        un-joined: the caller guarantees that a later run_all on the same device (which forks from the calling stream again and joins)
+        follows before anything on the calling stream reads what the lanes produce."""
         main = torch.cuda.current_stream(device)
         if len(jobs) == 1 or not (cls.enabled if enabled is None else enabled):
             return [job() for job in jobs]
@@ -823,8 +830,9 @@ class _Lanes:
             lanes.append(st)
         if not cls.main_first:
             out[0] = jobs[0]()
-        for st in lanes:
-            main.wait_stream(st)
+        if join:
+            for st in lanes:
+                main.wait_stream(st)
         return out
 
 
@@ -849,7 +857,8 @@ class DecodersFn(torch.autograd.Function):
             loss, coef, partial = K.masked_loss_fwd(d, img.device)
             return loss, sv, (d, coef, partial, img)
         jobs = [(lambda i=i, ad=ad: job(i, ad)) for i, ad in enumerate(adapters)]
-        res = _Lanes.run_all(jobs, enc32.device, enabled=_Lanes.enabled and _Lanes.fwd)
+        res = _Lanes.run_all(jobs, enc32.device, enabled=_Lanes.enabled and _Lanes.fwd,
+                             join=not (loss_spec is not None and LaneLosses.defer_join and _Lanes.bwd))
         outs = [r[0] for r in res]
         saved = [r[1] for r in res]
         ctx.adapters, ctx.saved, ctx.shape = adapters, saved, enc32.shape

@@ -16,6 +16,11 @@ import os
 from .dp import GradReducer
 
 IN_PLACE_INPUTS = os.environ.get("MRG_INPUT_SLOTS", "1") != "0"   # step(batch) re-points the input slots at the batch (0: staging copy, as load())
+# ... and, optionally, the lanes run from the loss forward straight into the backward pass without a join in between (each task loss is
+# seeded with the constant gradient 1 instead of differentiating the sum).  Bit-identical, but measured neutral at C2 (9.494 vs 9.495 ms)
+# and +5 % SLOWER at C4 (21.72 vs 20.64 ms, three adapters: adapter 0 lives on the calling stream, and without the join the two lanes
+# run their backward beside its forward tail instead of beside its backward) -- off by default, kept as an A/B knob
+LANE_DEFER_JOIN = os.environ.get("MRG_LANE_DEFER_JOIN", "0") != "0"
 LANE_LOSSES = os.environ.get("MRG_LANE_LOSSES", "1") != "0"   # the masked losses run on the output adapters' lane streams (engine.LaneLosses)
 TOKEN_PREDS = os.environ.get("MRG_TOKEN_PREDS", "1") != "0"   # predictions stay in the decoders' token layout inside the step (engine.PredLayout)
 
@@ -159,6 +164,7 @@ class TrainStep:
                                  and set(self.model.output_adapters.keys()) <= set(self.loss_fns) and all(t in x for t in self.model.output_adapters.keys()))
         if self._lane_losses:
             from . import _lib as L
+            E.LaneLosses.defer_join = self._defer_join = bool(LANE_DEFER_JOIN and self.reducer is None)
             E.LaneLosses.spec = {t: (L.MRG_LOSS_MSE if isinstance(self.loss_fns[t], MaskedMSELoss) else L.MRG_LOSS_CE, self.loss_fns[t].scale_factor,
                                      x[t], not self.loss_on_unmasked) for t in self.model.output_adapters.keys()}
         try:
@@ -167,6 +173,7 @@ class TrainStep:
         finally:
             E.PredLayout.tokens = False
             E.LaneLosses.spec = None
+            E.LaneLosses.defer_join = False
 
     def _losses(self, preds, masks, x):
         """task losses of a forward pass: computed by the adapters' lanes already (engine.LaneLosses) or here, as the reference does"""
@@ -188,21 +195,33 @@ class TrainStep:
         x = self.static_x
         preds, masks = self._forward(x)
         self.task_losses = self._losses(preds, masks, x)
-        self.loss = sum(self.task_losses.values())
         self.masks = masks                            # static tensors of the captured step (parity tests read them and self.preds after a replay)
         self.opt.zero_grad()
+        deferred = self._lane_losses and getattr(self, "_defer_join", False)
+        if deferred:
+            # the loss scalars still live on the adapters' lanes (engine.LaneLosses.defer_join): seed each with d(sum)/d(loss_t) = 1 --
+            # the gradient the sum's backward would hand it -- and form the logged sum after the backward pass has joined the lanes
+            ls = list(self.task_losses.values())
+            one = self._one if getattr(self, "_one", None) is not None else torch.ones((), dtype=ls[0].dtype, device=ls[0].device)
+            self._one = one
+            run_backward = lambda: torch.autograd.backward(ls, [one] * len(ls))
+        else:
+            self.loss = sum(self.task_losses.values())
+            run_backward = lambda: self.loss.backward()
         if self._early is not None:
             from . import engine as E
             E._Side.early_opt, E._Side.finished, self._early_seen = self._early_cb, [], 0
             try:
-                self.loss.backward()
+                run_backward()
                 E.join_side_stream()             # issues the update of the last blocks as well
             finally:
                 E._Side.early_opt, E._Side.finished = None, []
             if self._early_seen != len(self._early):      # e.g. side stream disabled: fall back to the single update
                 raise RuntimeError(f"early optimizer: {self._early_seen} of {len(self._early)} encoder blocks were updated")
         else:
-            self.loss.backward()
+            run_backward()
+        if deferred:
+            self.loss = sum(t.detach() for t in self.task_losses.values())
 
     def _fwd_bwd_upper(self):
         """forward + losses + backward down to the activation at the encoder cut; the gradients above the cut are final on return."""

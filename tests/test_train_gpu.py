@@ -696,8 +696,9 @@ def test_losses_on_the_adapter_lanes_are_the_same_step(monkeypatch):
     x = {d: t.to(DEV) for d, t in O.synthetic_batch(cfg, B, seed=177).items()}
     noise, _, _ = _noise_dev(cfg, B, Kk, 178)
 
-    def run(lanes, graph, unmasked):
+    def run(lanes, graph, unmasked, defer=False):
         monkeypatch.setattr(trainer, "LANE_LOSSES", lanes)
+        monkeypatch.setattr(trainer, "LANE_DEFER_JOIN", defer)
         model, args, _ = T._build(cfg)
         model.train()
         opt = optim.FusedAdamW(model, [1e-3] * 8, [0.05] * 8)
@@ -713,8 +714,10 @@ def test_losses_on_the_adapter_lanes_are_the_same_step(monkeypatch):
         return (float(ts.loss), {k: float(v) for k, v in ts.task_losses.items()}, opt.arena.flat_g.clone(), opt.arena.flat_p.clone(),
                 {k: v.clone() for k, v in ts.pred_images().items()})
     for graph, unmasked in ((True, False), (False, False), (True, True)):
-        a, b = run(True, graph, unmasked), run(False, graph, unmasked)
-        assert a[0] == b[0] and a[1] == b[1], (graph, unmasked, a[1], b[1])
-        assert torch.equal(a[2], b[2]) and torch.equal(a[3], b[3])
-        for k in a[4]:
-            assert torch.equal(a[4][k], b[4][k])
+        # losses on the lanes (default) / lanes running on into the backward pass without a join (MRG_LANE_DEFER_JOIN=1) / reference placement
+        a, c, b = run(True, graph, unmasked), run(True, graph, unmasked, defer=True), run(False, graph, unmasked)
+        for o in (a, c):
+            assert o[0] == b[0] and o[1] == b[1], (graph, unmasked, o[1], b[1])
+            assert torch.equal(o[2], b[2]) and torch.equal(o[3], b[3])
+            for k in o[4]:
+                assert torch.equal(o[4][k], b[4][k])
