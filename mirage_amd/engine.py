@@ -49,6 +49,7 @@ class _Side:
     taper = int(os.environ.get("MRG_SIDE_TAPER", "0"))
     tail_blocks = int(os.environ.get("MRG_SIDE_TAIL", "2"))
     reduce_early = True
+    inline = os.environ.get("MRG_SIDE_INLINE", "0") == "1"   # experiment: the queued work goes out on the calling stream (serial), same grouping
     _blocks = 0
     origin = None      # stream the queued jobs were produced on (the decoders' lanes queue from their own streams)
     early_opt = None   # optional callable(list of finished blocks): optimizer update of blocks whose gradients are final, issued on
@@ -74,14 +75,17 @@ class _Side:
         if not cls.queue:
             return
         main = cls.origin
-        if cls.stream is None or cls.stream.device != main.device:
+        if cls.inline:
+            cls.stream = main
+        elif cls.stream is None or cls.stream.device != main.device:
             cls.stream = torch.cuda.Stream(device=main.device)
         ev = torch.cuda.Event()
         ev.record(main)
         jobs, cls.queue = cls.queue, []
         tag = K.timestamp_seq("side_flush")
         with torch.cuda.stream(cls.stream):
-            cls.stream.wait_event(ev)
+            if cls.stream != main:
+                cls.stream.wait_event(ev)
             K.timestamp(f"{tag}.start")
             K.WgradGroup.begin()                 # the plain weight gradients of this flush go out as ONE grouped launch without split-K
             try:
@@ -148,7 +152,8 @@ class _Side:
                 ev = torch.cuda.Event()
                 ev.record(main)                  # LayerNorm / column-sum partials were produced on the calling stream
                 with torch.cuda.stream(cls.stream):
-                    cls.stream.wait_event(ev)
+                    if cls.stream != main:
+                        cls.stream.wait_event(ev)
                     K.Deferred.flush()
             else:
                 K.Deferred.flush()
@@ -161,7 +166,8 @@ class _Side:
                 cls.early_opt(done)
         K.Deferred.active = False
         if cls.pending:
-            torch.cuda.current_stream().wait_stream(cls.stream)
+            if cls.stream != torch.cuda.current_stream():
+                torch.cuda.current_stream().wait_stream(cls.stream)
             cls.keep.clear()
             cls.pending = False
         K.Deferred.release()
