@@ -429,7 +429,8 @@ __global__ __launch_bounds__(512) void gemm_p8_group_kernel(const P8GroupArgs ga
 // Workgroup -> range uses the XCD band order (consecutive ranges share an L2).
 struct P8SkArgs { float* slabs; int* cnt; int tiles; int nk; unsigned long long* trace; };
 // mrg_debug_sk_trace: per workgroup 32 x u64 = {start, then per segment: main loop end, exchange end, role (0 whole tile, 1 stored,
-// 2 finisher without a store, 3 finisher after storing) << 32 | tile, epilogue end} in wall_clock64 ticks (100 MHz)
+// 2 finisher without a store, 3 finisher after storing) << 32 | tile, epilogue end} in wall_clock64 ticks (100 MHz); slots 30 / 31:
+// clock64() (shader clock) at the start and after the first main loop -> the clock the CU ran that loop at
 #define SK_TRACE(slot, val) do { if (sk.trace && tid == 0) sk.trace[(long)blockIdx.x * 32 + (slot)] = (val); } while (0)
 constexpr int P8_SLAB_FLOATS = 256 * 256;
 
@@ -450,7 +451,7 @@ __device__ __forceinline__ void p8_streamk(const P8SkArgs& sk, char* smem, Probl
     const int tf = S / nk, tl = (E - 1) / nk;
     const int nseg = tl - tf + 1;
     volatile int* flag = reinterpret_cast<volatile int*>(smem);
-    { const int tid = threadIdx.x; SK_TRACE(0, wall_clock64()); }
+    { const int tid = threadIdx.x; SK_TRACE(0, wall_clock64()); SK_TRACE(30, clock64()); }
     for (int si = 0; si < nseg; ++si) {
         // the lane id is made opaque per segment: everything per-lane below (loader offsets, fragment addresses, epilogue columns,
         // partial-image offsets) would otherwise be loop-invariant, hoisted out of this loop and kept in registers across the main loop
@@ -470,6 +471,7 @@ __device__ __forceinline__ void p8_streamk(const P8SkArgs& sk, char* smem, Probl
         f32x16 acc[4][2];
         p8_mainloop<AMODE, BMODE, PHASES>(g, m0, n0, k0, k1 - k0, acc, smem, tid);
         if (si < 7) SK_TRACE(1 + 4 * si, wall_clock64());
+        if (si == 0) SK_TRACE(31, clock64());     // with slot 30: shader-clock cycles of the first main loop (slots 0 -> 1 are its wall time)
         bool finish = true;
         int role = 0;
         if (k1 - k0 < nk) {
