@@ -50,6 +50,13 @@ class _Side:
     tail_blocks = int(os.environ.get("MRG_SIDE_TAIL", "2"))
     reduce_early = True
     inline = os.environ.get("MRG_SIDE_INLINE", "0") == "1"   # experiment: the queued work goes out on the calling stream (serial), same grouping
+    # the LAST flush of a backward pass (join) is exposed: weight-gradient group, its reductions, the AdamW of its blocks, one after the
+    # other on an otherwise idle chip.  tail_split = n > 0 (with the early optimizer): the group is cut before its last n blocks and the
+    # AdamW of the first part (HBM-bound, small workgroups) runs on a third stream under the second part's group
+    tail_split = int(os.environ.get("MRG_TAIL_SPLIT", "0"))
+    opt_stream = None
+    opt_pending = False
+    marks = []         # (queue length, block) at every block_done since the last flush: where the queue can be cut between blocks
     _blocks = 0
     origin = None      # stream the queued jobs were produced on (the decoders' lanes queue from their own streams)
     early_opt = None   # optional callable(list of finished blocks): optimizer update of blocks whose gradients are final, issued on
@@ -82,27 +89,45 @@ class _Side:
         ev = torch.cuda.Event()
         ev.record(main)
         jobs, cls.queue = cls.queue, []
+        marks, cls.marks = cls.marks, []
+        parts = [(jobs, None)]
+        if (K.WgradGroup.exposed and cls.tail_split > 0 and cls.early_opt is not None and cls.reduce_early and len(marks) > cls.tail_split
+                and [m[1] for m in marks] == cls.finished[-len(marks):]):
+            n_a = len(marks) - cls.tail_split
+            cut = marks[n_a - 1][0]
+            parts = [(jobs[:cut], [m[1] for m in marks[:n_a]]), (jobs[cut:], None)]
         tag = K.timestamp_seq("side_flush")
         with torch.cuda.stream(cls.stream):
             if cls.stream != main:
                 cls.stream.wait_event(ev)
             K.timestamp(f"{tag}.start")
-            K.WgradGroup.begin()                 # the plain weight gradients of this flush go out as ONE grouped launch without split-K
-            try:
-                for fn in jobs:
-                    fn()
-            except BaseException:
-                K.WgradGroup.collecting, K.WgradGroup.tasks = False, []
-                raise
-            K.WgradGroup.flush()
-            K.timestamp(f"{tag}.wgrad_end")
-            if cls.reduce_early:
-                # finish the split-K slabs / column-sum partials produced so far (the event above covers the LayerNorm partials of
-                # the calling stream): only the last group's reductions are then left for the tail of the step
-                K.Deferred.flush()
-                if cls.early_opt is not None and cls.finished:
-                    done, cls.finished = cls.finished, []
-                    cls.early_opt(done)          # their gradients are final now: AdamW for these blocks overlaps the rest of backward
+            for part, early_blks in parts:
+                K.WgradGroup.begin()             # the plain weight gradients of this flush go out as ONE grouped launch without split-K
+                try:
+                    for fn in part:
+                        fn()
+                except BaseException:
+                    K.WgradGroup.collecting, K.WgradGroup.tasks = False, []
+                    raise
+                K.WgradGroup.flush()
+                K.timestamp(f"{tag}.wgrad_end")
+                if cls.reduce_early:
+                    # finish the split-K slabs / column-sum partials produced so far (the event above covers the LayerNorm partials of
+                    # the calling stream): only the last group's reductions are then left for the tail of the step
+                    K.Deferred.flush()
+                    if early_blks is not None:   # first part of a split tail: its AdamW goes under the second part's group
+                        cls.finished = [b for b in cls.finished if not any(b is e for e in early_blks)]
+                        if cls.opt_stream is None or cls.opt_stream.device != main.device:
+                            cls.opt_stream = torch.cuda.Stream(device=main.device)
+                        ev_a = torch.cuda.Event()
+                        ev_a.record(cls.stream)
+                        with torch.cuda.stream(cls.opt_stream):
+                            cls.opt_stream.wait_event(ev_a)
+                            cls.early_opt(early_blks)
+                        cls.opt_pending = True
+                    elif cls.early_opt is not None and cls.finished:
+                        done, cls.finished = cls.finished, []
+                        cls.early_opt(done)      # their gradients are final now: AdamW for these blocks overlaps the rest of backward
             K.timestamp(f"{tag}.end")
         cls.pending = True
 
@@ -117,6 +142,7 @@ class _Side:
         if cls.early_opt is not None and blk is not None:
             if cls.enabled:
                 cls.finished.append(blk)
+                cls.marks.append((len(cls.queue), blk))
             else:
                 cls.early_opt([blk])             # no side stream, no deferred reductions: the gradients are final already
         need = cls.blocks_per_flush
@@ -165,6 +191,9 @@ class _Side:
             else:
                 cls.early_opt(done)
         K.Deferred.active = False
+        if cls.opt_pending:
+            torch.cuda.current_stream().wait_stream(cls.opt_stream)
+            cls.opt_pending = False
         if cls.pending:
             if cls.stream != torch.cuda.current_stream():
                 torch.cuda.current_stream().wait_stream(cls.stream)
