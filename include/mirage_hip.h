@@ -337,6 +337,9 @@ int mrg_resize_label(const long* src, long* dst, int B, int Hi, int Wi, int Ho, 
 
 /* Profiling aid: *slot = wall_clock64() (constant 100 MHz counter) when `stream` reaches this point; capturable into a hipGraph. */
 int mrg_debug_timestamp(unsigned long long* slot, hipStream_t stream);
+/* profiling aid: one wave stores {wall_clock64 (100 MHz), clock64 (shader clock)} pairs into buf[2 * samples] every `period` wall ticks
+ * while other streams work: the clock the chip runs at, by phase of a step (tools/step_clock.py) */
+int mrg_debug_clock_monitor(unsigned long long* buf, int samples, int period, hipStream_t stream);
 /* Profiling aid: while buf != NULL every stream-K launch records per-workgroup phase timestamps into buf[workgroup * 32 ..] (u64, 100 MHz);
  * NULL switches it off.  Process-global, for tools only. */
 int mrg_debug_sk_trace(unsigned long long* buf);

@@ -82,6 +82,7 @@ class AdamWDesc(C.Structure):
 SIGNATURES = {
     "mrg_version": (ci, []),
     "mrg_debug_timestamp": (ci, [vp, vp]),
+    "mrg_debug_clock_monitor": (ci, [vp, ci, ci, vp]),
     "mrg_debug_sk_trace": (ci, [vp]),
     "mrg_last_error_string": (C.c_char_p, []),
     "mrg_gemm": (ci, [C.POINTER(GemmDesc), vp]),
