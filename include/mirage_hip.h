@@ -26,7 +26,7 @@ extern "C" {
 typedef struct ihipStream_t* hipStream_t;
 #endif
 
-#define MRG_ABI_VERSION 10   /* 10: MRG_GEMM_P8SK (stream-K schedule of the 8-phase kernel), mrg_gemm_desc.sk_grid, mrg_wgrad_group_desc.streamk / counters / sk_grid, mrg_streamk_ws_bytes; 9: mrg_maskgen_rng, input slots (mrg_set_slots, *_slot parameters, mrg_loss_desc.target_slot); 8: mrg_gemm_desc.drop_rng / drop_p / drop_stream, mrg_dropout_bwd_bf16; 7: mrg_wgrad_group, mrg_debug_timestamp; 2: mrg_gemm_desc grew row_scale / defer_reduce, act codes 3, 4, reduce_batch / augment / row_scale entry points; 3: colsum_out, attention colsum_*; 4: step = int[2], mrg_step_inc takes the skip decision; 5: splitk_counters, MRG_GEMM_P8, resize entry points; 6: mrg_adamw_desc.sumsq_out, mrg_sumsq_finish */
+#define MRG_ABI_VERSION 11   /* 11: mrg_attn_desc.drop_rng / drop_p / drop_stream (dropout on the attention probabilities), mrg_debug_clock_monitor; 10: MRG_GEMM_P8SK (stream-K schedule of the 8-phase kernel), mrg_gemm_desc.sk_grid, mrg_wgrad_group_desc.streamk / counters / sk_grid, mrg_streamk_ws_bytes; 9: mrg_maskgen_rng, input slots (mrg_set_slots, *_slot parameters, mrg_loss_desc.target_slot); 8: mrg_gemm_desc.drop_rng / drop_p / drop_stream, mrg_dropout_bwd_bf16; 7: mrg_wgrad_group, mrg_debug_timestamp; 2: mrg_gemm_desc grew row_scale / defer_reduce, act codes 3, 4, reduce_batch / augment / row_scale entry points; 3: colsum_out, attention colsum_*; 4: step = int[2], mrg_step_inc takes the skip decision; 5: splitk_counters, MRG_GEMM_P8, resize entry points; 6: mrg_adamw_desc.sumsq_out, mrg_sumsq_finish */
 
 enum { MRG_DT_BF16 = 0, MRG_DT_F32 = 1 };
 enum { MRG_OP_KCONTIG = 0, MRG_OP_KSTRIDED = 1 };
@@ -185,6 +185,13 @@ typedef struct mrg_attn_desc {
      * [b * colsum_bs + h * head_dim + c] -- summed over b they are the bias gradients of the q / k / v projections
      * (colsum_k and colsum_v are used together) */
     float* colsum_q; float* colsum_k; float* colsum_v; long colsum_bs;
+    /* optional: dropout on the attention probabilities (mirage/utils.py:181-185, 216-220: SDPA's dropout_p = attn_drop).  drop_rng:
+     * device [2] = {seed, step} as in mrg_gemm_desc; drop_p in (0, 1); drop_stream tells the launches of one step apart.  The
+     * probabilities of one launch form the matrix [B H Nq, Nk4] (Nk4 = Nk rounded up to 4): element (r, j) takes draw j & 3 of
+     * Philox4x32-10(counter = (r Nk4 / 4 + j / 4 as 64 bits, drop_stream, step), key = seed) and is kept (x 1 / (1 - p)) when
+     * draw >= floor(p 2^32); forward and backward regenerate the same mask.  This path is plain fp32 FMA code (no reference script
+     * sets attn_drop); colsum_* must be NULL with it.  drop_rng = NULL or drop_p = 0: no dropout. */
+    const unsigned long long* drop_rng; float drop_p; unsigned int drop_stream;
 } mrg_attn_desc;
 int mrg_attn_fwd(const mrg_attn_desc* d, hipStream_t stream);
 int mrg_attn_bwd(const mrg_attn_desc* d, hipStream_t stream);

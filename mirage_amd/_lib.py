@@ -52,7 +52,8 @@ class AttnDesc(C.Structure):
                 ("d_o", vp), ("do_bs", cl), ("do_rs", cl), ("dsum", vp),
                 ("dq", vp), ("dk", vp), ("dv", vp),
                 ("dq_bs", cl), ("dq_rs", cl), ("dk_bs", cl), ("dk_rs", cl), ("dv_bs", cl), ("dv_rs", cl),
-                ("colsum_q", vp), ("colsum_k", vp), ("colsum_v", vp), ("colsum_bs", cl)]
+                ("colsum_q", vp), ("colsum_k", vp), ("colsum_v", vp), ("colsum_bs", cl),
+                ("drop_rng", vp), ("drop_p", cf), ("drop_stream", C.c_uint)]
 
 
 class DecAssembleDesc(C.Structure):
@@ -141,7 +142,7 @@ for _name, (_res, _args) in SIGNATURES.items():
     _fn.argtypes = _args
 
 ABI_VERSION = lib.mrg_version()
-EXPECTED_ABI_VERSION = 10      # must match MRG_ABI_VERSION in include/mirage_hip.h: the ctypes structs above mirror that layout
+EXPECTED_ABI_VERSION = 11      # must match MRG_ABI_VERSION in include/mirage_hip.h: the ctypes structs above mirror that layout
 if ABI_VERSION != EXPECTED_ABI_VERSION:
     raise ImportError(f"{LIB_PATH} reports ABI version {ABI_VERSION}, the Python bindings expect {EXPECTED_ABI_VERSION}: rebuild it "
                       "(python -c 'import __graft_entry__ as g; g.build()')")

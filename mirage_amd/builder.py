@@ -51,9 +51,10 @@ def make_args(in_domains: Sequence[str], out_domains: Optional[Sequence[str]] = 
     return a
 
 
-def get_model(args, model_name: str = "miragepre_base", with_decoders: bool = True, **model_kwargs):
+def get_model(args, model_name: str = "miragepre_base", with_decoders: bool = True, decoder_attn_drop_rate: float = 0.0, **model_kwargs):
     """Adapters + model (run_pretraining.py:373-419).  model_kwargs (dim_tokens / depth / num_heads) allow the
-    reduced-size models used by the parity fixtures."""
+    reduced-size models used by the parity fixtures; decoder_attn_drop_rate is SpatialOutputAdapter's attn_drop_rate
+    (mirage/output_adapters.py:64; run_pretraining.py leaves it 0)."""
     input_adapters = {
         d: DOMAIN_CONF[d]["input_adapter"](stride_level=DOMAIN_CONF[d]["stride_level"], patch_size_full=tuple(args.patch_size[d]),
                                            image_size=args.input_size[d])
@@ -66,7 +67,7 @@ def get_model(args, model_name: str = "miragepre_base", with_decoders: bool = Tr
                                                 dim_tokens=args.decoder_dim, depth=args.decoder_depth, num_heads=args.decoder_num_heads,
                                                 use_task_queries=args.decoder_use_task_queries, task=d,
                                                 context_tasks=list(args.in_domains), use_xattn=args.decoder_use_xattn,
-                                                image_size=args.input_size[d])
+                                                image_size=args.input_size[d], attn_drop_rate=decoder_attn_drop_rate)
             for d in args.out_domains
         }
     if model_kwargs:

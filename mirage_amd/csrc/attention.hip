@@ -959,9 +959,15 @@ void fill(AttnArgs& a, const mrg_attn_desc* d) {
 
 }  // namespace
 
+namespace mrg_detail {       // attention_drop.hip: the plain path with dropout on the probabilities
+int attn_drop_fwd(const mrg_attn_desc* d, hipStream_t stream);
+int attn_drop_bwd(const mrg_attn_desc* d, hipStream_t stream);
+}
+
 extern "C" int mrg_attn_fwd(const mrg_attn_desc* d, hipStream_t stream) {
     int rc = check_common(d, "mrg_attn_fwd");
     if (rc) return rc;
+    if (d->drop_rng != nullptr && d->drop_p != 0.f) return mrg_detail::attn_drop_fwd(d, stream);
     AttnArgs a;
     fill(a, d);
     return d->head_dim == 64 ? launch_fwd<64>(a, stream) : launch_fwd<32>(a, stream);
@@ -972,6 +978,7 @@ extern "C" int mrg_attn_bwd(const mrg_attn_desc* d, hipStream_t stream) {
     if (rc) return rc;
     MRG_REQUIRE(d->d_o && d->lse && d->dsum && d->dq && d->dk && d->dv, MRG_ERR_ARG, "mrg_attn_bwd: null tensor");
     MRG_REQUIRE(d->do_bs % 8 == 0 && d->do_rs % 8 == 0, MRG_ERR_SHAPE, "mrg_attn_bwd: dO strides must be multiples of 8");
+    if (d->drop_rng != nullptr && d->drop_p != 0.f) return mrg_detail::attn_drop_bwd(d, stream);
     AttnArgs a;
     fill(a, d);
     const int HD = d->head_dim;

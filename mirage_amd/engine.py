@@ -309,6 +309,24 @@ class DropoutRNG:
 
 
 # ------------------------------------------------------------------------------------------- transformer block
+def attn_dropout_args(att):
+    """(rng snapshot, p, stream id) of an Attention / CrossAttention module whose attn_drop > 0, else None.  The reference hands attn_drop to
+    F.scaled_dot_product_attention as dropout_p (mirage/utils.py:181-185, 216-220), which applies it in eval mode too:
+    so does this.  The snapshot is the one the owning model's forward pass took (model.MIRAGEModel.forward -> att._mrg_adrop_rng); a module
+    used on its own takes one per call."""
+    p = float(getattr(att, "attn_drop", 0.0) or 0.0)
+    if p <= 0.0:
+        return None
+    rng = getattr(att, "_mrg_adrop_rng", None)
+    if rng is None:
+        rng = DropoutRNG.begin_forward(att.proj.weight.device)
+    return (rng, p, int(getattr(att, "attn_drop_stream", ATTN_DROP_STREAM0)))
+
+
+ATTN_DROP_STREAM0 = 0x10000      # mask streams of the attention-probability dropout: encoder block i 0x10000 + i; output adapter a:
+                                 # cross-attention 0x20000 + 256 a, its block j 0x20000 + 256 a + 1 + j (proj / fc2 dropout use 2 i, 2 i + 1)
+
+
 def block_fwd(blk, x32: torch.Tensor, save: bool, want_bf16_out: bool = False, dp=None):
     """Block.forward (mirage/utils.py:259-262): x + drop_path(attn(norm1(x))); x + drop_path(mlp(norm2(x))).  x32: fp32 [B, N, D].
     dp = (rows_attn, rows_mlp[, drop]): per-row stochastic-depth factors floor(keep + u) / keep (mirage/utils.py:103-118) or None, and
@@ -324,20 +342,21 @@ def block_fwd(blk, x32: torch.Tensor, save: bool, want_bf16_out: bool = False, d
     ln1, mean1, rstd1 = K.ln_fwd(x32, blk.norm1.weight, blk.norm1.bias, eps)
     qkv, _, _ = lin_fwd(ln1, blk.attn.qkv)
     st = (N * 3 * D, 3 * D)
-    o, lse = K.attn_fwd(qkv[..., :D], qkv[..., D:2 * D], qkv[..., 2 * D:], B, H, N, N, hd, blk.attn.scale, st, st, st, need_lse=save)
+    adrop = attn_dropout_args(blk.attn)
+    o, lse = K.attn_fwd(qkv[..., :D], qkv[..., D:2 * D], qkv[..., 2 * D:], B, H, N, N, hd, blk.attn.scale, st, st, st, need_lse=save, drop=adrop)
     x_mid, _, _ = lin_fwd(o, blk.attn.proj, out_dtype=F32, resid=x32, row_scale=dp[0] if dp else None, dropout=d_att)
     ln2, mean2, rstd2 = K.ln_fwd(x_mid, blk.norm2.weight, blk.norm2.bias, blk.norm2.eps)
     h_act, _, h_pre = lin_fwd(ln2, blk.mlp.fc1, gelu=True, save_pre=save)
     x_out, x_out16, _ = lin_fwd(h_act, blk.mlp.fc2, out_dtype=F32, resid=x_mid, want_bf16_copy=want_bf16_out,
                                 row_scale=dp[1] if dp else None, dropout=d_mlp)
-    saved = (x32, ln1, mean1, rstd1, qkv, o, lse, x_mid, ln2, mean2, rstd2, h_pre, h_act, dp) if save else None
+    saved = (x32, ln1, mean1, rstd1, qkv, o, lse, x_mid, ln2, mean2, rstd2, h_pre, h_act, dp, adrop) if save else None
     return x_out, x_out16, saved
 
 
 def block_bwd(blk, saved, dx32: torch.Tensor, dx16: Optional[torch.Tensor], remaining: Optional[int] = None):
     """Returns (dx_in fp32, dx_in bf16).  fc2 / proj bias gradients come out of the LayerNorm backward kernels
     (column sums of the residual-stream gradient)."""
-    x_in, ln1, mean1, rstd1, qkv, o, lse, x_mid, ln2, mean2, rstd2, h_pre, h_act, dp = saved
+    x_in, ln1, mean1, rstd1, qkv, o, lse, x_mid, ln2, mean2, rstd2, h_pre, h_act, dp, adrop = saved
     B, N, D = x_in.shape
     H = blk.attn.num_heads
     hd = D // H
@@ -366,10 +385,11 @@ def block_bwd(blk, saved, dx32: torch.Tensor, dx16: Optional[torch.Tensor], rema
         d_o, _ = lin_bwd(dx_mid16, o, blk.attn.proj, bias_grad=False)
     d_qkv = torch.empty_like(qkv)
     st = (N * 3 * D, 3 * D)
-    gb = grad_buffer(blk.attn.qkv.bias) if (blk.attn.qkv.bias is not None and FUSE_ATTN_BIAS) else None
+    gb = grad_buffer(blk.attn.qkv.bias) if (blk.attn.qkv.bias is not None and FUSE_ATTN_BIAS and adrop is None) else None
     K.attn_bwd(qkv[..., :D], qkv[..., D:2 * D], qkv[..., 2 * D:], o, lse, d_o, d_qkv[..., :D], d_qkv[..., D:2 * D], d_qkv[..., 2 * D:],
                B, H, N, N, hd, blk.attn.scale, st, st, st, st, st, st,
-               bias_grads=(gb[:D], gb[D:2 * D], gb[2 * D:]) if gb is not None else None)   # qkv bias gradient from inside the kernels
+               bias_grads=(gb[:D], gb[D:2 * D], gb[2 * D:]) if gb is not None else None,   # qkv bias gradient from inside the kernels
+               drop=adrop)
     d_ln1, _ = lin_bwd(d_qkv, ln1, blk.attn.qkv, bias_grad=gb is None)
     dx_in32, dx_in16 = K.ln_bwd(d_ln1, x_in, mean1, rstd1, blk.norm1.weight, dx_mid32, grad_buffer(blk.norm1.weight),
                                 grad_buffer(blk.norm1.bias), None if dp is not None else grad_buffer(blk.attn.proj.bias))
@@ -509,7 +529,7 @@ class EncoderFn(torch.autograd.Function):
         saved_all = []
         x16 = None
         n = len(blocks)
-        if (TWO_CHAINS == 2 or (TWO_CHAINS == 1 and not save)) and not dps and x.shape[0] % 2 == 0 and x.is_contiguous() and x.shape[0] * x.shape[1] >= TWO_CHAINS_MIN_ROWS:
+        if (TWO_CHAINS == 2 or (TWO_CHAINS == 1 and not save)) and not dps and not any(getattr(b.attn, "attn_drop", 0.0) for b in blocks) and x.shape[0] % 2 == 0 and x.is_contiguous() and x.shape[0] * x.shape[1] >= TWO_CHAINS_MIN_ROWS:
             x32, x16, saved_all = _encoder_fwd_two_chains(x, blocks, save, want_bf16)
         else:
             for i, blk in enumerate(blocks):
@@ -697,7 +717,8 @@ def decoder_fwd(ad, enc32: torch.Tensor, enc16: torch.Tensor, ids_keep, ids_rest
     qp, _, _ = lin_fwd(qn, ad.decoder.q)
     kv, _, _ = lin_fwd(cn, ad.decoder.kv)
     sq, skv = (Tq * Dd, Dd), (N * 2 * Dd, 2 * Dd)
-    o, lse = K.attn_fwd(qp, kv[..., :Dd], kv[..., Dd:], B, H, Tq, N, hd, ad.decoder.scale, sq, skv, skv, need_lse=save)
+    adrop = attn_dropout_args(ad.decoder)
+    o, lse = K.attn_fwd(qp, kv[..., :Dd], kv[..., Dd:], B, H, Tq, N, hd, ad.decoder.scale, sq, skv, skv, need_lse=save, drop=adrop)
     x1, _, _ = lin_fwd(o, ad.decoder.proj, out_dtype=F32)                                # :279 (no residual)
     on, mo, ro = K.ln_fwd(x1, ad.out_norm.weight, ad.out_norm.bias, eps)
     h_act, _, h_pre = lin_fwd(on, ad.mlp.fc1, gelu=True, save_pre=save)
@@ -718,7 +739,7 @@ def decoder_fwd(ad, enc32: torch.Tensor, enc16: torch.Tensor, ids_keep, ids_rest
     saved = None
     if save:
         saved = (desc, task_embs, queries, context, qn, mq, rq, cn, mc, rc, qp, kv, o, lse, x1, on, mo, ro, h_pre, h_act, x2,
-                 blk_saved, x16, enc16, (B, N, Tq, Dd, H, hd, g))
+                 blk_saved, x16, enc16, (B, N, Tq, Dd, H, hd, g, adrop))
     return img, saved
 
 
@@ -726,7 +747,7 @@ def decoder_bwd(ad, saved, d_img: torch.Tensor):
     """Backward of one adapter down to d(proj_context output); returns it in bf16.  The caller folds the proj_context dgrads of
     all adapters into one shared d_enc buffer (decoder_bwd_finish) after the per-adapter streams have joined."""
     (desc, task_embs, queries, context, qn, mq, rq, cn, mc, rc, qp, kv, o, lse, x1, on, mo, ro, h_pre, h_act, x2, blk_saved, x16,
-     enc16, (B, N, Tq, Dd, H, hd, g)) = saved
+     enc16, (B, N, Tq, Dd, H, hd, g, adrop)) = saved
     dev = d_img.device
     K.timestamp(f"dec_bwd_start.{ad.task}")
     blocks = list(ad.decoder_transformer) if isinstance(ad.decoder_transformer, torch.nn.Sequential) else []
@@ -751,9 +772,9 @@ def decoder_bwd(ad, saved, d_img: torch.Tensor):
     dkv = torch.empty_like(kv)
     sq, skv = (Tq * Dd, Dd), (N * 2 * Dd, 2 * Dd)
     gq, gkv = grad_buffer(ad.decoder.q.bias), grad_buffer(ad.decoder.kv.bias)
-    fused = gq is not None and gkv is not None and FUSE_ATTN_BIAS
+    fused = gq is not None and gkv is not None and FUSE_ATTN_BIAS and adrop is None
     K.attn_bwd(qp, kv[..., :Dd], kv[..., Dd:], o, lse, d_o, dq, dkv[..., :Dd], dkv[..., Dd:], B, H, Tq, N, hd, ad.decoder.scale,
-               sq, skv, skv, sq, skv, skv, bias_grads=(gq, gkv[:Dd], gkv[Dd:]) if fused else None)
+               sq, skv, skv, sq, skv, skv, bias_grads=(gq, gkv[:Dd], gkv[Dd:]) if fused else None, drop=adrop)
     d_qn, _ = lin_bwd(dq, qn, ad.decoder.q, bias_grad=not fused)
     d_cn, _ = lin_bwd(dkv, cn, ad.decoder.kv, bias_grad=not fused)
     d_queries, _ = K.ln_bwd(d_qn, queries, mq, rq, ad.query_norm.weight, None, grad_buffer(ad.query_norm.weight),

@@ -551,12 +551,24 @@ def _attn_desc(q, k, v, o, lse, B, H, Nq, Nk, hd, scale, strides):
     return d
 
 
-def attn_fwd(q, k, v, B, H, Nq, Nk, hd, scale, q_strides, k_strides, v_strides, need_lse=True):
-    """q/k/v: bf16 tensors (possibly views into fused projection buffers); strides = (batch, row) in elements."""
+def _attn_drop(d, drop):
+    """drop = (rng int64[2] device tensor {seed, step}, p, stream id): dropout on the attention probabilities (mrg_attn_desc.drop_*)"""
+    if drop is None:
+        return
+    rng, p, stream = drop
+    if rng.dtype != torch.int64 or rng.numel() != 2 or not rng.is_cuda:
+        raise ValueError("attention dropout: rng must be an int64[2] device tensor {seed, step}")
+    d.drop_rng, d.drop_p, d.drop_stream = rng.data_ptr(), float(p), int(stream)
+
+
+def attn_fwd(q, k, v, B, H, Nq, Nk, hd, scale, q_strides, k_strides, v_strides, need_lse=True, drop=None):
+    """q/k/v: bf16 tensors (possibly views into fused projection buffers); strides = (batch, row) in elements.
+    drop: see _attn_drop (the plain fp32 path of csrc/attention_drop.hip)."""
     _need_cuda(q, "attention input")
     o = new((B, Nq, H * hd), BF16, q.device)
     lse = new((B, H, Nq), F32, q.device) if need_lse else None
     d = _attn_desc(q, k, v, o, lse, B, H, Nq, Nk, hd, scale, (q_strides, k_strides, v_strides, (Nq * H * hd, H * hd)))
+    _attn_drop(d, drop)
     check(lib.mrg_attn_fwd(C.byref(d), _s()), "mrg_attn_fwd")
     return o, lse
 
@@ -573,10 +585,14 @@ def reduce_slices(src: torch.Tensor, src_off: int, dst: torch.Tensor, n: int, st
 
 
 def attn_bwd(q, k, v, o, lse, d_o, dq, dk, dv, B, H, Nq, Nk, hd, scale, q_strides, k_strides, v_strides, dq_strides, dk_strides,
-             dv_strides, bias_grads=None):
+             dv_strides, bias_grads=None, drop=None):
     """bias_grads = (gq, gk, gv): fp32 [H*hd] destinations for the column sums of dQ / dK / dV over all rows (the bias
-    gradients of the projections that produced q / k / v); formed inside the kernels per (batch, head) and summed over the batch."""
+    gradients of the projections that produced q / k / v); formed inside the kernels per (batch, head) and summed over the batch.
+    drop: the forward pass's (rng, p, stream) -- the mask is regenerated; not together with bias_grads."""
+    if drop is not None and bias_grads is not None:
+        raise ValueError("attn_bwd: the dropout path does not form the bias column sums")
     d = _attn_desc(q, k, v, o, lse, B, H, Nq, Nk, hd, scale, (q_strides, k_strides, v_strides, (Nq * H * hd, H * hd)))
+    _attn_drop(d, drop)
     part = None
     if bias_grads is not None:
         Dm = H * hd

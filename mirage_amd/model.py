@@ -54,6 +54,19 @@ class MIRAGEModel(nn.Module):
                   attn_drop=attn_drop_rate, drop_path=dpr[i], norm_layer=norm_layer) for i in range(depth)])
         for i, blk in enumerate(self.encoder):
             blk.drop_stream = 2 * i          # Philox mask streams of block i: 2i (after attn.proj), 2i + 1 (after mlp.fc2)
+            blk.attn.attn_drop_stream = E.ATTN_DROP_STREAM0 + i       # dropout on the attention probabilities (attn_drop_rate)
+        # modules with dropout on their attention probabilities: every forward pass hands them ONE Philox snapshot (engine.attn_dropout_args)
+        self._mrg_adrop = [b.attn for b in self.encoder if b.attn.attn_drop > 0.0]
+        for a, ad in enumerate((self.output_adapters or {}).values()):
+            dec = getattr(ad, "decoder", None)
+            if dec is not None:
+                dec.attn_drop_stream = 0x20000 + 256 * a
+                if dec.attn_drop > 0.0:
+                    self._mrg_adrop.append(dec)
+            for j, blk in enumerate(ad.decoder_transformer if isinstance(ad.decoder_transformer, nn.Sequential) else []):
+                blk.attn.attn_drop_stream = 0x20000 + 256 * a + 1 + j
+                if blk.attn.attn_drop > 0.0:
+                    self._mrg_adrop.append(blk.attn)
         # initialisation: same calls in the same order as mirage/model.py:95-121 (same RNG stream -> same weights)
         self.apply(self._init_weights)
         for name, m in self.named_modules():
@@ -283,6 +296,13 @@ class MIRAGEModel(nn.Module):
             ids_keep = ids_shuffle[:, :int((mask_all == 0).sum())].contiguous()
 
         save = torch.is_grad_enabled()
+        snap_a = None
+        if self._mrg_adrop:
+            # attn_drop_rate > 0 (mirage/model.py:88 -> utils.py:184, SDPA's dropout_p: also in eval mode): one Philox step per forward pass,
+            # shared with the proj / fc2 dropout below
+            snap_a = E.DropoutRNG.begin_forward(device)
+            for att in self._mrg_adrop:
+                att._mrg_adrop_rng = snap_a
         x0 = E.EmbedFn.apply(self, x, ids_keep.contiguous(), save, *self._embed_params())
         blocks = list(self.encoder)
 
@@ -309,7 +329,7 @@ class MIRAGEModel(nn.Module):
         if self.training and any(getattr(b, "drop_prob", 0.0) > 0.0 for b in blocks):
             # nn.Dropout after proj / fc2 (drop_rate, mirage/model.py:54,87): one Philox step per forward pass, one mask stream per
             # (block, branch); the snapshot keeps forward and backward of THIS pass on the same masks
-            snap = E.DropoutRNG.begin_forward(device)
+            snap = snap_a if snap_a is not None else E.DropoutRNG.begin_forward(device)
             dps = dps if dps is not None else [None] * len(blocks)
             for i, b in enumerate(blocks):
                 drop = b.dropout_args(snap)

@@ -35,6 +35,10 @@ class SpatialOutputAdapter(nn.Module):
         if not use_xattn or learnable_pos_emb or not qkv_bias:
             raise NotImplementedError("mirage_amd.SpatialOutputAdapter: use_xattn=False / learnable_pos_emb / qkv_bias=False are "
                                       "not on the pretraining path (run_pretraining.py:126-148 defaults)")
+        if drop_path_rate and drop_path_rate > 0.0 and depth > 0:
+            # the engine's decoder pass (engine.decoder_fwd) runs its blocks without stochastic depth: refuse instead of silently dropping it
+            raise NotImplementedError("mirage_amd.SpatialOutputAdapter: drop_path_rate > 0 is not implemented for the decoder blocks "
+                                      "(run_pretraining.py builds the output adapters without it)")
         self.P_H = max(1, self.patch_size_full[0] // stride_level)
         self.P_W = max(1, self.patch_size_full[1] // stride_level)
         if self.P_H != self.P_W:

@@ -202,14 +202,15 @@ class _AttentionFn(torch.autograd.Function):
         x16 = E.to_bf16(x.contiguous().float())
         qkv, _, _ = E.lin_fwd(x16, att.qkv)
         st = (N * 3 * C, 3 * C)
-        o, lse = K.attn_fwd(qkv[..., :C], qkv[..., C:2 * C], qkv[..., 2 * C:], B, H, N, N, hd, att.scale, st, st, st)
+        adrop = E.attn_dropout_args(att)
+        o, lse = K.attn_fwd(qkv[..., :C], qkv[..., C:2 * C], qkv[..., 2 * C:], B, H, N, N, hd, att.scale, st, st, st, drop=adrop)
         y, _, _ = E.lin_fwd(o, att.proj, out_dtype=F32)
-        ctx.att, ctx.keep = att, (x16, qkv, o, lse)
+        ctx.att, ctx.keep = att, (x16, qkv, o, lse, adrop)
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        x16, qkv, o, lse = ctx.keep
+        x16, qkv, o, lse, adrop = ctx.keep
         att = ctx.att
         B, N, C = x16.shape
         H = att.num_heads
@@ -219,7 +220,7 @@ class _AttentionFn(torch.autograd.Function):
         d_qkv = torch.empty_like(qkv)
         st = (N * 3 * C, 3 * C)
         K.attn_bwd(qkv[..., :C], qkv[..., C:2 * C], qkv[..., 2 * C:], o, lse, d_o, d_qkv[..., :C], d_qkv[..., C:2 * C], d_qkv[..., 2 * C:],
-                   B, H, N, N, hd, att.scale, st, st, st, st, st, st)
+                   B, H, N, N, hd, att.scale, st, st, st, st, st, st, drop=adrop)
         dx, _ = E.lin_bwd(d_qkv, x16, att.qkv, dx_dtype=F32)
         E.join_side_stream()
         return (dx, None) + (None,) * 4
@@ -230,9 +231,9 @@ class Attention(nn.Module):
 
     def __init__(self, dim, num_heads=8, qkv_bias=False, attn_drop=0.0, proj_drop=0.0, _in_block=False):
         super().__init__()
-        # dropout on the attention PROBABILITIES (F.scaled_dot_product_attention(dropout_p=...), mirage/utils.py:181-185) is not built:
-        # it would have to live inside the attention kernels' softmax; refuse it loudly rather than train without it
-        _check_no_dropout(attn_drop, "attn_drop (dropout on attention probabilities)")
+        # dropout on the attention PROBABILITIES (F.scaled_dot_product_attention(dropout_p=attn_drop), mirage/utils.py:181-185; applied in
+        # eval mode too, like the reference): the plain path of csrc/attention_drop.hip, see engine.attn_dropout_args
+        _check_prob(attn_drop, "attn_drop")
         if _in_block:
             _check_prob(proj_drop, "proj_drop")
         else:
@@ -263,14 +264,15 @@ class _CrossAttentionFn(torch.autograd.Function):
         q, _, _ = E.lin_fwd(x16, att.q)
         kv, _, _ = E.lin_fwd(c16, att.kv)
         sq, skv = (N * C, C), (M * 2 * C, 2 * C)
-        o, lse = K.attn_fwd(q, kv[..., :C], kv[..., C:], B, H, N, M, hd, att.scale, sq, skv, skv)
+        adrop = E.attn_dropout_args(att)
+        o, lse = K.attn_fwd(q, kv[..., :C], kv[..., C:], B, H, N, M, hd, att.scale, sq, skv, skv, drop=adrop)
         y, _, _ = E.lin_fwd(o, att.proj, out_dtype=F32)
-        ctx.att, ctx.keep = att, (x16, c16, q, kv, o, lse)
+        ctx.att, ctx.keep = att, (x16, c16, q, kv, o, lse, adrop)
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        x16, c16, q, kv, o, lse = ctx.keep
+        x16, c16, q, kv, o, lse, adrop = ctx.keep
         att = ctx.att
         B, N, C = x16.shape
         M = c16.shape[1]
@@ -282,7 +284,7 @@ class _CrossAttentionFn(torch.autograd.Function):
         dkv = torch.empty_like(kv)
         sq, skv = (N * C, C), (M * 2 * C, 2 * C)
         K.attn_bwd(q, kv[..., :C], kv[..., C:], o, lse, d_o, dq, dkv[..., :C], dkv[..., C:], B, H, N, M, hd, att.scale, sq, skv, skv,
-                   sq, skv, skv)
+                   sq, skv, skv, drop=adrop)
         dx, _ = E.lin_bwd(dq, x16, att.q, dx_dtype=F32)
         dc, _ = E.lin_bwd(dkv, c16, att.kv, dx_dtype=F32)
         E.join_side_stream()
@@ -294,7 +296,7 @@ class CrossAttention(nn.Module):
 
     def __init__(self, dim, num_heads=8, qkv_bias=False, attn_drop=0.0, proj_drop=0.0):
         super().__init__()
-        _check_no_dropout(attn_drop, "attn_drop")
+        _check_prob(attn_drop, "attn_drop")                # dropout on the probabilities: see Attention
         _check_no_dropout(proj_drop, "proj_drop")
         self.num_heads = num_heads
         head_dim = dim // num_heads

@@ -563,6 +563,55 @@ def test_cross_attention_fwd_bwd(K, B, H, Nq, Nk, hd):
     assert rel_rms(dkv[..., D:].float(), vf.grad.permute(0, 2, 1, 3).reshape(B, Nk, D)) < 1.5e-2
 
 
+@pytest.mark.parametrize("B,H,Nq,Nk,hd,self_attn,p", [(3, 4, 129, 129, 64, True, 0.15), (2, 2, 99, 99, 64, True, 0.5), (2, 8, 256, 129, 32, False, 0.1),
+                                                       (2, 2, 40, 17, 32, False, 0.3), (1, 2, 10, 5, 64, False, 0.2), (2, 3, 64, 64, 32, True, 0.25)])
+def test_attention_with_dropout_on_the_probabilities(K, B, H, Nq, Nk, hd, self_attn, p):
+    """mrg_attn_desc.drop_* (csrc/attention_drop.hip): O = (softmax(scale q k^T) . mask / (1 - p)) v with the oracle's restatement of the mask
+    (Philox over the padded [B H Nq, Nk4] matrix), forward + backward against torch autograd; a second forward at the same step repeats the
+    mask, another step or stream draws another."""
+    import sys, os
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from oracle import mirage_oracle as O
+    D = H * hd
+    scale = hd ** -0.5
+    if self_attn:
+        qkv = rnd(B, Nq, 3 * D, dtype=BF16, seed=40)
+        q, k, v = qkv[..., :D], qkv[..., D:2 * D], qkv[..., 2 * D:]
+        sq = skv = (Nq * 3 * D, 3 * D)
+    else:
+        q = rnd(B, Nq, D, dtype=BF16, seed=41); kv = rnd(B, Nk, 2 * D, dtype=BF16, seed=42)
+        k, v = kv[..., :D], kv[..., D:]
+        sq, skv = (Nq * D, D), (Nk * 2 * D, 2 * D)
+    seed, step, stream = 0x1234567890AB, 7, 0x10003
+    rng = torch.tensor([seed, step], dtype=torch.int64, device=dev())
+    o, lse = K.attn_fwd(q, k, v, B, H, Nq, Nk, hd, scale, sq, skv, skv, drop=(rng, p, stream))
+    qf = q.float().reshape(B, Nq, H, hd).permute(0, 2, 1, 3).detach().requires_grad_(True)
+    kf, vf = [t.float().reshape(B, Nk, H, hd).permute(0, 2, 1, 3).detach().requires_grad_(True) for t in (k, v)]
+    fac = O.attention_dropout_factor(B, H, Nq, Nk, (p, seed, step, stream)).to(dev())
+    att = torch.softmax((qf @ kf.transpose(-1, -2)) * scale, dim=-1)
+    ref = (att * fac) @ vf
+    assert rel_rms(o.float(), ref.permute(0, 2, 1, 3).reshape(B, Nq, D)) < 6e-3
+    nodrop = (att @ vf).permute(0, 2, 1, 3).reshape(B, Nq, D)
+    assert rel_rms(o.float(), nodrop) > 10 * rel_rms(o.float(), ref.permute(0, 2, 1, 3).reshape(B, Nq, D))      # the mask is really applied
+    torch.testing.assert_close(lse, torch.logsumexp((qf @ kf.transpose(-1, -2)) * scale, dim=-1), rtol=1e-3, atol=2e-3)
+    o2, _ = K.attn_fwd(q, k, v, B, H, Nq, Nk, hd, scale, sq, skv, skv, drop=(rng, p, stream))
+    assert torch.equal(o, o2)
+    o3, _ = K.attn_fwd(q, k, v, B, H, Nq, Nk, hd, scale, sq, skv, skv, drop=(rng, p, stream + 1))
+    o4, _ = K.attn_fwd(q, k, v, B, H, Nq, Nk, hd, scale, sq, skv, skv, drop=(rng + torch.tensor([0, 1], device=dev()), p, stream))
+    assert not torch.equal(o, o3) and not torch.equal(o, o4)
+    d_o = rnd(B, Nq, D, dtype=BF16, seed=43)
+    ref.backward(d_o.float().reshape(B, Nq, H, hd).permute(0, 2, 1, 3))
+    dq = torch.zeros(B, Nq, D, dtype=BF16, device=dev()); dkv = torch.zeros(B, Nk, 2 * D, dtype=BF16, device=dev())
+    sdq, sdkv = (Nq * D, D), (Nk * 2 * D, 2 * D)
+    K.attn_bwd(q, k, v, o, lse, d_o, dq, dkv[..., :D], dkv[..., D:], B, H, Nq, Nk, hd, scale, sq, skv, skv, sdq, sdkv, sdkv, drop=(rng, p, stream))
+    assert rel_rms(dq.float(), qf.grad.permute(0, 2, 1, 3).reshape(B, Nq, D)) < 1.5e-2
+    assert rel_rms(dkv[..., :D].float(), kf.grad.permute(0, 2, 1, 3).reshape(B, Nk, D)) < 1.5e-2
+    assert rel_rms(dkv[..., D:].float(), vf.grad.permute(0, 2, 1, 3).reshape(B, Nk, D)) < 1.5e-2
+    with pytest.raises(ValueError, match="column sums"):
+        K.attn_bwd(q, k, v, o, lse, d_o, dq, dkv[..., :D], dkv[..., D:], B, H, Nq, Nk, hd, scale, sq, skv, skv, sdq, sdkv, sdkv,
+                   bias_grads=(None, None, None), drop=(rng, p, stream))
+
+
 def test_attention_spiky_scores(K):
     # one key dominating one query row (forces large max / tiny probabilities); fp64 reference
     B, H, N, hd = 1, 2, 300, 64

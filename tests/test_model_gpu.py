@@ -33,8 +33,10 @@ def _build(cfg, with_decoders=True):
                              decoder_depth=cfg["decoder_depth"], decoder_num_heads=cfg["decoder_heads"],
                              drop_path=cfg.get("drop_path_rate", 0.0))
     extra = {"drop_rate": cfg["drop_rate"]} if cfg.get("drop_rate", 0.0) > 0.0 else {}
+    if cfg.get("attn_drop_rate", 0.0) > 0.0:
+        extra["attn_drop_rate"] = cfg["attn_drop_rate"]
     model = builder.get_model(args, with_decoders=with_decoders and bool(cfg["out_domains"]), dim_tokens=cfg["dim"], depth=cfg["depth"],
-                              num_heads=cfg["heads"], **extra)
+                              num_heads=cfg["heads"], decoder_attn_drop_rate=cfg.get("decoder_attn_drop_rate", 0.0), **extra)
     sd = O.procedural_state_dict(cfg)
     missing = model.load_state_dict(sd, strict=True)
     return model.to(DEV), args, sd
@@ -346,18 +348,73 @@ def test_dropout_training_parity():
         v1, _ = model({d: x[d] for d in doms}, num_encoded_tokens=Kk, mask_noise=noise)
         v2, _ = model({d: x[d] for d in doms}, num_encoded_tokens=Kk, mask_noise=noise)
         assert torch.equal(v1[d0], v2[d0])
-    # dropout on the attention probabilities is not built: the constructor must say so instead of silently training without it
-    with pytest.raises(NotImplementedError, match="attn_drop"):
-        builder.get_model(args, dim_tokens=cfg["dim"], depth=1, num_heads=cfg["heads"], attn_drop_rate=0.1)
 
 
-def test_dropout_graph_replay_draws_new_masks_and_matches_eager():
-    """TrainStep with drop_rate > 0: the Philox step lives on the device and is advanced inside the captured graph, so replays draw fresh
-    masks, and a graph-replayed run equals the eager run step for step (same seed): losses bit-identical over 4 steps."""
+def test_attention_probability_dropout_matches_reference_fixture():
+    """attn_drop_rate > 0 in the encoder (0.15) and in the output adapters (0.1) (A16; mirage/model.py:55,88, output_adapters.py:64 ->
+    utils.py:181-185, 216-220: SDPA's dropout_p): the HIP path against the REFERENCE model run with scaled_dot_product_attention replayed on the
+    same Philox masks (tests/golden/tiny3_attn_dropout.npz, tools/gen_golden.py run_attn_dropout_case): encoder tokens, predictions, loss,
+    every gradient norm, a few whole gradients.  Like the reference's SDPA call the dropout also applies in eval mode."""
+    from mirage_amd import builder, engine as E
+    from oracle import mirage_oracle as O
+    fx, meta = load_golden("tiny3_attn_dropout")
+    cfg, B, Kk = meta["cfg"], meta["B"], meta["K"]
+    model, args, _ = _build(cfg)
+    model.train()
+    assert [a.attn_drop_stream for a in model._mrg_adrop] == ([0x10000 + i for i in range(cfg["depth"])]
+            + [0x20000 + 256 * a + j for a in range(len(cfg["out_domains"])) for j in range(1 + cfg["decoder_depth"])])
+    x = {d: t.to(DEV) for d, t in O.synthetic_batch(cfg, B, seed=meta["data_seed"]).items()}
+    doms = cfg["in_domains"]
+    noise = (torch.from_numpy(fx["p"]).to(DEV), torch.cat([torch.from_numpy(fx[f"u.{d}"]) for d in doms], 1).to(DEV),
+             torch.from_numpy(fx["g"]).to(DEV))
+    loss_fns = builder.get_losses(args)
+    E.DropoutRNG.set(DEV, meta["drop_seed"], meta["drop_step"] - 1)            # the next forward runs at the fixture's step
+    preds, masks = model({d: x[d] for d in doms}, num_encoded_tokens=Kk, mask_noise=noise)
+    meas = {}
+    for d in preds:
+        meas[f"pred_rel_rms.{d}"] = rel_rms(preds[d].float().cpu(), torch.from_numpy(fx[f"pred.{d}"]))
+        assert meas[f"pred_rel_rms.{d}"] <= 2e-2, meas
+    total = sum(loss_fns[d](preds[d], x[d], mask=masks.get(d)) for d in preds)
+    meas["loss_rel"] = abs(float(total) - float(fx["loss"])) / abs(float(fx["loss"]))
+    meas["loss_rel_if_dropout_were_off"] = abs(float(fx["loss_without_dropout"]) - float(fx["loss"])) / abs(float(fx["loss"]))
+    assert meas["loss_rel"] <= 3e-3 and meas["loss_rel"] < 0.5 * meas["loss_rel_if_dropout_were_off"], meas
+    total.backward()
+    params = dict(model.named_parameters())
+    tot = float(fx["grad_total_norm"])
+    worst = 0.0
+    for n, gn in zip(fx["grad_names"], fx["grad_norms"]):
+        mine = float(params[str(n)].grad.double().norm())
+        worst = max(worst, abs(mine - gn) / max(gn, 1e-3 * tot))
+    worst_t = 0.0
+    for key in fx:
+        if key.startswith("grad."):
+            r = torch.from_numpy(fx[key]).double()
+            worst_t = max(worst_t, float((params[key[5:]].grad.cpu().double() - r).norm() / max(float(r.norm()), 1e-3 * tot)))
+    meas.update(grad_worst_rel=worst, grad_tensor_worst_rel=worst_t)
+    report("tiny3_attn_dropout", **meas)
+    assert worst <= 1.5e-2 and worst_t <= 3e-2, meas
+    # encoder alone at the fixture's step; every forward advances the step (new masks) -- also in eval mode, as with the reference's SDPA call
+    oa = model.output_adapters
+    model.output_adapters = None
+    with torch.no_grad():
+        E.DropoutRNG.set(DEV, meta["drop_seed"], meta["drop_step"] - 1)
+        enc, _ = model({d: x[d] for d in doms}, num_encoded_tokens=Kk, mask_noise=noise)
+        assert rel_rms(enc.float().cpu(), torch.from_numpy(fx["enc_tokens"])) <= 1e-2
+        model.eval()
+        v1, _ = model({d: x[d] for d in doms}, num_encoded_tokens=Kk, mask_noise=noise)
+        v2, _ = model({d: x[d] for d in doms}, num_encoded_tokens=Kk, mask_noise=noise)
+        assert not torch.equal(v1, v2)
+    model.output_adapters = oa
+
+
+@pytest.mark.parametrize("fixture", ["tiny3_dropout", "tiny3_attn_dropout"])
+def test_dropout_graph_replay_draws_new_masks_and_matches_eager(fixture):
+    """TrainStep with drop_rate > 0 (or attn_drop_rate > 0): the Philox step lives on the device and is advanced inside the captured graph, so
+    replays draw fresh masks, and a graph-replayed run equals the eager run step for step (same seed): losses bit-identical over 4 steps."""
     from mirage_amd import builder, optim, engine as E
     from mirage_amd.trainer import TrainStep
     from oracle import mirage_oracle as O
-    fx, meta = load_golden("tiny3_dropout")
+    fx, meta = load_golden(fixture)
     cfg, B, Kk = meta["cfg"], meta["B"], meta["K"]
     doms = cfg["in_domains"]
     x = {d: t.to(DEV) for d, t in O.synthetic_batch(cfg, B, seed=meta["data_seed"]).items()}

@@ -298,3 +298,39 @@ def test_dropout_training_mode_matches_reference():
         l0, _, _, _ = O.forward_loss(cfg, sd, x, _t(fx["ids_keep"]), _t(fx["ids_restore"]))
     assert abs(float(l0) - float(fx["loss_without_dropout"])) <= 1e-5 * abs(float(l0))
     assert abs(float(l0) - float(fx["loss"])) > 1e-3 * abs(float(l0))
+
+
+def test_attention_probability_dropout_matches_reference():
+    """attn_drop_rate > 0 (A16; mirage/model.py:55,88 and output_adapters.py:64 -> utils.py:181-185, 216-220: SDPA's dropout_p): the fixture
+    is the reference model with scaled_dot_product_attention replayed as softmax -> dropout of the probabilities -> @ v on the engine's
+    Philox masks (tools/gen_golden.py run_attn_dropout_case; encoder 0.15, decoders 0.1).  The oracle must reproduce its encoder tokens,
+    predictions, loss and every gradient norm, and must differ when the masks are left out."""
+    fx, meta = load_golden("tiny3_attn_dropout")
+    cfg, B, K = meta["cfg"], meta["B"], meta["K"]
+    assert cfg["attn_drop_rate"] == pytest.approx(0.15) and cfg["decoder_attn_drop_rate"] == pytest.approx(0.1)
+    state = (meta["drop_seed"], meta["drop_step"])
+    sd = {k: v.clone().requires_grad_(O.param_shapes(cfg)[k][1]) for k, v in O.procedural_state_dict(cfg).items()}
+    x = O.synthetic_batch(cfg, B, seed=meta["data_seed"])
+    loss, ls, enc, preds = O.forward_loss(cfg, sd, x, _t(fx["ids_keep"]), _t(fx["ids_restore"]), drop_state=state)
+    np.testing.assert_allclose(enc.detach().numpy(), fx["enc_tokens"], rtol=2e-5, atol=5e-5)
+    for d in preds:
+        np.testing.assert_allclose(preds[d].detach().numpy(), fx[f"pred.{d}"], rtol=1e-4, atol=1e-4)
+        assert abs(float(ls[d]) - float(fx[f"loss.{d}"])) <= 1e-5 * abs(float(fx[f"loss.{d}"]))
+    assert abs(float(loss) - float(fx["loss"])) <= 1e-5 * abs(float(fx["loss"]))
+    loss.backward()
+    for n, gn in zip(fx["grad_names"], fx["grad_norms"]):
+        g = sd[str(n)].grad
+        assert g is not None, n
+        assert abs(float(g.double().norm()) - gn) <= 2e-4 * max(gn, 1e-3 * float(fx["grad_total_norm"])), (str(n), float(g.double().norm()), gn)
+    for key in fx:
+        if key.startswith("grad."):
+            np.testing.assert_allclose(sd[key[5:]].grad.numpy(), fx[key], rtol=2e-3, atol=2e-6 * float(fx["grad_total_norm"]))
+    with torch.no_grad():
+        l0, _, _, _ = O.forward_loss(cfg, sd, x, _t(fx["ids_keep"]), _t(fx["ids_restore"]))
+    assert abs(float(l0) - float(fx["loss_without_dropout"])) <= 1e-5 * abs(float(l0))
+    assert abs(float(l0) - float(fx["loss"])) > 1e-4 * abs(float(l0))
+    # the mask: padded-to-4 key axis, the rate follows p, streams differ
+    f = O.attention_dropout_factor(2, 3, 50, 129, (0.2, 7, 1, 0x10000))
+    assert f.shape == (2, 3, 50, 129) and abs(float((f == 0).float().mean()) - 0.2) < 0.01 and float(f.max()) == pytest.approx(1.25)
+    assert torch.equal(f.reshape(-1, 129), O.dropout_factor(2 * 3 * 50, 132, 0.2, 7, 1, 0x10000)[:, :129])
+    assert not torch.equal(f, O.attention_dropout_factor(2, 3, 50, 129, (0.2, 7, 1, 0x10001)))

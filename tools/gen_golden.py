@@ -41,7 +41,7 @@ with contextlib.redirect_stdout(io.StringIO()):
 OUT = os.path.join(ROOT, "tests", "golden")
 
 
-def build_reference(cfg, drop_path_rate=0.0, drop_rate=0.0):
+def build_reference(cfg, drop_path_rate=0.0, drop_rate=0.0, attn_drop_rate=0.0, decoder_attn_drop_rate=0.0):
     """Adapters exactly as run_pretraining.py:380-403 builds them, model as mirage/model.py:43."""
     args = types.SimpleNamespace()
     args.input_size = {d: (c["image"], c["image"]) for d, c in cfg["domains"].items()}
@@ -61,10 +61,10 @@ def build_reference(cfg, drop_path_rate=0.0, drop_rate=0.0):
                                      dim_tokens=cfg["decoder_dim"], depth=cfg["decoder_depth"],
                                      num_heads=cfg["decoder_heads"], use_task_queries=True, task=d,
                                      context_tasks=list(cfg["in_domains"]), use_xattn=True,
-                                     image_size=(c["image"], c["image"]))
+                                     image_size=(c["image"], c["image"]), attn_drop_rate=decoder_attn_drop_rate)
     model = MIRAGEModel(args, input_adapters=ia, output_adapters=oa if cfg["out_domains"] else None,
                         num_global_tokens=cfg["num_global_tokens"], dim_tokens=cfg["dim"], depth=cfg["depth"],
-                        num_heads=cfg["heads"], drop_path_rate=drop_path_rate, drop_rate=drop_rate)
+                        num_heads=cfg["heads"], drop_path_rate=drop_path_rate, drop_rate=drop_rate, attn_drop_rate=attn_drop_rate)
     return model
 
 
@@ -329,6 +329,110 @@ def run_dropout_case(name, cfg, B, K, data_seed, mask_seed, drop_seed, drop_step
     np.savez_compressed(os.path.join(OUT, name + ".npz"), **fx)
 
 
+class ReplayedSDPA:
+    """Stand-in for torch.nn.functional inside the reference's mirage/utils.py: scaled_dot_product_attention(q, k, v, scale, dropout_p)
+    (utils.py:181-185, 216-220) computed as torch documents it -- softmax(scale q k^T), torch.dropout of the probabilities, @ v -- with
+    the dropout mask taken from the engine's counter-based definition (oracle.attention_dropout_factor) instead of torch's generator.
+    `streams`: the mask stream of every attention call of one forward pass, in call order.  Everything else is torch.nn.functional."""
+
+    def __init__(self, seed, step, streams):
+        self.seed, self.step, self.streams, self.calls = seed, step, list(streams), 0
+
+    def __getattr__(self, name):
+        return getattr(torch.nn.functional, name)
+
+    def scaled_dot_product_attention(self, q, k, v, scale=None, dropout_p=0.0):
+        B, H, Nq, hd = q.shape
+        att = torch.softmax((q @ k.transpose(-1, -2)) * (scale if scale is not None else hd ** -0.5), dim=-1)
+        stream = self.streams[self.calls % len(self.streams)]
+        self.calls += 1
+        if dropout_p > 0.0:
+            att = att * O.attention_dropout_factor(B, H, Nq, k.shape[2], (dropout_p, self.seed, self.step, stream)).to(att.dtype)
+        return att @ v
+
+
+def run_attn_dropout_case(name, cfg, B, K, data_seed, mask_seed, drop_seed, drop_step):
+    """attn_drop_rate > 0 in the encoder blocks (mirage/model.py:55,88) and in the output adapters (output_adapters.py:64): the REFERENCE
+    model, forward + losses + backward, with torch.nn.functional.scaled_dot_product_attention replayed by ReplayedSDPA inside mirage.utils."""
+    import mirage.utils as RU
+    pe, pd = cfg["attn_drop_rate"], cfg["decoder_attn_drop_rate"]
+    print(f"== {name}: B={B} K={K} attn_drop_rate={pe} decoder attn_drop_rate={pd}")
+    with contextlib.redirect_stdout(io.StringIO()):
+        model = build_reference(cfg, attn_drop_rate=pe, decoder_attn_drop_rate=pd)
+    model.load_state_dict(O.procedural_state_dict(cfg), strict=True)
+    model.train()
+    streams = [0x10000 + i for i in range(cfg["depth"])]
+    for a in range(len(cfg["out_domains"])):
+        streams += [0x20000 + 256 * a] + [0x20000 + 256 * a + 1 + j for j in range(cfg["decoder_depth"])]
+    x = O.synthetic_batch(cfg, B, seed=data_seed)
+    x_in = {d: x[d] for d in cfg["in_domains"]}
+    p, u, g = replay_mask_noise(cfg, B, mask_seed)
+    fx = {"p": p, "g": g}
+    for d, ud in zip(cfg["in_domains"], u):
+        fx[f"u.{d}"] = ud
+    captured = {}
+    first = cfg["out_domains"][0]
+    orig = model.output_adapters[first].forward
+
+    def spy(encoder_tokens, input_info, ids_keep, ids_restore):
+        captured["enc"] = encoder_tokens
+        captured["ids_keep"], captured["ids_restore"] = ids_keep, ids_restore
+        return orig(encoder_tokens=encoder_tokens, input_info=input_info, ids_keep=ids_keep, ids_restore=ids_restore)
+    model.output_adapters[first].forward = spy
+    shim = ReplayedSDPA(drop_seed, drop_step, streams)
+    real_F, RU.F = RU.F, shim
+    try:
+        torch.manual_seed(mask_seed)
+        with contextlib.redirect_stdout(io.StringIO()):
+            preds, task_masks = model(x_in, num_encoded_tokens=K, alphas=1.0, sample_tasks_uniformly=False)
+        assert shim.calls == len(streams), (shim.calls, len(streams))      # every attention of the model went through the replay
+        fx["ids_keep"], fx["ids_restore"] = captured["ids_keep"].numpy(), captured["ids_restore"].numpy()
+        fx["enc_tokens"] = captured["enc"].detach().numpy()
+        loss_fns = reference_losses(cfg)
+        task_losses = {d: loss_fns[d](preds[d].float(), x[d], mask=task_masks.get(d)) for d in preds}
+        loss = sum(task_losses.values())
+        for d in preds:
+            fx[f"loss.{d}"] = np.float64(task_losses[d].item())
+            fx[f"pred.{d}"] = preds[d].detach().numpy().astype(np.float32)
+        fx["loss"] = np.float64(loss.item())
+        loss.backward()
+    finally:
+        RU.F = real_F
+    names, norms = [], []
+    for n_, p_ in model.named_parameters():
+        if p_.grad is not None:
+            names.append(n_); norms.append(p_.grad.double().norm().item())
+    fx["grad_names"] = np.array(names)
+    fx["grad_norms"] = np.array(norms, dtype=np.float64)
+    fx["grad_total_norm"] = np.float64(get_grad_norm_(model.parameters()).item())
+    for n_ in ("encoder.0.attn.qkv.weight", f"encoder.{cfg['depth'] - 1}.attn.qkv.bias", f"output_adapters.{first}.decoder.kv.weight",
+               f"output_adapters.{first}.decoder_transformer.0.attn.qkv.weight", "global_tokens"):
+        fx[f"grad.{n_}"] = dict(model.named_parameters())[n_].grad.detach().numpy()
+    # the same pass without the dropout: the masks must matter
+    with contextlib.redirect_stdout(io.StringIO()):
+        ref0 = build_reference(cfg)
+    ref0.load_state_dict(O.procedural_state_dict(cfg), strict=True)
+    ref0.train()
+    torch.manual_seed(mask_seed)
+    with contextlib.redirect_stdout(io.StringIO()):
+        preds0, tm0 = ref0(x_in, num_encoded_tokens=K, alphas=1.0, sample_tasks_uniformly=False)
+    loss0 = sum(loss_fns[d](preds0[d].float(), x[d], mask=tm0.get(d)) for d in preds0)
+    fx["loss_without_dropout"] = np.float64(loss0.item())
+    # the oracle must reproduce the reference
+    ik, ir = torch.from_numpy(fx["ids_keep"]), torch.from_numpy(fx["ids_restore"])
+    sd = {k: v.clone().requires_grad_(False) for k, v in O.procedural_state_dict(cfg).items()}
+    with torch.no_grad():
+        ol, _, oenc, opreds = O.forward_loss(cfg, sd, x, ik, ir, drop_state=(drop_seed, drop_step))
+    err = (oenc - captured["enc"].detach()).abs().max().item()
+    perr = max((opreds[d] - preds[d].detach()).abs().max().item() for d in preds)
+    print(f"   oracle vs reference: enc max abs err {err:.3e}, pred max abs err {perr:.3e}, loss {float(ol):.6f} vs {loss.item():.6f} "
+          f"(without dropout {loss0.item():.6f}); {shim.calls} attention calls replayed")
+    assert err < 1e-4 and perr < 1e-3 and abs(float(ol) - loss.item()) < 1e-5 * abs(loss.item())
+    assert abs(loss0.item() - loss.item()) > 1e-4 * abs(loss.item())
+    fx["meta"] = np.array(json.dumps(dict(cfg=cfg, B=B, K=K, data_seed=data_seed, mask_seed=mask_seed, drop_seed=drop_seed, drop_step=drop_step)))
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **fx)
+
+
 def run_train_curve(name, cfg, B, K, steps=5):
     """5-step AdamW curve through the reference's optimizer factory + cosine schedules
     (run_pretraining.py:496-515,683-742), fp32, no AMP."""
@@ -589,6 +693,11 @@ def main():
                                                   layermap_size=16, layermap_patch=2, decoder_dim=64, decoder_depth=2, decoder_heads=2,
                                                   dim=128, depth=4, heads=2), drop_rate=0.1), B=6, K=24, data_seed=17, mask_seed=29,
                                                   drop_seed=0x1234ABCD5678, drop_step=3),
+        "tiny3_attn_dropout": lambda: run_attn_dropout_case("tiny3_attn_dropout", dict(O.make_config(model="tiny", in_domains=three, input_size=64,
+                                                            patch_size=8, layermap_size=16, layermap_patch=2, decoder_dim=64, decoder_depth=2,
+                                                            decoder_heads=2, dim=128, depth=4, heads=2), attn_drop_rate=0.15,
+                                                            decoder_attn_drop_rate=0.1), B=6, K=24, data_seed=19, mask_seed=31,
+                                                            drop_seed=0x0BADC0FFEE12, drop_step=5),
         "tiny3_droppath": lambda: run_droppath_case("tiny3_droppath", dict(O.make_config(model="tiny", in_domains=three, input_size=64, patch_size=8,
                                                     layermap_size=16, layermap_patch=2, decoder_dim=64, decoder_depth=2, decoder_heads=2,
                                                     dim=128, depth=4, heads=2, drop_path_rate=0.4)), B=6, K=24, data_seed=13, mask_seed=23),
