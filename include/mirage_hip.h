@@ -26,7 +26,7 @@ extern "C" {
 typedef struct ihipStream_t* hipStream_t;
 #endif
 
-#define MRG_ABI_VERSION 11   /* 11: mrg_attn_desc.drop_rng / drop_p / drop_stream (dropout on the attention probabilities), mrg_debug_clock_monitor; 10: MRG_GEMM_P8SK (stream-K schedule of the 8-phase kernel), mrg_gemm_desc.sk_grid, mrg_wgrad_group_desc.streamk / counters / sk_grid, mrg_streamk_ws_bytes; 9: mrg_maskgen_rng, input slots (mrg_set_slots, *_slot parameters, mrg_loss_desc.target_slot); 8: mrg_gemm_desc.drop_rng / drop_p / drop_stream, mrg_dropout_bwd_bf16; 7: mrg_wgrad_group, mrg_debug_timestamp; 2: mrg_gemm_desc grew row_scale / defer_reduce, act codes 3, 4, reduce_batch / augment / row_scale entry points; 3: colsum_out, attention colsum_*; 4: step = int[2], mrg_step_inc takes the skip decision; 5: splitk_counters, MRG_GEMM_P8, resize entry points; 6: mrg_adamw_desc.sumsq_out, mrg_sumsq_finish */
+#define MRG_ABI_VERSION 11   /* 11: mrg_attn_desc.drop_rng / drop_p / drop_stream (dropout on the attention probabilities), mrg_posemb_grad, mrg_debug_clock_monitor; 10: MRG_GEMM_P8SK (stream-K schedule of the 8-phase kernel), mrg_gemm_desc.sk_grid, mrg_wgrad_group_desc.streamk / counters / sk_grid, mrg_streamk_ws_bytes; 9: mrg_maskgen_rng, input slots (mrg_set_slots, *_slot parameters, mrg_loss_desc.target_slot); 8: mrg_gemm_desc.drop_rng / drop_p / drop_stream, mrg_dropout_bwd_bf16; 7: mrg_wgrad_group, mrg_debug_timestamp; 2: mrg_gemm_desc grew row_scale / defer_reduce, act codes 3, 4, reduce_batch / augment / row_scale entry points; 3: colsum_out, attention colsum_*; 4: step = int[2], mrg_step_inc takes the skip decision; 5: splitk_counters, MRG_GEMM_P8, resize entry points; 6: mrg_adamw_desc.sumsq_out, mrg_sumsq_finish */
 
 enum { MRG_DT_BF16 = 0, MRG_DT_F32 = 1 };
 enum { MRG_OP_KCONTIG = 0, MRG_OP_KSTRIDED = 1 };
@@ -221,6 +221,12 @@ int mrg_embed_plan(const long* ids_keep, int B, int K, int N, int ndom, const in
  * mirage/input_adapters.py:101,229) is a plain k-strided GEMM over contiguous rows. */
 int mrg_gather_rows_bf16(const void* src_bf16, long src_ld, const int* map, const int* count_dev, int cap, int D, void* dst_bf16,
                          hipStream_t stream);
+/* d pos_emb of a learnable positional embedding (mirage/input_adapters.py:72,104-108 / :185,232-236): out fp32 [D][T] (the parameter's
+ * [1, D, h, w] layout) = for every token t the sum, over the samples that kept it, of the embedding-gradient row dx[row][0 .. D) (row
+ * stride ld floats).  rows / toks / srcb / count_dev: one modality's compact lists from mrg_embed_plan; inv_ws: workspace int [B * T].
+ * rows = NULL: every sample holds every token at row b * T + t (the adapter's stand-alone forward).  Sample order, no atomics. */
+int mrg_posemb_grad(const float* dx, long ld, int D, const int* rows, const int* toks, const int* srcb, const int* count_dev,
+                    int cap, int B, int T, int* inv_ws, float* out, hipStream_t stream);
 int mrg_im2col_image(const float* img, const int* srcb, const int* toks, const int* count_dev, int cap, int C, int H, int W,
                      int P, void* out_bf16, const void* const* img_slot, hipStream_t stream);
 int mrg_im2col_layermap(const long* labels, const float* class_emb, const int* srcb, const int* toks, const int* count_dev,

@@ -82,6 +82,7 @@ class AdamWDesc(C.Structure):
 # name -> (restype, argtypes); kept in sync with include/mirage_hip.h (tests/test_abi.py checks the exports)
 SIGNATURES = {
     "mrg_version": (ci, []),
+    "mrg_posemb_grad": (ci, [vp, cl, ci, vp, vp, vp, vp, ci, ci, ci, vp, vp, vp]),
     "mrg_debug_timestamp": (ci, [vp, vp]),
     "mrg_debug_clock_monitor": (ci, [vp, ci, ci, vp]),
     "mrg_debug_sk_trace": (ci, [vp]),

@@ -51,13 +51,15 @@ def make_args(in_domains: Sequence[str], out_domains: Optional[Sequence[str]] = 
     return a
 
 
-def get_model(args, model_name: str = "miragepre_base", with_decoders: bool = True, decoder_attn_drop_rate: float = 0.0, **model_kwargs):
+def get_model(args, model_name: str = "miragepre_base", with_decoders: bool = True, decoder_attn_drop_rate: float = 0.0,
+              learnable_pos_emb: bool = False, **model_kwargs):
     """Adapters + model (run_pretraining.py:373-419).  model_kwargs (dim_tokens / depth / num_heads) allow the
     reduced-size models used by the parity fixtures; decoder_attn_drop_rate is SpatialOutputAdapter's attn_drop_rate
-    (mirage/output_adapters.py:64; run_pretraining.py leaves it 0)."""
+    (mirage/output_adapters.py:64; run_pretraining.py leaves it 0); learnable_pos_emb is the INPUT adapters' option
+    (mirage/input_adapters.py:34,140; run_pretraining.py leaves it False)."""
     input_adapters = {
         d: DOMAIN_CONF[d]["input_adapter"](stride_level=DOMAIN_CONF[d]["stride_level"], patch_size_full=tuple(args.patch_size[d]),
-                                           image_size=args.input_size[d])
+                                           image_size=args.input_size[d], learnable_pos_emb=learnable_pos_emb)
         for d in args.in_domains
     }
     output_adapters = None

@@ -330,6 +330,46 @@ extern "C" int mrg_class_emb_grad(const void* dA_bf16, const long* labels, const
     return mrg_check_launch("mrg_class_emb_grad/finish");
 }
 
+// ---- gradient of a learnable positional embedding (mirage/input_adapters.py:72,185: nn.Parameter(pos_emb, requires_grad=learnable_pos_emb);
+// x = proj(patch) + pos_emb[token], so d pos_emb[:, token] = sum over the samples that kept the token of the embedding gradient row).
+// Deterministic: the compact (sample, token) -> row lists of mrg_embed_plan are first inverted into inv[b][t] (each pair occurs at most
+// once), then every token sums its rows in sample order.  The parameter is laid out [1, D, h, w]: out[d * T + t].
+namespace {
+__global__ void posemb_inv_kernel(const int* __restrict__ rows, const int* __restrict__ toks, const int* __restrict__ srcb,
+                                  const int* __restrict__ count_dev, int cap, int T, int* __restrict__ inv) {
+    const int n = count_dev ? min(*count_dev, cap) : cap;
+    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < n; e += gridDim.x * blockDim.x) inv[(long)srcb[e] * T + toks[e]] = rows[e];
+}
+__global__ __launch_bounds__(256) void posemb_grad_kernel(const float* __restrict__ dx, long ld, int D, const int* __restrict__ inv, int B, int T,
+                                                          float* __restrict__ out) {
+    const int t = blockIdx.x;
+    for (int d = threadIdx.x; d < D; d += blockDim.x) {
+        float acc = 0.f;
+        for (int b = 0; b < B; ++b) {
+            const int r = inv ? inv[(long)b * T + t] : b * T + t;
+            if (r >= 0) acc += dx[(long)r * ld + d];
+        }
+        out[(long)d * T + t] = acc;
+    }
+}
+}  // namespace
+
+extern "C" int mrg_posemb_grad(const float* dx, long ld, int D, const int* rows, const int* toks, const int* srcb, const int* count_dev,
+                               int cap, int B, int T, int* inv_ws, float* out, hipStream_t stream) {
+    MRG_REQUIRE(dx && out && D > 0 && B > 0 && T > 0, MRG_ERR_ARG, "mrg_posemb_grad: bad arguments");
+    if (rows != nullptr) {
+        MRG_REQUIRE(toks && srcb && inv_ws && cap > 0, MRG_ERR_ARG, "mrg_posemb_grad: the compact lists need toks, srcb and inv_ws[B * T]");
+        hipError_t e = hipMemsetAsync(inv_ws, 0xFF, sizeof(int) * (size_t)B * T, stream);
+        MRG_REQUIRE(e == hipSuccess, MRG_ERR_ARG, "mrg_posemb_grad: memset failed: %s", hipGetErrorString(e));
+        hipLaunchKernelGGL(posemb_inv_kernel, dim3((unsigned)((cap + 255) / 256 < 1024 ? (cap + 255) / 256 : 1024)), dim3(256), 0, stream,
+                           rows, toks, srcb, count_dev, cap, T, inv_ws);
+        const int rc = mrg_check_launch("mrg_posemb_grad/invert");
+        if (rc) return rc;
+    }
+    hipLaunchKernelGGL(posemb_grad_kernel, dim3(T), dim3(256), 0, stream, dx, ld, D, rows ? inv_ws : nullptr, B, T, out);
+    return mrg_check_launch("mrg_posemb_grad");
+}
+
 extern "C" int mrg_fill_global(float* x, const float* global_tokens, int B, int N, int K, int ng, int D, hipStream_t stream) {
     MRG_REQUIRE(x && global_tokens, MRG_ERR_ARG, "mrg_fill_global: null pointer");
     MRG_REQUIRE(N == K + ng, MRG_ERR_SHAPE, "mrg_fill_global: N != K + ng");

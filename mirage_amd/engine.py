@@ -583,7 +583,9 @@ def _pos_tokens(adapter) -> torch.Tensor:
     identity: input_adapters.py:104,232, output_adapters.py:176,221)."""
     pe = adapter.pos_emb
     cache = getattr(adapter, "_mrg_pos_tok", None)
-    if cache is None or cache[0] != (pe.data_ptr(), pe._version):
+    # a learnable table (learnable_pos_emb, mirage/input_adapters.py:72) is re-read every pass: the fused optimizer updates the arena in
+    # place without touching the tensor's version counter
+    if cache is None or pe.requires_grad or cache[0] != (pe.data_ptr(), pe._version):
         _, D, h, w = pe.shape
         tok = pe.detach()[0].permute(1, 2, 0).reshape(h * w, D).contiguous().float()
         adapter._mrg_pos_tok = ((pe.data_ptr(), pe._version), tok)
@@ -653,6 +655,9 @@ def embed_bwd(model, saved_all, dx32: torch.Tensor, dx16: Optional[torch.Tensor]
                        splitk=K.pick_splitk(D, Kp, max(cap // len(doms), 64)))
         if ad.proj.bias.requires_grad:
             K.colsum(dx32.view(B * N, D), grad_buffer(ad.proj.bias), M=cap, row_map=rows[d], m_dev=cnt)
+        if ad.pos_emb.requires_grad:
+            dom_start = model._dom_start(doms)
+            K.posemb_grad(dx32.view(B * N, D), grad_buffer(ad.pos_emb), B, dom_start[d + 1] - dom_start[d], plan=(rows[d], toks[d], srcb[d], cnt, cap))
         if ad.kind == "semseg" and ad.class_emb.weight.requires_grad:
             W = shadow(ad.proj.weight)
             dA = torch.empty((cap, Kp), dtype=BF16, device=dx32.device)

@@ -58,6 +58,8 @@ class _AllTokensFn(torch.autograd.Function):
             K.gemm(dy16, shadow(ad.proj.weight), cap, Kp, D, b_mode=KS, lda=D, ldb=Kp, out=dA, ldc=Kp)
             ncls, Ee = ad.class_emb.weight.shape
             K.class_emb_grad(dA, x.contiguous(), srcb[0], toks[0], counts[0:1], ncls, Ee, ad.P_H, grad_buffer(ad.class_emb.weight))
+        if ad.pos_emb.requires_grad:                 # learnable_pos_emb (mirage/input_adapters.py:72,185): every sample holds every token
+            K.posemb_grad(dy32.view(cap, D), grad_buffer(ad.pos_emb), B, T)
         return (None,) * len(ctx.needs_input_grad)
 
 
@@ -94,8 +96,6 @@ class PatchedInputAdapter(nn.Module):
         else:
             self.pos_emb = nn.Parameter(torch.zeros(1, self.dim_tokens, h_posemb, w_posemb))
             trunc_normal_(self.pos_emb, std=0.02)
-        if self.pos_emb.requires_grad:
-            raise NotImplementedError("mirage_amd: learnable positional embeddings are not implemented (pretraining freezes them)")
         self.proj = nn.Conv2d(in_channels=self.num_channels, out_channels=self.dim_tokens, kernel_size=(self.P_H, self.P_W),
                               stride=(self.P_H, self.P_W))
 
@@ -110,7 +110,7 @@ class PatchedInputAdapter(nn.Module):
         if (H // self.P_H, W // self.P_W) != tuple(self.pos_emb.shape[-2:]):
             raise NotImplementedError("mirage_amd: positional-embedding resampling at forward time is not implemented; "
                                       "resample the checkpoint with mirage_amd.checkpoint.interpolate_pos_embed")
-        return _AllTokensFn.apply(x, self, self.proj.weight, self.proj.bias)
+        return _AllTokensFn.apply(x, self, self.proj.weight, self.proj.bias, self.pos_emb)
 
 
 class SemSegInputAdapter(nn.Module):
@@ -153,8 +153,6 @@ class SemSegInputAdapter(nn.Module):
         else:
             self.pos_emb = nn.Parameter(torch.zeros(1, self.dim_tokens, h_posemb, w_posemb))
             trunc_normal_(self.pos_emb, std=0.02)
-        if self.pos_emb.requires_grad:
-            raise NotImplementedError("mirage_amd: learnable positional embeddings are not implemented (pretraining freezes them)")
         self.class_emb = nn.Embedding(num_embeddings=self.num_classes, embedding_dim=self.dim_class_emb, padding_idx=self.emb_padding_idx)
         trunc_normal_(self.class_emb.weight, std=0.02)
         self.proj = nn.Conv2d(in_channels=self.dim_class_emb, out_channels=self.dim_tokens, kernel_size=(self.P_H, self.P_W),
@@ -170,4 +168,4 @@ class SemSegInputAdapter(nn.Module):
         assert (H % self.P_H == 0) and (W % self.P_W == 0), f"Image sizes {H}x{W} must be divisible by patch sizes {self.P_H}x{self.P_W}"
         if (H // self.P_H, W // self.P_W) != tuple(self.pos_emb.shape[-2:]):
             raise NotImplementedError("mirage_amd: positional-embedding resampling at forward time is not implemented")
-        return _AllTokensFn.apply(x, self, self.proj.weight, self.proj.bias, self.class_emb.weight)
+        return _AllTokensFn.apply(x, self, self.proj.weight, self.proj.bias, self.class_emb.weight, self.pos_emb)

@@ -626,6 +626,21 @@ def gather_rows_bf16(src: torch.Tensor, row_map: torch.Tensor, count_dev: torch.
     return out
 
 
+def posemb_grad(dx32: torch.Tensor, out: torch.Tensor, B: int, T: int, plan=None):
+    """out (the [1, D, h, w] gradient buffer of a learnable pos_emb) = per-token sums of the embedding-gradient rows dx32 [rows, D];
+    plan = (rows, toks, srcb, count_dev, cap) of one modality (mrg_embed_plan), or None when dx32 is [B * T, D] with every token present."""
+    D = dx32.shape[-1]
+    if plan is None:
+        check(lib.mrg_posemb_grad(dx32.data_ptr(), dx32.stride(-2), D, None, None, None, None, 0, B, T, None, out.data_ptr(), _s()),
+              "mrg_posemb_grad")
+        return out
+    rows, toks, srcb, cnt, cap = plan
+    inv = torch.empty(B * T, dtype=torch.int32, device=dx32.device)
+    check(lib.mrg_posemb_grad(dx32.data_ptr(), dx32.stride(-2), D, rows.data_ptr(), toks.data_ptr(), srcb.data_ptr(), cnt.data_ptr(), cap,
+                              B, T, inv.data_ptr(), out.data_ptr(), _s()), "mrg_posemb_grad")
+    return out
+
+
 def embed_plan(ids_keep: torch.Tensor, N: int, dom_start: Sequence[int]):
     _need_cuda(ids_keep, "ids_keep")
     B, K = ids_keep.shape

@@ -36,7 +36,8 @@ def _build(cfg, with_decoders=True):
     if cfg.get("attn_drop_rate", 0.0) > 0.0:
         extra["attn_drop_rate"] = cfg["attn_drop_rate"]
     model = builder.get_model(args, with_decoders=with_decoders and bool(cfg["out_domains"]), dim_tokens=cfg["dim"], depth=cfg["depth"],
-                              num_heads=cfg["heads"], decoder_attn_drop_rate=cfg.get("decoder_attn_drop_rate", 0.0), **extra)
+                              num_heads=cfg["heads"], decoder_attn_drop_rate=cfg.get("decoder_attn_drop_rate", 0.0),
+                              learnable_pos_emb=bool(cfg.get("learnable_pos_emb", False)), **extra)
     sd = O.procedural_state_dict(cfg)
     missing = model.load_state_dict(sd, strict=True)
     return model.to(DEV), args, sd
@@ -161,6 +162,53 @@ def test_tiny3_end_to_end():
 
 def test_tiny2_end_to_end():
     _case("tiny2")
+
+
+def test_learnable_positional_embeddings_end_to_end():
+    """learnable_pos_emb=True on the input adapters (mirage/input_adapters.py:34,72 / :140,185): the tables are trainable parameters; the
+    fixture is the reference's forward + losses + backward with them (tests/golden/tiny3_learnpos.npz), so `grad_names` holds the three
+    pos_emb gradients (mrg_posemb_grad: per-token sums over the samples that kept the token).  An optimizer step then moves the tables and
+    the next forward reads the moved values."""
+    from mirage_amd import builder, optim
+    from oracle import mirage_oracle as O
+    fx, meta = load_golden("tiny3_learnpos")
+    assert sum("pos_emb" in str(n) for n in fx["grad_names"]) == 3
+    _case("tiny3_learnpos")
+    cfg, B, Kk = meta["cfg"], meta["B"], meta["K"]
+    model, args, _ = _build(cfg)
+    model.train()
+    x = {d: t.to(DEV) for d, t in O.synthetic_batch(cfg, B, seed=meta["data_seed"]).items()}
+    doms = cfg["in_domains"]
+    noise = (torch.from_numpy(fx["p"]).to(DEV), torch.cat([torch.from_numpy(fx[f"u.{d}"]) for d in doms], 1).to(DEV), torch.from_numpy(fx["g"]).to(DEV))
+    opt = optim.FusedAdamW(model, [1e-2] * 4, [0.0] * 4)
+    loss_fns = builder.get_losses(args)
+    pe0 = {d: model.input_adapters[d].pos_emb.detach().clone() for d in doms}
+    def loss_of():
+        preds, masks = model({d: x[d] for d in doms}, num_encoded_tokens=Kk, mask_noise=noise)
+        return sum(loss_fns[d](preds[d], x[d], mask=masks.get(d)) for d in preds)
+    l0 = loss_of()
+    opt.zero_grad(); l0.backward(); opt.step()
+    for d in doms:
+        pe = model.input_adapters[d].pos_emb
+        assert pe.requires_grad and float((pe.detach() - pe0[d]).abs().max()) > 1e-3, d       # lr 1e-2: every touched entry moves by ~lr
+    from mirage_amd import engine as E
+    for d in doms:                         # the next forward reads the moved table (the fused optimizer updates the arena behind the tensor's back)
+        ad = model.input_adapters[d]
+        D, (h, wd) = ad.pos_emb.shape[1], ad.pos_emb.shape[-2:]
+        assert torch.equal(E._pos_tokens(ad), ad.pos_emb.detach()[0].permute(1, 2, 0).reshape(h * wd, D).float())
+    with torch.no_grad():
+        assert torch.isfinite(loss_of())
+    # the stand-alone adapter forward (every token of every sample) differentiates the table too: d pos_emb = sum over the batch of dy
+    ad = model.input_adapters[doms[0]]
+    img = x[doms[0]]
+    model.zero_grad(set_to_none=False)
+    y = ad(img)
+    w = torch.randn_like(y)
+    (y * w).sum().backward()
+    D, (h, wd) = y.shape[-1], ad.pos_emb.shape[-2:]
+    want = w.sum(0).t().reshape(1, D, h, wd)
+    from mirage_amd.arena import grad_buffer
+    torch.testing.assert_close(grad_buffer(ad.pos_emb).view(1, D, h, wd), want, rtol=1e-5, atol=1e-5)
 
 
 def test_c2_base_end_to_end():

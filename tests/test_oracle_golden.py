@@ -72,6 +72,16 @@ def test_tiny2_forward_backward():
     _run_case("tiny2", check_inter=True)
 
 
+def test_tiny3_learnable_positional_embeddings():
+    """learnable_pos_emb=True on the input adapters (mirage/input_adapters.py:72,185): the reference's gradients of the three positional
+    tables are in the fixture, and the oracle's autograd reproduces them (they are ordinary differentiable inputs of input_tokens)."""
+    fx, meta = load_golden("tiny3_learnpos")
+    assert meta["cfg"]["learnable_pos_emb"] is True
+    assert sorted(str(n) for n in fx["grad_names"] if "pos_emb" in str(n)) == sorted(f"input_adapters.{d}.pos_emb" for d in meta["cfg"]["in_domains"])
+    assert all(O.param_shapes(meta["cfg"])[f"input_adapters.{d}.pos_emb"][1] for d in meta["cfg"]["in_domains"])
+    _run_case("tiny3_learnpos")
+
+
 def test_c2_base_full_size():
     _run_case("c2_base")
 

@@ -51,10 +51,11 @@ def build_reference(cfg, drop_path_rate=0.0, drop_rate=0.0, attn_drop_rate=0.0, 
         c = cfg["domains"][d]
         if c["kind"] == "semseg":
             ia[d] = SemSegInputAdapter(num_classes=13, dim_class_emb=64, interpolate_class_emb=False, stride_level=1,
-                                       patch_size_full=(c["patch"], c["patch"]), image_size=(c["image"], c["image"]))
+                                       patch_size_full=(c["patch"], c["patch"]), image_size=(c["image"], c["image"]),
+                                       learnable_pos_emb=bool(cfg.get("learnable_pos_emb", False)))
         else:
             ia[d] = PatchedInputAdapter(num_channels=1, stride_level=1, patch_size_full=(c["patch"], c["patch"]),
-                                        image_size=(c["image"], c["image"]))
+                                        image_size=(c["image"], c["image"]), learnable_pos_emb=bool(cfg.get("learnable_pos_emb", False)))
     for d in cfg["out_domains"]:
         c = cfg["domains"][d]
         oa[d] = SpatialOutputAdapter(num_channels=c["channels"], stride_level=1, patch_size_full=(c["patch"], c["patch"]),
@@ -686,6 +687,8 @@ def main():
     jobs = {
         "tiny3": lambda: run_case("tiny3", tiny_cfg(three), B=3, K=24, data_seed=11, mask_seed=21, keep_intermediate=True),
         "tiny2": lambda: run_case("tiny2", tiny_cfg(("bscan", "slo")), B=2, K=32, data_seed=12, mask_seed=22, keep_intermediate=True),
+        # learnable_pos_emb=True on the input adapters (mirage/input_adapters.py:72,185): the positional tables get gradients
+        "tiny3_learnpos": lambda: run_case("tiny3_learnpos", dict(tiny_cfg(three), learnable_pos_emb=True), B=5, K=24, data_seed=14, mask_seed=24),
         "tiny3_curve": lambda: run_train_curve("tiny3_curve", tiny_cfg(three), B=4, K=24, steps=5),
         "harness": lambda: run_harness_fixtures(tiny_cfg(three)),
         "tiny3_optstate": lambda: run_optstate_case("tiny3_optstate", tiny_cfg(three), B=4, K=24, steps=4),
