@@ -69,7 +69,7 @@ class LossDesc(C.Structure):
     _fields_ = [("kind", ci), ("pred", vp), ("pred_dtype", ci), ("target", vp), ("mask", vp),
                 ("B", ci), ("C", ci), ("H", ci), ("W", ci), ("P", ci),
                 ("partial", vp), ("loss", vp), ("coef", vp), ("per_sample", vp), ("gout", vp), ("dpred", vp),
-                ("target_slot", vp), ("pred_tokens", ci)]
+                ("target_slot", vp), ("pred_tokens", ci), ("label_smoothing", cf), ("norm_pix", ci), ("stats", vp)]
 
 
 class AdamWDesc(C.Structure):

@@ -20,11 +20,11 @@ class MaskedCrossEntropyLoss(nn.Module):
         self.scale_factor = patch_size[0] // stride
         self.label_smoothing = label_smoothing
         self.epoch = 0
-        if label_smoothing != 0.0:
-            raise NotImplementedError("mirage_amd: label_smoothing != 0 is not implemented (run_pretraining.py:55 uses 0.0)")
+        if not (0.0 <= float(label_smoothing) < 1.0):
+            raise ValueError(f"MaskedCrossEntropyLoss: label_smoothing = {label_smoothing!r} must be in [0, 1)")
 
     def forward(self, input, target, mask=None):
-        return MaskedLossFn.apply(input, target, mask, L.MRG_LOSS_CE, self.scale_factor)
+        return MaskedLossFn.apply(input, target, mask, L.MRG_LOSS_CE, self.scale_factor, float(self.label_smoothing))
 
 
 class MaskedMSELoss(nn.Module):
@@ -38,8 +38,6 @@ class MaskedMSELoss(nn.Module):
             self.scale_factor = patch_size[0] // stride
         self.norm_pix = norm_pix
         self.epoch = 0
-        if norm_pix:
-            raise NotImplementedError("mirage_amd: norm_pix targets are not implemented (the pretraining config leaves it False)")
 
     def forward(self, input, target, mask=None):
-        return MaskedLossFn.apply(input, target, mask, L.MRG_LOSS_MSE, self.scale_factor)
+        return MaskedLossFn.apply(input, target, mask, L.MRG_LOSS_MSE, self.scale_factor, 0.0, bool(self.norm_pix))

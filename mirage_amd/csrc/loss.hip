@@ -39,12 +39,40 @@ __device__ __forceinline__ float block_sum(float v, float* red) {
     return s;  // valid in thread 0
 }
 
+// norm_pix (criterion.py:92-98): the MSE target is normalised per patch over its (ph pw c) elements -- (t - mean) / sqrt(var + 1e-6) with
+// torch.var's unbiased estimate.  One workgroup per (token, sample) writes stats[(b ntok + tok) 2] = {mean, 1 / sqrt(var + eps)}.
+__global__ __launch_bounds__(256) void patch_stats_kernel(const float* __restrict__ target, const void* const* __restrict__ tslot, int C, int H, int W,
+                                                          int P, float* __restrict__ stats) {
+    if (tslot) target = reinterpret_cast<const float*>(*tslot);
+    __shared__ float red[4];
+    __shared__ float s_mean;
+    const int tk = blockIdx.x, b = blockIdx.y, nw = W / P, ntok = (H / P) * nw;
+    const int ty = tk / nw, tx = tk - ty * nw;
+    const int n = C * P * P;
+    const long HW = (long)H * W;
+    auto at = [&](int e) { const int c = e / (P * P), r = e - c * P * P, py = r / P, px = r - py * P;
+                           return target[((long)b * C + c) * HW + (long)(ty * P + py) * W + tx * P + px]; };
+    float s = 0.f;
+    for (int e = threadIdx.x; e < n; e += blockDim.x) s += at(e);
+    const float ts = block_sum(s, red);
+    if (threadIdx.x == 0) s_mean = ts / (float)n;
+    __syncthreads();
+    const float mean = s_mean;
+    float q = 0.f;
+    for (int e = threadIdx.x; e < n; e += blockDim.x) { const float d = at(e) - mean; q += d * d; }
+    const float tq = block_sum(q, red);
+    if (threadIdx.x == 0) {
+        stats[((long)b * ntok + tk) * 2 + 0] = mean;
+        stats[((long)b * ntok + tk) * 2 + 1] = rsqrtf(tq / (float)(n - 1) + 1e-6f);
+    }
+}
+
 // grid (LOSS_CHUNKS, B); partial [B][LOSS_CHUNKS][2] = (sum of masked per-pixel loss, masked pixel count)
 template <typename T, bool CE>
 __global__ __launch_bounds__(256) void loss_fwd_kernel(const T* __restrict__ pred, const void* __restrict__ target,
                                                        const void* const* __restrict__ tslot,
                                                        const long* __restrict__ mask, int B, int C, int H, int W, int P, int tok,
-                                                       float* __restrict__ partial) {
+                                                       float smooth, const float* __restrict__ stats, float* __restrict__ partial) {
     if (tslot) target = *tslot;                              // input slot: the batch is read where it lies (mirage_hip.h, "Input slots")
     __shared__ float red[4];
     const int b = blockIdx.y, chunk = blockIdx.x;
@@ -58,15 +86,19 @@ __global__ __launch_bounds__(256) void loss_fwd_kernel(const T* __restrict__ pre
         float l;
         if (CE) {
             const int t = (int)reinterpret_cast<const long*>(target)[(long)b * HW + px];
-            float mx = -INFINITY, zt = 0.f;
-            for (int c = 0; c < C; ++c) { const float z = ldf<T>(pred, pred_index(tok, b, c, y, x, C, H, W, P)); mx = fmaxf(mx, z); zt = (c == t) ? z : zt; }
+            float mx = -INFINITY, zt = 0.f, zs = 0.f;
+            for (int c = 0; c < C; ++c) { const float z = ldf<T>(pred, pred_index(tok, b, c, y, x, C, H, W, P)); mx = fmaxf(mx, z); zt = (c == t) ? z : zt; zs += z; }
             float se = 0.f;
             for (int c = 0; c < C; ++c) se += __expf(ldf<T>(pred, pred_index(tok, b, c, y, x, C, H, W, P)) - mx);
-            l = mx + __logf(se) - zt;
+            // F.cross_entropy(label_smoothing = e) = (1 - e) nll + e mean_c(-log p_c) = lse - (1 - e) z_t - e mean_c z_c  (criterion.py:33)
+            l = mx + __logf(se) - (1.f - smooth) * zt - smooth * zs / (float)C;
         } else {
             float q = 0.f;
+            const float* st = stats ? stats + ((long)b * (H / P) * nw + (y / P) * nw + x / P) * 2 : nullptr;
             for (int c = 0; c < C; ++c) {
-                const float d = ldf<T>(pred, pred_index(tok, b, c, y, x, C, H, W, P)) - reinterpret_cast<const float*>(target)[((long)b * C + c) * HW + px];
+                float tv = reinterpret_cast<const float*>(target)[((long)b * C + c) * HW + px];
+                if (st) tv = (tv - st[0]) * st[1];
+                const float d = ldf<T>(pred, pred_index(tok, b, c, y, x, C, H, W, P)) - tv;
                 q += d * d;
             }
             l = q / (float)C;
@@ -126,7 +158,7 @@ __global__ __launch_bounds__(256) void loss_bwd_kernel(const T* __restrict__ pre
                                                        const void* const* __restrict__ tslot,
                                                        const long* __restrict__ mask, const float* __restrict__ coef,
                                                        const float* __restrict__ gout, int B, int C, int H, int W, int P, int tok,
-                                                       T* __restrict__ dpred) {
+                                                       float smooth, const float* __restrict__ stats, T* __restrict__ dpred) {
     if (tslot) target = *tslot;
     const long HW = (long)H * W;
     const long total = (long)B * HW;
@@ -149,13 +181,16 @@ __global__ __launch_bounds__(256) void loss_bwd_kernel(const T* __restrict__ pre
             for (int c = 0; c < C; ++c) {
                 const long j = pred_index(tok, b, c, y, x, C, H, W, P);
                 const float p = __expf(ldf<T>(pred, j) - mx) * inv;
-                stf<T>(dpred, j, k * (p - (c == t ? 1.f : 0.f)));
+                stf<T>(dpred, j, k * (p - (c == t ? 1.f - smooth : 0.f) - smooth / (float)C));
             }
         } else {
             const float kk = k * 2.f / (float)C;
+            const float* st = stats ? stats + ((long)b * (H / P) * nw + (y / P) * nw + x / P) * 2 : nullptr;
             for (int c = 0; c < C; ++c) {
                 const long j = ((long)b * C + c) * HW + px, jp = pred_index(tok, b, c, y, x, C, H, W, P);
-                stf<T>(dpred, jp, kk * (ldf<T>(pred, jp) - reinterpret_cast<const float*>(target)[j]));
+                float tv = reinterpret_cast<const float*>(target)[j];
+                if (st) tv = (tv - st[0]) * st[1];
+                stf<T>(dpred, jp, kk * (ldf<T>(pred, jp) - tv));
             }
         }
     }
@@ -265,13 +300,21 @@ extern "C" int mrg_masked_loss_fwd(const mrg_loss_desc* d, hipStream_t stream) {
     if (rc) return rc;
     MRG_REQUIRE(d->loss, MRG_ERR_ARG, "mrg_masked_loss_fwd: null loss pointer");
     dim3 grid(LOSS_CHUNKS, d->B), block(256);
-    const bool vec_mse = d->kind == MRG_LOSS_MSE && d->C == 1 && d->pred_dtype == MRG_DT_BF16 && d->P % 8 == 0 && d->W % 8 == 0 &&
+    const bool vec_mse = d->kind == MRG_LOSS_MSE && d->C == 1 && d->pred_dtype == MRG_DT_BF16 && d->P % 8 == 0 && d->W % 8 == 0 && !d->norm_pix &&
                          (((uintptr_t)d->pred | (uintptr_t)d->target) & 15) == 0;
+    if (d->norm_pix) {
+        MRG_REQUIRE(d->kind == MRG_LOSS_MSE && d->stats != nullptr && d->C * d->P * d->P > 1, MRG_ERR_ARG,
+                    "mrg_masked_loss_fwd: norm_pix needs the MSE kind, a stats workspace and more than one element per patch");
+        hipLaunchKernelGGL(patch_stats_kernel, dim3((d->H / d->P) * (d->W / d->P), d->B), dim3(256), 0, stream, (const float*)d->target, d->target_slot,
+                           d->C, d->H, d->W, d->P, d->stats);
+        rc = mrg_check_launch("mrg_masked_loss_fwd/norm_pix");
+        if (rc) return rc;
+    }
     if (vec_mse) {
         hipLaunchKernelGGL(mse1_fwd_vec_kernel, grid, block, 0, stream, (const bf16_t*)d->pred, (const float*)d->target, d->target_slot, d->mask, d->B, d->H,
                            d->W, d->P, d->pred_tokens, d->partial);
     } else {
-#define MRG_L(T, CE) hipLaunchKernelGGL((loss_fwd_kernel<T, CE>), grid, block, 0, stream, (const T*)d->pred, d->target, d->target_slot, d->mask, d->B, d->C, d->H, d->W, d->P, d->pred_tokens, d->partial)
+#define MRG_L(T, CE) hipLaunchKernelGGL((loss_fwd_kernel<T, CE>), grid, block, 0, stream, (const T*)d->pred, d->target, d->target_slot, d->mask, d->B, d->C, d->H, d->W, d->P, d->pred_tokens, d->label_smoothing, d->norm_pix ? d->stats : nullptr, d->partial)
     if (d->pred_dtype == MRG_DT_BF16) { if (d->kind == MRG_LOSS_CE) MRG_L(bf16_t, true); else MRG_L(bf16_t, false); }
     else { if (d->kind == MRG_LOSS_CE) MRG_L(float, true); else MRG_L(float, false); }
 #undef MRG_L
@@ -288,14 +331,15 @@ extern "C" int mrg_masked_loss_bwd(const mrg_loss_desc* d, hipStream_t stream) {
     MRG_REQUIRE(d->dpred, MRG_ERR_ARG, "mrg_masked_loss_bwd: null dpred");
     const long total = (long)d->B * d->H * d->W;
     dim3 grid((unsigned)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096)), block(256);
-    const bool vec_mse = d->kind == MRG_LOSS_MSE && d->C == 1 && d->pred_dtype == MRG_DT_BF16 && d->P % 8 == 0 && d->W % 8 == 0 &&
+    const bool vec_mse = d->kind == MRG_LOSS_MSE && d->C == 1 && d->pred_dtype == MRG_DT_BF16 && d->P % 8 == 0 && d->W % 8 == 0 && !d->norm_pix &&
                          (((uintptr_t)d->pred | (uintptr_t)d->target | (uintptr_t)d->dpred) & 15) == 0;
+    MRG_REQUIRE(!d->norm_pix || d->stats != nullptr, MRG_ERR_ARG, "mrg_masked_loss_bwd: norm_pix needs the stats the forward call filled");
     if (vec_mse) {
         hipLaunchKernelGGL(mse1_bwd_vec_kernel, dim3((unsigned)((total / 8 + 255) / 256 < 4096 ? (total / 8 + 255) / 256 : 4096)), block, 0, stream,
                            (const bf16_t*)d->pred, (const float*)d->target, d->target_slot, d->mask, d->coef, d->gout, d->B, d->H, d->W, d->P, d->pred_tokens, (bf16_t*)d->dpred);
         return mrg_check_launch("mrg_masked_loss_bwd");
     }
-#define MRG_L(T, CE) hipLaunchKernelGGL((loss_bwd_kernel<T, CE>), grid, block, 0, stream, (const T*)d->pred, d->target, d->target_slot, d->mask, d->coef, d->gout, d->B, d->C, d->H, d->W, d->P, d->pred_tokens, (T*)d->dpred)
+#define MRG_L(T, CE) hipLaunchKernelGGL((loss_bwd_kernel<T, CE>), grid, block, 0, stream, (const T*)d->pred, d->target, d->target_slot, d->mask, d->coef, d->gout, d->B, d->C, d->H, d->W, d->P, d->pred_tokens, d->label_smoothing, d->norm_pix ? d->stats : nullptr, (T*)d->dpred)
     if (d->pred_dtype == MRG_DT_BF16) { if (d->kind == MRG_LOSS_CE) MRG_L(bf16_t, true); else MRG_L(bf16_t, false); }
     else { if (d->kind == MRG_LOSS_CE) MRG_L(float, true); else MRG_L(float, false); }
 #undef MRG_L

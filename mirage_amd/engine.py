@@ -829,6 +829,7 @@ class LaneLosses:
     computes the task losses after the model call (run_pretraining.py:713-721); as separate autograd nodes they run one after the other
     on the calling stream between the join of the decoders' forward lanes and the fork of their backward lanes -- 150 us (C2) / 300 us
     (C4) of serial small launches.  With `spec` = {task: (kind, patch, target, use_mask)} model.forward hands each adapter its loss:
+    (optionally a fifth and sixth entry: the label smoothing of a cross-entropy loss, norm_pix of an MSE loss);
     the lane that ran the adapter runs the loss forward right behind out_proj, DecodersFn returns the loss scalars, and its backward
     starts every lane with that task's loss backward.  Same kernels on the same data: bit-identical to the separate nodes
     (MRG_LANE_LOSSES=0).  `preds` keeps the (detached) predictions of the last pass for callers that read them (parity tests)."""
@@ -902,7 +903,7 @@ class DecodersFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, enc32, enc16, adapters, dom_names, dom_start, ng, ids_keep, ids_restore, save, defer_join, loss_spec, *params):
-        """loss_spec: None, or one (kind, patch, target, mask or None) per adapter (LaneLosses): the node then returns the task LOSSES"""
+        """loss_spec: None, or one (kind, patch, target, mask or None, label smoothing, norm_pix) per adapter (LaneLosses): the node then returns the task LOSSES"""
         ctx.defer_join = defer_join
         enc32 = enc32.contiguous().float()
         if enc16 is None:
@@ -913,8 +914,8 @@ class DecodersFn(torch.autograd.Function):
             img, sv = decoder_fwd(ad, enc32, enc16, ids_keep, ids_restore, doms_l, start_l, ng, save)
             if loss_spec is None:
                 return img, sv, None
-            kind, patch, target, mask = loss_spec[i]
-            d = K.loss_desc(kind, img, target, mask, patch)
+            kind, patch, target, mask, smooth, npix = loss_spec[i]
+            d = K.loss_desc(kind, img, target, mask, patch, smoothing=smooth, norm_pix=npix)
             loss, coef, partial = K.masked_loss_fwd(d, img.device)
             return loss, sv, (d, coef, partial, img)
         jobs = [(lambda i=i, ad=ad: job(i, ad)) for i, ad in enumerate(adapters)]
@@ -968,14 +969,14 @@ class MaskedLossFn(torch.autograd.Function):
     """MaskedMSELoss / MaskedCrossEntropyLoss (mirage/criterion.py:31-51, 87-117)."""
 
     @staticmethod
-    def forward(ctx, pred, target, mask, kind, patch):
+    def forward(ctx, pred, target, mask, kind, patch, smoothing=0.0, norm_pix=False):
         pred = pred.contiguous()
         target = target.contiguous()
         if kind == L.MRG_LOSS_MSE:
             target = target.float()
         if mask is not None:
             mask = mask.contiguous().long()
-        d = K.loss_desc(kind, pred, target, mask, patch)
+        d = K.loss_desc(kind, pred, target, mask, patch, smoothing=smoothing, norm_pix=norm_pix)
         loss, coef, partial = K.masked_loss_fwd(d, pred.device)
         ctx.d, ctx.keep = d, (pred, target, mask, coef, partial)
         return loss
@@ -985,4 +986,4 @@ class MaskedLossFn(torch.autograd.Function):
         pred, target, mask, coef, partial = ctx.keep
         dpred = K.masked_loss_bwd(ctx.d, coef, partial, gout.contiguous().float(), pred)
         ctx.keep = None
-        return dpred, None, None, None, None
+        return dpred, None, None, None, None, None, None

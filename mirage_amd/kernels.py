@@ -791,9 +791,11 @@ def dec_assemble_bwd(d: "L.DecAssembleDesc", d_queries, d_context, d_task_embs, 
 
 
 # ---------------------------------------------------------------------------------------------- losses
-def loss_desc(kind, pred, target, mask, P):
+def loss_desc(kind, pred, target, mask, P, smoothing: float = 0.0, norm_pix: bool = False):
+    """smoothing: label smoothing of the cross entropy (criterion.py:22,33); norm_pix: per-patch normalised MSE targets (criterion.py:92-98)"""
     _need_cuda(pred, "loss input")
     d = L.LossDesc()
+    d.label_smoothing = float(smoothing) if kind == L.MRG_LOSS_CE else 0.0
     if pred.dim() == 3:
         # predictions in the decoder's token layout [B, tokens, C*P*P] (engine.DecodersFn with token_layout): geometry from the target
         H, W = target.shape[-2:]
@@ -807,7 +809,11 @@ def loss_desc(kind, pred, target, mask, P):
     d.kind, d.pred, d.pred_dtype = kind, pred.data_ptr(), (L.MRG_DT_BF16 if pred.dtype == BF16 else L.MRG_DT_F32)
     d.target, d.mask, d.target_slot = target.data_ptr(), _p(mask), slot_of(target)
     d.B, d.C, d.H, d.W, d.P = B, Cc, H, W, P
-    d._refs = (pred, target, mask)
+    stats = None
+    if norm_pix and kind == L.MRG_LOSS_MSE:
+        stats = torch.empty(B * (H // P) * (W // P) * 2, dtype=F32, device=pred.device)
+        d.norm_pix, d.stats = 1, stats.data_ptr()
+    d._refs = (pred, target, mask, stats)
     return d
 
 

@@ -166,7 +166,9 @@ class TrainStep:
             from . import _lib as L
             E.LaneLosses.defer_join = self._defer_join = bool(LANE_DEFER_JOIN and self.reducer is None)
             E.LaneLosses.spec = {t: (L.MRG_LOSS_MSE if isinstance(self.loss_fns[t], MaskedMSELoss) else L.MRG_LOSS_CE, self.loss_fns[t].scale_factor,
-                                     x[t], not self.loss_on_unmasked) for t in self.model.output_adapters.keys()}
+                                     x[t], not self.loss_on_unmasked, float(getattr(self.loss_fns[t], "label_smoothing", 0.0)),
+                                     bool(getattr(self.loss_fns[t], "norm_pix", False)))
+                                 for t in self.model.output_adapters.keys()}
         try:
             return self.model({d: x[d] for d in self.in_domains}, num_encoded_tokens=self.K, alphas=self.alphas,
                               sample_tasks_uniformly=self.uniform, mask_noise=self.static_noise)

@@ -758,6 +758,88 @@ def test_masked_mse_and_ce(K, dtype):
     assert float(loss) == 0.0 and float(coef.abs().max()) == 0.0
 
 
+@pytest.mark.parametrize("dtype", [F32, BF16])
+def test_cross_entropy_label_smoothing(K, dtype):
+    """mrg_loss_desc.label_smoothing against the REFERENCE's MaskedCrossEntropyLoss(label_smoothing = e) on the committed problem
+    (tests/golden/loss_smoothing.npz: losses + logit gradients, e in {0.1, 0.3}, masked / plain), image and token layout; and through the
+    criterion module."""
+    from mirage_amd import _lib as L
+    from mirage_amd.criterion import MaskedCrossEntropyLoss
+    from conftest import load_golden
+    fx, meta = load_golden("loss_smoothing")
+    logits32 = torch.from_numpy(fx["logits"]).to(dev())
+    target, mask, P = torch.from_numpy(fx["target"]).to(dev()), torch.from_numpy(fx["mask"]).to(dev()), int(fx["patch"])
+    logits = logits32.to(dtype)
+    B, C, H, W = logits.shape
+    g = H // P
+    tok = logits.reshape(B, C, g, P, g, P).permute(0, 2, 4, 1, 3, 5).reshape(B, g * g, C * P * P).contiguous()
+    for e in (0.1, 0.3):
+        for tag, m in (("masked", mask), ("plain", None)):
+            want_l, want_g = float(fx[f"loss.{e}.{tag}"]), torch.from_numpy(fx[f"dlogits.{e}.{tag}"]).to(dev())
+            keep = ~torch.isnan(want_g)
+            for pred in (logits, tok):
+                d = K.loss_desc(L.MRG_LOSS_CE, pred, target, m, P, smoothing=e)
+                loss, coef, part = K.masked_loss_fwd(d, dev())
+                assert abs(float(loss) - want_l) <= (2e-3 if dtype == BF16 else 1e-5) * abs(want_l), (e, tag, float(loss), want_l)
+                dp = K.masked_loss_bwd(d, coef, part, None, pred).float()
+                if pred is tok:
+                    dp = dp.reshape(B, g, g, C, P, P).permute(0, 3, 1, 4, 2, 5).reshape(B, C, H, W)
+                if dtype == BF16:                     # bf16 logits in, bf16 gradients out: compare in the rms sense
+                    assert rel_rms(dp[keep], want_g[keep]) < 1e-2
+                else:
+                    torch.testing.assert_close(dp[keep], want_g[keep], rtol=1e-4, atol=1e-8)
+            fn = MaskedCrossEntropyLoss(patch_size=(P, P), stride=1, label_smoothing=e)
+            x = logits.clone().requires_grad_(True)
+            l = fn(x, target, mask=m)
+            assert abs(float(l) - want_l) <= (2e-3 if dtype == BF16 else 1e-5) * abs(want_l)
+            l.backward()
+            if dtype == BF16:
+                assert rel_rms(x.grad.float()[keep], want_g[keep]) < 1e-2
+            else:
+                torch.testing.assert_close(x.grad.float()[keep], want_g[keep], rtol=1e-4, atol=1e-8)
+    with pytest.raises(ValueError, match="label_smoothing"):
+        MaskedCrossEntropyLoss(patch_size=(P, P), label_smoothing=1.0)
+
+
+@pytest.mark.parametrize("dtype", [F32, BF16])
+def test_mse_with_per_patch_normalised_targets(K, dtype):
+    """mrg_loss_desc.norm_pix against the REFERENCE's MaskedMSELoss(norm_pix=True) on the committed problems (tests/golden/loss_norm_pix.npz),
+    image and token layout, masked / plain, and through the criterion module (1-channel bf16 leaves the vector fast path for this option)."""
+    from mirage_amd import _lib as L
+    from mirage_amd.criterion import MaskedMSELoss
+    from conftest import load_golden
+    fx, meta = load_golden("loss_norm_pix")
+    for tag in meta["cases"]:
+        pred32, target = torch.from_numpy(fx[f"{tag}.pred"]).to(dev()), torch.from_numpy(fx[f"{tag}.target"]).to(dev())
+        mask, P = torch.from_numpy(fx[f"{tag}.mask"]).to(dev()), int(fx[f"{tag}.patch"])
+        pred = pred32.to(dtype)
+        B, C, H, W = pred.shape
+        g = H // P
+        tok = pred.reshape(B, C, g, P, g, P).permute(0, 2, 4, 1, 3, 5).reshape(B, g * g, C * P * P).contiguous()
+        for mt, m in (("masked", mask), ("plain", None)):
+            want_l, want_g = float(fx[f"{tag}.loss.{mt}"]), torch.from_numpy(fx[f"{tag}.dpred.{mt}"]).to(dev())
+            keep = ~torch.isnan(want_g)
+            for pr in (pred, tok):
+                d = K.loss_desc(L.MRG_LOSS_MSE, pr, target, m, P, norm_pix=True)
+                loss, coef, part = K.masked_loss_fwd(d, dev())
+                assert abs(float(loss) - want_l) <= (3e-3 if dtype == BF16 else 1e-5) * abs(want_l), (tag, mt, float(loss), want_l)
+                dp = K.masked_loss_bwd(d, coef, part, None, pr).float()
+                if pr is tok:
+                    dp = dp.reshape(B, g, g, C, P, P).permute(0, 3, 1, 4, 2, 5).reshape(B, C, H, W)
+                if dtype == BF16:
+                    assert rel_rms(dp[keep], want_g[keep]) < 1e-2
+                else:
+                    torch.testing.assert_close(dp[keep], want_g[keep], rtol=1e-4, atol=1e-8)
+            fn = MaskedMSELoss(patch_size=P, stride=1, norm_pix=True)
+            x = pred.clone().requires_grad_(True)
+            l = fn(x, target, mask=m)
+            assert abs(float(l) - want_l) <= (3e-3 if dtype == BF16 else 1e-5) * abs(want_l)
+            l.backward()
+            assert rel_rms(x.grad.float()[keep], want_g[keep]) < (1e-2 if dtype == BF16 else 1e-5)
+            l0 = MaskedMSELoss(patch_size=P, stride=1)(pred, target, mask=m)
+            assert abs(float(l0) - want_l) > 1e-2 * abs(want_l)                      # the option really changes the loss
+
+
 def test_patch_rearrange(K):
     B, C, g, P = 3, 13, 4, 2
     x = torch.randn(B, g * g, C * P * P, device=dev()).to(BF16)

@@ -344,3 +344,36 @@ def test_attention_probability_dropout_matches_reference():
     assert f.shape == (2, 3, 50, 129) and abs(float((f == 0).float().mean()) - 0.2) < 0.01 and float(f.max()) == pytest.approx(1.25)
     assert torch.equal(f.reshape(-1, 129), O.dropout_factor(2 * 3 * 50, 132, 0.2, 7, 1, 0x10000)[:, :129])
     assert not torch.equal(f, O.attention_dropout_factor(2, 3, 50, 129, (0.2, 7, 1, 0x10001)))
+
+
+def test_label_smoothing_of_the_cross_entropy_matches_reference():
+    """MaskedCrossEntropyLoss(label_smoothing = e) (mirage/criterion.py:22,33): losses and logit gradients of the reference on a committed
+    random problem (tests/golden/loss_smoothing.npz, tools/gen_golden.py run_loss_smoothing_fixture), e in {0.1, 0.3}, masked and plain."""
+    fx, _ = load_golden("loss_smoothing")
+    logits, target, mask, P = _t(fx["logits"]), _t(fx["target"]), _t(fx["mask"]), int(fx["patch"])
+    for e in (0.1, 0.3):
+        for tag, m in (("masked", mask), ("plain", None)):
+            x = logits.clone().requires_grad_(True)
+            l = O.masked_ce(x, target, m, P, label_smoothing=e)
+            assert abs(float(l) - float(fx[f"loss.{e}.{tag}"])) <= 1e-6 * abs(float(l))
+            l.backward()
+            want = fx[f"dlogits.{e}.{tag}"]
+            ok = ~np.isnan(want)                       # the reference back-propagates 0 / 0 into the sample without a masked token
+            np.testing.assert_allclose(x.grad.numpy()[ok], want[ok], rtol=1e-4, atol=1e-8)
+    assert abs(float(O.masked_ce(logits, target, mask, P)) - float(O.masked_ce(logits, target, mask, P, label_smoothing=0.1))) > 1e-3
+
+
+def test_norm_pix_targets_match_reference():
+    """MaskedMSELoss(norm_pix=True) (mirage/criterion.py:92-98): losses and prediction gradients of the reference on committed random
+    problems (tests/golden/loss_norm_pix.npz: 1 channel / patch 8 and 3 channels / patch 4; masked and plain)."""
+    fx, meta = load_golden("loss_norm_pix")
+    for tag in meta["cases"]:
+        pred, target, mask, P = _t(fx[f"{tag}.pred"]), _t(fx[f"{tag}.target"]), _t(fx[f"{tag}.mask"]), int(fx[f"{tag}.patch"])
+        for mt, m in (("masked", mask), ("plain", None)):
+            x = pred.clone().requires_grad_(True)
+            l = O.masked_mse(x, target, m, P, norm_pix=True)
+            assert abs(float(l) - float(fx[f"{tag}.loss.{mt}"])) <= 1e-6 * abs(float(l))
+            l.backward()
+            want = fx[f"{tag}.dpred.{mt}"]
+            ok = ~np.isnan(want)
+            np.testing.assert_allclose(x.grad.numpy()[ok], want[ok], rtol=1e-4, atol=1e-8)

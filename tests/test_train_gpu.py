@@ -696,13 +696,18 @@ def test_losses_on_the_adapter_lanes_are_the_same_step(monkeypatch):
     x = {d: t.to(DEV) for d, t in O.synthetic_batch(cfg, B, seed=177).items()}
     noise, _, _ = _noise_dev(cfg, B, Kk, 178)
 
-    def run(lanes, graph, unmasked, defer=False):
+    def run(lanes, graph, unmasked, defer=False, options=False):
         monkeypatch.setattr(trainer, "LANE_LOSSES", lanes)
         monkeypatch.setattr(trainer, "LANE_DEFER_JOIN", defer)
         model, args, _ = T._build(cfg)
         model.train()
         opt = optim.FusedAdamW(model, [1e-3] * 8, [0.05] * 8)
-        ts = trainer.TrainStep(model, builder.get_losses(args), opt, x, Kk, use_graph=graph, feed_mask_noise=True, loss_on_unmasked=unmasked)
+        fns = builder.get_losses(args)
+        if options:                       # the criteria's constructor options travel with the loss onto the lane (LaneLosses.spec)
+            from mirage_amd.criterion import MaskedCrossEntropyLoss, MaskedMSELoss
+            fns = {d: (MaskedCrossEntropyLoss(patch_size=f.patch_size, stride=f.stride, label_smoothing=0.1) if isinstance(f, MaskedCrossEntropyLoss)
+                       else MaskedMSELoss(patch_size=f.patch_size, stride=f.stride, norm_pix=True)) for d, f in fns.items()}
+        ts = trainer.TrainStep(model, fns, opt, x, Kk, use_graph=graph, feed_mask_noise=True, loss_on_unmasked=unmasked)
         ts.load(x)
         for dst, src in zip(ts.static_noise, noise):
             dst.copy_(src)
@@ -721,3 +726,8 @@ def test_losses_on_the_adapter_lanes_are_the_same_step(monkeypatch):
             assert torch.equal(o[2], b[2]) and torch.equal(o[3], b[3])
             for k in o[4]:
                 assert torch.equal(o[4][k], b[4][k])
+    # label smoothing (cross entropy) and norm_pix (MSE): same placement-independence, and the losses differ from the plain criteria's
+    a, b = run(True, True, False, options=True), run(False, True, False, options=True)
+    assert a[0] == b[0] and a[1] == b[1] and torch.equal(a[2], b[2]) and torch.equal(a[3], b[3])
+    plain = run(True, True, False)
+    assert all(abs(a[1][k] - plain[1][k]) > 1e-3 * abs(plain[1][k]) for k in a[1]), (a[1], plain[1])

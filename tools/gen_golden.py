@@ -434,6 +434,60 @@ def run_attn_dropout_case(name, cfg, B, K, data_seed, mask_seed, drop_seed, drop
     np.savez_compressed(os.path.join(OUT, name + ".npz"), **fx)
 
 
+def run_loss_smoothing_fixture(name="loss_smoothing"):
+    """MaskedCrossEntropyLoss(label_smoothing = e) of the reference (mirage/criterion.py:11-51) on a small random problem: inputs, the
+    loss and d loss / d logits for e in {0.1, 0.3}, with a token mask (one sample fully unmasked-out: the nanmean branch) and without."""
+    print(f"== {name}")
+    g = torch.Generator().manual_seed(77)
+    B, C, H, P = 4, 13, 16, 4
+    logits = torch.randn(B, C, H, H, generator=g) * 2.0
+    target = torch.randint(0, C, (B, H, H), generator=g)
+    mask = (torch.rand(B, (H // P) ** 2, generator=g) < 0.6).long()
+    mask[2] = 0                                                   # a sample without a masked token: 0 / 0 -> dropped by nanmean
+    fx = {"logits": logits.numpy(), "target": target.numpy(), "mask": mask.numpy(), "patch": np.int64(P)}
+    for e in (0.1, 0.3):
+        fn = MaskedCrossEntropyLoss(patch_size=(P, P), stride=1, label_smoothing=e)
+        for tag, m in (("masked", mask), ("plain", None)):
+            x = logits.clone().requires_grad_(True)
+            l = fn(x, target, mask=m)
+            l.backward()
+            fx[f"loss.{e}.{tag}"] = np.float64(l.item())
+            fx[f"dlogits.{e}.{tag}"] = x.grad.numpy().copy()
+            o = O.masked_ce(logits, target, m, P, label_smoothing=e)
+            assert abs(float(o) - l.item()) < 1e-6 * abs(l.item()), (e, tag, float(o), l.item())
+    fx["meta"] = np.array(json.dumps(dict(B=B, C=C, H=H, P=P)))
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **fx)
+    print("   losses:", {k: float(v) for k, v in fx.items() if k.startswith("loss.")})
+
+
+def run_norm_pix_fixture(name="loss_norm_pix"):
+    """MaskedMSELoss(norm_pix=True) of the reference (mirage/criterion.py:70-117) on small random problems (1 and 3 channels, patch 8 / 4):
+    inputs, loss and d loss / d pred, with a token mask (one sample without a masked token) and without."""
+    print(f"== {name}")
+    g = torch.Generator().manual_seed(78)
+    fx = {}
+    for tag, (B, C, H, P) in (("c1", (4, 1, 32, 8)), ("c3", (3, 3, 16, 4))):
+        pred = torch.randn(B, C, H, H, generator=g)
+        target = torch.rand(B, C, H, H, generator=g) * 3.0 + 0.5
+        mask = (torch.rand(B, (H // P) ** 2, generator=g) < 0.6).long()
+        mask[1] = 0
+        fx[f"{tag}.pred"], fx[f"{tag}.target"], fx[f"{tag}.mask"], fx[f"{tag}.patch"] = pred.numpy(), target.numpy(), mask.numpy(), np.int64(P)
+        fn = MaskedMSELoss(patch_size=P, stride=1, norm_pix=True)
+        for mt, m in (("masked", mask), ("plain", None)):
+            x = pred.clone().requires_grad_(True)
+            l = fn(x, target, mask=m)
+            l.backward()
+            fx[f"{tag}.loss.{mt}"] = np.float64(l.item())
+            fx[f"{tag}.dpred.{mt}"] = x.grad.numpy().copy()
+            o = O.masked_mse(pred, target, m, P, norm_pix=True)
+            assert abs(float(o) - l.item()) < 1e-6 * abs(l.item()), (tag, mt, float(o), l.item())
+            plain = MaskedMSELoss(patch_size=P, stride=1)(pred, target, mask=m)
+            assert abs(plain.item() - l.item()) > 1e-2 * abs(l.item())
+    fx["meta"] = np.array(json.dumps(dict(cases=["c1", "c3"])))
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **fx)
+    print("   losses:", {k: float(v) for k, v in fx.items() if ".loss." in k})
+
+
 def run_train_curve(name, cfg, B, K, steps=5):
     """5-step AdamW curve through the reference's optimizer factory + cosine schedules
     (run_pretraining.py:496-515,683-742), fp32, no AMP."""
@@ -689,6 +743,8 @@ def main():
         "tiny2": lambda: run_case("tiny2", tiny_cfg(("bscan", "slo")), B=2, K=32, data_seed=12, mask_seed=22, keep_intermediate=True),
         # learnable_pos_emb=True on the input adapters (mirage/input_adapters.py:72,185): the positional tables get gradients
         "tiny3_learnpos": lambda: run_case("tiny3_learnpos", dict(tiny_cfg(three), learnable_pos_emb=True), B=5, K=24, data_seed=14, mask_seed=24),
+        "loss_smoothing": lambda: run_loss_smoothing_fixture(),
+        "loss_norm_pix": lambda: run_norm_pix_fixture(),
         "tiny3_curve": lambda: run_train_curve("tiny3_curve", tiny_cfg(three), B=4, K=24, steps=5),
         "harness": lambda: run_harness_fixtures(tiny_cfg(three)),
         "tiny3_optstate": lambda: run_optstate_case("tiny3_optstate", tiny_cfg(three), B=4, K=24, steps=4),
