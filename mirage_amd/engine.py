@@ -595,8 +595,8 @@ def _pos_tokens(adapter) -> torch.Tensor:
 
 def embed_fwd(model, x: Dict[str, torch.Tensor], ids_keep: torch.Tensor, save: bool):
     """input adapters (mirage/input_adapters.py:87-110, 211-238) + token select + global tokens
-    (mirage/model.py:384-391), computing only the kept tokens."""
-    doms = list(model.input_adapters.keys())
+    (mirage/model.py:384-391), computing only the kept tokens.  The modalities and their order are x's (mirage/model.py:352-356)."""
+    doms = list(x.keys())
     B, Kk = ids_keep.shape
     ng = model.num_global_tokens
     N = Kk + ng
@@ -629,7 +629,15 @@ def embed_fwd(model, x: Dict[str, torch.Tensor], ids_keep: torch.Tensor, save: b
 
 def embed_bwd(model, saved_all, dx32: torch.Tensor, dx16: Optional[torch.Tensor]):
     (rows, toks, srcb, counts), A_list, inputs = saved_all
-    doms = list(model.input_adapters.keys())
+    doms = list(inputs.keys())
+    for name, ad in model.input_adapters.items():
+        if name not in inputs:
+            # a modality that was not in x: torch leaves its parameters' .grad at None and the optimizer skips them; here gradients are
+            # buffers that every backward pass overwrites, so the unused adapter's are cleared (an AdamW step then still applies its
+            # momentum and weight decay to them -- the one difference to the reference for such a training call)
+            for p_ in ad.parameters():
+                if p_.requires_grad:
+                    grad_buffer(p_).zero_()
     B, N, D = dx32.shape
     ng = model.num_global_tokens
     Kk = N - ng

@@ -258,10 +258,16 @@ class MIRAGEModel(nn.Module):
         mask generator (bit-exact parity tests); `drop_path_noise` [blocks with drop_path > 0, 2, B] feeds the uniform
         draws of stochastic depth (default: torch.rand on the device)."""
         x = {"bscan": x} if isinstance(x, Tensor) else x
+        # the reference tokenises x.items() in x's OWN order and only the modalities it finds there (mirage/model.py:352-356): a subset of the
+        # input adapters (features of one modality from a multi-modal checkpoint) and any key order are valid calls
         x = {d: t for d, t in x.items() if d in self.input_adapters}
-        doms = [d for d in self.input_adapters.keys() if d in x]
-        if len(doms) != len(self.input_adapters):
-            raise NotImplementedError("mirage_amd: every input adapter's modality must be present in x")
+        doms = list(x.keys())
+        if not doms:
+            raise ValueError(f"MIRAGEModel.forward: x holds none of the input adapters' modalities {list(self.input_adapters.keys())}")
+        if self.output_adapters is not None:
+            for task in self.output_adapters.keys():
+                if task not in x:
+                    raise KeyError(task)             # input_info['tasks'][self.task] (mirage/output_adapters.py:266): an output task must be an input
         first = x[doms[0]]
         B, device = first.shape[0], first.device
         self._ensure_arena(device)

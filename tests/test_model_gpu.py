@@ -491,6 +491,44 @@ def test_dropout_graph_replay_draws_new_masks_and_matches_eager(fixture):
     assert len(set(eager)) == 4
 
 
+def test_modalities_follow_the_keys_of_x():
+    """mirage/model.py:352-356 tokenises `x.items()`: the modalities present, in x's own order.  A 3-modal encoder fed {slo, bscan} (a subset, in
+    another order than the adapters') must equal the oracle run on that order with the same weights; with output adapters an absent output task
+    is the reference's KeyError (output_adapters.py:266)."""
+    from mirage_amd import builder
+    from oracle import mirage_oracle as O
+    _, meta = load_golden("tiny3")
+    cfg = meta["cfg"]
+    model, args, sd = _build(dict(cfg, out_domains=[]))
+    model.eval()
+    sub = ["slo", "bscan"]
+    assert list(model.input_adapters.keys()) != sub and len(model.input_adapters) == 3
+    cfg_sub = dict(cfg, in_domains=sub, out_domains=[])
+    B, Kk = 4, 20
+    x = O.synthetic_batch(cfg, B, seed=91)
+    rs = np.random.RandomState(5)
+    T = [cfg["domains"][d]["grid"] ** 2 for d in sub]
+    p = rs.gamma(1.0, size=(B, 2)).astype(np.float32); p /= p.sum(1, keepdims=True)
+    u = [rs.rand(B, t).astype(np.float32) for t in T]
+    g = rs.rand(B, sum(T)).astype(np.float32)
+    tm, ids_keep, ids_restore = O.generate_masks_from_noise(p, u, g, Kk)
+    with torch.no_grad():
+        want, _ = O.forward(cfg_sub, sd, {d: x[d] for d in sub}, torch.from_numpy(ids_keep), torch.from_numpy(ids_restore), decode=False)
+        noise = (torch.from_numpy(p).to(DEV), torch.cat([torch.from_numpy(a) for a in u], 1).to(DEV), torch.from_numpy(g).to(DEV))
+        enc, masks = model({d: x[d].to(DEV) for d in sub}, num_encoded_tokens=Kk, mask_noise=noise)
+        assert list(masks.keys()) == sub
+        assert rel_rms(enc.float().cpu(), want) <= 1e-2
+        enc2, masks2 = model({d: x[d].to(DEV) for d in reversed(sub)}, num_encoded_tokens=Kk, mask_noise=noise)
+        assert list(masks2.keys()) == sub[::-1] and not torch.equal(enc, enc2)      # same noise, other token order: another selection
+        one, _ = model({"bscan": x["bscan"].to(DEV)}, mask_inputs=False)
+        assert one.shape[1] == cfg["domains"]["bscan"]["grid"] ** 2 + cfg["num_global_tokens"]
+    full, _, _ = _build(cfg)
+    with pytest.raises(KeyError):
+        full({d: x[d].to(DEV) for d in sub}, num_encoded_tokens=Kk)
+    with pytest.raises(ValueError, match="none of the input adapters"):
+        model({"other": x["bscan"].to(DEV)})
+
+
 def test_mixed_token_grids_raise_like_the_reference():
     """The reference asserts that every context task has as many tokens as the decoding adapter's grid
     (mirage/output_adapters.py:176-179); the HIP path must fail the same way, not read out of bounds."""

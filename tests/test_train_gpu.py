@@ -731,3 +731,12 @@ def test_losses_on_the_adapter_lanes_are_the_same_step(monkeypatch):
     assert a[0] == b[0] and a[1] == b[1] and torch.equal(a[2], b[2]) and torch.equal(a[3], b[3])
     plain = run(True, True, False)
     assert all(abs(a[1][k] - plain[1][k]) > 1e-3 * abs(plain[1][k]) for k in a[1]), (a[1], plain[1])
+
+
+def test_graft_entry_smoke_runs():
+    """the driver's round-end smoke check (one tiny forward + backward + AdamW step against the oracle), as a test: it is not part of any
+    other test's path, and a change of the model's calling convention broke it unnoticed once"""
+    import importlib, sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    g = importlib.import_module("__graft_entry__")
+    g.smoke()
