@@ -1,6 +1,7 @@
 #!/bin/bash
 # same-box A/B of bench.py under environment settings: tools/ab.sh "<config> [config ...]" "ENV=a ENV2=b" "ENV=c" ...  (each quoted group is one arm)
-# an arm that starts with BASE runs the baseline worktree .ab_base (git worktree add .ab_base <rev>; build its csrc) with the rest as env
+# an arm that starts with BASE runs the baseline worktree .ab_base (git worktree add .ab_base <rev>; build its csrc; keep it out of commits
+# with `echo .ab_base/ >> .git/info/exclude`, remove it with `git worktree remove --force .ab_base`) with the rest as env
 # arms run interleaved, REPS (default 2) repetitions; prints ms_per_step per arm and repetition
 cfgs="$1"; shift
 reps=${REPS:-2}
