@@ -32,8 +32,14 @@ class SpatialOutputAdapter(nn.Module):
         self.use_xattn = use_xattn
         assert self.patch_size_full is not None
         assert self.image_size is not None
-        if not use_xattn or learnable_pos_emb or not qkv_bias:
-            raise NotImplementedError("mirage_amd.SpatialOutputAdapter: use_xattn=False / learnable_pos_emb / qkv_bias=False are "
+        if learnable_pos_emb:
+            # the reference allocates this table channels-LAST ([1, h, w, D], mirage/output_adapters.py:107) and then resamples it with
+            # F.interpolate as if it were [1, D, h, w] (:176, :221): its own forward fails on the shape mismatch, so there is no behaviour
+            # to reproduce
+            raise NotImplementedError("mirage_amd.SpatialOutputAdapter: learnable_pos_emb=True cannot run in the reference either "
+                                      "(mirage/output_adapters.py:107 vs :176)")
+        if not use_xattn or not qkv_bias:
+            raise NotImplementedError("mirage_amd.SpatialOutputAdapter: use_xattn=False / qkv_bias=False are "
                                       "not on the pretraining path (run_pretraining.py:126-148 defaults)")
         if drop_path_rate and drop_path_rate > 0.0 and depth > 0:
             # the engine's decoder pass (engine.decoder_fwd) runs its blocks without stochastic depth: refuse instead of silently dropping it
