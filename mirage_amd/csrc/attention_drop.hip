@@ -30,8 +30,6 @@ struct DropAttnArgs {
     MrgDropout drop;
 };
 
-__device__ __forceinline__ float bf2f(bf16_t x) { return __uint_as_float((uint32_t)x << 16); }
-
 template <int HD>
 __device__ __forceinline__ void load_row(const bf16_t* p, float (&r)[HD]) {
 #pragma unroll
