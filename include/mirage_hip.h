@@ -26,7 +26,7 @@ extern "C" {
 typedef struct ihipStream_t* hipStream_t;
 #endif
 
-#define MRG_ABI_VERSION 11   /* 11: mrg_attn_desc.drop_rng / drop_p / drop_stream (dropout on the attention probabilities), mrg_posemb_grad, mrg_loss_desc.label_smoothing / norm_pix / stats, mrg_debug_clock_monitor; 10: MRG_GEMM_P8SK (stream-K schedule of the 8-phase kernel), mrg_gemm_desc.sk_grid, mrg_wgrad_group_desc.streamk / counters / sk_grid, mrg_streamk_ws_bytes; 9: mrg_maskgen_rng, input slots (mrg_set_slots, *_slot parameters, mrg_loss_desc.target_slot); 8: mrg_gemm_desc.drop_rng / drop_p / drop_stream, mrg_dropout_bwd_bf16; 7: mrg_wgrad_group, mrg_debug_timestamp; 2: mrg_gemm_desc grew row_scale / defer_reduce, act codes 3, 4, reduce_batch / augment / row_scale entry points; 3: colsum_out, attention colsum_*; 4: step = int[2], mrg_step_inc takes the skip decision; 5: splitk_counters, MRG_GEMM_P8, resize entry points; 6: mrg_adamw_desc.sumsq_out, mrg_sumsq_finish */
+#define MRG_ABI_VERSION 11   /* 11: mrg_attn_desc.drop_rng / drop_p / drop_stream (dropout on the attention probabilities), mrg_posemb_grad, mrg_loss_desc.label_smoothing / norm_pix / stats, mrg_wgrad_group_desc.fuse + mrg_adamw_hp (AdamW in the weight-gradient epilogue), mrg_debug_clock_monitor; 10: MRG_GEMM_P8SK (stream-K schedule of the 8-phase kernel), mrg_gemm_desc.sk_grid, mrg_wgrad_group_desc.streamk / counters / sk_grid, mrg_streamk_ws_bytes; 9: mrg_maskgen_rng, input slots (mrg_set_slots, *_slot parameters, mrg_loss_desc.target_slot); 8: mrg_gemm_desc.drop_rng / drop_p / drop_stream, mrg_dropout_bwd_bf16; 7: mrg_wgrad_group, mrg_debug_timestamp; 2: mrg_gemm_desc grew row_scale / defer_reduce, act codes 3, 4, reduce_batch / augment / row_scale entry points; 3: colsum_out, attention colsum_*; 4: step = int[2], mrg_step_inc takes the skip decision; 5: splitk_counters, MRG_GEMM_P8, resize entry points; 6: mrg_adamw_desc.sumsq_out, mrg_sumsq_finish */
 
 enum { MRG_DT_BF16 = 0, MRG_DT_F32 = 1 };
 enum { MRG_OP_KCONTIG = 0, MRG_OP_KSTRIDED = 1 };
@@ -134,7 +134,20 @@ typedef struct mrg_wgrad_group_desc {
     int streamk;       /* != 0: stream-K schedule over the concatenated tile lists (splitk must be <= 1): ws = mrg_streamk_ws_bytes(sk_grid)
                           bytes of scratch, counters = one int per 256 x 256 tile of the whole group, ZERO on entry and left zero */
     int* counters; int sk_grid;
+    /* optional: AdamW applied by the launch itself.  A weight gradient produced here is final (the tile holds the whole contraction), so
+     * the epilogue of every tile also performs torch.optim.AdamW's update (mutils/optim_factory.py:180) of the parameter elements it
+     * covers: C_p must then point INTO the gradient arena fuse->g0 (contiguous, ldc_p == N_p), and element i of the arenas p / m / v /
+     * shadow_bf16 is updated from element i of g0 exactly as mrg_adamw would (same rounding: csrc/common.h adamw_elem); the gradient is
+     * still stored.  hp: device fp32 [4] from mrg_adamw_hp (this step); n_decay: elements [0, n_decay) of the arenas take weight decay;
+     * ss[p]: fp32 [8 * tiles of problem p] partial sums of g^2 (per tile and wave) for the gradient norm (mrg_sumsq_finish).  Not with
+     * splitk > 1 or streamk.  NULL: gradients only. */
+    const struct mrg_adamw_fuse* fuse;
 } mrg_wgrad_group_desc;
+typedef struct mrg_adamw_fuse {
+    const float* g0; float* p; float* m; float* v; void* shadow_bf16;
+    const float* hp; long n_decay; float beta1, beta2, eps;
+    float* ss[MRG_WGRAD_GROUP_MAX];
+} mrg_adamw_fuse;
 int mrg_wgrad_group(const mrg_wgrad_group_desc* d, hipStream_t stream);
 
 /* ---------------------------------------------------------------------------------------------------
@@ -326,6 +339,9 @@ int mrg_sumsq_finish(const float* partials, int n, float* out, hipStream_t strea
 int mrg_sumsq_nblocks(long n);
 int mrg_grad_norm(const float* g, long n, float* partials, float* out, hipStream_t stream);
 int mrg_adamw(const mrg_adamw_desc* d, hipStream_t stream);
+/* hp_out fp32 [4] = {lr, wd, 1 / (1 - beta1^t), 1 / sqrt(1 - beta2^t)} of the CURRENT step, as mrg_adamw derives them from the tables and
+ * the step counters of `d` (only those fields are read): what mrg_wgrad_group's fused update (mrg_wgrad_group_desc.fuse) consumes. */
+int mrg_adamw_hp(const mrg_adamw_desc* d, float* hp_out, hipStream_t stream);
 int mrg_step_inc(int* step, const float* grad_norm, float clip_norm, float skip_norm, hipStream_t stream);
 int mrg_cast_bf16(const float* src, void* dst_bf16, long n, hipStream_t stream);
 /* dst_bf16[r, :] = src[r, :] * row_scale[r] for an [M, D] fp32 matrix (D % 4 == 0): the gradient entering a stochastic-depth

@@ -42,7 +42,12 @@ class WgradGroupDesc(C.Structure):
     _fields_ = [("count", ci), ("K", ci), ("A", vp * MRG_WGRAD_GROUP_MAX), ("B", vp * MRG_WGRAD_GROUP_MAX), ("C", vp * MRG_WGRAD_GROUP_MAX),
                 ("M", ci * MRG_WGRAD_GROUP_MAX), ("N", ci * MRG_WGRAD_GROUP_MAX), ("lda", ci * MRG_WGRAD_GROUP_MAX),
                 ("ldb", ci * MRG_WGRAD_GROUP_MAX), ("ldc", ci * MRG_WGRAD_GROUP_MAX), ("ev_start", vp), ("ev_stop", vp),
-                ("splitk", ci), ("ws", vp), ("streamk", ci), ("counters", vp), ("sk_grid", ci)]
+                ("splitk", ci), ("ws", vp), ("streamk", ci), ("counters", vp), ("sk_grid", ci), ("fuse", vp)]
+
+
+class AdamWFuse(C.Structure):
+    _fields_ = [("g0", vp), ("p", vp), ("m", vp), ("v", vp), ("shadow_bf16", vp), ("hp", vp), ("n_decay", cl),
+                ("beta1", cf), ("beta2", cf), ("eps", cf), ("ss", vp * MRG_WGRAD_GROUP_MAX)]
 
 
 class AttnDesc(C.Structure):
@@ -117,6 +122,7 @@ SIGNATURES = {
     "mrg_sumsq_nblocks": (ci, [cl]),
     "mrg_grad_norm": (ci, [vp, cl, vp, vp, vp]),
     "mrg_adamw": (ci, [C.POINTER(AdamWDesc), vp]),
+    "mrg_adamw_hp": (ci, [C.POINTER(AdamWDesc), vp, vp]),
     "mrg_adamw_nblocks": (ci, [cl]),
     "mrg_sumsq_finish": (ci, [vp, ci, vp, vp]),
     "mrg_step_inc": (ci, [vp, vp, C.c_float, C.c_float, vp]),

@@ -66,6 +66,20 @@ __device__ __forceinline__ void gelu_parts(float x, float& cdf, float& pdf) {
 __device__ __forceinline__ float gelu_f(float x) { float c, p; gelu_parts(x, c, p); return x * c; }
 __device__ __forceinline__ float gelu_grad_f(float x) { float c, p; gelu_parts(x, c, p); return c + x * p; }
 
+// ---- one AdamW element update (torch.optim.AdamW, mutils/optim_factory.py:180), shared by the flat-arena kernel (optim.hip) and the
+// weight-gradient epilogue that applies the update to the tile it has just produced (gemm8p.hip, epi_kind 9).  No contraction: both
+// callers must round identically (a fused and an unfused step are bit-identical).  hyper-parameters: lr, decay (0 for the no-decay
+// segment), 1 / (1 - beta1^t), 1 / sqrt(1 - beta2^t).
+__device__ __forceinline__ void adamw_elem(float& p, const float g, float& m, float& v, const float lr, const float decay, const float b1,
+                                           const float b2, const float ibc1, const float isbc2, const float eps) {
+#pragma clang fp contract(off)
+    p *= (1.f - lr * decay);
+    m = b1 * m + (1.f - b1) * g;
+    v = b2 * v + (1.f - b2) * g * g;
+    const float denom = sqrtf(v) * isbc2 + eps;
+    p -= lr * ibc1 * (m / denom);
+}
+
 // ---- dropout (mirage/utils.py:152,158,172,184-187: nn.Dropout after proj / fc2) ------------------------------------------
 // Counter-based masks: Philox4x32-10 (Salmon et al., "Parallel random numbers: as easy as 1, 2, 3", SC'11; the generator behind
 // torch's CUDA dropout as well) keyed by the run's seed, counted by (element quad, launch stream id, step).  One call yields the four

@@ -1515,6 +1515,23 @@ extern "C" int mrg_wgrad_group(const mrg_wgrad_group_desc* d, hipStream_t stream
         ga.M[p] = d->M[p]; ga.N[p] = d->N[p]; ga.lda[p] = d->lda[p]; ga.ldb[p] = d->ldb[p]; ga.ldc[p] = d->ldc[p];
         vec = vec && (d->N[p] % 4 == 0) && (d->ldc[p] % 4 == 0) && (((uintptr_t)d->C[p]) % 16 == 0);
     }
+    for (int p = 0; p < P8_GROUP_MAX; ++p) ga.ss[p] = nullptr;
+    ga.af = AdamFuseArgs();
+    if (d->fuse) {
+        const mrg_adamw_fuse* f = d->fuse;
+        MRG_REQUIRE(splitk == 1 && !d->streamk, MRG_ERR_UNSUPPORTED, "mrg_wgrad_group: the fused AdamW update needs splitk <= 1 and no stream-K");
+        MRG_REQUIRE(f->g0 && f->p && f->m && f->v && f->hp && f->n_decay >= 0, MRG_ERR_ARG, "mrg_wgrad_group: fuse: null arena / hp pointer");
+        MRG_REQUIRE((((uintptr_t)f->g0 | (uintptr_t)f->p | (uintptr_t)f->m | (uintptr_t)f->v) & 15) == 0 && (((uintptr_t)f->shadow_bf16) & 7) == 0,
+                    MRG_ERR_ARG, "mrg_wgrad_group: fuse: arenas must be 16-B aligned");
+        for (int p = 0; p < d->count; ++p) {
+            MRG_REQUIRE(d->ldc[p] == d->N[p] && d->N[p] % 4 == 0 && (const float*)d->C[p] >= f->g0 && ((const float*)d->C[p] - f->g0) % 4 == 0 && f->ss[p],
+                        MRG_ERR_ARG, "mrg_wgrad_group: fuse: C must be a contiguous 16-B aligned view into the gradient arena, ss given (problem %d)", p);
+            ga.ss[p] = f->ss[p];
+        }
+        g.epi_kind = 9;
+        ga.af.g0 = f->g0; ga.af.p = f->p; ga.af.m = f->m; ga.af.v = f->v; ga.af.sh = (bf16_t*)f->shadow_bf16; ga.af.hp = f->hp; ga.af.ndecay = f->n_decay;
+        ga.af.b1 = f->beta1; ga.af.b2 = f->beta2; ga.af.eps = f->eps;
+    }
     for (int p = d->count; p <= P8_GROUP_MAX; ++p) ga.tile_start[p] = tiles;
     for (int p = d->count; p < P8_GROUP_MAX; ++p) { ga.A[p] = nullptr; ga.B[p] = nullptr; ga.C[p] = nullptr; ga.M[p] = ga.N[p] = ga.lda[p] = ga.ldb[p] = ga.ldc[p] = 0; ga.ws_off[p] = 0; }
     if (splitk > 1) vec = vec && (((uintptr_t)d->ws) % 16 == 0);

@@ -292,7 +292,8 @@ __device__ __forceinline__ void p8_bias(const GemmArgs& g, const int n0, bool wa
 // ws != nullptr: split-K slab stores instead.
 template <bool VEC, int ps>
 __device__ __forceinline__ void p8_epilogue_pass(const GemmArgs& g, const int m0, const int n0, f32x16 (&acc)[4][2], char* smem, float* ws,
-                                                 const float (&bv)[4], unsigned long long* etr, const int tid) {
+                                                 const float (&bv)[4], unsigned long long* etr, const int tid, float* ssacc = nullptr,
+                                                 const AdamFuseArgs* af = nullptr) {
     const int Meff = g.M;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -330,6 +331,11 @@ __device__ __forceinline__ void p8_epilogue_pass(const GemmArgs& g, const int m0
             else if (VEC && (g.side_drain & 1) && g.epi_kind == 3) { P8_DRAIN16(3, nullptr); }
             else if (VEC && (g.side_drain & 1) && g.epi_kind == 5) { P8_DRAIN16(5, nullptr); }
             else if (VEC && (g.side_drain & 1) && g.epi_kind == 7) { P8_DRAIN16(8, nullptr); }
+            else if (VEC && g.epi_kind == 9) {   // fused AdamW: three more 16-B operands per row segment -> batches of four
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    drain_side<9, false, 4, 256>(g, ct, cl, col, bv, Meff, [&](int it, int& rl, int& row) { row_of(it + 4 * q, rl, row); }, ssacc, af);
+            }
             else {
 #pragma unroll 1
                 for (int it = 0; it < 16; ++it) {
@@ -349,15 +355,17 @@ __device__ __forceinline__ void p8_epilogue_pass(const GemmArgs& g, const int m0
 
 template <bool VEC>
 __device__ __forceinline__ void p8_epilogue(const GemmArgs& g, const int m0, const int n0, f32x16 (&acc)[4][2], char* smem, float* ws,
-                                            const float (&bv)[4], const int tid, unsigned long long* etr = nullptr) {
+                                            const float (&bv)[4], const int tid, unsigned long long* etr = nullptr, float* ssacc = nullptr,
+                                            const AdamFuseArgs* af = nullptr) {
     // two calls with a compile-time pass index: inside a loop the accumulator array is indexed at run time and moves to scratch memory
-    p8_epilogue_pass<VEC, 0>(g, m0, n0, acc, smem, ws, bv, etr, tid);
-    p8_epilogue_pass<VEC, 1>(g, m0, n0, acc, smem, ws, bv, etr, tid);
+    p8_epilogue_pass<VEC, 0>(g, m0, n0, acc, smem, ws, bv, etr, tid, ssacc, af);
+    p8_epilogue_pass<VEC, 1>(g, m0, n0, acc, smem, ws, bv, etr, tid, ssacc, af);
 }
 
 // one 256 x 256 output tile (tile `bid` of the problem in grouped row-major order, k-range `ksplit` of g.splitk)
 template <int AMODE, int BMODE, bool VEC, int PHASES>
-__device__ __forceinline__ void p8_tile(const GemmArgs& g, const int bid, const int ksplit, char* smem) {
+__device__ __forceinline__ void p8_tile(const GemmArgs& g, const int bid, const int ksplit, char* smem, float* ssacc = nullptr,
+                                        const AdamFuseArgs* af = nullptr) {
     int m0, n0;
     p8_tile_origin(g, bid, m0, n0);
     const int ntiles = g.K / BK;
@@ -373,7 +381,7 @@ __device__ __forceinline__ void p8_tile(const GemmArgs& g, const int bid, const 
     f32x16 acc[4][2];
     p8_mainloop<AMODE, BMODE, PHASES>(g, m0, n0, t0, t1 - t0, acc, smem, tid);
     float* ws = g.splitk > 1 ? g.ws + (long)ksplit * g.M * g.N : nullptr;
-    p8_epilogue<VEC>(g, m0, n0, acc, smem, ws, bv, tid);
+    p8_epilogue<VEC>(g, m0, n0, acc, smem, ws, bv, tid, nullptr, ssacc, af);
     if (ws && g.tile_cnt) splitk_finish<VEC>(g, bid, m0, n0, 256, 256, g.M, smem, threadIdx.x, 512);
 }
 
@@ -406,7 +414,13 @@ __global__ __launch_bounds__(512) void gemm_p8_group_kernel(const P8GroupArgs ga
     g.A = ga.A[p]; g.B = ga.B[p]; g.C = ga.C[p];
     g.M = ga.M[p]; g.N = ga.N[p]; g.lda = ga.lda[p]; g.ldb = ga.ldb[p]; g.ldc = ga.ldc[p];
     if (g.splitk > 1) g.ws = ga.base.ws + ga.ws_off[p];
-    p8_tile<MRG_OP_KSTRIDED, MRG_OP_KSTRIDED, VEC, PHASES>(g, bid - ga.tile_start[p], ksplit, smem);
+    // fused AdamW (epi_kind 9): the epilogue updates the parameter elements of its tile and every wave leaves its partial sum of g^2
+    float ss = 0.f;
+    p8_tile<MRG_OP_KSTRIDED, MRG_OP_KSTRIDED, VEC, PHASES>(g, bid - ga.tile_start[p], ksplit, smem, &ss, &ga.af);
+    if (g.epi_kind == 9) {
+        ss = wave_sum(ss);
+        if ((threadIdx.x & 63) == 0) ga.ss[p][(long)(bid - ga.tile_start[p]) * 8 + (threadIdx.x >> 6)] = ss;
+    }
 }
 
 

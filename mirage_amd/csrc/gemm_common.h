@@ -44,6 +44,14 @@ struct GemmArgs {
                        // only the DROP instantiation of the single-stage kernel reads it (epi_row_drop), the tuned kernels do not
 };
 
+// epi_kind 9 (8-phase grouped weight gradients): the tile's elements are final gradients -> AdamW of the parameter elements they belong to,
+// in the epilogue (common.h adamw_elem); element offset in the arenas = (C - g0) + row * ldc + col.  Read through a pointer into the
+// kernel-argument segment only where the epilogue needs it: as GemmArgs fields these eleven values stayed live across the main loop and
+// cost 39 spilled SGPRs
+struct AdamFuseArgs {
+    const float* g0; float* p; float* m; float* v; bf16_t* sh; const float* hp; long ndecay; float b1, b2, eps;
+};
+
 // grouped weight-gradient launch of the 8-phase kernel (gemm8p.hip): per-problem operands, everything else from `base`
 constexpr int P8_GROUP_MAX = 48;
 struct P8GroupArgs {
@@ -53,6 +61,8 @@ struct P8GroupArgs {
     const bf16_t* A[P8_GROUP_MAX]; const bf16_t* B[P8_GROUP_MAX]; void* C[P8_GROUP_MAX];
     int M[P8_GROUP_MAX], N[P8_GROUP_MAX], lda[P8_GROUP_MAX], ldb[P8_GROUP_MAX], ldc[P8_GROUP_MAX];
     long ws_off[P8_GROUP_MAX];               // split-K (base.splitk > 1): problem p's slabs [splitk][M_p * N_p] start at base.ws + ws_off[p]
+    AdamFuseArgs af;                         // fused AdamW (base.epi_kind 9)
+    float* ss[P8_GROUP_MAX];                 // ... problem p's partial sums of g^2, [8 * tiles of p]
 };
 
 }  // namespace mrg_detail
@@ -452,17 +462,34 @@ __device__ __forceinline__ void epi_any_cs(const GemmArgs& g, const float4 a4, c
     else epi_row<VEC, true>(g, a4, bv, ws, row, col, nv, cs);
 }
 
+// arena accesses of the fused AdamW epilogue (KIND 9): streaming (nontemporal) by default -- they are touched once per step (same box: C2 9.402 -> 9.364 ms, C4 20.14 -> 20.11; -DMRG_AF_NT=0 for plain accesses)
+#ifndef MRG_AF_NT
+#define MRG_AF_NT 1
+#endif
+__device__ __forceinline__ float4 AF_LD(const float* p) {
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    if (MRG_AF_NT) { const f4 v = __builtin_nontemporal_load(reinterpret_cast<const f4*>(p)); return make_float4(v.x, v.y, v.z, v.w); }
+    return *reinterpret_cast<const float4*>(p);
+}
+__device__ __forceinline__ void AF_ST(float* p, const float4 v) {
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    if (MRG_AF_NT) { const f4 w = {v.x, v.y, v.z, v.w}; __builtin_nontemporal_store(w, reinterpret_cast<f4*>(p)); return; }
+    *reinterpret_cast<float4*>(p) = v;
+}
+
 // Two-phase drain of one staged pass for the epilogues that read a side operand per output (fp32 residual, fp16 GELU'): the side
 // operands of all NIT row segments are requested before the first one is consumed.  The row-at-a-time loop exposes one global
 // round trip per iteration (8-16 dependent ones per thread and pass).  row_of(it, rl, row): staging row / output row of step it.
 template <int KIND, bool CS, int NIT, int CTW, typename RowOf>
 __device__ __forceinline__ void drain_side(const GemmArgs& g, const float* ct, int cl, int col, const float (&bv)[4], int Meff,
-                                           RowOf row_of, float* cs) {
+                                           RowOf row_of, float* cs, const AdamFuseArgs* af = nullptr) {
     typedef _Float16 h4 __attribute__((ext_vector_type(4)));
     float4 a[NIT], t[NIT];
+    float4 pm[KIND == 9 ? NIT : 1], pv[KIND == 9 ? NIT : 1];      // KIND 9: t = parameter, pm / pv = AdamW moments
     h4 x[NIT];
     float rs[NIT];
     int rows[NIT];
+    const long af0 = KIND == 9 ? (long)(reinterpret_cast<const float*>(g.C) - af->g0) : 0;
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
         int rl, row;
@@ -470,7 +497,12 @@ __device__ __forceinline__ void drain_side(const GemmArgs& g, const float* ct, i
         rows[it] = row;
         const long rr = row < Meff ? row : Meff - 1;              // clamped: the load is unconditional, only the store is masked
         a[it] = *reinterpret_cast<const float4*>(ct + rl * CTW + cl);
-        if (KIND == 2) {
+        if (KIND == 9) {
+            const long o = af0 + rr * g.ldc + col;
+            t[it] = AF_LD(af->p + o);
+            pm[it] = AF_LD(af->m + o);
+            pv[it] = AF_LD(af->v + o);
+        } else if (KIND == 2) {
             t[it] = *reinterpret_cast<const float4*>(g.resid + rr * g.ldr + col);
             rs[it] = g.row_scale ? g.row_scale[rr] : 1.f;
         } else if (KIND == 4) {
@@ -483,6 +515,21 @@ __device__ __forceinline__ void drain_side(const GemmArgs& g, const float* ct, i
         if (row < Meff) {
             if (KIND == 7) { st_slab(cs + (long)row * g.N + col, a[it], g.tile_cnt != nullptr); continue; }      // split-K slab (cs = slab base)
             if (KIND == 8) { *reinterpret_cast<float4*>(reinterpret_cast<float*>(g.C) + (long)row * g.ldc + col) = a[it]; continue; }   // plain fp32 tile (weight gradients)
+            if (KIND == 9) {       // weight gradient + AdamW of the same elements; cs[0] collects this lane's sum of g^2
+                const long o = af0 + (long)row * g.ldc + col;
+                const float lr = af->hp[0], wd = af->hp[1], ibc1 = af->hp[2], isbc2 = af->hp[3];
+                float gv[4] = {a[it].x, a[it].y, a[it].z, a[it].w};
+                float pp[4] = {t[it].x, t[it].y, t[it].z, t[it].w}, mm[4] = {pm[it].x, pm[it].y, pm[it].z, pm[it].w}, vv[4] = {pv[it].x, pv[it].y, pv[it].z, pv[it].w};
+                cs[0] += (gv[0] * gv[0] + gv[1] * gv[1]) + (gv[2] * gv[2] + gv[3] * gv[3]);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) adamw_elem(pp[e], gv[e], mm[e], vv[e], lr, (o + e) < af->ndecay ? wd : 0.f, af->b1, af->b2, ibc1, isbc2, af->eps);
+                AF_ST(reinterpret_cast<float*>(g.C) + (long)row * g.ldc + col, a[it]);
+                AF_ST(af->p + o, make_float4(pp[0], pp[1], pp[2], pp[3]));
+                AF_ST(af->m + o, make_float4(mm[0], mm[1], mm[2], mm[3]));
+                AF_ST(af->v + o, make_float4(vv[0], vv[1], vv[2], vv[3]));
+                if (af->sh) *reinterpret_cast<u32x2*>(af->sh + o) = u32x2{pack_bf2(pp[0], pp[1]), pack_bf2(pp[2], pp[3])};
+                continue;
+            }
             if (KIND == 1) { epi_row_bf16<true, CS>(g, a[it], bv, row, col, 4, cs); continue; }
             if (KIND == 3) { epi_row_gelu_save<true>(g, a[it], bv, row, col, 4); continue; }
             if (KIND == 5) { epi_row_gelu<true>(g, a[it], bv, row, col, 4); continue; }

@@ -91,12 +91,7 @@ __global__ __launch_bounds__(256) void adamw_kernel(const AdamArgs a) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             const float decay = ((i << 2) + e) < a.n_decay ? wd : 0.f;
-            const float gg = gp[e] * gs;
-            pp[e] *= (1.f - lr * decay);
-            mp[e] = b1 * mp[e] + (1.f - b1) * gg;
-            vp[e] = b2 * vp[e] + (1.f - b2) * gg * gg;
-            const float denom = sqrtf(vp[e]) * isbc2 + a.eps;
-            pp[e] -= lr * ibc1 * (mp[e] / denom);
+            adamw_elem(pp[e], gp[e] * gs, mp[e], vp[e], lr, decay, b1, b2, ibc1, isbc2, a.eps);
         }
         reinterpret_cast<float4*>(a.p)[i] = p;
         reinterpret_cast<float4*>(a.m)[i] = m;
@@ -110,6 +105,20 @@ __global__ __launch_bounds__(256) void adamw_kernel(const AdamArgs a) {
         __syncthreads();
         if (threadIdx.x == 0) a.sumsq_out[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
     }
+}
+
+// the step's hyper-parameters {lr, wd, 1 / (1 - beta1^t), 1 / sqrt(1 - beta2^t)} as adamw_kernel derives them, for the weight-gradient
+// epilogue that applies AdamW itself (gemm8p.hip epi_kind 9): written once per step before the backward pass
+__global__ void adamw_hp_kernel(const float* lr_table, const float* wd_table, const int* step, int table_len, float lr_scale, float beta1,
+                                float beta2, float* out) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const int st = step[0];
+    const int ti = st < table_len ? st : table_len - 1;
+    const double t = (double)(step[1] + 1);
+    out[0] = lr_table[ti] * lr_scale;
+    out[1] = wd_table[ti];
+    out[2] = (float)(1.0 / (1.0 - pow((double)beta1, t)));
+    out[3] = (float)(1.0 / sqrt(1.0 - pow((double)beta2, t)));
 }
 
 // end of an iteration: the schedule index always advances, the AdamW step count only when the update was applied
@@ -209,6 +218,13 @@ extern "C" int mrg_adamw(const mrg_adamw_desc* d, hipStream_t stream) {
     long nb = mrg_adamw_nblocks(d->n);
     hipLaunchKernelGGL(adamw_kernel, dim3((unsigned)nb), dim3(256), 0, stream, a);
     return mrg_check_launch("mrg_adamw");
+}
+
+extern "C" int mrg_adamw_hp(const mrg_adamw_desc* d, float* hp_out, hipStream_t stream) {
+    MRG_REQUIRE(d && d->lr_table && d->wd_table && d->step && hp_out && d->table_len > 0, MRG_ERR_ARG, "mrg_adamw_hp: bad argument");
+    hipLaunchKernelGGL(adamw_hp_kernel, dim3(1), dim3(64), 0, stream, d->lr_table, d->wd_table, d->step, d->table_len, d->lr_scale, d->beta1,
+                       d->beta2, hp_out);
+    return mrg_check_launch("mrg_adamw_hp");
 }
 
 extern "C" int mrg_step_inc(int* step, const float* grad_norm, float clip_norm, float skip_norm, hipStream_t stream) {

@@ -369,6 +369,9 @@ class WgradGroup:
     # 64 / 12288 = encoder blocks only)
     min_tiles = int(os.environ.get("MRG_WGRAD_GROUP_MIN_TILES", "16"))
     # optional split-K 2 inside groups with fewer tiles than this (the exposed last groups of a backward pass): measured neutral
+    # fuse: set by trainer.TrainStep around a backward pass whose optimizer allows it (optim.AdamWFusion): the grouped launch then applies
+    # AdamW to the parameters whose gradients it produces, and `fused` collects their arena ranges for the step's bookkeeping
+    fuse = None
     # (C2 9.93 vs 9.95 ms, C4 21.66 vs 21.65: the slabs and their reduction cost what the fuller launch gains) -> off by default
     split_below = int(os.environ.get("MRG_WGRAD_GROUP_SPLIT_BELOW", "0"))
     split_max_k = int(os.environ.get("MRG_WGRAD_GROUP_SPLIT_MAX_K", "12288"))
@@ -443,10 +446,11 @@ class WgradGroup:
                 # end of the step) cuts every tile's k-range in two: slabs + the batched reduction, as the per-GEMM path does
                 sk = 2 if (ctiles <= cls.split_below and K_ // 64 >= 32 and K_ <= cls.split_max_k and Deferred.active
                            and all(t[8] == t[3] and Deferred.ok(t[7], t[2] * t[3], t[2] * t[3]) for t in chunk)) else 1
-                wgrad_group(chunk, K_, sk)
+                fz = cls.fuse if (sk == 1 and cls.fuse is not None and (cls.exposed or not cls.fuse.only_exposed)) else None
+                wgrad_group(chunk, K_, sk, fuse=fz)
 
 
-def wgrad_group(ts, K: int, splitk: int = 1, streamk: Optional[bool] = None):
+def wgrad_group(ts, K: int, splitk: int = 1, streamk: Optional[bool] = None, fuse=None):
     """one mrg_wgrad_group launch: ts = [(A, B, M, N, K, lda, ldb, out, ldc, _)], out_p[M_p, N_p] = A_p^T B_p (fp32, overwritten);
     splitk > 1: slabs + deferred batched reduction (only inside a backward pass: Deferred.active); streamk (default: on for groups
     that do not fill a whole number of rounds): the concatenated tile lists on the stream-K schedule"""
@@ -454,6 +458,14 @@ def wgrad_group(ts, K: int, splitk: int = 1, streamk: Optional[bool] = None):
     d.count, d.K = len(ts), K
     fl = 0.0
     tiles_all = sum(((t[2] + 255) // 256) * ((t[3] + 255) // 256) for t in ts)
+    fz = None
+    if fuse is not None and splitk == 1:
+        # AdamW applied by the launch (mrg_wgrad_group_desc.fuse): every output must be a contiguous view into the optimizer's gradient arena
+        fz = fuse.descriptor(ts)
+        if fz is not None:
+            streamk = False
+            d.fuse = C.cast(C.pointer(fz), C.c_void_p)
+            d._fz = fz
     if streamk is None:
         streamk = STREAMK and (WgradGroup.streamk_mode == 1 or (WgradGroup.streamk_mode == 2 and WgradGroup.exposed))
     if streamk and splitk == 1:
@@ -894,6 +906,15 @@ def adamw(p, g, m, v, shadow, n_decay, lr_table, wd_table, step, beta1, beta2, e
     d.grad_norm, d.clip_norm, d.skip_norm = _p(grad_norm_t), clip_norm or 0.0, skip_norm or 0.0
     d.sumsq_out = _p(sumsq_out)
     check(lib.mrg_adamw(C.byref(d), _s()), "mrg_adamw")
+
+
+def adamw_hp(lr_table, wd_table, step, beta1, beta2, out: torch.Tensor, lr_scale=1.0):
+    """out fp32 [4] = {lr, wd, 1 / (1 - beta1^t), 1 / sqrt(1 - beta2^t)} of the current step (mrg_adamw_hp), for the fused update of
+    mrg_wgrad_group"""
+    d = L.AdamWDesc()
+    d.lr_table, d.wd_table, d.step, d.table_len = lr_table.data_ptr(), wd_table.data_ptr(), step.data_ptr(), lr_table.numel()
+    d.lr_scale, d.beta1, d.beta2 = lr_scale, beta1, beta2
+    check(lib.mrg_adamw_hp(C.byref(d), out.data_ptr(), _s()), "mrg_adamw_hp")
 
 
 def adamw_nblocks(n: int) -> int:

@@ -12,6 +12,7 @@ from typing import Dict, List, Optional
 import numpy as np
 import torch
 
+from . import _lib as L
 from . import kernels as K
 from .arena import build_arena
 
@@ -81,6 +82,68 @@ class PartialSumSlots:
         """do the registered ranges tile [0, n) without gap or overlap (the last range may run past n: alignment padding)?"""
         cov = sorted(self.slots)
         return bool(cov) and cov[0][0] == 0 and cov[-1][1] >= n and all(x[1] == y[0] for x, y in zip(cov, cov[1:]))
+
+
+class AdamWFusion:
+    """AdamW inside the grouped weight-gradient launches (mrg_wgrad_group_desc.fuse; csrc/gemm8p.hip epi_kind 9).  A weight gradient that
+    comes out of such a launch is final, so the tile's epilogue also updates the parameter elements it covers -- the optimizer pass over
+    those elements (read p, g, m, v; write p, m, v, shadow) disappears from the end of the step, where the last group's update ran alone
+    on an idle matrix unit (C2 175 us, C4 440 us).  Only without clipping / skipping (the update must not depend on the global gradient
+    norm), on one GPU (no gradient exchange between the weight gradient and the update), and for outputs that are contiguous views into
+    the gradient arena.  The per-element arithmetic is mrg_adamw's (csrc/common.h adamw_elem): a fused and an unfused step leave
+    bit-identical parameters and moments.  `ranges` collects the arena ranges updated so far in the current backward pass; the caller
+    (trainer.TrainStep) keeps them out of its own update launches."""
+
+    def __init__(self, opt: "FusedAdamW"):
+        assert opt.fuse_norm, "the fused update needs the gradient norm to be log-only (no clip_grad / skip_grad)"
+        self.opt = opt
+        self.hp = torch.zeros(4, dtype=torch.float32, device=opt.arena.flat_p.device)
+        self.ranges: List[tuple] = []
+        # MRG_FUSE_OPT=2: only in the groups launched from a join (the exposed last group of a backward pass); 1: in every group
+        self.only_exposed = os.environ.get("MRG_FUSE_OPT", "1") == "2"
+
+    def begin_step(self):
+        """before the backward pass of a step: this step's hyper-parameters (device side, replayable) and an empty range list"""
+        o = self.opt
+        self.ranges = []
+        K.adamw_hp(o.lr_table, o.wd_table, o.step_dev, o.betas[0], o.betas[1], self.hp)
+
+    def descriptor(self, ts):
+        """mrg_adamw_fuse for the tasks of one grouped launch, or None when one of their outputs is not an arena view"""
+        o, a = self.opt, self.opt.arena
+        g0 = a.flat_g.data_ptr()
+        items = []
+        for t in ts:
+            out, M, N, ldc = t[7], t[2], t[3], t[8]
+            off_b = out.data_ptr() - g0
+            if off_b < 0 or off_b % 256 or ldc != N or N % 4 or (M * N) % 64 or off_b // 4 + M * N > a.n_trainable:
+                return None
+            items.append((off_b // 4, off_b // 4 + M * N, ((M + 255) // 256) * ((N + 255) // 256)))
+        fz = L.AdamWFuse()
+        fz.g0, fz.p, fz.m, fz.v = g0, a.flat_p.data_ptr(), o.exp_avg.data_ptr(), o.exp_avg_sq.data_ptr()
+        fz.shadow_bf16, fz.hp, fz.n_decay = a.flat_bf16.data_ptr(), self.hp.data_ptr(), a.n_decay
+        fz.beta1, fz.beta2, fz.eps = o.betas[0], o.betas[1], o.eps
+        for i, (s0, e0, tiles) in enumerate(items):
+            fz.ss[i] = o._ss_slot(s0, e0, 8 * tiles).data_ptr()
+            self.ranges.append((s0, e0))
+        return fz
+
+    @staticmethod
+    def subtract(ranges, done):
+        """ranges minus the union of `done` (both lists of half-open intervals)"""
+        out = []
+        done = sorted(done)
+        for s0, e0 in ranges:
+            cur = s0
+            for ds, de in done:
+                if de <= cur or ds >= e0:
+                    continue
+                if ds > cur:
+                    out.append((cur, ds))
+                cur = max(cur, de)
+            if cur < e0:
+                out.append((cur, e0))
+        return out
 
 
 class FusedAdamW:
@@ -154,10 +217,11 @@ class FusedAdamW:
             K.adamw(a.flat_p[s:e], a.flat_g[s:e], self.exp_avg[s:e], self.exp_avg_sq[s:e], a.flat_bf16[s:e], nd, self.lr_table,
                     self.wd_table, self.step_dev, self.betas[0], self.betas[1], self.eps, sumsq_out=ss)
 
-    def _ss_slot(self, s, e):
+    def _ss_slot(self, s, e, length=None):
         """The fixed slice of the partial-sum buffer that the update of [s, e) writes (PartialSumSlots); slices of ranges this one
-        supersedes are zeroed so that the finish kernel, which sums every slice ever handed out, does not count them."""
-        off, n, retired = self._slots.get(s, e, K.adamw_nblocks(e - s))
+        supersedes are zeroed so that the finish kernel, which sums every slice ever handed out, does not count them.  length: number of
+        partial sums the writer leaves (default: one per workgroup of an mrg_adamw launch over the range)."""
+        off, n, retired = self._slots.get(s, e, K.adamw_nblocks(e - s) if length is None else int(length))
         for o1, n1 in retired:
             self._ss[o1:o1 + n1].zero_()
         return self._ss[off:off + n]

@@ -20,6 +20,8 @@ IN_PLACE_INPUTS = os.environ.get("MRG_INPUT_SLOTS", "1") != "0"   # step(batch) 
 # seeded with the constant gradient 1 instead of differentiating the sum).  Bit-identical, but measured neutral at C2 (9.494 vs 9.495 ms)
 # and +5 % SLOWER at C4 (21.72 vs 20.64 ms, three adapters: adapter 0 lives on the calling stream, and without the join the two lanes
 # run their backward beside its forward tail instead of beside its backward) -- off by default, kept as an A/B knob
+# AdamW inside the grouped weight-gradient launches (optim.AdamWFusion; MRG_FUSE_OPT=0: separate update launches as before)
+FUSE_OPT = os.environ.get("MRG_FUSE_OPT", "1") != "0"
 LANE_DEFER_JOIN = os.environ.get("MRG_LANE_DEFER_JOIN", "0") != "0"
 LANE_LOSSES = os.environ.get("MRG_LANE_LOSSES", "1") != "0"   # the masked losses run on the output adapters' lane streams (engine.LaneLosses)
 TOKEN_PREDS = os.environ.get("MRG_TOKEN_PREDS", "1") != "0"   # predictions stay in the decoders' token layout inside the step (engine.PredLayout)
@@ -127,6 +129,12 @@ class TrainStep:
             if per_blk:
                 self._early = per_blk
                 self._early_all = self._merge([r for rs in per_blk.values() for r in rs])
+        # ... and the weight gradients that leave a grouped launch are final there: that launch's epilogue applies AdamW to them itself
+        # (optim.AdamWFusion), so the update of the LAST group's blocks no longer runs alone after the backward pass
+        self._fusion = None
+        if self._early is not None and FUSE_OPT and optimizer.fuse_norm:
+            from .optim import AdamWFusion
+            self._fusion = AdamWFusion(optimizer)
 
     def _stage_then(self, j):
         """several ranks, no clipping: AdamW of a stage's parameters runs on the communication stream right behind their all-reduce,
@@ -149,6 +157,8 @@ class TrainStep:
     def _early_cb(self, blks):
         key = lambda b: b if isinstance(b, str) else id(b)
         rs = self._merge([r for b in blks for r in self._early.get(key(b), [])])
+        if self._fusion is not None and self._fusion.ranges:
+            rs = self._fusion.subtract(rs, self._fusion.ranges)      # already updated by the grouped weight-gradient launches
         if rs:
             self.opt.step_ranges(rs)
             self._early_seen += len([b for b in blks if key(b) in self._early])
@@ -213,11 +223,15 @@ class TrainStep:
         if self._early is not None:
             from . import engine as E
             E._Side.early_opt, E._Side.finished, self._early_seen = self._early_cb, [], 0
+            if self._fusion is not None and E._Side.enabled:
+                self._fusion.begin_step()
+                _K.WgradGroup.fuse = self._fusion
             try:
                 run_backward()
                 E.join_side_stream()             # issues the update of the last blocks as well
             finally:
                 E._Side.early_opt, E._Side.finished = None, []
+                _K.WgradGroup.fuse = None
             if self._early_seen != len(self._early):      # e.g. side stream disabled: fall back to the single update
                 raise RuntimeError(f"early optimizer: {self._early_seen} of {len(self._early)} encoder blocks were updated")
         else:
