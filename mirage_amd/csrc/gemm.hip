@@ -1517,10 +1517,7 @@ extern "C" int mrg_wgrad_group(const mrg_wgrad_group_desc* d, hipStream_t stream
     }
     for (int p = 0; p < P8_GROUP_MAX; ++p) ga.ss[p] = nullptr;
     ga.af = AdamFuseArgs();
-    ga.stagger = 0;
     if (d->fuse) {
-        static const int stag = [] { const char* e = getenv("MRG_P8_STAGGER_US"); return e ? atoi(e) * 100 : 0; }();
-        ga.stagger = tiles > 256 ? stag : 0;
         const mrg_adamw_fuse* f = d->fuse;
         MRG_REQUIRE(splitk == 1 && !d->streamk, MRG_ERR_UNSUPPORTED, "mrg_wgrad_group: the fused AdamW update needs splitk <= 1 and no stream-K");
         MRG_REQUIRE(f->g0 && f->p && f->m && f->v && f->hp && f->n_decay >= 0, MRG_ERR_ARG, "mrg_wgrad_group: fuse: null arena / hp pointer");

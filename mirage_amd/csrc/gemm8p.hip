@@ -406,12 +406,6 @@ template <bool VEC, int PHASES>
 __global__ __launch_bounds__(512) void gemm_p8_group_kernel(const P8GroupArgs ga) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int total = ga.tile_start[ga.nprob];
-    if (ga.stagger > 0 && ((blockIdx.x >> 3) & 1) && blockIdx.x < 256) {
-        // experiment: half of the first round starts late, so that from then on half of the CUs are in their (HBM-bound) fused epilogue
-        // while the other half is in its (MFMA-bound) main loop
-        const unsigned long long t0 = wall_clock64();
-        while (wall_clock64() - t0 < (unsigned long long)ga.stagger) __builtin_amdgcn_s_sleep(64);
-    }
     int bid, ksplit;
     wg_remap(total, 1, bid, ksplit);             // gridDim.y = split-K factor (1 for groups that fill the chip by themselves)
     int p = 0;

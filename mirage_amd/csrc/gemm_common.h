@@ -61,7 +61,6 @@ struct P8GroupArgs {
     const bf16_t* A[P8_GROUP_MAX]; const bf16_t* B[P8_GROUP_MAX]; void* C[P8_GROUP_MAX];
     int M[P8_GROUP_MAX], N[P8_GROUP_MAX], lda[P8_GROUP_MAX], ldb[P8_GROUP_MAX], ldc[P8_GROUP_MAX];
     long ws_off[P8_GROUP_MAX];               // split-K (base.splitk > 1): problem p's slabs [splitk][M_p * N_p] start at base.ws + ws_off[p]
-    int stagger;                             // experiment (MRG_P8_STAGGER_US): every other first-round workgroup starts this many 10-ns ticks late
     AdamFuseArgs af;                         // fused AdamW (base.epi_kind 9)
     float* ss[P8_GROUP_MAX];                 // ... problem p's partial sums of g^2, [8 * tiles of p]
 };
