@@ -471,7 +471,7 @@ def _run(real_stdout: int):
         if world == 1 and a.config == "c2" and not a.batch and not a.no_other_configs and not force_dp:
             import gc
             others = {}
-            for name, (st, wu) in (("c4", (20, 3)), ("c5", (10, 2))):
+            for name, (st, wu) in (("c4", (20, 5)), ("c5", (10, 3))):
                 gc.collect()
                 torch.cuda.empty_cache()
                 K.TUNE["log"].clear()
