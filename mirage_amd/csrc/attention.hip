@@ -137,6 +137,9 @@ struct AttnArgs {
     int rmax;         // forward, resident K / V stored compactly: index of the zero row every out-of-range key row is clamped to (else INT_MAX)
     int stage_tail;   // forward: rows of the LAST wave's staging tile when it was allocated short (0: every wave has 32 rows)
     float* cs_q; float* cs_k; float* cs_v; long cs_bs;   // optional per-(batch, head) column sums of dQ / dK / dV (bias gradients)
+    int tail_off;     // forward TAIL: byte offset (in the dynamic LDS) of the waves' exchange area for the last query row, [waves][66] floats
+    int tail;         // forward, Nq == Nk == 32 m + 1 (the global token is appended LAST, mirage/model.py:391): the tiled kernel covers the 32 m
+                      // leading tokens, folds the last KEY into every row's softmax state by hand and does the last QUERY row with plain FMAs at the end
 };
 
 // ---- transposed accumulators -> full-line stores (forward output, fused backward outputs) ----------------------------------
@@ -199,10 +202,18 @@ __device__ __forceinline__ void fused_flush(const char* stg, bf16_t* __restrict_
 // ================================================ forward ===============================================
 // STAGE: the output tile goes through a per-wave LDS staging tile (behind K / V) and leaves as full rows; otherwise (K / V + staging
 // would cost the second workgroup per CU) as 8-byte stores from the registers.
-template <int HD, int CB, bool STAGE>
-__global__ __launch_bounds__(512, 2) void attn_fwd_kernel(const AttnArgs a) {
+// TAIL (a.tail): sequence = 32 m tokens + one more (N = 129 / 257: the patches and the global token).  As a ninth tile that one token costs a
+// whole second round of tiles and a padded key block per row (N = 257: 252 us against 170 us at N = 256).  Here the tiles cover the 32 m
+// leading queries and keys; the last key enters every row's online-softmax state as its INITIAL value (score by a 64-term dot product per
+// lane pair, weight exp(0) = 1, output = its value row); the last query's row is computed at the end by all waves together from the K / V
+// rows already in LDS (wave w: keys of block w with lane = key for the scores and lane = head-dim column for P V; partial softmax states
+// are merged by wave 0 through a small LDS area).
+template <int HD, int CB, bool STAGE, bool TAIL = false>
+__global__ __launch_bounds__(512, 4) void attn_fwd_kernel(const AttnArgs a0) {     // (HIP: second value = minimum waves per SIMD -> at most 128 VGPRs)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int KS = HD / 16, DJ = HD / 32, ROWS = CB * 32;
+    AttnArgs a = a0;
+    if (TAIL) { a.Nq -= 1; a.Nk -= 1; }                   // the tiled part; strides, lse and output rows keep the full length below
     // a.chunk_rows = rows of K and of V resident in LDS: all keys (padded to 32) when they fit, so that longer rows stage K/V
     // once and the chunk loop below only walks LDS; otherwise ROWS and every chunk is re-staged
     const int lds_rows = a.chunk_rows;
@@ -245,7 +256,25 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_kernel(const AttnArgs a) {
         for (int dj = 0; dj < DJ; ++dj)
 #pragma unroll
             for (int r = 0; r < 16; ++r) o[dj][r] = 0.f;
-        float m_run = -INFINITY, l_run = 0.f;
+        float m_run = -INFINITY, l_run = 0.f, s_tail = 0.f;
+        if (TAIL) {
+            // the last key (row a.Nk of k / v): this lane pair's query . k_tail, each lane over the half of the head dimension it holds
+            const bf16_t* kt = kp + (long)a.Nk * a.k_rs;
+            float part = 0.f;
+#pragma unroll
+            for (int kk = 0; kk < KS; ++kk) {
+                const uint4 kv4 = *reinterpret_cast<const uint4*>(kt + kk * 16 + 8 * (lane >> 5));
+                const uint32_t kw[4] = {kv4.x, kv4.y, kv4.z, kv4.w};
+                const uint32_t* qw = reinterpret_cast<const uint32_t*>(&qf[kk]);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    part = fmaf(__uint_as_float(qw[e] << 16), __uint_as_float(kw[e] << 16), part);
+                    part = fmaf(__uint_as_float(qw[e] & 0xffff0000u), __uint_as_float(kw[e] & 0xffff0000u), part);
+                }
+            }
+            s_tail = part + __shfl_xor(part, 32, 64);
+            m_run = s_tail;                                   // the running maximum knows the last key from the start; its weight and its value
+        }                                                     // row are added after the tiles (fewer registers live across the chunk loop)
 
         for (int ch = 0; ch < nchunks; ++ch) {
             const int kbase = ch * ROWS;
@@ -290,7 +319,7 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_kernel(const AttnArgs a) {
             ls += __shfl_xor(ls, 32, 64);
             l_run = l_run * alpha + ls;
             m_run = m_new;
-            if (ch > 0) {                            // o is accumulated transposed (lane = query): the row factor is lane-local
+            if (ch > 0 || TAIL) {                    // o is accumulated transposed (lane = query): the row factor is lane-local
 #pragma unroll
                 for (int r = 0; r < 16; ++r)
 #pragma unroll
@@ -311,6 +340,21 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_kernel(const AttnArgs a) {
             }
         }
         if (!active) continue;
+        if (TAIL) {                                           // m_run >= s_tail by construction
+            const float w = fast_exp2((s_tail - m_run) * sc);
+            l_run += w;
+            const bf16_t* vt = vp + (long)a.Nk * a.v_rs;
+#pragma unroll
+            for (int dj = 0; dj < DJ; ++dj)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {                 // registers 4 g .. 4 g + 3 = columns dj 32 + 8 g + 4 (lane >> 5) + 0 .. 3
+                    const uint2 v2 = *reinterpret_cast<const uint2*>(vt + dj * 32 + 8 * g + 4 * (lane >> 5));
+                    o[dj][4 * g + 0] = fmaf(w, __uint_as_float(v2.x << 16), o[dj][4 * g + 0]);
+                    o[dj][4 * g + 1] = fmaf(w, __uint_as_float(v2.x & 0xffff0000u), o[dj][4 * g + 1]);
+                    o[dj][4 * g + 2] = fmaf(w, __uint_as_float(v2.y << 16), o[dj][4 * g + 2]);
+                    o[dj][4 * g + 3] = fmaf(w, __uint_as_float(v2.y & 0xffff0000u), o[dj][4 * g + 3]);
+                }
+        }
         const float linv = 1.f / l_run;
         bf16_t* op = a.o + (long)b * a.o_bs + h * HD;
 #pragma unroll
@@ -337,7 +381,90 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_kernel(const AttnArgs a) {
             }
         }
         if (a.lse && lane < 32 && q0 + lane < a.Nq)
-            a.lse[((long)b * a.H + h) * a.Nq + q0 + lane] = m_run * a.scale + __logf(l_run);
+            a.lse[((long)b * a.H + h) * a0.Nq + q0 + lane] = m_run * a.scale + __logf(l_run);
+    }
+    if (TAIL) {
+        // ---- the last query row (index a.Nq): scores with lane = key (half of the head dimension per lane of a pair), P V with lane = column
+        float* xch = reinterpret_cast<float*>(smem + a.tail_off);
+        const bf16_t* qt = qp + (long)a.Nq * a.q_rs;
+        int hf = lane >> 5;
+        asm volatile("" : "+v"(hf));          // opaque: the loads below depend on it and cannot be hoisted above the tiles (16 + VGPRs live there)
+        const int kl = lane & 31;
+        uint32_t qw[HD / 4];                                  // this half's HD / 2 query values, packed pairs
+#pragma unroll
+        for (int c = 0; c < HD / 16; ++c) {
+            const uint4 v = *reinterpret_cast<const uint4*>(qt + (HD / 2) * hf + 8 * c);
+            qw[4 * c] = v.x; qw[4 * c + 1] = v.y; qw[4 * c + 2] = v.z; qw[4 * c + 3] = v.w;
+        }
+        float mrun = -INFINITY, lrun = 0.f, od = 0.f;        // od: column `lane` of the (unnormalised) output row
+        const int nkb = a.Nk >> 5;
+        for (int kb = wave; kb < nkb; kb += nwav) {
+            const int r = kb * 32 + kl;
+            float part = 0.f;
+#pragma unroll
+            for (int c = 0; c < HD / 16; ++c) {
+                const uint4 v = *reinterpret_cast<const uint4*>(ldsK + tile_off<HD, SWZ_ROW>(r, (HD / 16) * hf + c));
+                const uint32_t kw[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    part = fmaf(__uint_as_float(qw[4 * c + e] << 16), __uint_as_float(kw[e] << 16), part);
+                    part = fmaf(__uint_as_float(qw[4 * c + e] & 0xffff0000u), __uint_as_float(kw[e] & 0xffff0000u), part);
+                }
+            }
+            const float sj = part + __shfl_xor(part, 32, 64);
+            const float mn = fmaxf(mrun, wave_max(sj));
+            const float alpha = fast_exp2((mrun - mn) * sc);
+            const float p = fast_exp2((sj - mn) * sc);
+            lrun = lrun * alpha + 0.5f * wave_sum(p);        // both lanes of a pair hold the key's p
+            od *= alpha;
+            mrun = mn;
+            const float pb = __uint_as_float(pack_bf2(p, 0.f) << 16);      // P enters the P V product rounded to bf16, as in the tiles
+            const uint32_t pbits = __float_as_uint(pb);
+#pragma unroll
+            for (int j = 0; j < 32; ++j) {                    // lane j (first half) holds key j's weight: a scalar read per key
+                const float pj = __uint_as_float(__builtin_amdgcn_readlane(pbits, j));
+                const int rr = kb * 32 + j;
+                const bf16_t vv = *reinterpret_cast<const bf16_t*>(ldsV + tile_off<HD, SWZ_TR>(rr, lane >> 3) + ((lane & 7) << 1));
+                od = fmaf(pj, __uint_as_float((uint32_t)vv << 16), od);
+            }
+        }
+        if (wave == 0) {                                      // the last key, for the last query: one more single-key block
+            const bf16_t* kt = kp + (long)a.Nk * a.k_rs;
+            float part = 0.f;
+#pragma unroll
+            for (int c = 0; c < HD / 16; ++c) {
+                const uint4 v = *reinterpret_cast<const uint4*>(kt + (HD / 2) * hf + 8 * c);
+                const uint32_t kw[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    part = fmaf(__uint_as_float(qw[4 * c + e] << 16), __uint_as_float(kw[e] << 16), part);
+                    part = fmaf(__uint_as_float(qw[4 * c + e] & 0xffff0000u), __uint_as_float(kw[e] & 0xffff0000u), part);
+                }
+            }
+            const float sj = part + __shfl_xor(part, 32, 64);      // the same value in every lane
+            const float mn = fmaxf(mrun, sj);
+            const float alpha = fast_exp2((mrun - mn) * sc);
+            const float p = fast_exp2((sj - mn) * sc);
+            lrun = lrun * alpha + p;
+            const float pb = __uint_as_float(pack_bf2(p, 0.f) << 16);
+            od = fmaf(pb, bf2f(vp[(long)a.Nk * a.v_rs + lane]), od * alpha);
+            mrun = mn;
+        }
+        xch[wave * 66 + lane] = od;
+        if (lane == 0) { xch[wave * 66 + 64] = mrun; xch[wave * 66 + 65] = lrun; }
+        __syncthreads();
+        if (wave == 0) {
+            float M = -INFINITY;
+            for (int w = 0; w < nwav; ++w) M = fmaxf(M, xch[w * 66 + 64]);
+            float L = 0.f, O = 0.f;
+            for (int w = 0; w < nwav; ++w) {
+                const float f = fast_exp2((xch[w * 66 + 64] - M) * sc);      // a wave without keys has m = -inf: factor 0
+                L = fmaf(xch[w * 66 + 65], f, L);
+                O = fmaf(xch[w * 66 + lane], f, O);
+            }
+            a.o[(long)b * a.o_bs + (long)a.Nq * a.o_rs + h * HD + lane] = f2bf(O / L);
+            if (a.lse && lane == 0) a.lse[((long)b * a.H + h) * a0.Nq + a.Nq] = M * a.scale + __logf(L);
+        }
     }
 }
 
@@ -899,38 +1026,48 @@ static int waves_for(int ntiles) {
 template <int HD>
 int launch_fwd(const AttnArgs& a0, hipStream_t stream) {
     AttnArgs a = a0;
-    const int nkb = (a.Nk + 31) / 32;
-    dim3 grid(a.H, a.B), block(64 * waves_for((a.Nq + 31) / 32));
+    // one token more than a multiple of 32 (the global token behind 128 / 256 patches): see attn_fwd_kernel<.., TAIL>.  MRG_ATTN_TAIL=0: off
+    static const int tail_on = [] { const char* e = getenv("MRG_ATTN_TAIL"); return e ? atoi(e) : 1; }();
+    const bool tail = tail_on && HD == 64 && a.Nq == a.Nk && (a.Nk & 31) == 1 && a.Nk >= (tail_on == 1 ? 193 : 33) &&   /* N = 129: 21.2 against 20.2 us for the compact five-tile form; N = 257: 217 against 251 */
+                      (size_t)2 * (a.Nk - 1) * HD * 2 <= 80 * 1024;
+    const int Nq = tail ? a.Nq - 1 : a.Nq, Nk = tail ? a.Nk - 1 : a.Nk;       // what the tiles cover
+    a.tail = tail ? 1 : 0;
+    const int nkb = (Nk + 31) / 32;
+    dim3 grid(a.H, a.B), block(64 * waves_for((Nq + 31) / 32));
     // K and V of the whole row stay in LDS when that leaves room for two workgroups per CU (<= 80 KiB)
     // Resident K / V are stored compactly: rows N .. (padded to 32) alias ONE zero row (index rmax), and the last wave's staging tile holds
     // only its valid rows -- at N = 129 that is 132 instead of 160 rows per tile and 52.8 instead of 63 KiB per workgroup: three
     // workgroups per CU instead of two, i.e. the 768 (batch, head) pairs of C2 in ONE round instead of two (19.4 -> ~14 us);
     // N = 99 (C4): 40 instead of 50 KiB, four per CU instead of three (1024 pairs in one round).
     static const int compact = [] { const char* e = getenv("MRG_ATTN_COMPACT"); return e ? atoi(e) : 1; }();
+#define MRG_LAUNCH(CB_, ST_, TL_) do { \
+        if (sh > 65536) (void)hipFuncSetAttribute((const void*)attn_fwd_kernel<HD, CB_, ST_, TL_>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+        hipLaunchKernelGGL((attn_fwd_kernel<HD, CB_, ST_, TL_>), grid, block, sh, stream, a); } while (0)
 #define MRG_FWD(CB_) do { const bool fits = (size_t)2 * nkb * 32 * HD * 2 <= 80 * 1024; \
         a.chunk_rows = fits ? nkb * 32 : CB_ * 32; \
         if (a.chunk_rows < CB_ * 32) a.chunk_rows = CB_ * 32; \
         a.rmax = 0x7fffffff; a.stage_tail = 0; \
-        const int nwav = block.x / 64, nqt_ = (a.Nq + 31) / 32; \
-        if (compact && fits && (a.Nk & 31) && CB_ == 1) { a.chunk_rows = ((a.Nk + 1 + 3) / 4) * 4; a.rmax = a.chunk_rows - 1; } \
+        const int nwav = block.x / 64, nqt_ = (Nq + 31) / 32; \
+        if (compact && fits && (Nk & 31) && CB_ == 1) { a.chunk_rows = ((Nk + 1 + 3) / 4) * 4; a.rmax = a.chunk_rows - 1; } \
         const size_t kv = (size_t)2 * a.chunk_rows * HD * 2; \
         size_t stg = (size_t)nwav * 32 * FUSED_SP; \
-        if (compact && nqt_ == nwav && (a.Nq & 31) && (a.Nq & 31) <= 16) { a.stage_tail = (((a.Nq & 31) + 3) / 4) * 4; \
-                                                                          stg = (size_t)(nwav - 1) * 32 * FUSED_SP + (size_t)a.stage_tail * FUSED_SP; } \
-        const bool stage = kv + stg <= 80 * 1024;        /* staging must not cost the second workgroup per CU */ \
+        if (compact && nqt_ == nwav && (Nq & 31) && (Nq & 31) <= 16) { a.stage_tail = (((Nq & 31) + 3) / 4) * 4; \
+                                                                      stg = (size_t)(nwav - 1) * 32 * FUSED_SP + (size_t)a.stage_tail * FUSED_SP; } \
+        const size_t xch = tail ? (size_t)nwav * 66 * 4 + 16 : 0;     /* TAIL: the waves' exchange area for the last query row */ \
+        const bool stage = kv + stg + xch <= 80 * 1024;        /* staging must not cost the second workgroup per CU */ \
         if (!stage) a.stage_tail = 0; \
-        const size_t sh = stage ? kv + stg : kv; \
-        if (stage) { if (sh > 65536) (void)hipFuncSetAttribute((const void*)attn_fwd_kernel<HD, CB_, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
-                     hipLaunchKernelGGL((attn_fwd_kernel<HD, CB_, true>), grid, block, sh, stream, a); } \
-        else { if (sh > 65536) (void)hipFuncSetAttribute((const void*)attn_fwd_kernel<HD, CB_, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
-               hipLaunchKernelGGL((attn_fwd_kernel<HD, CB_, false>), grid, block, sh, stream, a); } } while (0)
+        a.tail_off = (int)(stage ? kv + stg : kv); \
+        const size_t sh = (stage ? kv + stg : kv) + xch; \
+        if (tail && HD == 64) { if (stage) MRG_LAUNCH(1, true, true); else MRG_LAUNCH(1, false, true); } \
+        else if (stage) MRG_LAUNCH(CB_, true, false); \
+        else MRG_LAUNCH(CB_, false, false); } while (0)
     // Scores are kept in registers one chunk of CB key blocks at a time with an online-softmax rescale between chunks.  Small
     // chunks win on these short rows: CB = 1 needs 128 VGPRs (4 waves per SIMD) against 256 for CB = 5, and the kernel is bound
     // by latency chains, not MFMA throughput (C2 30.7 -> 23.2 us, C5 400 -> 297 us; tools/bench_attn_fwd.py)
-    (void)nkb;
     if (HD == 64) MRG_FWD(1);
     else MRG_FWD(2);
 #undef MRG_FWD
+#undef MRG_LAUNCH
     return mrg_check_launch("mrg_attn_fwd");
 }
 
@@ -954,7 +1091,7 @@ void fill(AttnArgs& a, const mrg_attn_desc* d) {
     a.d_o = (const bf16_t*)d->d_o; a.do_bs = d->do_bs; a.do_rs = d->do_rs; a.dsum = d->dsum;
     a.dq = (bf16_t*)d->dq; a.dk = (bf16_t*)d->dk; a.dv = (bf16_t*)d->dv;
     a.dq_bs = d->dq_bs; a.dq_rs = d->dq_rs; a.dk_bs = d->dk_bs; a.dk_rs = d->dk_rs; a.dv_bs = d->dv_bs; a.dv_rs = d->dv_rs;
-    a.chunk_rows = 0; a.rmax = 0x7fffffff; a.stage_tail = 0;
+    a.chunk_rows = 0; a.rmax = 0x7fffffff; a.stage_tail = 0; a.tail = 0; a.tail_off = 0;
 }
 
 }  // namespace
