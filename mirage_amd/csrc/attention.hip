@@ -231,6 +231,14 @@ __global__ __launch_bounds__(512, 4) void attn_fwd_kernel(const AttnArgs a0) {  
     const int nchunks = (a.Nk + ROWS - 1) / ROWS;
     const float sc = a.scale * LOG2E;
 
+    // TAIL: the last token's q, k and v rows (HD bf16 each, plain layout) in front of the exchange area -- read several times below, and a
+    // global round trip in front of every tile and of the last query's row is what made the path lose at N = 129
+    const bf16_t* tl = reinterpret_cast<const bf16_t*>(smem + (TAIL ? a.tail_off : 0));
+    if (TAIL && tid < 3 * (HD / 8)) {
+        const int rw = tid / (HD / 8), c = tid % (HD / 8);
+        const bf16_t* src = rw == 0 ? qp + (long)a.Nq * a.q_rs : rw == 1 ? kp + (long)a.Nk * a.k_rs : vp + (long)a.Nk * a.v_rs;
+        *reinterpret_cast<uint4*>(smem + a.tail_off + rw * HD * 2 + c * 16) = *reinterpret_cast<const uint4*>(src + c * 8);
+    }
     if (resident) {
         load_rows2<HD, SWZ_ROW, SWZ_TR>(ldsK, kp, a.k_rs, ldsV, vp, a.v_rs, lds_rows, a.Nk, tid, nthr);
         __syncthreads();
@@ -259,7 +267,7 @@ __global__ __launch_bounds__(512, 4) void attn_fwd_kernel(const AttnArgs a0) {  
         float m_run = -INFINITY, l_run = 0.f, s_tail = 0.f;
         if (TAIL) {
             // the last key (row a.Nk of k / v): this lane pair's query . k_tail, each lane over the half of the head dimension it holds
-            const bf16_t* kt = kp + (long)a.Nk * a.k_rs;
+            const bf16_t* kt = tl + HD;
             float part = 0.f;
 #pragma unroll
             for (int kk = 0; kk < KS; ++kk) {
@@ -343,7 +351,7 @@ __global__ __launch_bounds__(512, 4) void attn_fwd_kernel(const AttnArgs a0) {  
         if (TAIL) {                                           // m_run >= s_tail by construction
             const float w = fast_exp2((s_tail - m_run) * sc);
             l_run += w;
-            const bf16_t* vt = vp + (long)a.Nk * a.v_rs;
+            const bf16_t* vt = tl + 2 * HD;
 #pragma unroll
             for (int dj = 0; dj < DJ; ++dj)
 #pragma unroll
@@ -385,8 +393,8 @@ __global__ __launch_bounds__(512, 4) void attn_fwd_kernel(const AttnArgs a0) {  
     }
     if (TAIL) {
         // ---- the last query row (index a.Nq): scores with lane = key (half of the head dimension per lane of a pair), P V with lane = column
-        float* xch = reinterpret_cast<float*>(smem + a.tail_off);
-        const bf16_t* qt = qp + (long)a.Nq * a.q_rs;
+        float* xch = reinterpret_cast<float*>(smem + a.tail_off + 3 * HD * 2);
+        const bf16_t* qt = tl;
         int hf = lane >> 5;
         asm volatile("" : "+v"(hf));          // opaque: the loads below depend on it and cannot be hoisted above the tiles (16 + VGPRs live there)
         const int kl = lane & 31;
@@ -429,7 +437,7 @@ __global__ __launch_bounds__(512, 4) void attn_fwd_kernel(const AttnArgs a0) {  
             }
         }
         if (wave == 0) {                                      // the last key, for the last query: one more single-key block
-            const bf16_t* kt = kp + (long)a.Nk * a.k_rs;
+            const bf16_t* kt = tl + HD;
             float part = 0.f;
 #pragma unroll
             for (int c = 0; c < HD / 16; ++c) {
@@ -447,7 +455,7 @@ __global__ __launch_bounds__(512, 4) void attn_fwd_kernel(const AttnArgs a0) {  
             const float p = fast_exp2((sj - mn) * sc);
             lrun = lrun * alpha + p;
             const float pb = __uint_as_float(pack_bf2(p, 0.f) << 16);
-            od = fmaf(pb, bf2f(vp[(long)a.Nk * a.v_rs + lane]), od * alpha);
+            od = fmaf(pb, bf2f(tl[2 * HD + lane]), od * alpha);
             mrun = mn;
         }
         xch[wave * 66 + lane] = od;
@@ -1053,7 +1061,7 @@ int launch_fwd(const AttnArgs& a0, hipStream_t stream) {
         size_t stg = (size_t)nwav * 32 * FUSED_SP; \
         if (compact && nqt_ == nwav && (Nq & 31) && (Nq & 31) <= 16) { a.stage_tail = (((Nq & 31) + 3) / 4) * 4; \
                                                                       stg = (size_t)(nwav - 1) * 32 * FUSED_SP + (size_t)a.stage_tail * FUSED_SP; } \
-        const size_t xch = tail ? (size_t)nwav * 66 * 4 + 16 : 0;     /* TAIL: the waves' exchange area for the last query row */ \
+        const size_t xch = tail ? (size_t)3 * HD * 2 + (size_t)nwav * 66 * 4 + 16 : 0;     /* TAIL: the last token's q / k / v rows + the waves' exchange area */ \
         const bool stage = kv + stg + xch <= 80 * 1024;        /* staging must not cost the second workgroup per CU */ \
         if (!stage) a.stage_tail = 0; \
         a.tail_off = (int)(stage ? kv + stg : kv); \
