@@ -619,7 +619,7 @@ __global__ __launch_bounds__(512, 3) void attn_bwd_dq_kernel(const AttnArgs a) {
 
 // key-owner pass: dK, dV.  LDS: Q chunk and dO chunk (row + tr reads), lse*log2e and dsum per query of the chunk.
 template <int HD>
-__global__ __launch_bounds__(512, 2) void attn_bwd_dkv_kernel(const AttnArgs a) {
+__global__ __launch_bounds__(512, HD == 32 ? 4 : 2) void attn_bwd_dkv_kernel(const AttnArgs a) {   // (HIP: minimum waves per SIMD; 4 = at most 128 VGPRs: two 8-wave workgroups per CU at head_dim 32)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int KS = HD / 16, DJ = HD / 32;
     const int ROWS = a.chunk_rows;
