@@ -61,7 +61,8 @@ const char* mrg_last_error_string(void);
  *   splitk  >1: partial sums to ws [splitk][M][N] fp32, then reduced (bias/accumulate epilogue only)
  *   variant kernel variant for aligned, map-free problems: single-stage LDS-DMA kernel at 3 or 4 workgroups/CU,
  *           two-stage pipelined 128x128 kernel, two- / three-stage pipelined 256x128 kernel (8 waves), two-stage 256x256 kernel, warp-specialised 256x128 kernel (8 compute + 4 loader waves, 3-stage ring), single-stage 64x128 kernel (A k-contiguous only), (9 reserved: a persistent 256x256 kernel that was measured and dropped), single-stage 256x128 kernel with 4 waves x (128x64) (K a multiple of 64);
- *           0 picks by shape; MRG_GEMM_P8 / MRG_GEMM_P8SK = the 256 x 256 8-phase kernel, one tile per workgroup / stream-K (see sk_grid)
+ *           0 picks by shape; MRG_GEMM_P8 / MRG_GEMM_P8SK = the 256 x 256 8-phase kernel, one tile per workgroup / stream-K (see sk_grid);
+ *           MRG_GEMM_DUO = the 128 x 256 kernel with two co-resident workgroups per CU (A k-contiguous, K a multiple of 64: forward / dgrad)
  */
 typedef struct mrg_gemm_desc {
     const void* A; const void* B;
@@ -110,7 +111,7 @@ typedef struct mrg_gemm_desc {
                                         (partial accumulator images) and splitk_counters = ceil(M/256) * ceil(N/256) ints, ZERO on entry and
                                         left zero on exit.  The result is a deterministic function of the operands and sk_grid. */
 } mrg_gemm_desc;
-enum { MRG_GEMM_AUTO = 0, MRG_GEMM_GLDS3 = 1, MRG_GEMM_GLDS4 = 2, MRG_GEMM_PIPE128 = 3, MRG_GEMM_PIPE256 = 4, MRG_GEMM_PIPE256X3 = 5, MRG_GEMM_PIPE256SQ = 6, MRG_GEMM_WS256 = 7, MRG_GEMM_GLDS64 = 8, MRG_GEMM_SQP = 9, MRG_GEMM_G256 = 10, MRG_GEMM_P8 = 11, MRG_GEMM_P8SK = 12 };
+enum { MRG_GEMM_AUTO = 0, MRG_GEMM_GLDS3 = 1, MRG_GEMM_GLDS4 = 2, MRG_GEMM_PIPE128 = 3, MRG_GEMM_PIPE256 = 4, MRG_GEMM_PIPE256X3 = 5, MRG_GEMM_PIPE256SQ = 6, MRG_GEMM_WS256 = 7, MRG_GEMM_GLDS64 = 8, MRG_GEMM_SQP = 9, MRG_GEMM_G256 = 10, MRG_GEMM_P8 = 11, MRG_GEMM_P8SK = 12, MRG_GEMM_DUO = 13 };
 /* bytes of `ws` a stream-K launch with sk_grid workgroups needs (sk_grid <= 0: one workgroup per CU of the current device) */
 long mrg_streamk_ws_bytes(int sk_grid);
 

@@ -19,8 +19,8 @@ MRG_OP_KCONTIG, MRG_OP_KSTRIDED = 0, 1
 MRG_ACT_NONE, MRG_ACT_GELU, MRG_ACT_GELU_BWD, MRG_ACT_GELU_SAVE_GRAD, MRG_ACT_MUL_AUX_F16 = 0, 1, 2, 3, 4
 MRG_LOSS_MSE, MRG_LOSS_CE = 0, 1
 MRG_MAX_DOMAINS = 4
-MRG_GEMM_AUTO, MRG_GEMM_GLDS3, MRG_GEMM_GLDS4, MRG_GEMM_PIPE128, MRG_GEMM_PIPE256, MRG_GEMM_PIPE256X3, MRG_GEMM_PIPE256SQ, MRG_GEMM_WS256, MRG_GEMM_GLDS64, MRG_GEMM_SQP, MRG_GEMM_G256, MRG_GEMM_P8, MRG_GEMM_P8SK = 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12
-MRG_GEMM_P8_GROUP = 13     # not a mrg_gemm variant: the kernel-family code of mrg_wgrad_group in timing records
+MRG_GEMM_AUTO, MRG_GEMM_GLDS3, MRG_GEMM_GLDS4, MRG_GEMM_PIPE128, MRG_GEMM_PIPE256, MRG_GEMM_PIPE256X3, MRG_GEMM_PIPE256SQ, MRG_GEMM_WS256, MRG_GEMM_GLDS64, MRG_GEMM_SQP, MRG_GEMM_G256, MRG_GEMM_P8, MRG_GEMM_P8SK, MRG_GEMM_DUO = 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13
+MRG_GEMM_P8_GROUP = 100     # not a mrg_gemm variant: the kernel-family code of mrg_wgrad_group in timing records
 
 vp, ci, cl, cf = C.c_void_p, C.c_int, C.c_long, C.c_float
 

@@ -117,6 +117,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs g) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) if (e < nv) bv[e] = g.bias[col + e];
         }
+        MRG_RETIRE4(bv);
 #pragma unroll 1
         for (int it = 0; it < 16; ++it) {
             const int rl = (tid >> 5) + (it << 3);
@@ -327,6 +328,7 @@ __global__ __launch_bounds__(256, OCC) void gemm_glds_kernel(const GemmArgs g) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) if (e < nv) bv[e] = g.bias[col + e];
     }
+    MRG_RETIRE4(bv);
 #pragma unroll
     for (int pss = 0; pss < 2; ++pss) {
         __syncthreads();
@@ -525,6 +527,7 @@ __global__ __launch_bounds__(256, 2) void gemm_pipe_kernel(const GemmArgs g) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) if (e < nv) bv[e] = g.bias[col + e];
         }
+        MRG_RETIRE4(bv);
         if (VEC && ((ws && (g.side_drain & 2)) || (!ws && (g.side_drain & 1) && g.epi_kind >= 1 && g.epi_kind <= 5))) {
 #pragma unroll
             for (int hh = 0; hh < 2; ++hh) {
@@ -659,6 +662,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pipe256_kernel(const GemmArgs g) 
 #pragma unroll
         for (int e = 0; e < 4; ++e) if (e < nv) bv[e] = g.bias[col + e];
     }
+    MRG_RETIRE4(bv);
 #pragma unroll 1
     for (int h = 0; h < 2; ++h) {
         __syncthreads();
@@ -827,6 +831,7 @@ __global__ __launch_bounds__(768) void gemm_ws256_kernel(const GemmArgs g) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) if (e < nv) bv[e] = g.bias[col + e];
     }
+    MRG_RETIRE4(bv);
 #pragma unroll 1
     for (int h = 0; h < 2; ++h) {
         __syncthreads();
@@ -968,6 +973,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pipe256sq_kernel(const GemmArgs g
 #pragma unroll
         for (int e = 0; e < 4; ++e) if (e < nv) bv[e] = g.bias[col + e];
     }
+    MRG_RETIRE4(bv);
 #pragma unroll
     for (int sl = 0; sl < 4; ++sl) {
         __syncthreads();
@@ -1091,6 +1097,7 @@ __global__ __launch_bounds__(256, 2) void gemm_g256_kernel(const GemmArgs g) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) if (e < nv) bv[e] = g.bias[col + e];
     }
+    MRG_RETIRE4(bv);
 #pragma unroll
     for (int ps = 0; ps < 4; ++ps) {
         __syncthreads();
@@ -1219,6 +1226,7 @@ __global__ __launch_bounds__(256, 4) void gemm_glds64_kernel(const GemmArgs g) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) if (e < nv) bv[e] = g.bias[col + e];
     }
+    MRG_RETIRE4(bv);
 #pragma unroll 1
     for (int it = 0; it < 8; ++it) {
         const int rl = (tid >> 5) + (it << 3);
@@ -1296,7 +1304,7 @@ extern "C" int mrg_gemm(const mrg_gemm_desc* d, hipStream_t stream) {
         g.drop.scale = 1.f / (1.f - d->drop_p);
         g.drop.stream = d->drop_stream;
     }
-    MRG_REQUIRE(d->variant >= 0 && d->variant <= MRG_GEMM_P8SK, MRG_ERR_ARG, "mrg_gemm: bad variant");
+    MRG_REQUIRE(d->variant >= 0 && d->variant <= MRG_GEMM_DUO, MRG_ERR_ARG, "mrg_gemm: bad variant");
     g.tiles_m = cdiv(d->M, BM); g.tiles_n = cdiv(d->N, BN);
     { static const int abl = [] { const char* e = getenv("MRG_GEMM_ABLATE"); return e ? atoi(e) : 0; }(); g.ablate = abl; }
     { static const int nt = [] { const char* e = getenv("MRG_GEMM_NT"); return e ? atoi(e) : 2; }(); g.nt = nt; }
@@ -1319,7 +1327,7 @@ extern "C" int mrg_gemm(const mrg_gemm_desc* d, hipStream_t stream) {
                      !d->C2 && g.c_f32 && !d->colsum_out && !g.drop.rng) g.epi_kind = 6;
             else if (splitk == 1 && d->act == MRG_ACT_NONE && !d->add_tab && !d->row_map && !d->accumulate && !d->colsum_out && d->resid && g.c_f32) g.epi_kind = 2;
             else if (splitk == 1 && d->act == MRG_ACT_NONE && !d->add_tab && !d->row_map && !d->accumulate && !d->colsum_out && !d->resid && !d->row_scale &&
-                     !d->C2 && !d->bias && g.c_f32 && !g.drop.rng && (d->variant == MRG_GEMM_P8 || d->variant == MRG_GEMM_P8SK)) g.epi_kind = 7;
+                     !d->C2 && !d->bias && g.c_f32 && !g.drop.rng && (d->variant == MRG_GEMM_P8 || d->variant == MRG_GEMM_P8SK || d->variant == MRG_GEMM_DUO)) g.epi_kind = 7;
         }
     }
     dim3 grid(g.tiles_m * g.tiles_n, splitk), block(256);
@@ -1411,6 +1419,11 @@ extern "C" int mrg_gemm(const mrg_gemm_desc* d, hipStream_t stream) {
         if (d->ev_stop) (void)hipEventRecord((hipEvent_t)d->ev_stop, stream);
         int rc8 = mrg_check_launch("mrg_gemm");
         return rc8 ? rc8 : finish_splitk();
+    }
+    if (fast && !mapped && d->variant == MRG_GEMM_DUO && !d->colsum_out && d->N > 128 && mrg_gemm_duo_launch(g, d->a_mode, d->b_mode, vec, splitk, stream)) {
+        if (d->ev_stop) (void)hipEventRecord((hipEvent_t)d->ev_stop, stream);
+        int rcd = mrg_check_launch("mrg_gemm");
+        return rcd ? rcd : finish_splitk();
     }
     const bool use_sq = !d->colsum_out && fast && !mapped && d->variant == MRG_GEMM_PIPE256SQ && d->M > 128 && d->N > 128;
     const bool use_ws = !d->colsum_out && fast && !mapped && d->variant == MRG_GEMM_WS256 && d->M > 128;

@@ -380,6 +380,7 @@ __device__ __forceinline__ void p8_tile(const GemmArgs& g, const int bid, const 
     p8_bias(g, n0, g.splitk <= 1, bv, tid);
     f32x16 acc[4][2];
     p8_mainloop<AMODE, BMODE, PHASES>(g, m0, n0, t0, t1 - t0, acc, smem, tid);
+    MRG_RETIRE4(bv);
     float* ws = g.splitk > 1 ? g.ws + (long)ksplit * g.M * g.N : nullptr;
     p8_epilogue<VEC>(g, m0, n0, acc, smem, ws, bv, tid, nullptr, ssacc, af);
     if (ws && g.tile_cnt) splitk_finish<VEC>(g, bid, m0, n0, 256, 256, g.M, smem, threadIdx.x, 512);

@@ -76,6 +76,8 @@ bool mrg_gemm8p_group_launch(const mrg_detail::P8GroupArgs& ga, bool vec, hipStr
 bool mrg_gemm8p_sk_launch(const mrg_detail::GemmArgs& g, int a_mode, int b_mode, bool vec, float* slabs, int* cnt, int grid, hipStream_t stream);
 bool mrg_gemm8p_sk_group_launch(const mrg_detail::P8GroupArgs& ga, bool vec, float* slabs, int* cnt, int grid, hipStream_t stream);
 int mrg_num_cus();
+// launcher of the 128 x 256 two-workgroups-per-CU kernel (gemm_duo.hip); returns false when the problem is outside its domain
+bool mrg_gemm_duo_launch(const mrg_detail::GemmArgs& g, int a_mode, int b_mode, bool vec, int splitk, hipStream_t stream);
 
 namespace {
 
@@ -220,6 +222,11 @@ __device__ __forceinline__ void st_slab(float* w, const float4 a4, bool write_th
         *reinterpret_cast<float4*>(w) = a4;
     }
 }
+
+// Unconditional use of four loaded registers (the bias values of a thread).  They are loaded once and consumed inside `if (row < M)`
+// blocks; hipcc's wait insertion keeps such a load "pending" at the join after a block that may have been skipped, so WITHOUT this every
+// row segment opened with s_waitcnt vmcnt(0) and drained the stores of the segment before it (profiles/r05_epilogue_waits.md).
+#define MRG_RETIRE4(v_) asm volatile("" :: "v"((v_)[0]), "v"((v_)[1]), "v"((v_)[2]), "v"((v_)[3]))
 
 // one output row segment (4 consecutive columns) of the fused epilogue
 template <bool VEC, bool CS = false>
@@ -480,7 +487,7 @@ __device__ __forceinline__ void AF_ST(float* p, const float4 v) {
 // Two-phase drain of one staged pass for the epilogues that read a side operand per output (fp32 residual, fp16 GELU'): the side
 // operands of all NIT row segments are requested before the first one is consumed.  The row-at-a-time loop exposes one global
 // round trip per iteration (8-16 dependent ones per thread and pass).  row_of(it, rl, row): staging row / output row of step it.
-template <int KIND, bool CS, int NIT, int CTW, typename RowOf>
+template <int KIND, bool CS, int NIT, int CTW, bool SWZ = false, typename RowOf>
 __device__ __forceinline__ void drain_side(const GemmArgs& g, const float* ct, int cl, int col, const float (&bv)[4], int Meff,
                                            RowOf row_of, float* cs, const AdamFuseArgs* af = nullptr) {
     typedef _Float16 h4 __attribute__((ext_vector_type(4)));
@@ -496,7 +503,7 @@ __device__ __forceinline__ void drain_side(const GemmArgs& g, const float* ct, i
         row_of(it, rl, row);
         rows[it] = row;
         const long rr = row < Meff ? row : Meff - 1;              // clamped: the load is unconditional, only the store is masked
-        a[it] = *reinterpret_cast<const float4*>(ct + rl * CTW + cl);
+        a[it] = *reinterpret_cast<const float4*>(ct + rl * CTW + (SWZ ? (cl ^ ((rl & 7) << 2)) : cl));     // SWZ: 16-B chunk index XOR (row & 7), gemm_duo.hip
         if (KIND == 9) {
             const long o = af0 + rr * g.ldc + col;
             t[it] = AF_LD(af->p + o);
@@ -508,6 +515,17 @@ __device__ __forceinline__ void drain_side(const GemmArgs& g, const float* ct, i
         } else if (KIND == 4) {
             x[it] = *reinterpret_cast<const h4*>(reinterpret_cast<const _Float16*>(g.aux_in) + rr * g.ldaux + col);
         }
+    }
+    // Retire every side load HERE, unconditionally.  The values are consumed inside `if (row < Meff)` blocks: hipcc's wait insertion keeps a
+    // load "pending" at the join after a block that may have been skipped, so every later block (and every later pass / batch that reuses
+    // the registers) opened with s_waitcnt vmcnt(0) -- which also drains the STORES of the row segments before it: one store round trip
+    // per 4 outputs and thread, the reason a 256 x 256 tile's epilogue took as long as its 12 k-tiles (profiles/r05_epilogue_waits.md).
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        if (KIND == 2 || KIND == 9) asm volatile("" :: "v"(t[it].x), "v"(t[it].y), "v"(t[it].z), "v"(t[it].w));
+        if (KIND == 2) asm volatile("" :: "v"(rs[it]));
+        if (KIND == 4) asm volatile("" :: "v"(x[it]));
+        if (KIND == 9) asm volatile("" :: "v"(pm[it].x), "v"(pm[it].y), "v"(pm[it].z), "v"(pm[it].w), "v"(pv[it].x), "v"(pv[it].y), "v"(pv[it].z), "v"(pv[it].w));
     }
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {

@@ -4,7 +4,9 @@ and the vendor BLAS on the encoder shapes of C2 / C4 / C5 WITH the production ep
 bias + GELU + fp16 GELU' side output, multiply by the GELU' side input).  Every variant is timed as a captured graph of `reps`
 launches that rotate through `nrot` operand / output sets (cold-ish operands as inside the step), interleaved rounds, median.
 
-usage: bench_sk.py [c2|c4|c5|all] [grid ...]      grid: stream-K grids to try (0 = one workgroup per CU)"""
+"duo" = the 128 x 256 two-workgroups-per-CU kernel (variant 13, gemm_duo.hip, round 5).
+
+usage: bench_sk.py [c2|c4|c5|all] [grid ...]      grid: stream-K grids to time as well (0 = one workgroup per CU)"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -56,10 +58,18 @@ def case(tag, mode, epi, M, N, Kd, grids, reps=16, nrot=4, rounds=5):
         elif epi == "gelu":
             kw.update(bias=torch.randn(N, device=dev), out=torch.empty(M, N, dtype=BF16, device=dev), act=L.MRG_ACT_GELU_SAVE_GRAD,
                       aux_out=torch.empty(M, N, dtype=torch.float16, device=dev))
+        elif epi == "gelu5":
+            kw.update(bias=torch.randn(N, device=dev), out=torch.empty(M, N, dtype=BF16, device=dev), act=L.MRG_ACT_GELU)
+        elif epi == "f32":
+            kw.update(bias=torch.randn(N, device=dev), out=torch.empty(M, N, dtype=F32, device=dev))
         elif epi == "mulaux":
             kw.update(out=torch.empty(M, N, dtype=BF16, device=dev), act=L.MRG_ACT_MUL_AUX_F16,
                       aux_in=torch.rand(M, N, device=dev).half())
         sets.append((A, B, kw))
+
+    if os.environ.get("MRG_BENCH_ZERO") == "1":      # zero operands: the matrix units draw less power, the clock stays high (power vs issue experiments)
+        for A, B, kw in sets:
+            A.zero_(); B.zero_()
 
     def runner(variant, grid=0):
         def f(i):
@@ -76,7 +86,7 @@ def case(tag, mode, epi, M, N, Kd, grids, reps=16, nrot=4, rounds=5):
                 K.SK_GRID = 0
         return f
 
-    fns = {"vendor": runner("vendor"), "tuned": runner(None), "p8": runner(L.MRG_GEMM_P8)}
+    fns = {"vendor": runner("vendor"), "tuned": runner(None), "p8": runner(L.MRG_GEMM_P8), "duo": runner(L.MRG_GEMM_DUO)}
     for gr in grids:
         fns[f"sk{gr}"] = runner(L.MRG_GEMM_P8SK, gr)
     graphs = {k: graph_of(f, reps) for k, f in fns.items()}
@@ -102,7 +112,11 @@ def shapes(M, D):
 
 if __name__ == "__main__":
     which = sys.argv[1] if len(sys.argv) > 1 else "all"
-    grids = [int(x) for x in sys.argv[2:]] or [0]
+    grids = [int(x) for x in sys.argv[2:]]        # stream-K grids to time as well (none by default: round 4 measured it, profiles/r04_streamk.md)
+    if which == "epi":          # one shape per configuration under every epilogue: what the epilogue costs on top of the main loop
+        for tag, M, N, Kd in (("c2 fc1", 8256, 3072, 768), ("c5h fc1", 32896, 4096, 1024)):
+            for epi in ("plain", "bias", "gelu5", "gelu", "mulaux", "f32", "resid"):
+                case(tag, "fwd", epi, M, N, Kd, grids, reps=(6 if M > 30000 else 16), nrot=(2 if M > 30000 else 4))
     if which in ("all", "c2"):
         for (nm, mode, epi, M, N, Kd) in shapes(8256, 768):
             case("c2 " + nm, mode, epi, M, N, Kd, grids)
