@@ -491,6 +491,22 @@ def _run(real_stdout: int):
                                 "gemm_table": r.get("gemm_table")}
                 if "final_loss" in r:
                     others[name]["final_loss"] = r["final_loss"]
+                if name == "c4":
+                    # C4 is DEFINED on 8 GPUs, and with N > 1 the update cannot ride in the weight-gradient epilogues (the exchange sits
+                    # between a gradient and its update): the per-GPU step a scaling efficiency should be read against is the
+                    # one with separate update launches (MRG_FUSE_OPT=0), printed beside the fused one
+                    from mirage_amd import trainer as _T
+                    was = _T.FUSE_OPT
+                    _T.FUSE_OPT = False
+                    try:
+                        gc.collect(); torch.cuda.empty_cache()
+                        r2 = measure(a, name, st, wu, None, rank, world, dev, False, ranks_seen)
+                        others[name]["unfused_update"] = {"ms_per_step": r2["ms_per_step"], "value": r2["value"],
+                                                          "note": "MRG_FUSE_OPT=0: the per-GPU step of an N > 1 run before communication"}
+                    except Exception as exc:
+                        others[name]["unfused_update"] = {"error": f"{type(exc).__name__}: {exc}"[:300]}
+                    finally:
+                        _T.FUSE_OPT = was
             result["other_configs"] = others
             gc.collect()
             torch.cuda.empty_cache()

@@ -173,7 +173,6 @@ __device__ __forceinline__ void d2_mainloop(const GemmArgs& g, const int m0, con
     stage_a(0); stage_b(0, 0); stage_b(0, 1);
     if (nt > 1) stage_a(1);
     uint32_t rslot = 0;                                                 // slot offset of the next chunk to read
-    const bool noprio = (g.ablate & 0x100) != 0;                        // experiment knob (MRG_GEMM_ABLATE): no priority raise around the MFMA clusters
     bf16x8 fa[2][4], fb[2][4];
     for (int t = 0; t < nt; ++t) {
         const bool more = t + 1 < nt;
@@ -196,7 +195,7 @@ __device__ __forceinline__ void d2_mainloop(const GemmArgs& g, const int m0, con
         }
 #define D2_MFMA16(J0) do { \
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); \
-        if (!noprio) __builtin_amdgcn_s_setprio(1); \
+        __builtin_amdgcn_s_setprio(1); \
         asm volatile("" : "+v"(acc[0][J0]), "+v"(acc[1][J0]), "+v"(acc[0][J0 + 1]), "+v"(acc[1][J0 + 1]) :: "memory"); \
         _Pragma("unroll") for (int kk = 0; kk < 4; ++kk) { \
             acc[0][J0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[0][kk], fa[0][kk], acc[0][J0], 0, 0, 0); \
@@ -294,10 +293,6 @@ __global__ __launch_bounds__(256, 2) void gemm_duo_kernel(const GemmArgs g) {
         t1 = min(ntiles, t0 + per);
     }
     const int tid = threadIdx.x;
-    // experiment knob (MRG_GEMM_ABLATE & 0xff = n): the workgroups that the dispatcher most likely places SECOND on a CU start ~n us late
-    if ((g.ablate & 0xff) && ((blockIdx.x >> 3) & 32)) {
-        for (int i = 0; i < (g.ablate & 0xff); ++i) __builtin_amdgcn_s_sleep(32);
-    }
     float bv[4];
     {
         const int col = n0 + ((tid >> 6) & 1) * 128 + ((tid & 31) << 2);

@@ -15,6 +15,12 @@ conservative choice and can be A/B-ed on the first real node without code change
   MRG_DP_DTYPE = fp32 (default): gradients travel as produced (393 MB Base / 1.27 GB Large per step);
                = bf16: buckets are cast to bf16 into a staging buffer, summed in bf16 on the wire, cast back and divided in fp32
                  (half the xGMI bytes, two extra HBM passes over the bucket, ~3 significant digits per addend).
+  MRG_DP_UPDATE = replicated (default): every rank applies AdamW to the whole arena after the exchange;
+               = sharded: per bucket reduce-scatter -> AdamW on THIS rank's 1/world shard -> all-gather of the updated fp32 parameters
+                 (+ a local re-cast of the bf16 shadow).  Same wire bytes as reduce-scatter + all-gather of the gradients, the optimizer's
+                 HBM traffic (30 B per parameter: p, g, m, v read, p, m, v, shadow written) divided by world -- Large: 8.9 GB -> 1.1 GB
+                 per rank and step at 8 ranks -- and the moments of a shard live on its owner only (gather_moments() before a
+                 checkpoint).  Needs a norm-independent update (no clip_grad / skip_grad) and the fp32 wire format.
 """
 import os
 from typing import List, Optional, Tuple
@@ -53,12 +59,18 @@ class GradReducer:
         self.exposed = []          # exchange, i.e. the communication the backward pass did not hide
         self.comm = os.environ.get("MRG_DP_COMM", "allreduce")
         self.wire = os.environ.get("MRG_DP_DTYPE", "fp32")
-        if self.comm not in ("allreduce", "rs_ag") or self.wire not in ("fp32", "bf16"):
-            raise ValueError(f"GradReducer: MRG_DP_COMM={self.comm!r} / MRG_DP_DTYPE={self.wire!r} (allreduce|rs_ag, fp32|bf16)")
+        self.update = os.environ.get("MRG_DP_UPDATE", "replicated")
+        if self.comm not in ("allreduce", "rs_ag") or self.wire not in ("fp32", "bf16") or self.update not in ("replicated", "sharded"):
+            raise ValueError(f"GradReducer: MRG_DP_COMM={self.comm!r} / MRG_DP_DTYPE={self.wire!r} / MRG_DP_UPDATE={self.update!r} "
+                             "(allreduce|rs_ag, fp32|bf16, replicated|sharded)")
+        if self.update == "sharded" and self.wire != "fp32":
+            raise ValueError("GradReducer: MRG_DP_UPDATE=sharded exchanges fp32 shards (MRG_DP_DTYPE=bf16 is not implemented for it)")
+        self.rank = dist.get_rank(process_group) if dist.is_initialized() else 0
+        self._plan = {}            # sharded update: (s, e) -> (main_end, sub) of every bucket exchanged so far (gather_moments walks it)
         active = dist.is_initialized() and (self.world > 1 or self.force)
         self._stage16 = torch.empty(self.bucket_elems, dtype=torch.bfloat16, device=flat_grad.device) if (active and self.wire == "bf16") else None
         self._shard = None
-        if active and self.comm == "rs_ag":
+        if active and (self.comm == "rs_ag" or self.update == "sharded"):
             per = (self.bucket_elems + self.world - 1) // self.world
             self._shard = torch.empty(per, dtype=torch.bfloat16 if self.wire == "bf16" else torch.float32, device=flat_grad.device)
         # ncclAvg needs NCCL/RCCL >= 2.10; probe once (this also brings the communicator up before the first timed step) and
@@ -154,6 +166,85 @@ class GradReducer:
             self._done = torch.cuda.Event()
             self._done.record(self.side)
 
+    # -- sharded update (MRG_DP_UPDATE=sharded) -----------------------------------------------------------------------------
+    def shard_plan(self, s: int, e: int):
+        """-> (main_end, sub): flat[s:main_end) is cut into `world` shards of `sub` elements (a multiple of 64: the update kernel's
+        alignment), rank r owning [s + r sub, s + (r + 1) sub); [main_end, e) is the ragged tail (< 64 world elements), which every
+        rank reduces and updates in full."""
+        sub = (e - s) // (self.world * 64) * 64
+        return s + sub * self.world, sub
+
+    def _exchange_update(self, s: int, e: int, op, flat_p: torch.Tensor, update, recast):
+        main_end, sub = self.shard_plan(s, e)
+        self._plan[(s, e)] = (main_end, sub)
+        own = (s + self.rank * sub, s + (self.rank + 1) * sub)
+        inplace = self.backend == "nccl"           # RCCL runs both collectives in place when the shard sits at rank * count of the buffer
+        if sub:
+            if inplace:
+                dist.reduce_scatter_tensor(self.flat[own[0]:own[1]], self.flat[s:main_end], op=op, group=self.group)
+            else:
+                tmp = self._shard[:sub]
+                dist.reduce_scatter_tensor(tmp, self.flat[s:main_end].clone(), op=op, group=self.group)
+                self.flat[own[0]:own[1]].copy_(tmp)
+            if op != dist.ReduceOp.AVG:
+                self.flat[own[0]:own[1]].div_(self.world)
+        if main_end < e:
+            dist.all_reduce(self.flat[main_end:e], op=op, group=self.group)
+            if op != dist.ReduceOp.AVG:
+                self.flat[main_end:e].div_(self.world)
+        # AdamW of the owned shard and of the tail; the tail's sum of g^2 is counted by rank 0 only (the per-rank sums are added up)
+        update([own] if sub else [], [(main_end, e)] if main_end < e else [], self.rank == 0)
+        if sub:
+            if inplace:
+                dist.all_gather_into_tensor(flat_p[s:main_end], flat_p[own[0]:own[1]], group=self.group)
+            else:
+                dist.all_gather_into_tensor(flat_p[s:main_end], flat_p[own[0]:own[1]].clone(), group=self.group)
+            if recast is not None:
+                recast(s, main_end)                # bf16 shadow of the gathered parameters (the owner's update wrote its own shard only)
+
+    def exchange_update_async(self, ranges, flat_p: torch.Tensor, update, recast=None):
+        """Sharded update of the element ranges `ranges` (default: the whole buffer), bucket by bucket on the communication stream:
+        reduce-scatter of the gradients -> update(owned_ranges, tail_ranges, count_tails) on this rank's shard -> all-gather of the updated
+        fp32 parameters into `flat_p` -> recast(s, e) of whatever mirrors them (the bf16 shadow).  Call wait() before anything reads the
+        parameters.  After it the gradient buffer holds the averaged gradient only inside the ranges this rank owns."""
+        if self.world == 1 and not self.force:
+            rs = ranges if ranges is not None else [(0, self.flat.numel())]
+            update(list(rs), [], True)
+            return
+        op = dist.ReduceOp.AVG if self.use_avg else dist.ReduceOp.SUM
+        if self.side is not None:
+            ready = torch.cuda.Event()
+            ready.record(torch.cuda.current_stream(self.flat.device))
+            with torch.cuda.stream(self.side):
+                self.side.wait_event(ready)
+                for s, e in self._buckets(ranges):
+                    self._exchange_update(s, e, op, flat_p, update, recast)
+                self._done = torch.cuda.Event()
+                self._done.record(self.side)
+        else:
+            for s, e in self._buckets(ranges):
+                self._exchange_update(s, e, op, flat_p, update, recast)
+
+    def finish_norm(self, grad_norm: torch.Tensor):
+        """sharded update: every rank's gradient norm covers the ranges it updated; the global norm is the root of the summed squares"""
+        if self.world == 1 and not self.force:
+            return
+        grad_norm.pow_(2)
+        dist.all_reduce(grad_norm, op=dist.ReduceOp.SUM, group=self.group)
+        grad_norm.sqrt_()
+
+    def gather_moments(self, *moments: torch.Tensor):
+        """sharded update: bring every rank's copy of the optimizer moments up to date (all-gather over the recorded bucket plan) --
+        collective, call it on every rank before a checkpoint is written."""
+        if self.world == 1 and not self.force:
+            return
+        for (s, e), (main_end, sub) in sorted(self._plan.items()):
+            if not sub:
+                continue
+            own = (s + self.rank * sub, s + (self.rank + 1) * sub)
+            for m in moments:
+                dist.all_gather_into_tensor(m[s:main_end], m[own[0]:own[1]].clone(), group=self.group)
+
     def _buckets(self, ranges):
         if ranges is None:
             return list(reversed(self.ranges))       # arena tail (decoders / last blocks) finishes first in backward
@@ -182,7 +273,7 @@ class GradReducer:
         return t
 
     def describe(self) -> dict:
-        return {"backend": self.backend, "comm": self.comm, "wire_dtype": self.wire, "bucket_mib": self.bucket_elems * 4 / 2 ** 20,
+        return {"backend": self.backend, "comm": self.comm, "wire_dtype": self.wire, "update": self.update, "bucket_mib": self.bucket_elems * 4 / 2 ** 20,
                 "buckets": len(self.ranges), "avg_op": bool(self.use_avg), "bytes_per_step": int(self.flat.numel()) * (2 if self.wire == "bf16" else 4)}
 
     def reduce(self):

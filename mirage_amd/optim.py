@@ -188,6 +188,7 @@ class FusedAdamW:
         # writes the same slice of `_ss`, and the finish kernel sums every slot handed out so far.  Nothing here depends on a host
         # cursor, so eager calls, captured graphs and any mix of the two (data parallel: stage updates issued eagerly between
         # graph replays, the rest inside the optimizer graph) stay consistent across replays.
+        self.sharded = False        # set by trainer.TrainStep when the data-parallel exchange also carries the update (MRG_DP_UPDATE=sharded)
         self._ss = torch.zeros(1 << 19, dtype=torch.float32, device=dev) if self.fuse_norm else None     # <= 4096 partials per launch, <= 128 ranges
         self._slots = PartialSumSlots(1 << 19)
         self.param_groups = [
@@ -206,14 +207,15 @@ class FusedAdamW:
         self.step_dev[0:1].fill_(int(it))
         self._host_step = int(it)
 
-    def step_ranges(self, ranges):
+    def step_ranges(self, ranges, count: bool = True):
         """AdamW over element ranges [s, e) of the arena (64-element aligned) with the CURRENT step counters: the element updates
         are independent, so any partition of the arena gives bit-identical results to the single launch.  Only without clip / skip
-        (the update must not depend on the global gradient norm)."""
+        (the update must not depend on the global gradient norm).  count=False: the ranges' g^2 stay out of this rank's gradient norm
+        (data parallel with a sharded update: a range every rank updates is counted by rank 0 only)."""
         a = self.arena
         for s, e in ranges:
             nd = max(0, min(e, a.n_decay) - s)
-            ss = self._ss_slot(s, e) if self.fuse_norm else None
+            ss = self._ss_slot(s, e) if (self.fuse_norm and count) else None
             K.adamw(a.flat_p[s:e], a.flat_g[s:e], self.exp_avg[s:e], self.exp_avg_sq[s:e], a.flat_bf16[s:e], nd, self.lr_table,
                     self.wd_table, self.step_dev, self.betas[0], self.betas[1], self.eps, sumsq_out=ss)
 
@@ -246,7 +248,8 @@ class FusedAdamW:
                 rest.append((pos, a.n_trainable))
             self.step_ranges(rest)
             if self.fuse_norm:
-                if not self._slots.is_partition(a.n_trainable):
+                # sharded data-parallel update (dp.GradReducer.exchange_update_async): this rank updated -- and counted -- its shards only
+                if not self.sharded and not self._slots.is_partition(a.n_trainable):
                     raise RuntimeError("FusedAdamW: the update ranges of this step do not partition the arena (gradient norm would be wrong)")
                 K.sumsq_finish(self._ss, self._slots.used, self.grad_norm)
         else:

@@ -279,8 +279,11 @@ def main(args):
         stats = {f"[Epoch] {k}": v / max(n_log, 1) for k, v in sums.items()}
         stats.update({"[Epoch] lr": float(lrs[gi]), "[Epoch] min_lr": float(lrs[gi]), "[Epoch] weight_decay": float(wds[gi]),
                       "[Epoch] loss_scale": 1.0, "epoch": epoch, "n_parameters": n_parameters})
+        saving = (epoch + 1) % args.save_ckpt_freq == 0 or epoch + 1 == args.epochs
+        if saving and reducer is not None and reducer.update == "sharded":
+            reducer.gather_moments(optimizer.exp_avg, optimizer.exp_avg_sq)      # collective: the moments of a shard live on its owner
         if rank == 0:
-            if (epoch + 1) % args.save_ckpt_freq == 0 or epoch + 1 == args.epochs:
+            if saving:
                 save_model(args, epoch, model, optimizer)
             with open(os.path.join(args.output_dir, "log.txt"), mode="a", encoding="utf-8") as f:
                 f.write(json.dumps(stats) + "\n")

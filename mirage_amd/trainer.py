@@ -98,7 +98,15 @@ class TrainStep:
         from .optim import FusedAdamW
         self._first_merged = None            # union of the ranges updated early in data-parallel mode (None: single update)
         self._stage_merged = []
-        if (self.split and os.environ.get("MRG_EARLY_OPT", "1") != "0" and isinstance(optimizer, FusedAdamW)
+        # MRG_DP_UPDATE=sharded: the exchange carries the update (reduce-scatter -> AdamW on this rank's shard -> all-gather of the
+        # parameters, dp.GradReducer.exchange_update_async); the optimizer graph only finishes the norm and advances the counters
+        self._sharded = False
+        if reducer is not None and getattr(reducer, "update", "replicated") == "sharded":
+            if not (isinstance(optimizer, FusedAdamW) and optimizer.fuse_norm):
+                raise RuntimeError("MRG_DP_UPDATE=sharded needs FusedAdamW without clip_grad / skip_grad (the update must not depend on the global gradient norm)")
+            self._sharded = True
+            optimizer.sharded = True
+        if (self.split and not self._sharded and os.environ.get("MRG_EARLY_OPT", "1") != "0" and isinstance(optimizer, FusedAdamW)
                 and not optimizer.clip_grad and not optimizer.skip_grad):
             self._stage_merged = [self._merge(r) for r in self.stage_ranges]
             self._first_merged = self._merge([r for rs in self.stage_ranges for r in rs])
@@ -135,6 +143,19 @@ class TrainStep:
         if self._early is not None and FUSE_OPT and optimizer.fuse_norm:
             from .optim import AdamWFusion
             self._fusion = AdamWFusion(optimizer)
+
+    def _exchange(self, ranges, j=None):
+        """gradient exchange of `ranges` (None: the whole arena) -- with the update inside it when it is sharded, else with stage j's AdamW
+        behind it (`then`)"""
+        if self._sharded:
+            a = self.opt.arena
+            from . import kernels as _K
+            self.reducer.exchange_update_async(
+                ranges, a.flat_p,
+                lambda owned, tails, count_tails: (self.opt.step_ranges(owned), self.opt.step_ranges(tails, count=count_tails)),
+                lambda s0, e0: _K.cast_bf16(a.flat_p[s0:e0], a.flat_bf16[s0:e0]))
+        else:
+            self.reducer.reduce_async(ranges, then=self._stage_then(j) if j is not None else None)
 
     def _stage_then(self, j):
         """several ranks, no clipping: AdamW of a stage's parameters runs on the communication stream right behind their all-reduce,
@@ -266,7 +287,9 @@ class TrainStep:
     def _opt(self):
         from . import kernels as _K
         _K.timestamp("opt_start")
-        if self._early is not None:
+        if self._sharded:
+            self.opt.step(done_ranges=[(0, self.opt.arena.n_trainable)])      # every range was updated inside the exchange
+        elif self._early is not None:
             self.opt.step(done_ranges=self._early_all)
         elif self._first_merged is not None:
             self.opt.step(done_ranges=self._first_merged)
@@ -277,18 +300,21 @@ class TrainStep:
     def _eager(self):
         if self.split:
             self._fwd_bwd_upper()
-            self.reducer.reduce_async(self.stage_ranges[0], then=self._stage_then(0))
+            self._exchange(self.stage_ranges[0], 0)
             for j in range(1, len(self.cuts)):
                 self._bwd_mid(len(self.cuts) - 1 - j)
-                self.reducer.reduce_async(self.stage_ranges[j], then=self._stage_then(j))
+                self._exchange(self.stage_ranges[j], j)
             self._bwd_lower()
-            self.reducer.reduce_async(self.r_rest)
+            self._exchange(self.r_rest)
             self.reducer.wait()
         else:
             self._fwd_bwd()
             if self.reducer is not None:
-                self.reducer.reduce()
+                self._exchange(None)
+                self.reducer.wait()
         self._opt()
+        if self._sharded:
+            self.reducer.finish_norm(self.opt.grad_norm)
 
     def warmup_and_capture(self, warm_iters: int = 2):
         """A few eager iterations on a side stream (allocator warm-up, workspace sizing, GEMM autotuning), then graph capture.
@@ -393,16 +419,21 @@ class TrainStep:
             self.g_fb.replay()
             # each stage's all-reduce overlaps the following stages of the backward pass (and, without clipping, takes the stage's
             # AdamW along)
-            self.reducer.reduce_async(self.stage_ranges[0], then=self._stage_then(0))
+            self._exchange(self.stage_ranges[0], 0)
             for j, gm in enumerate(self.g_mids, start=1):
                 gm.replay()
-                self.reducer.reduce_async(self.stage_ranges[j], then=self._stage_then(j))
+                self._exchange(self.stage_ranges[j], j)
             self.g_b.replay()
-            self.reducer.reduce_async(self.r_rest)
+            self._exchange(self.r_rest)
             self.reducer.wait()
             self.g_opt.replay()
+            if self._sharded:
+                self.reducer.finish_norm(self.opt.grad_norm)
         else:
             self.g_fb.replay()
-            self.reducer.reduce()
+            self._exchange(None)
+            self.reducer.wait()
             self.g_opt.replay()
+            if self._sharded:
+                self.reducer.finish_norm(self.opt.grad_norm)
         return self.loss

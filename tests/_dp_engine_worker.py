@@ -1,6 +1,6 @@
 """Helper process for tests/test_fullsize_gpu.py::test_two_engine_ranks_on_one_gpu (not a test module).
 
-    python tests/_dp_engine_worker.py <rank> <world> <port> <outfile> [comm] [wire]
+    python tests/_dp_engine_worker.py <rank> <world> <port> <outfile> [comm] [wire] [update]
 
 world > 1: one data-parallel rank of the HIP engine (all ranks share GPU 0, gloo backend) running trainer.TrainStep's staged
 schedule -- upper / middle / lower backward graphs with the gradient exchange between them and the optimizer graph -- on its
@@ -32,6 +32,8 @@ def main():
         os.environ["MRG_DP_COMM"] = sys.argv[5]
     if len(sys.argv) > 6:
         os.environ["MRG_DP_DTYPE"] = sys.argv[6]
+    if len(sys.argv) > 7:
+        os.environ["MRG_DP_UPDATE"] = sys.argv[7]
     torch.cuda.set_device(0)
     dev = torch.device("cuda", 0)
     if world > 1:
@@ -74,7 +76,12 @@ def main():
         ts.step(batches[i], noise=noises[i])
         losses.append(float(ts.loss))
     torch.cuda.synchronize()
+    if reducer is not None and reducer.update == "sharded":
+        reducer.gather_moments(opt.exp_avg, opt.exp_avg_sq)          # what a checkpoint does first (run_pretraining.main)
+        torch.cuda.synchronize()
     torch.save({"flat_p": opt.arena.flat_p.cpu(), "flat_g": opt.arena.flat_g.cpu(), "losses": losses, "grad_norm": float(opt.grad_norm),
+                "exp_avg": opt.exp_avg.cpu(), "exp_avg_sq": opt.exp_avg_sq.cpu(), "shadow": opt.arena.flat_bf16.cpu(),
+                "update": reducer.update if reducer is not None else "single",
                 "n_graphs": n_graphs, "cuts": list(ts.cuts), "steps": opt.step_dev.tolist()}, out)
     if world > 1:
         dist.barrier()

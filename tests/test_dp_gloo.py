@@ -51,6 +51,59 @@ def _worker(rank, world, port, out):
         r3.reduce_async([(0, 4096), (4096, n)]); r3.wait()
         ok1 = ok1 and bool(((flat3 - want3).abs() <= tol * want3.abs() + 1e-6).all())
     os.environ.pop("MRG_DP_COMM"); os.environ.pop("MRG_DP_DTYPE")
+    # 1d) MRG_DP_UPDATE=sharded: reduce-scatter -> AdamW on this rank's shard -> all-gather of the parameters, against the replicated
+    #     update (all-reduce, then AdamW of everything on every rank).  A torch AdamW over element ranges stands in for mrg_adamw (the
+    #     GPU path hands FusedAdamW.step_ranges to the same call); ragged ranges exercise the tails every rank updates in full.
+    os.environ["MRG_DP_UPDATE"] = "sharded"
+    nn = 10_000 + 37 * 64
+    gen = torch.Generator().manual_seed(11)
+    p0 = torch.randn(nn, generator=gen)
+    g_r = [torch.randn(nn, generator=gen) for _ in range(world)]
+
+    def adamw_ranges(p, g, m, v, ranges, lr=1e-2, wd=0.05, b1=0.9, b2=0.95, eps=1e-8, t=1):
+        ss = 0.0
+        for s0, e0 in ranges:
+            gg = g[s0:e0]
+            p[s0:e0].mul_(1 - lr * wd)
+            m[s0:e0].mul_(b1).add_(gg, alpha=1 - b1)
+            v[s0:e0].mul_(b2).addcmul_(gg, gg, value=1 - b2)
+            p[s0:e0].addcdiv_(m[s0:e0] / (1 - b1 ** t), (v[s0:e0] / (1 - b2 ** t)).sqrt() + eps, value=-lr)
+            ss += float((gg.double() ** 2).sum())
+        return ss
+
+    ranges4 = [(0, 4096), (4096 + 64, 9000 // 64 * 64), (9984, nn)]              # 64-aligned, lengths not multiples of 64 * world
+    covered = torch.zeros(nn, dtype=torch.bool)
+    for s0, e0 in ranges4:
+        covered[s0:e0] = True
+    g_avg = sum(g_r) / world
+    p_ref, m_ref, v_ref = p0.clone(), torch.zeros(nn), torch.zeros(nn)
+    ss_ref = adamw_ranges(p_ref, g_avg, m_ref, v_ref, ranges4)
+    p_sh, m_sh, v_sh, g_sh = p0.clone(), torch.zeros(nn), torch.zeros(nn), g_r[rank].clone()
+    r4 = GradReducer(g_sh, bucket_bytes=4096)
+    counted = [0.0]
+
+    def upd(owned, tails, count_tails):
+        counted[0] += adamw_ranges(p_sh, g_sh, m_sh, v_sh, owned)
+        t_ss = adamw_ranges(p_sh, g_sh, m_sh, v_sh, tails)
+        if count_tails:
+            counted[0] += t_ss
+
+    recast_calls = []
+    r4.exchange_update_async(ranges4, p_sh, upd, lambda s0, e0: recast_calls.append((s0, e0)))
+    r4.wait()
+    gn = torch.tensor([counted[0] ** 0.5])
+    r4.finish_norm(gn)
+    r4.gather_moments(m_sh, v_sh)
+    plan_ok = all(sub % 64 == 0 and (me - s0) == sub * world and e0 - me < 64 * world for (s0, e0), (me, sub) in r4._plan.items())
+    ok_sh = (plan_ok and len(recast_calls) > 0 and torch.equal(p_sh, p_ref) and torch.equal(m_sh[covered], m_ref[covered])
+             and torch.equal(v_sh[covered], v_ref[covered]) and abs(float(gn[0]) - ss_ref ** 0.5) < 1e-4 * ss_ref ** 0.5
+             and torch.equal(p_sh[~covered], p0[~covered]))
+    # replicas bit-identical: compare against rank 0's parameters
+    p_chk = p_sh.clone()
+    dist.broadcast(p_chk, src=0)
+    ok_sh = ok_sh and torch.equal(p_chk, p_sh)
+    ok1 = ok1 and ok_sh
+    os.environ.pop("MRG_DP_UPDATE")
     # 2) broadcast
     p = torch.full((100,), float(rank))
     broadcast_params(p, src=0)

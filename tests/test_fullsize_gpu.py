@@ -329,14 +329,14 @@ def _wait_ranks(procs, timeout):
 
 def _spawn(rank, world, port, out, *extra):
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
-    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "MRG_DP_COMM", "MRG_DP_DTYPE"):
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "MRG_DP_COMM", "MRG_DP_DTYPE", "MRG_DP_UPDATE"):
         env.pop(k, None)
     return subprocess.Popen([sys.executable, "-X", "faulthandler", os.path.join(ROOT, "tests", "_dp_engine_worker.py"), str(rank), str(world),
                              str(port), out, *extra], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
 
 
-@pytest.mark.parametrize("comm,wire", [("allreduce", "fp32"), ("rs_ag", "bf16")])
-def test_two_engine_ranks_on_one_gpu(tmp_path, comm, wire):
+@pytest.mark.parametrize("comm,wire,update", [("allreduce", "fp32", "replicated"), ("rs_ag", "bf16", "replicated"), ("allreduce", "fp32", "sharded")])
+def test_two_engine_ranks_on_one_gpu(tmp_path, comm, wire, update):
     """Two data-parallel ranks of the HIP engine (child processes sharing GPU 0, gloo) through trainer.TrainStep's staged schedule
     (three backward graphs with the gradient exchange in between + the optimizer graph, AdamW of each stage behind its exchange)
     == one process on the concatenated batch: same losses, gradients and weights after two optimizer steps."""
@@ -344,7 +344,7 @@ def test_two_engine_ranks_on_one_gpu(tmp_path, comm, wire):
     port = _free_port()
     outs = [str(tmp_path / f"r{r}.pt") for r in range(2)]
     single = str(tmp_path / "single.pt")
-    procs = [_spawn(r, 2, port, outs[r], comm, wire) for r in range(2)]
+    procs = [_spawn(r, 2, port, outs[r], comm, wire, update) for r in range(2)]
     logs = _wait_ranks(procs, 300)
     for p, lg in zip(procs, logs):
         assert p.returncode == 0, lg[-3000:]
@@ -354,9 +354,19 @@ def test_two_engine_ranks_on_one_gpu(tmp_path, comm, wire):
     r0, r1, s = (torch.load(f, weights_only=False) for f in (outs[0], outs[1], single))
     assert r0["n_graphs"] == 4 and r0["cuts"] == [1, 2] and s["n_graphs"] == 1          # upper / middle / lower / optimizer
     assert r0["steps"] == [2, 2] and s["steps"] == [2, 2]
-    assert torch.equal(r0["flat_p"], r1["flat_p"]) and torch.equal(r0["flat_g"], r1["flat_g"])     # replicas stay identical
+    assert r0["update"] == update
+    assert torch.equal(r0["flat_p"], r1["flat_p"]) and torch.equal(r0["shadow"], r1["shadow"])     # replicas stay identical
     mean_losses = [(a + b) / 2 for a, b in zip(r0["losses"], r1["losses"])]
-    g_rel = float((r0["flat_g"].double() - s["flat_g"].double()).norm() / s["flat_g"].double().norm())
+    if update == "sharded":
+        # MRG_DP_UPDATE=sharded (reduce-scatter -> AdamW on the owned shard -> all-gather of the parameters): a rank's gradient arena holds
+        # the average only inside its shards, so the averaged gradient is each element's owner's: after gather_moments both ranks hold
+        # the same moments, and exp_avg = (1 - beta1) (beta1 g_1 + g_2) stands in for the gradient in the comparison below
+        assert torch.equal(r0["exp_avg"], r1["exp_avg"]) and torch.equal(r0["exp_avg_sq"], r1["exp_avg_sq"])
+        assert torch.equal(r0["shadow"].float(), r0["flat_p"].to(torch.bfloat16).float())          # the re-cast covers the gathered shards
+        g_rel = float((r0["exp_avg"].double() - s["exp_avg"].double()).norm() / s["exp_avg"].double().norm())
+    else:
+        assert torch.equal(r0["flat_g"], r1["flat_g"])
+        g_rel = float((r0["flat_g"].double() - s["flat_g"].double()).norm() / s["flat_g"].double().norm())
     dw = float((r0["flat_p"] - s["flat_p"]).abs().max())
     l_rel = [abs(a - b) / abs(b) for a, b in zip(mean_losses, s["losses"])]
     # The two runs use different GEMM tilings / split-K factors (M = 4 x N vs 8 x N rows), so bf16 intermediates round differently:
@@ -364,7 +374,7 @@ def test_two_engine_ranks_on_one_gpu(tmp_path, comm, wire):
     # identical weights and must agree to fp32 roundoff, the second one follows an Adam step taken on those gradients.
     gtol = 5e-3 if wire == "fp32" else 2e-2
     gn_rel = abs(r0["grad_norm"] - s["grad_norm"]) / s["grad_norm"]
-    T.report(f"dp2_one_gpu_{comm}_{wire}", grad_rel=g_rel, grad_tol=gtol, weight_max_abs=dw, loss_rel_step0=l_rel[0], loss_rel_step1=l_rel[1],
+    T.report(f"dp2_one_gpu_{comm}_{wire}_{update}", grad_rel=g_rel, grad_tol=gtol, weight_max_abs=dw, loss_rel_step0=l_rel[0], loss_rel_step1=l_rel[1],
              grad_norm_rel=gn_rel)
     # the logged norm (mutils/native_scaler.py:46-61 over the AVERAGED gradients) is assembled from the partial sums of three stage
     # updates issued eagerly between the graphs and of the rest inside the optimizer graph: all of them must be in it
@@ -408,6 +418,7 @@ def test_bench_self_launch_two_ranks():
     assert len(dp["exposed_comm_ms_per_step"]) == 2 and all(0 <= t < r["ms_per_step"] * 1.05 for t in dp["exposed_comm_ms_per_step"])
     assert max(dp["ranks_ms_per_step"]) <= r["ms_per_step"] * 1.05
     assert dp["comm"] in ("allreduce", "rs_ag") and dp["wire_dtype"] in ("fp32", "bf16") and dp["backend"] == "gloo"
+    assert dp["update"] in ("replicated", "sharded")
     assert dp["bucket_mib"] == 64 and dp["buckets"] >= 1 and dp["bytes_per_step"] > 0 and isinstance(dp["encoder_cuts"], list)
 
 
