@@ -5,8 +5,9 @@ the same mask noise; eager == graph bit-exactly at these shapes; and two data-pa
 against one process on the concatenated batch.
 
 Reference: mirage/model.py:305-431 (forward), mirage/criterion.py:31-117 (losses), run_pretraining.py:683-742 (step).
-Tolerances: total and per-task loss <= 1e-3 relative (BASELINE.json north_star); global gradient norm <= 1e-2; sampled
-parameter gradients: norm within 2e-2, full-tensor rel-RMS within 4e-2 of the fp32 oracle (bf16 operands).  Every measured
+Tolerances: total loss <= 1e-3 relative to the fp32 oracle (BASELINE.json north_star) and <= 2e-4 to the oracle with bf16 weight matrices
+(O.autocast_weights: what the reference's autocast multiplies with); per task <= 1.5e-3 / 4e-4; global gradient norm <= 1e-2; sampled
+parameter gradients: norm within 2e-2, full-tensor rel-RMS within 2e-2 of the fp32 oracle (bf16 operands).  Every measured
 error is printed and appended to gpurun_out/parity_measured.jsonl.
 """
 import os
@@ -60,12 +61,13 @@ def _run_engine(cfg, B, Kk, x, noise, use_graph):
     return model, opt, ts
 
 
-def _fullsize_case(tag, kind, doms, B, Kk, check_eager=True):
+def _fullsize_case(tag, kind, doms, B, Kk, check_eager=True, data_seed=1234, mask_seed=99, asserts=True):
+    """-> the measured errors; asserts=False (tools/parity_seeds.py: the same case over other data / mask seeds) only measures"""
     from oracle import mirage_oracle as O
     import test_model_gpu as T
     cfg = O.make_config(kind, doms)
-    x = O.synthetic_batch(cfg, B, seed=1234)
-    (p, u, g), tm, ids_keep, ids_restore = O.synthetic_masks(cfg, B, Kk, seed=99)
+    x = O.synthetic_batch(cfg, B, seed=data_seed)
+    (p, u, g), tm, ids_keep, ids_restore = O.synthetic_masks(cfg, B, Kk, seed=mask_seed)
     noise = (torch.from_numpy(p).to(DEV), torch.cat([torch.from_numpy(a) for a in u], 1).to(DEV), torch.from_numpy(g).to(DEV))
     model, opt, ts = _run_engine(cfg, B, Kk, x, noise, use_graph=True)
     loss = float(ts.loss)
@@ -86,6 +88,15 @@ def _fullsize_case(tag, kind, doms, B, Kk, check_eager=True):
             "grad_norm_rel": abs(gn - ref_gn) / ref_gn, "grad_norm_tol": 1e-2}
     for d in task:
         meas[f"loss_rel.{d}"] = abs(task[d] - float(ref_ls[d])) / max(1.0, abs(float(ref_ls[d])))
+    # ... and against the oracle evaluated with the weight matrices in the format the reference's autocast region multiplies with
+    # (O.autocast_weights: bf16-rounded, everything else fp32).  For a fixed set of weights that rounding shifts every task's loss by a
+    # fixed amount whatever the batch (C2 slo -9.5e-4, C4 bscan -8.8e-4: tools/debug/parity_bias.py, profiles/r05_parity_measured.md),
+    # which is most of the distance to the fp32 oracle; what is left is the engine's own arithmetic
+    with torch.no_grad():
+        w_total, w_ls, _, _ = O.forward_loss(cfg, O.autocast_weights(O.procedural_state_dict(cfg)), x, ids_keep, ids_restore)
+    meas["loss_rel_w16"] = abs(loss - float(w_total)) / abs(float(w_total))
+    for d in task:
+        meas[f"loss_rel_w16.{d}"] = abs(task[d] - float(w_ls[d])) / max(1.0, abs(float(w_ls[d])))
     worst_n, worst_r = (0.0, ""), (0.0, "")
     for n in names:
         r = sdr[n].grad.double()
@@ -95,7 +106,7 @@ def _fullsize_case(tag, kind, doms, B, Kk, check_eager=True):
         er = float((mine - r).norm()) / scale
         worst_n = max(worst_n, (en, n)); worst_r = max(worst_r, (er, n))
     meas.update(grad_norm_worst=worst_n[0], grad_norm_worst_name=worst_n[1], grad_norm_worst_tol=2e-2,
-                grad_rms_worst=worst_r[0], grad_rms_worst_name=worst_r[1], grad_rms_worst_tol=4e-2)
+                grad_rms_worst=worst_r[0], grad_rms_worst_name=worst_r[1], grad_rms_worst_tol=2e-2, data_seed=data_seed, mask_seed=mask_seed)
     del sdr
     if check_eager:
         model_e, opt_e, ts_e = _run_engine(cfg, B, Kk, x, noise, use_graph=False)
@@ -104,15 +115,24 @@ def _fullsize_case(tag, kind, doms, B, Kk, check_eager=True):
     T.report(tag, **meas)
     # masks the engine drew from the noise == the oracle's (bit-exact integer path at full size)
     tmg, ikg, irg = model.generate_random_masks_from_noise(*noise, Kk, list(doms))
-    assert torch.equal(ikg.cpu(), ids_keep) and torch.equal(irg.cpu(), ids_restore)
-    assert meas["loss_rel"] <= 1e-3, meas
+    meas["masks_bit_exact"] = bool(torch.equal(ikg.cpu(), ids_keep) and torch.equal(irg.cpu(), ids_restore))
+    if not asserts:
+        return meas
+    assert meas["masks_bit_exact"]
+    assert meas["loss_rel"] <= 1e-3, meas                      # BASELINE.json north_star: the masked-reconstruction loss within 1e-3
+    assert meas["loss_rel_w16"] <= 2e-4, meas                  # ... and within 2e-4 once the oracle multiplies with the same bf16 weight matrices
     for d in task:
-        assert meas[f"loss_rel.{d}"] <= 1e-3, (d, meas)
+        # per task: 4e-4 against the oracle with bf16 weight matrices (measured <= 7.7e-5 at C2, <= 1.8e-4 at C4 over 9 data x mask seeds);
+        # 1.5e-3 against the fp32 oracle -- the weight format alone moves a task by up to 9.5e-4 (C2 slo) / 8.8e-4 (C4 bscan), the same for every
+        # batch, and the reference's own autocast run sits 1.9e-3 from its fp32 run on C4's bscan (tests/golden/c4_large.npz floor.loss.bscan)
+        assert meas[f"loss_rel_w16.{d}"] <= 4e-4, (d, meas)
+        assert meas[f"loss_rel.{d}"] <= 1.5e-3, (d, meas)
     assert meas["grad_norm_rel"] <= 1e-2, meas
     assert worst_n[0] <= 2e-2, worst_n
-    assert worst_r[0] <= 4e-2, worst_r
+    assert worst_r[0] <= 2e-2, worst_r            # 2e-2 (measured 8-9e-3)
     if check_eager:
         assert meas["eager_equals_graph"]
+    return meas
 
 
 @pytest.mark.parametrize("kind,doms,B,Kk,chains", [("base", ("bscan", "slo"), 64, 128, 1), ("base", ("bscan", "slo"), 64, 128, 2),
@@ -192,6 +212,10 @@ def test_c4_large_b16_graph_step_vs_oracle():
 
 
 def test_c4_large_b64_production_step_vs_oracle_on_8_samples():
+    _c4_b64_case()
+
+
+def _c4_b64_case(data_seed=1234, mask_seed=99, asserts=True):
     """C4 at the PRODUCTION per-GPU batch (Large, 3 modalities, B = 64, M = 64 x 99 = 6336 rows: the shapes gemm_tune_gfx950.json is
     keyed on, grouped weight gradients, early AdamW) through the graph-replayed TrainStep; samples are independent in the forward
     pass, so the CPU oracle runs on 8 of the 64 samples: their encoder tokens (rel-RMS <= 1e-2, cosine >= 0.9999) and their masked
@@ -201,8 +225,8 @@ def test_c4_large_b64_production_step_vs_oracle_on_8_samples():
     import test_model_gpu as T
     doms, B, Kk = ("bscan", "slo", "bscanlayermap"), 64, 98
     cfg = O.make_config("large", doms)
-    x = O.synthetic_batch(cfg, B, seed=1234)
-    (p, u, g), tm, ids_keep, ids_restore = O.synthetic_masks(cfg, B, Kk, seed=99)
+    x = O.synthetic_batch(cfg, B, seed=data_seed)
+    (p, u, g), tm, ids_keep, ids_restore = O.synthetic_masks(cfg, B, Kk, seed=mask_seed)
     noise = (torch.from_numpy(p).to(DEV), torch.cat([torch.from_numpy(a) for a in u], 1).to(DEV), torch.from_numpy(g).to(DEV))
     model, opt, ts = _run_engine(cfg, B, Kk, x, noise, use_graph=True)
     assert opt.step_dev.tolist() == [1, 1] and np.isfinite(float(ts.loss)) and np.isfinite(float(opt.grad_norm))
@@ -230,13 +254,22 @@ def test_c4_large_b64_production_step_vs_oracle_on_8_samples():
     for d in sub_losses:
         meas[f"loss_rel.{d}"] = abs(sub_losses[d] - float(ref_ls[d])) / max(1.0, abs(float(ref_ls[d])))
     meas["loss_rel"] = abs(sum(sub_losses.values()) - float(ref_total)) / abs(float(ref_total))
-    T.report("c4_b64_production_8samples", **meas)
-    for d in doms:
-        assert torch.equal(ts.masks[d].cpu(), torch.from_numpy(tm[list(doms).index(d)]))         # mask indices bit-exact at full size
-    assert meas["enc_rel_rms"] <= 1e-2 and meas["enc_cos"] >= 0.9999, meas
-    assert meas["loss_rel"] <= 1e-3, meas
+    with torch.no_grad():                 # the same against the oracle with the weight matrices as autocast multiplies with them (see _fullsize_case)
+        w_total, w_ls, _, _ = O.forward_loss(cfg, O.autocast_weights(sd), xs, ids_keep[idx], ids_restore[idx])
     for d in sub_losses:
-        assert meas[f"loss_rel.{d}"] <= 1e-3, (d, meas)
+        meas[f"loss_rel_w16.{d}"] = abs(sub_losses[d] - float(w_ls[d])) / max(1.0, abs(float(w_ls[d])))
+    meas["loss_rel_w16"] = abs(sum(sub_losses.values()) - float(w_total)) / abs(float(w_total))
+    meas.update(data_seed=data_seed, mask_seed=mask_seed)
+    T.report("c4_b64_production_8samples", **meas)
+    meas["masks_bit_exact"] = all(torch.equal(ts.masks[d].cpu(), torch.from_numpy(tm[list(doms).index(d)])) for d in doms)
+    if not asserts:
+        return meas
+    assert meas["masks_bit_exact"]                                                                # mask indices bit-exact at full size
+    assert meas["enc_rel_rms"] <= 1e-2 and meas["enc_cos"] >= 0.9999, meas
+    assert meas["loss_rel"] <= 1e-3 and meas["loss_rel_w16"] <= 2e-4, meas
+    for d in sub_losses:                       # tolerances: see _fullsize_case
+        assert meas[f"loss_rel_w16.{d}"] <= 4e-4, (d, meas)
+        assert meas[f"loss_rel.{d}"] <= 1.5e-3, (d, meas)
 
 
 def test_c5_large_b256_two_chain_graph_forward_vs_oracle_on_8_samples():
