@@ -486,7 +486,7 @@ def _encoder_fwd_two_chains(x: torch.Tensor, blocks, save: bool, want_bf16: bool
             # B of a block runs beside chain A of the same block, so this never stalls it): chain B of block j + lag follows such a
             # wait at a block >= j + 1, i.e. on chain A of a block >= j.  One edge per lag blocks: each cross-stream edge of a captured
             # graph costs dependent-launch latency (an edge per block: -0.5 % at C2; waiting for the CURRENT block: -1.4 %).
-            if i % lag == lag - 1 and i + 1 < n and ev_a_prev is not None:
+            if i % lag == lag - 1 and ev_a_prev is not None:          # also before the LAST block (depths 12 / 24 are multiples of the lag)
                 s2.wait_event(ev_a_prev)
             ev_a_prev = torch.cuda.Event()
             ev_a_prev.record(main)
@@ -630,14 +630,17 @@ def embed_fwd(model, x: Dict[str, torch.Tensor], ids_keep: torch.Tensor, save: b
 def embed_bwd(model, saved_all, dx32: torch.Tensor, dx16: Optional[torch.Tensor]):
     (rows, toks, srcb, counts), A_list, inputs = saved_all
     doms = list(inputs.keys())
+    unused = []
     for name, ad in model.input_adapters.items():
         if name not in inputs:
             # a modality that was not in x: torch leaves its parameters' .grad at None and the optimizer skips them; here gradients are
-            # buffers that every backward pass overwrites, so the unused adapter's are cleared (an AdamW step then still applies its
-            # momentum and weight decay to them -- the one difference to the reference for such a training call)
+            # buffers that every backward pass overwrites, so the unused adapter's are cleared -- and the adapter is reported to the fused
+            # optimizer, which refuses to step it (momentum and weight decay on parameters the reference's optimizer would skip)
             for p_ in ad.parameters():
                 if p_.requires_grad:
                     grad_buffer(p_).zero_()
+                    unused.append(name)
+    model._mrg_unused_adapters = sorted(set(unused))
     B, N, D = dx32.shape
     ng = model.num_global_tokens
     Kk = N - ng

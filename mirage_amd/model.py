@@ -257,6 +257,17 @@ class MIRAGEModel(nn.Module):
         """Same contract as mirage/model.py:305-431.  Extra keywords: `mask_noise=(p, u, g)` feeds explicit noise to the
         mask generator (bit-exact parity tests); `drop_path_noise` [blocks with drop_path > 0, 2, B] feeds the uniform
         draws of stochastic depth (default: torch.rand on the device)."""
+        try:
+            return self._forward(x, mask_inputs, task_masks, num_encoded_tokens, alphas, sample_tasks_uniformly, return_all_layers, reshape,
+                                 mask_noise, drop_path_noise)
+        finally:
+            # the Philox snapshot handed to the attention modules belongs to THIS pass (their saved tuples keep it for the backward pass):
+            # a later stand-alone call of such a module must draw its own (engine.attn_dropout_args), not replay this pass's masks
+            for att in self._mrg_adrop:
+                att._mrg_adrop_rng = None
+
+    def _forward(self, x, mask_inputs, task_masks, num_encoded_tokens, alphas, sample_tasks_uniformly, return_all_layers, reshape, mask_noise,
+                 drop_path_noise):
         x = {"bscan": x} if isinstance(x, Tensor) else x
         # the reference tokenises x.items() in x's OWN order and only the modalities it finds there (mirage/model.py:352-356): a subset of the
         # input adapters (features of one modality from a multi-modal checkpoint) and any key order are valid calls

@@ -233,6 +233,12 @@ class FusedAdamW:
         element ranges already updated this step through step_ranges() (early, overlapped with backward)."""
         from .engine import join_side_stream
         join_side_stream()
+        skipped = getattr(self.model, "_mrg_unused_adapters", None)
+        if skipped:
+            # the reference's optimizer skips parameters whose .grad is None (a modality that was not in the batch); one fused launch over the
+            # arena cannot, and stepping them anyway would apply weight decay and momentum decay the reference does not
+            raise RuntimeError(f"FusedAdamW.step: input adapter(s) {skipped} had trainable parameters but were not in the batch of the last backward "
+                               "pass; pass every modality, or freeze the unused adapter (requires_grad_(False)) before building the optimizer")
         a = self.arena
         g = a.flat_g
         if not self.fuse_norm:

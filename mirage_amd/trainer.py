@@ -39,8 +39,13 @@ class TrainStep:
         # The placeholders have the dtype the batch-reading kernels take (fp32 images, int64 label maps), whatever the example batch
         # holds: a placeholder of another dtype would be cast by the engine into a NEW tensor that no slot stands for, and every step
         # would silently train on the staging buffer.  Batches of another dtype are converted by the staging copy (step -> load).
-        self.static_x = {k: torch.empty(v.shape, dtype=torch.float32 if v.is_floating_point() else torch.int64, device=v.device)
-                         for k, v in batch_example.items()}
+        # ... chosen by the KIND of the modality's adapter, not by the example's dtype: an image modality whose example arrives as uint8 would
+        # otherwise get an int64 placeholder that binds later int64 batches directly and trains on a cast copy no slot stands for
+        def _dtype_of(k, v):
+            if k in model.input_adapters:
+                return torch.int64 if hasattr(model.input_adapters[k], "class_emb") else torch.float32
+            return torch.float32 if v.is_floating_point() else torch.int64     # a target-only key: the loss kernels read fp32 images / int64 labels
+        self.static_x = {k: torch.empty(v.shape, dtype=_dtype_of(k, v), device=v.device) for k, v in batch_example.items()}
         from . import kernels as _K
         self.slots = _K.InputSlots(self.static_x)
         self.in_domains = list(model.input_adapters.keys())
@@ -392,10 +397,9 @@ class TrainStep:
         pointed at it (one tiny launch) and it is kept alive until the next step; the caller must not overwrite it on another stream
         before this step has run.  Without `batch` the step re-reads what is bound (after load(): the staging buffers)."""
         if batch is not None:
-            unknown = [k for k in batch if k not in self.static_x]
             if not any(k in self.static_x for k in batch):
                 raise ValueError(f"TrainStep.step: the batch has none of the inputs the step was built for ({sorted(self.static_x)}); got {sorted(batch)}")
-            del unknown                               # extra keys (targets of other tasks, metadata) are ignored, as load() does
+            # extra keys (targets of other tasks, metadata) are ignored, as load() does
             if not IN_PLACE_INPUTS:
                 self.load(batch)
             else:

@@ -529,6 +529,45 @@ def test_modalities_follow_the_keys_of_x():
         model({"other": x["bscan"].to(DEV)})
 
 
+def test_optimizer_refuses_to_step_an_adapter_that_was_not_in_the_batch():
+    """A training call on a subset of the modalities: torch leaves the unused adapter's .grad at None and the reference's optimizer skips
+    its parameters (mutils/optim_factory.py:180 -> torch.optim.AdamW skips p.grad is None).  One fused launch over the arena cannot skip, and
+    stepping the cleared gradients would still apply weight decay and momentum decay: FusedAdamW.step must refuse (round-4 advisor item)."""
+    from mirage_amd import optim
+    from oracle import mirage_oracle as O
+    _, meta = load_golden("tiny3")
+    cfg = meta["cfg"]
+    model, args, sd = _build(dict(cfg, out_domains=[]))
+    model.train()
+    opt = optim.FusedAdamW(model, [1e-3], [0.05])
+    x = O.synthetic_batch(cfg, 4, seed=91)
+    enc, _ = model({d: x[d].to(DEV) for d in ("slo", "bscan")}, num_encoded_tokens=20)
+    opt.zero_grad()
+    enc.float().square().mean().backward()
+    assert model._mrg_unused_adapters == ["bscanlayermap"]
+    with pytest.raises(RuntimeError, match="were not in the batch"):
+        opt.step()
+    enc, _ = model({d: x[d].to(DEV) for d in cfg["in_domains"]}, num_encoded_tokens=20)
+    enc.float().square().mean().backward()
+    assert model._mrg_unused_adapters == []
+    opt.step()
+    torch.cuda.synchronize()
+
+
+def test_attention_dropout_snapshot_does_not_outlive_the_forward_pass():
+    """model.forward hands its attention modules ONE Philox snapshot per pass (engine.attn_dropout_args); it must be gone afterwards, so
+    that a stand-alone call of such a module draws its own masks instead of replaying the last pass's (round-4 advisor item)."""
+    _, meta = load_golden("tiny3_attn_dropout")
+    model, args, sd = _build(meta["cfg"])
+    model.train()
+    from oracle import mirage_oracle as O
+    x = O.synthetic_batch(meta["cfg"], 2, seed=3)
+    assert model._mrg_adrop
+    model({d: x[d].to(DEV) for d in meta["cfg"]["in_domains"]}, num_encoded_tokens=meta["K"])
+    assert all(getattr(a, "_mrg_adrop_rng", None) is None for a in model._mrg_adrop)
+    torch.cuda.synchronize()
+
+
 def test_mixed_token_grids_raise_like_the_reference():
     """The reference asserts that every context task has as many tokens as the decoding adapter's grid
     (mirage/output_adapters.py:176-179); the HIP path must fail the same way, not read out of bounds."""
