@@ -123,9 +123,11 @@ __device__ __forceinline__ uint32_t d2_next(uint32_t soff) { return soff == (uin
 // main loop of one 128 x 256 tile at (m0, n0) over the k-tiles [t0, t0 + nt).  acc[i][j]: rows wm*64 + i*32.., columns wn*128 + (j>>1)*64
 // + (j&1)*32.. in the TRANSPOSED register layout (lane & 31 = row, register 4q + e = column 8q + 4 (lane >> 5) + e of the block).
 // On return no LDS-DMA of this call is outstanding; the caller must pass a barrier before it reuses the ring.
-template <int BMODE>
+// FILL (experiment builds only, -DMRG_DUO_EXPERIMENT): FILL dummy v_fma_f32 behind every MFMA of a cluster, pinned there by
+// sched_group_barrier -- does VALU work issued from INSIDE a wave's own MFMA cluster cost time (profiles/r05_gemm_epilogue.md)?
+template <int BMODE, int FILL = 0>
 __device__ __forceinline__ void d2_mainloop(const GemmArgs& g, const int m0, const int n0, const int t0, const int nt,
-                                            f32x16 (&acc)[2][4], char* smem, const int tid) {
+                                            f32x16 (&acc)[2][4], char* smem, const int tid, float* fill_out = nullptr) {
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;
@@ -174,6 +176,11 @@ __device__ __forceinline__ void d2_mainloop(const GemmArgs& g, const int m0, con
     if (nt > 1) stage_a(1);
     uint32_t rslot = 0;                                                 // slot offset of the next chunk to read
     bf16x8 fa[2][4], fb[2][4];
+    float fd[8];
+    if constexpr (FILL > 0) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) fd[q] = (float)(lane + q);
+    }
     for (int t = 0; t < nt; ++t) {
         const bool more = t + 1 < nt;
         // ---- phase a: A(t) x B0(t)
@@ -202,6 +209,10 @@ __device__ __forceinline__ void d2_mainloop(const GemmArgs& g, const int m0, con
             acc[1][J0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[0][kk], fa[1][kk], acc[1][J0], 0, 0, 0); \
             acc[0][J0 + 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[1][kk], fa[0][kk], acc[0][J0 + 1], 0, 0, 0); \
             acc[1][J0 + 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[1][kk], fa[1][kk], acc[1][J0 + 1], 0, 0, 0); \
+            if constexpr (FILL > 0) { \
+                _Pragma("unroll") for (int q = 0; q < 4 * FILL; ++q) asm volatile("v_fma_f32 %0, %0, %1, %1" : "+v"(fd[q & 7]) : "v"(fd[(q + 1) & 7] )); \
+                _Pragma("unroll") for (int q = 0; q < 4; ++q) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x002, FILL, 0); } \
+            } \
         } \
         asm volatile("" : "+v"(acc[0][J0]), "+v"(acc[1][J0]), "+v"(acc[0][J0 + 1]), "+v"(acc[1][J0 + 1]) :: "memory"); \
         __builtin_amdgcn_s_setprio(0); } while (0)
@@ -221,6 +232,12 @@ __device__ __forceinline__ void d2_mainloop(const GemmArgs& g, const int m0, con
         }
         D2_MFMA16(2);
 #undef D2_MFMA16
+    }
+    if constexpr (FILL > 0) {
+        float t = 0.f;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) t += fd[q];
+        if (fill_out && t == 12345.678f) fill_out[tid] = t;      // keeps the dummy chains alive; never true in practice
     }
 }
 
@@ -277,7 +294,7 @@ __device__ __forceinline__ void d2_epilogue_pass(const GemmArgs& g, const int m0
     }
 }
 
-template <int BMODE, bool VEC>
+template <int BMODE, bool VEC, int FILL = 0>
 __global__ __launch_bounds__(256, 2) void gemm_duo_kernel(const GemmArgs g) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int nwg = ((g.M + D2_BM - 1) / D2_BM) * ((g.N + D2_BN - 1) / D2_BN);
@@ -300,7 +317,7 @@ __global__ __launch_bounds__(256, 2) void gemm_duo_kernel(const GemmArgs g) {
         for (int e = 0; e < 4; ++e) bv[e] = (g.splitk <= 1 && g.bias && col + e < g.N) ? g.bias[col + e] : 0.f;
     }
     f32x16 acc[2][4];
-    d2_mainloop<BMODE>(g, m0, n0, t0, t1 - t0, acc, smem, tid);
+    d2_mainloop<BMODE, FILL>(g, m0, n0, t0, t1 - t0, acc, smem, tid, FILL > 0 ? reinterpret_cast<float*>(g.C) : nullptr);
     __syncthreads();                                   // every wave has read its last fragments: the ring becomes the staging areas
     // The bias registers were loaded before the main loop and are first used inside the epilogue's `if (row < M)` blocks.  hipcc's wait
     // insertion then keeps them "pending" at every join (the block that waited may have been skipped) and opens EVERY row segment with
@@ -323,6 +340,18 @@ bool mrg_gemm_duo_launch(const mrg_detail::GemmArgs& g, int a_mode, int b_mode, 
 #define MRG_DUO(BM_, V) do { const void* fn = (const void*)gemm_duo_kernel<BM_, V>; \
         (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, D2_LDS); \
         hipLaunchKernelGGL((gemm_duo_kernel<BM_, V>), grid, block, (size_t)D2_LDS, stream, g); } while (0)
+#ifdef MRG_DUO_EXPERIMENT
+    static const int fill = [] { const char* e = getenv("MRG_DUO_FILL"); return e ? atoi(e) : 0; }();
+#define MRG_DUOF(F) do { const void* fn = (const void*)gemm_duo_kernel<0, true, F>; \
+        (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, D2_LDS); \
+        hipLaunchKernelGGL((gemm_duo_kernel<0, true, F>), grid, block, (size_t)D2_LDS, stream, g); } while (0)
+    if (fill > 0 && b_mode == MRG_OP_KCONTIG && vec) {
+        if (fill == 1) MRG_DUOF(1); else if (fill == 2) MRG_DUOF(2); else if (fill == 3) MRG_DUOF(3); else if (fill == 4) MRG_DUOF(4);
+        else if (fill == 6) MRG_DUOF(6); else MRG_DUOF(8);
+        return true;
+    }
+#undef MRG_DUOF
+#endif
     if (b_mode == MRG_OP_KCONTIG) { if (vec) MRG_DUO(0, true); else MRG_DUO(0, false); }
     else { if (vec) MRG_DUO(1, true); else MRG_DUO(1, false); }
 #undef MRG_DUO

@@ -71,22 +71,30 @@ def case(tag, mode, epi, M, N, Kd, grids, reps=16, nrot=4, rounds=5):
         for A, B, kw in sets:
             A.zero_(); B.zero_()
 
-    def runner(variant, grid=0):
+    def runner(variant, grid=0, splitk=1):
         def f(i):
             A, B, kw = sets[i % nrot]
+            if splitk > 1:
+                kw = dict(kw, splitk=splitk)
             if variant == "vendor":
                 torch.mm(A, B.t() if mode == "fwd" else B)
                 return
             K.TUNE["force"] = variant
             K.SK_GRID = grid
+            was = K.TUNE["enabled"]
+            if splitk > 1:
+                K.TUNE["enabled"] = False          # the table would overwrite the split factor
             try:
                 K.gemm(A, B, M, N, Kd, **kw)
             finally:
                 K.TUNE["force"] = None
                 K.SK_GRID = 0
+                K.TUNE["enabled"] = was
         return f
 
     fns = {"vendor": runner("vendor"), "tuned": runner(None), "p8": runner(L.MRG_GEMM_P8), "duo": runner(L.MRG_GEMM_DUO)}
+    for sk_ in [int(x) for x in os.environ.get("MRG_BENCH_DUO_SPLITK", "").split(",") if x]:
+        fns[f"duo/{sk_}"] = runner(L.MRG_GEMM_DUO, 0, sk_)
     for gr in grids:
         fns[f"sk{gr}"] = runner(L.MRG_GEMM_P8SK, gr)
     graphs = {k: graph_of(f, reps) for k, f in fns.items()}
@@ -113,6 +121,17 @@ def shapes(M, D):
 if __name__ == "__main__":
     which = sys.argv[1] if len(sys.argv) > 1 else "all"
     grids = [int(x) for x in sys.argv[2:]]        # stream-K grids to time as well (none by default: round 4 measured it, profiles/r04_streamk.md)
+    if which == "under":        # shapes with fewer 128 x 256 tiles than workgroup slots: split-K inside the duo kernel (MRG_BENCH_DUO_SPLITK=2,3,4)
+        for tag, mode, epi, M, N, Kd in (("c2 proj", "fwd", "resid", 8256, 768, 768), ("c2 fc2", "fwd", "resid", 8256, 768, 3072),
+                                         ("c2 fc1", "dgrad", "plain", 8256, 768, 3072), ("c2 qkv", "dgrad", "plain", 8256, 768, 2304),
+                                         ("c4 proj", "fwd", "resid", 6336, 1024, 1024), ("c4 fc2", "fwd", "resid", 6336, 1024, 4096),
+                                         ("c4 fc1", "dgrad", "plain", 6336, 1024, 4096), ("c4 qkv", "dgrad", "plain", 6336, 1024, 3072),
+                                         ("dec fc2", "fwd", "resid", 16384, 256, 1024), ("dec fc1", "dgrad", "plain", 16384, 256, 1024),
+                                         ("c2h fc2", "fwd", "resid", 4128, 768, 3072), ("c2h fc1", "fwd", "gelu", 4128, 3072, 768)):
+            case(tag, mode, epi, M, N, Kd, grids)
+    if which == "fill":         # tools/debug/run_duo_fill.sh: main-loop-dominated shapes with the cheapest epilogue
+        for tag, M, N, Kd in (("c2 fc1", 8256, 3072, 768), ("c5h fc1", 32896, 4096, 1024), ("square4k", 8192, 8192, 4096)):
+            case(tag, "fwd", "bias", M, N, Kd, grids, reps=(6 if M > 30000 or Kd > 2000 else 16), nrot=(2 if M > 30000 or Kd > 2000 else 4))
     if which == "epi":          # one shape per configuration under every epilogue: what the epilogue costs on top of the main loop
         for tag, M, N, Kd in (("c2 fc1", 8256, 3072, 768), ("c5h fc1", 32896, 4096, 1024)):
             for epi in ("plain", "bias", "gelu5", "gelu", "mulaux", "f32", "resid"):
