@@ -26,7 +26,7 @@ extern "C" {
 typedef struct ihipStream_t* hipStream_t;
 #endif
 
-#define MRG_ABI_VERSION 11   /* 11: mrg_attn_desc.drop_rng / drop_p / drop_stream (dropout on the attention probabilities), mrg_posemb_grad, mrg_loss_desc.label_smoothing / norm_pix / stats, mrg_wgrad_group_desc.fuse + mrg_adamw_hp (AdamW in the weight-gradient epilogue), mrg_debug_clock_monitor; 10: MRG_GEMM_P8SK (stream-K schedule of the 8-phase kernel), mrg_gemm_desc.sk_grid, mrg_wgrad_group_desc.streamk / counters / sk_grid, mrg_streamk_ws_bytes; 9: mrg_maskgen_rng, input slots (mrg_set_slots, *_slot parameters, mrg_loss_desc.target_slot); 8: mrg_gemm_desc.drop_rng / drop_p / drop_stream, mrg_dropout_bwd_bf16; 7: mrg_wgrad_group, mrg_debug_timestamp; 2: mrg_gemm_desc grew row_scale / defer_reduce, act codes 3, 4, reduce_batch / augment / row_scale entry points; 3: colsum_out, attention colsum_*; 4: step = int[2], mrg_step_inc takes the skip decision; 5: splitk_counters, MRG_GEMM_P8, resize entry points; 6: mrg_adamw_desc.sumsq_out, mrg_sumsq_finish */
+#define MRG_ABI_VERSION 12   /* 12: MRG_GEMM_DUO (mrg_gemm_desc.variant 13: the 128 x 256 two-workgroups-per-CU kernel, csrc/gemm_duo.hip); 11: mrg_attn_desc.drop_rng / drop_p / drop_stream (dropout on the attention probabilities), mrg_posemb_grad, mrg_loss_desc.label_smoothing / norm_pix / stats, mrg_wgrad_group_desc.fuse + mrg_adamw_hp (AdamW in the weight-gradient epilogue), mrg_debug_clock_monitor; 10: MRG_GEMM_P8SK (stream-K schedule of the 8-phase kernel), mrg_gemm_desc.sk_grid, mrg_wgrad_group_desc.streamk / counters / sk_grid, mrg_streamk_ws_bytes; 9: mrg_maskgen_rng, input slots (mrg_set_slots, *_slot parameters, mrg_loss_desc.target_slot); 8: mrg_gemm_desc.drop_rng / drop_p / drop_stream, mrg_dropout_bwd_bf16; 7: mrg_wgrad_group, mrg_debug_timestamp; 2: mrg_gemm_desc grew row_scale / defer_reduce, act codes 3, 4, reduce_batch / augment / row_scale entry points; 3: colsum_out, attention colsum_*; 4: step = int[2], mrg_step_inc takes the skip decision; 5: splitk_counters, MRG_GEMM_P8, resize entry points; 6: mrg_adamw_desc.sumsq_out, mrg_sumsq_finish */
 
 enum { MRG_DT_BF16 = 0, MRG_DT_F32 = 1 };
 enum { MRG_OP_KCONTIG = 0, MRG_OP_KSTRIDED = 1 };

@@ -149,7 +149,7 @@ for _name, (_res, _args) in SIGNATURES.items():
     _fn.argtypes = _args
 
 ABI_VERSION = lib.mrg_version()
-EXPECTED_ABI_VERSION = 11      # must match MRG_ABI_VERSION in include/mirage_hip.h: the ctypes structs above mirror that layout
+EXPECTED_ABI_VERSION = 12      # must match MRG_ABI_VERSION in include/mirage_hip.h: the ctypes structs above mirror that layout
 if ABI_VERSION != EXPECTED_ABI_VERSION:
     raise ImportError(f"{LIB_PATH} reports ABI version {ABI_VERSION}, the Python bindings expect {EXPECTED_ABI_VERSION}: rebuild it "
                       "(python -c 'import __graft_entry__ as g; g.build()')")

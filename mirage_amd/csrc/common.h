@@ -63,7 +63,30 @@ __device__ __forceinline__ void gelu_parts(float x, float& cdf, float& pdf) {
     cdf = 0.5f * (1.0f + erfv);
     pdf = 0.3989422804014327f * e;
 }
-__device__ __forceinline__ float gelu_f(float x) { float c, p; gelu_parts(x, c, p); return x * c; }
+// GELU alone (inference forward: no derivative wanted, so no Gaussian factor either): Phi(x) - 0.5 = x P(x^2) / Q(x^2) on |x| <= 5,
+// clamped beyond (Phi(-5) = 2.9e-7); |error| <= 6.1e-7 in exact arithmetic, 8.9e-7 as evaluated here in fp32 (tools/fit_gelu_cdf.py,
+// tests/test_host_cpu.py::test_gelu_cdf_rational_coefficients) -- the class of the erf formula above, with ONE quarter-rate instruction
+// (v_rcp) and 17 issue slots per element instead of two (v_exp, v_rcp) and 24: the GELU epilogue is VALU-issue-bound and its cost adds to
+// the main loop's whatever the schedule (profiles/r05_gemm_epilogue.md), so fewer instructions is the one lever it has.
+#define MRG_GELU_P0 0.39894565560789313f
+#define MRG_GELU_P1 0.015060430819950503f
+#define MRG_GELU_P2 0.003054712685341789f
+#define MRG_GELU_P3 (-8.205621222599123e-05f)
+#define MRG_GELU_P4 (-1.049850072496286e-06f)
+#define MRG_GELU_Q0 0.20446006730028407f
+#define MRG_GELU_Q1 0.016672357899504955f
+#define MRG_GELU_Q2 0.0004785680281318415f
+#define MRG_GELU_Q3 (-3.6057791006505383e-05f)
+__device__ __forceinline__ float gelu_cdf_rational(float x) {
+    const float xc = __builtin_amdgcn_fmed3f(x, -5.0f, 5.0f);
+    const float u = xc * xc;
+    float p = fmaf(MRG_GELU_P4, u, MRG_GELU_P3);
+    p = fmaf(p, u, MRG_GELU_P2); p = fmaf(p, u, MRG_GELU_P1); p = fmaf(p, u, MRG_GELU_P0);
+    float q = fmaf(MRG_GELU_Q3, u, MRG_GELU_Q2);
+    q = fmaf(q, u, MRG_GELU_Q1); q = fmaf(q, u, MRG_GELU_Q0); q = fmaf(q, u, 1.0f);
+    return fmaf(xc * p, __builtin_amdgcn_rcpf(q), 0.5f);
+}
+__device__ __forceinline__ float gelu_f(float x) { return x * gelu_cdf_rational(x); }
 __device__ __forceinline__ float gelu_grad_f(float x) { float c, p; gelu_parts(x, c, p); return c + x * p; }
 
 // ---- one AdamW element update (torch.optim.AdamW, mutils/optim_factory.py:180), shared by the flat-arena kernel (optim.hip) and the

@@ -190,3 +190,29 @@ def test_partial_sum_slots_are_replay_safe():
     assert sl.is_partition(1000) and not sl.is_partition(2000)
     with pytest.raises(RuntimeError, match="exhausted"):
         PartialSumSlots(capacity=4).get(0, 64, 5)
+
+
+def test_gelu_cdf_rational_coefficients():
+    """The GELU-only epilogue (csrc/common.h gelu_cdf_rational; replaces nn.GELU() of mirage/utils.py:142,156 in the inference forward)
+    evaluates Phi(x) - 0.5 = x P(x^2) / Q(x^2), clamped at |x| = 5, in fp32 Horner form.  The coefficients are read from the header and
+    re-evaluated here exactly as the kernel does (numpy float32) against erf: |error| of Phi <= 1e-6 everywhere, of x Phi(x) <= 1e-5 (|x| <= 9: the absolute error of Phi times |x|)."""
+    import os, re
+    from scipy.special import erf
+    src = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "mirage_amd", "csrc", "common.h")).read()
+    co = {m.group(1): np.float32(float(m.group(2))) for m in re.finditer(r"#define MRG_GELU_([PQ]\d)\s+\(?(-?[0-9.e+-]+)f\)?", src)}
+    assert sorted(co) == ["P0", "P1", "P2", "P3", "P4", "Q0", "Q1", "Q2", "Q3"]
+    x = np.linspace(-9, 9, 1_800_001).astype(np.float32)
+    xc = np.clip(x, np.float32(-5), np.float32(5))
+    u = (xc * xc).astype(np.float32)
+    p = co["P4"]
+    for k in ("P3", "P2", "P1", "P0"):
+        p = (p * u + co[k]).astype(np.float32)
+    q = co["Q3"]
+    for k in ("Q2", "Q1", "Q0"):
+        q = (q * u + co[k]).astype(np.float32)
+    q = (q * u + np.float32(1)).astype(np.float32)
+    phi = ((xc * p).astype(np.float32) * (np.float32(1) / q).astype(np.float32) + np.float32(0.5)).astype(np.float32)
+    ref = 0.5 * (1 + erf(x.astype(np.float64) / np.sqrt(2)))
+    assert float(np.abs(phi - ref).max()) <= 1e-6
+    assert float(np.abs(x.astype(np.float64) * phi - x.astype(np.float64) * ref).max()) <= 1e-5
+    assert float(phi.min()) >= -1e-6 and float(phi.max()) <= 1.0 + 1e-6
