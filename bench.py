@@ -77,6 +77,20 @@ def synth_batches(doms, B, n, seed, device):
     return pool
 
 
+def step_traffic(cfg_name):
+    """{'measured_gb', 'algorithmic_gb', 'ratio', 'source'} of one C2 step, or None (other configurations / no committed PMC pass)"""
+    if cfg_name != "c2":
+        return None
+    for tname in ("r05_c2_step_traffic.json",):
+        f = os.path.join(ROOT, "profiles", tname)
+        if os.path.exists(f):
+            t = json.load(open(f))
+            alg = 23.0
+            return {"measured_gb": round(t["total_gb"], 2), "read_gb": round(t["read_gb"], 2), "written_gb": round(t["written_gb"], 2),
+                    "algorithmic_gb": alg, "ratio": round(t["total_gb"] / alg, 3), "source": "profiles/" + tname}
+    return None
+
+
 def cpu_baseline(model_name, doms, K, train, budget_s=25.0):
     """CPU oracle (parity-pinned restatement of the reference) on the host cores; bounded sample of the same workload."""
     from oracle import mirage_oracle as O
@@ -107,7 +121,31 @@ def cpu_baseline(model_name, doms, K, train, budget_s=25.0):
         if len(times) >= 3 or (time.perf_counter() - t_start > budget_s and len(times) >= 1):
             break
     best = min(times)
-    return {"value": round(B / best, 3), "unit": "images/sec", "cores": n_threads, "host_cores": os.cpu_count(), "kind": "port",
+    # ... and once more on EVERY host thread (SURVEY section 8d says os.cpu_count()): the small CPU matmuls of this workload do not scale past
+    # ~32 threads, which is why `value` is the 32-thread figure; the all-thread figure is reported beside it
+    all_cores = None
+    n_all = os.cpu_count() or 1
+    if n_all > n_threads and os.environ.get("MRG_CPU_ALL_CORES") == "1":      # opt-in: measured once on a 256-thread host, 0.09 images/s (three orders
+        # of magnitude of oversubscription: minutes per iteration), which would take the default run far beyond "a few minutes"
+        torch.set_num_threads(n_all)
+        t_all = []
+        for i in range(3):
+            t0 = time.perf_counter()
+            if train:
+                for p in sd.values():
+                    p.grad = None
+                loss, _, _, _ = O.forward_loss(cfg, sd, x, ids_keep, ids_restore)
+                loss.backward()
+            else:
+                with torch.no_grad():
+                    O.forward(cfg, sd, {d: x[d] for d in doms}, ids_keep, ids_restore, decode=False)
+            if i > 0:
+                t_all.append(time.perf_counter() - t0)
+            if time.perf_counter() - t_start > 2.2 * budget_s and t_all:
+                break
+        all_cores = {"value": round(B / min(t_all), 3), "cores": n_all}
+        torch.set_num_threads(n_threads)
+    return {"value": round(B / best, 3), "unit": "images/sec", "cores": n_threads, "host_cores": os.cpu_count(), "kind": "port", "all_cores": all_cores,
             "sample": f"CPU oracle fp32, B={B}, {'fwd+loss+bwd' if train else 'fwd'}, 2 warm-up + {len(times)} timed iterations (best), "
                       f"{n_threads} threads of {os.cpu_count()} host cores"}
 
@@ -278,7 +316,7 @@ def measure(a, cfg_name, steps, warmup, batch, rank, world, dev, force_dp, ranks
         # HBM bytes per launch of the dominant kernel come from a separate rocprofv3 --pmc pass (counters cannot be read from
         # inside the process): the committed summary of that pass is quoted and its file named in `traffic_source`
         traffic, traffic_src = None, None
-        for tname in ("r04_c2_pmc_traffic.json", "r03_c2_pmc_traffic.json", "r02_c2_pmc_traffic.json", "r01_c2_pmc_traffic.json"):
+        for tname in ("r05_c2_pmc_traffic.json", "r04_c2_pmc_traffic.json", "r03_c2_pmc_traffic.json", "r02_c2_pmc_traffic.json", "r01_c2_pmc_traffic.json"):
             tfile = os.path.join(ROOT, "profiles", tname)
             if cfg_name == "c2" and os.path.exists(tfile):
                 tj = json.load(open(tfile))
@@ -296,6 +334,10 @@ def measure(a, cfg_name, steps, warmup, batch, rank, world, dev, force_dp, ranks
                     "families": [{"kernel": m, "launches": gg[2], "ms": round(gg[1] * 1e3, 3), "achieved": round(gg[0] / gg[1] / 1e12, 1),
                                   "frac": round(gg[0] / gg[1] / MFMA_BF16_PEAK, 4)}
                                  for m, gg in sorted(groups.items(), key=lambda kv: -kv[1][1])],
+                    # HBM bytes of ONE whole step (PMC pass over a graph-replayed step, profiles/r05_c2_step_traffic.json) against the bytes the
+                    # step's dataflow needs (encoder dataflow 19.0 GB + adapters / optimizer ~4 GB at C2): the family-average
+                    # `traffic` above hides the re-fetches, this ratio does not
+                    "step_traffic": step_traffic(cfg_name),
                     "whole_step_achieved": round(value / world * fpi / 1e12, 2),
                     "whole_step_frac": round(value / world * fpi / MFMA_BF16_PEAK, 4)}
         result = {
