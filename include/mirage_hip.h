@@ -26,7 +26,7 @@ extern "C" {
 typedef struct ihipStream_t* hipStream_t;
 #endif
 
-#define MRG_ABI_VERSION 12   /* 12: MRG_GEMM_DUO (mrg_gemm_desc.variant 13: the 128 x 256 two-workgroups-per-CU kernel, csrc/gemm_duo.hip); 11: mrg_attn_desc.drop_rng / drop_p / drop_stream (dropout on the attention probabilities), mrg_posemb_grad, mrg_loss_desc.label_smoothing / norm_pix / stats, mrg_wgrad_group_desc.fuse + mrg_adamw_hp (AdamW in the weight-gradient epilogue), mrg_debug_clock_monitor; 10: MRG_GEMM_P8SK (stream-K schedule of the 8-phase kernel), mrg_gemm_desc.sk_grid, mrg_wgrad_group_desc.streamk / counters / sk_grid, mrg_streamk_ws_bytes; 9: mrg_maskgen_rng, input slots (mrg_set_slots, *_slot parameters, mrg_loss_desc.target_slot); 8: mrg_gemm_desc.drop_rng / drop_p / drop_stream, mrg_dropout_bwd_bf16; 7: mrg_wgrad_group, mrg_debug_timestamp; 2: mrg_gemm_desc grew row_scale / defer_reduce, act codes 3, 4, reduce_batch / augment / row_scale entry points; 3: colsum_out, attention colsum_*; 4: step = int[2], mrg_step_inc takes the skip decision; 5: splitk_counters, MRG_GEMM_P8, resize entry points; 6: mrg_adamw_desc.sumsq_out, mrg_sumsq_finish */
+#define MRG_ABI_VERSION 13   /* 13: the stream-K schedule of round 4 is gone (measured slower everywhere it was meant to win and selected nowhere: profiles/r04_streamk.md; the code is tools/debug/patches/streamk_r04.patch) -- variant 12 reserved, mrg_gemm_desc.sk_grid, mrg_wgrad_group_desc.streamk / counters / sk_grid, mrg_streamk_ws_bytes and mrg_debug_sk_trace removed; 12: MRG_GEMM_DUO (mrg_gemm_desc.variant 13: the 128 x 256 two-workgroups-per-CU kernel, csrc/gemm_duo.hip); 11: mrg_attn_desc.drop_rng / drop_p / drop_stream (dropout on the attention probabilities), mrg_posemb_grad, mrg_loss_desc.label_smoothing / norm_pix / stats, mrg_wgrad_group_desc.fuse + mrg_adamw_hp (AdamW in the weight-gradient epilogue), mrg_debug_clock_monitor; 10: MRG_GEMM_P8SK (stream-K schedule of the 8-phase kernel), mrg_gemm_desc.sk_grid, mrg_wgrad_group_desc.streamk / counters / sk_grid, mrg_streamk_ws_bytes; 9: mrg_maskgen_rng, input slots (mrg_set_slots, *_slot parameters, mrg_loss_desc.target_slot); 8: mrg_gemm_desc.drop_rng / drop_p / drop_stream, mrg_dropout_bwd_bf16; 7: mrg_wgrad_group, mrg_debug_timestamp; 2: mrg_gemm_desc grew row_scale / defer_reduce, act codes 3, 4, reduce_batch / augment / row_scale entry points; 3: colsum_out, attention colsum_*; 4: step = int[2], mrg_step_inc takes the skip decision; 5: splitk_counters, MRG_GEMM_P8, resize entry points; 6: mrg_adamw_desc.sumsq_out, mrg_sumsq_finish */
 
 enum { MRG_DT_BF16 = 0, MRG_DT_F32 = 1 };
 enum { MRG_OP_KCONTIG = 0, MRG_OP_KSTRIDED = 1 };
@@ -60,8 +60,8 @@ const char* mrg_last_error_string(void);
  *           (positional-embedding add of the input adapters, mirage/input_adapters.py:104-108)
  *   splitk  >1: partial sums to ws [splitk][M][N] fp32, then reduced (bias/accumulate epilogue only)
  *   variant kernel variant for aligned, map-free problems: single-stage LDS-DMA kernel at 3 or 4 workgroups/CU,
- *           two-stage pipelined 128x128 kernel, two- / three-stage pipelined 256x128 kernel (8 waves), two-stage 256x256 kernel, warp-specialised 256x128 kernel (8 compute + 4 loader waves, 3-stage ring), single-stage 64x128 kernel (A k-contiguous only), (9 reserved: a persistent 256x256 kernel that was measured and dropped), single-stage 256x128 kernel with 4 waves x (128x64) (K a multiple of 64);
- *           0 picks by shape; MRG_GEMM_P8 / MRG_GEMM_P8SK = the 256 x 256 8-phase kernel, one tile per workgroup / stream-K (see sk_grid);
+ *           two-stage pipelined 128x128 kernel, two-stage pipelined 256x128 kernel (8 waves), warp-specialised 256x128 kernel (8 compute + 4 loader waves, 3-stage ring), single-stage 64x128 kernel (A k-contiguous only), single-stage 256x128 kernel with 4 waves x (128x64) (K a multiple of 64);
+ *           0 picks by shape; MRG_GEMM_P8 = the 256 x 256 8-phase kernel, one tile per workgroup (12 reserved: its stream-K schedule, measured and dropped);
  *           MRG_GEMM_DUO = the 128 x 256 kernel with two co-resident workgroups per CU (A k-contiguous, K a multiple of 64: forward / dgrad)
  */
 typedef struct mrg_gemm_desc {
@@ -104,16 +104,8 @@ typedef struct mrg_gemm_desc {
                                         kept when the draw >= floor(drop_p * 2^32).  act must be NONE, N %% 4 == 0, no split-K.
                                         mrg_dropout_bwd_bf16 regenerates the same mask for the backward pass. */
     float drop_p; unsigned drop_stream;
-    int sk_grid;                     /* variant MRG_GEMM_P8SK only: number of persistent workgroups (0 = one per CU).  That variant runs the
-                                        256 x 256 8-phase kernel on a stream-K schedule: the (tile, k-tile) iteration space is cut into
-                                        sk_grid equal ranges, tiles shared by several ranges are finished by their last arriver inside the
-                                        launch (any epilogue).  It needs splitk <= 1, ws = mrg_streamk_ws_bytes(sk_grid) bytes of scratch
-                                        (partial accumulator images) and splitk_counters = ceil(M/256) * ceil(N/256) ints, ZERO on entry and
-                                        left zero on exit.  The result is a deterministic function of the operands and sk_grid. */
 } mrg_gemm_desc;
-enum { MRG_GEMM_AUTO = 0, MRG_GEMM_GLDS3 = 1, MRG_GEMM_GLDS4 = 2, MRG_GEMM_PIPE128 = 3, MRG_GEMM_PIPE256 = 4, MRG_GEMM_PIPE256X3 = 5, MRG_GEMM_PIPE256SQ = 6, MRG_GEMM_WS256 = 7, MRG_GEMM_GLDS64 = 8, MRG_GEMM_SQP = 9, MRG_GEMM_G256 = 10, MRG_GEMM_P8 = 11, MRG_GEMM_P8SK = 12, MRG_GEMM_DUO = 13 };
-/* bytes of `ws` a stream-K launch with sk_grid workgroups needs (sk_grid <= 0: one workgroup per CU of the current device) */
-long mrg_streamk_ws_bytes(int sk_grid);
+enum { MRG_GEMM_AUTO = 0, MRG_GEMM_GLDS3 = 1, MRG_GEMM_GLDS4 = 2, MRG_GEMM_PIPE128 = 3, MRG_GEMM_PIPE256 = 4, /* 5, 6, 9 reserved: a three-stage 256 x 128 kernel, a two-stage 256 x 256 kernel and a persistent one, measured and dropped */ MRG_GEMM_WS256 = 7, MRG_GEMM_GLDS64 = 8, MRG_GEMM_G256 = 10, MRG_GEMM_P8 = 11, /* 12 reserved */ MRG_GEMM_DUO = 13 };
 
 int mrg_gemm(const mrg_gemm_desc* d, hipStream_t stream);
 
@@ -132,16 +124,13 @@ typedef struct mrg_wgrad_group_desc {
     int M[MRG_WGRAD_GROUP_MAX], N[MRG_WGRAD_GROUP_MAX], lda[MRG_WGRAD_GROUP_MAX], ldb[MRG_WGRAD_GROUP_MAX], ldc[MRG_WGRAD_GROUP_MAX];
     void* ev_start; void* ev_stop;
     int splitk; float* ws;
-    int streamk;       /* != 0: stream-K schedule over the concatenated tile lists (splitk must be <= 1): ws = mrg_streamk_ws_bytes(sk_grid)
-                          bytes of scratch, counters = one int per 256 x 256 tile of the whole group, ZERO on entry and left zero */
-    int* counters; int sk_grid;
     /* optional: AdamW applied by the launch itself.  A weight gradient produced here is final (the tile holds the whole contraction), so
      * the epilogue of every tile also performs torch.optim.AdamW's update (mutils/optim_factory.py:180) of the parameter elements it
      * covers: C_p must then point INTO the gradient arena fuse->g0 (contiguous, ldc_p == N_p), and element i of the arenas p / m / v /
      * shadow_bf16 is updated from element i of g0 exactly as mrg_adamw would (same rounding: csrc/common.h adamw_elem); the gradient is
      * still stored.  hp: device fp32 [4] from mrg_adamw_hp (this step); n_decay: elements [0, n_decay) of the arenas take weight decay;
      * ss[p]: fp32 [8 * tiles of problem p] partial sums of g^2 (per tile and wave) for the gradient norm (mrg_sumsq_finish).  Not with
-     * splitk > 1 or streamk.  NULL: gradients only. */
+     * splitk > 1.  NULL: gradients only. */
     const struct mrg_adamw_fuse* fuse;
 } mrg_wgrad_group_desc;
 typedef struct mrg_adamw_fuse {
@@ -374,9 +363,6 @@ int mrg_debug_timestamp(unsigned long long* slot, hipStream_t stream);
 /* profiling aid: one wave stores {wall_clock64 (100 MHz), clock64 (shader clock)} pairs into buf[2 * samples] every `period` wall ticks
  * while other streams work: the clock the chip runs at, by phase of a step (tools/step_clock.py) */
 int mrg_debug_clock_monitor(unsigned long long* buf, int samples, int period, hipStream_t stream);
-/* Profiling aid: while buf != NULL every stream-K launch records per-workgroup phase timestamps into buf[workgroup * 32 ..] (u64, 100 MHz);
- * NULL switches it off.  Process-global, for tools only. */
-int mrg_debug_sk_trace(unsigned long long* buf);
 
 #ifdef __cplusplus
 }

@@ -19,7 +19,7 @@ MRG_OP_KCONTIG, MRG_OP_KSTRIDED = 0, 1
 MRG_ACT_NONE, MRG_ACT_GELU, MRG_ACT_GELU_BWD, MRG_ACT_GELU_SAVE_GRAD, MRG_ACT_MUL_AUX_F16 = 0, 1, 2, 3, 4
 MRG_LOSS_MSE, MRG_LOSS_CE = 0, 1
 MRG_MAX_DOMAINS = 4
-MRG_GEMM_AUTO, MRG_GEMM_GLDS3, MRG_GEMM_GLDS4, MRG_GEMM_PIPE128, MRG_GEMM_PIPE256, MRG_GEMM_PIPE256X3, MRG_GEMM_PIPE256SQ, MRG_GEMM_WS256, MRG_GEMM_GLDS64, MRG_GEMM_SQP, MRG_GEMM_G256, MRG_GEMM_P8, MRG_GEMM_P8SK, MRG_GEMM_DUO = 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13
+MRG_GEMM_AUTO, MRG_GEMM_GLDS3, MRG_GEMM_GLDS4, MRG_GEMM_PIPE128, MRG_GEMM_PIPE256, MRG_GEMM_WS256, MRG_GEMM_GLDS64, MRG_GEMM_G256, MRG_GEMM_P8, MRG_GEMM_DUO = 0, 1, 2, 3, 4, 7, 8, 10, 11, 13      # 5, 6, 9, 12 reserved (variants measured and dropped)
 MRG_GEMM_P8_GROUP = 100     # not a mrg_gemm variant: the kernel-family code of mrg_wgrad_group in timing records
 
 vp, ci, cl, cf = C.c_void_p, C.c_int, C.c_long, C.c_float
@@ -32,7 +32,7 @@ class GemmDesc(C.Structure):
                 ("resid", vp), ("ldr", ci), ("accumulate", ci), ("act", ci),
                 ("aux_out", vp), ("aux_in", vp), ("ldaux", ci), ("row_map", vp),
                 ("add_tab", vp), ("add_row", vp), ("ldt", ci), ("splitk", ci), ("ws", vp), ("variant", ci), ("ev_start", vp), ("ev_stop", vp), ("row_scale", vp), ("colsum_out", vp), ("defer_reduce", ci), ("splitk_counters", vp),
-                ("drop_rng", vp), ("drop_p", cf), ("drop_stream", C.c_uint), ("sk_grid", ci)]
+                ("drop_rng", vp), ("drop_p", cf), ("drop_stream", C.c_uint)]
 
 
 MRG_WGRAD_GROUP_MAX = 48
@@ -42,7 +42,7 @@ class WgradGroupDesc(C.Structure):
     _fields_ = [("count", ci), ("K", ci), ("A", vp * MRG_WGRAD_GROUP_MAX), ("B", vp * MRG_WGRAD_GROUP_MAX), ("C", vp * MRG_WGRAD_GROUP_MAX),
                 ("M", ci * MRG_WGRAD_GROUP_MAX), ("N", ci * MRG_WGRAD_GROUP_MAX), ("lda", ci * MRG_WGRAD_GROUP_MAX),
                 ("ldb", ci * MRG_WGRAD_GROUP_MAX), ("ldc", ci * MRG_WGRAD_GROUP_MAX), ("ev_start", vp), ("ev_stop", vp),
-                ("splitk", ci), ("ws", vp), ("streamk", ci), ("counters", vp), ("sk_grid", ci), ("fuse", vp)]
+                ("splitk", ci), ("ws", vp), ("fuse", vp)]
 
 
 class AdamWFuse(C.Structure):
@@ -90,11 +90,9 @@ SIGNATURES = {
     "mrg_posemb_grad": (ci, [vp, cl, ci, vp, vp, vp, vp, ci, ci, ci, vp, vp, vp]),
     "mrg_debug_timestamp": (ci, [vp, vp]),
     "mrg_debug_clock_monitor": (ci, [vp, ci, ci, vp]),
-    "mrg_debug_sk_trace": (ci, [vp]),
     "mrg_last_error_string": (C.c_char_p, []),
     "mrg_gemm": (ci, [C.POINTER(GemmDesc), vp]),
     "mrg_wgrad_group": (ci, [C.POINTER(WgradGroupDesc), vp]),
-    "mrg_streamk_ws_bytes": (cl, [ci]),
     "mrg_ln_fwd": (ci, [vp, vp, vp, vp, vp, vp, vp, ci, ci, cf, vp]),
     "mrg_ln_bwd_nblocks": (ci, [ci]),
     "mrg_ln_bwd": (ci, [vp] * 13 + [ci, ci, vp]),
@@ -149,7 +147,7 @@ for _name, (_res, _args) in SIGNATURES.items():
     _fn.argtypes = _args
 
 ABI_VERSION = lib.mrg_version()
-EXPECTED_ABI_VERSION = 12      # must match MRG_ABI_VERSION in include/mirage_hip.h: the ctypes structs above mirror that layout
+EXPECTED_ABI_VERSION = 13      # must match MRG_ABI_VERSION in include/mirage_hip.h: the ctypes structs above mirror that layout
 if ABI_VERSION != EXPECTED_ABI_VERSION:
     raise ImportError(f"{LIB_PATH} reports ABI version {ABI_VERSION}, the Python bindings expect {EXPECTED_ABI_VERSION}: rebuild it "
                       "(python -c 'import __graft_entry__ as g; g.build()')")

@@ -873,138 +873,6 @@ __global__ __launch_bounds__(768) void gemm_ws256_kernel(const GemmArgs g) {
     if (ws && g.tile_cnt) splitk_finish<VEC>(g, bid, m0, n0, 256, BN, Meff, smem, tid, 768);
 }
 
-// 256 x 256 output tile (128 flop per operand byte): 8 waves as 2 (M) x 4 (N), each 128 x 64 (8 accumulator tiles), operands as
-// 2 + 2 standard [128][64] sub-tiles per stage, two stages = 128 KiB.  Only pays when there are enough 256 x 256 tiles to fill
-// 256 CUs (large M: the encoder-only configuration, Large-model MLP shapes).
-template <int AMODE, int BMODE, bool VEC>
-__global__ __launch_bounds__(512, 2) void gemm_pipe256sq_kernel(const GemmArgs g) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int STAGE = 4 * TILE_BYTES;
-    const int tiles_m = (g.M + 255) / 256, tiles_n = (g.N + 255) / 256;
-    const int nwg = tiles_m * tiles_n;
-    int bid, ksplit;
-    wg_remap(nwg, g.xcd_split, bid, ksplit);
-    constexpr int GROUP_M = 4;
-    int tm, tn;
-    {
-        const int per_group = GROUP_M * tiles_n;
-        const int grp = fast_udiv(bid, per_group), in_grp = bid - grp * per_group;
-        const int first = grp * GROUP_M;
-        const int rows = min(GROUP_M, tiles_m - first);
-        tn = fast_udiv(in_grp, rows);
-        tm = first + in_grp - tn * rows;
-    }
-    const int m0 = tm * 256, n0 = tn * 256;
-    const int Meff = g.m_dev ? min(g.M, *g.m_dev) : g.M;
-    const int Keff = g.k_dev ? min(g.K, *g.k_dev) : g.K;
-    if (m0 >= Meff) return;
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 2, wn = wave & 3;             // rows wm*128.., cols wn*64..
-    const int hsub = wave >> 2, wl = wave & 3;           // DMA assignment: sub-tile index, 4-block group inside it
-    const int ntiles = (Keff + BK - 1) / BK;
-    int t0 = 0, t1 = ntiles;
-    if (g.splitk > 1) {
-        const int per = (ntiles + g.splitk - 1) / g.splitk;
-        t0 = ksplit * per;
-        t1 = min(ntiles, t0 + per);
-    }
-    f32x16 acc[4][2];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-    const uint32_t sbase = __builtin_amdgcn_readfirstlane(lds_addr(smem));
-    const bf16_t* pa[4]; const bf16_t* pb[4];
-    long ia[4], ib[4];
-    int ka[4], kb[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        glds_setup<AMODE>(g.A, g.lda, m0 + hsub * 128, Meff, t0 * BK, wl * 4 + j, lane, pa[j], ia[j], ka[j]);
-        glds_setup<BMODE>(g.B, g.ldb, n0 + hsub * 128, g.N, t0 * BK, wl * 4 + j, lane, pb[j], ib[j], kb[j]);
-    }
-    const bf16_t* zero = reinterpret_cast<const bf16_t*>(g_zero_page);
-    auto issue = [&](int t, int buf) {
-        const uint32_t la = sbase + buf * STAGE + hsub * TILE_BYTES + wl * 4096;
-        const uint32_t lb = la + 2 * TILE_BYTES;
-        const int krem = Keff - t * BK;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            glds16_asm((krem >= BK || ka[j] < krem) ? pa[j] : zero, la + j * 1024);
-            glds16_asm((krem >= BK || kb[j] < krem) ? pb[j] : zero, lb + j * 1024);
-        }
-#pragma unroll
-        for (int j = 0; j < 4; ++j) { pa[j] += ia[j]; pb[j] += ib[j]; }
-    };
-    if (t0 < t1) issue(t0, 0);
-    for (int t = t0; t < t1; ++t) {
-        const int cur = (t - t0) & 1;
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        __builtin_amdgcn_sched_barrier(0);
-        if (t + 1 < t1) issue(t + 1, cur ^ 1);
-        const char* ldsA = smem + cur * STAGE + wm * TILE_BYTES;
-        const char* ldsB = smem + cur * STAGE + (2 + (wn >> 1)) * TILE_BYTES;
-        const uint32_t la_u = sbase + cur * STAGE + wm * TILE_BYTES, lb_u = sbase + cur * STAGE + (2 + (wn >> 1)) * TILE_BYTES;
-#pragma unroll
-        for (int kk = 0; kk < 4; ++kk) {
-            bf16x8 fa[4], fb[2];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) fa[i] = read_frag<AMODE>(ldsA, la_u, i * 32, kk, lane);
-#pragma unroll
-            for (int j = 0; j < 2; ++j) fb[j] = read_frag<BMODE>(ldsB, lb_u, (wn & 1) * 64 + j * 32, kk, lane);
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int j = 0; j < 2; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
-        }
-    }
-    // ---- epilogue: four 64-row x 256-col slabs through a 64 KiB fp32 staging tile
-    float* ct = reinterpret_cast<float*>(smem);
-    const int cl = (tid & 63) << 2;
-    const int col = n0 + cl;
-    const int nv = min(4, g.N - col);
-    float* ws = g.splitk > 1 ? g.ws + (long)ksplit * g.M * g.N : nullptr;
-    float bv[4] = {0.f, 0.f, 0.f, 0.f};
-    if (g.bias && !ws && col < g.N) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) if (e < nv) bv[e] = g.bias[col + e];
-    }
-    MRG_RETIRE4(bv);
-#pragma unroll
-    for (int sl = 0; sl < 4; ++sl) {
-        __syncthreads();
-        if (wm == (sl >> 1)) {
-#pragma unroll
-            for (int ii = 0; ii < 2; ++ii)
-#pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    const int c2 = wn * 64 + j * 32 + (lane & 31);
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int rl = ii * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                        ct[rl * 256 + c2] = acc[2 * (sl & 1) + ii][j][r];
-                    }
-                }
-        }
-        __syncthreads();
-        if (col < g.N) {
-#pragma unroll 1
-            for (int it = 0; it < 8; ++it) {
-                const int rl = (tid >> 6) + (it << 3);                  // 0..63
-                const int row = m0 + sl * 64 + rl;
-                if (row < Meff) {
-                    const float4 a4 = *reinterpret_cast<const float4*>(ct + rl * 256 + cl);
-                    epi_any<VEC>(g, a4, bv, ws, row, col, nv);
-                }
-            }
-        }
-    }
-}
-
 // 256 x 128 tile, single stage, 4 waves x (128 x 64): the single-stage kernel's structure (two co-resident workgroups cover each
 // other's load -> barrier -> MFMA chain; scalar-base loader; K a multiple of 64) with twice the MFMA work per wave and barrier
 // and 85 instead of 64 flop per operand byte moved from L2 to LDS.  48 KiB LDS, accumulators 128 VGPRs, 2 waves per SIMD.
@@ -1304,7 +1172,7 @@ extern "C" int mrg_gemm(const mrg_gemm_desc* d, hipStream_t stream) {
         g.drop.scale = 1.f / (1.f - d->drop_p);
         g.drop.stream = d->drop_stream;
     }
-    MRG_REQUIRE(d->variant >= 0 && d->variant <= MRG_GEMM_DUO, MRG_ERR_ARG, "mrg_gemm: bad variant");
+    MRG_REQUIRE(d->variant >= 0 && d->variant <= MRG_GEMM_DUO && d->variant != 5 && d->variant != 6 && d->variant != 9 && d->variant != 12, MRG_ERR_ARG, "mrg_gemm: bad variant %d", d->variant);
     g.tiles_m = cdiv(d->M, BM); g.tiles_n = cdiv(d->N, BN);
     { static const int abl = [] { const char* e = getenv("MRG_GEMM_ABLATE"); return e ? atoi(e) : 0; }(); g.ablate = abl; }
     { static const int nt = [] { const char* e = getenv("MRG_GEMM_NT"); return e ? atoi(e) : 2; }(); g.nt = nt; }
@@ -1327,7 +1195,7 @@ extern "C" int mrg_gemm(const mrg_gemm_desc* d, hipStream_t stream) {
                      !d->C2 && g.c_f32 && !d->colsum_out && !g.drop.rng) g.epi_kind = 6;
             else if (splitk == 1 && d->act == MRG_ACT_NONE && !d->add_tab && !d->row_map && !d->accumulate && !d->colsum_out && d->resid && g.c_f32) g.epi_kind = 2;
             else if (splitk == 1 && d->act == MRG_ACT_NONE && !d->add_tab && !d->row_map && !d->accumulate && !d->colsum_out && !d->resid && !d->row_scale &&
-                     !d->C2 && !d->bias && g.c_f32 && !g.drop.rng && (d->variant == MRG_GEMM_P8 || d->variant == MRG_GEMM_P8SK || d->variant == MRG_GEMM_DUO)) g.epi_kind = 7;
+                     !d->C2 && !d->bias && g.c_f32 && !g.drop.rng && (d->variant == MRG_GEMM_P8 || d->variant == MRG_GEMM_DUO)) g.epi_kind = 7;
         }
     }
     dim3 grid(g.tiles_m * g.tiles_n, splitk), block(256);
@@ -1366,7 +1234,7 @@ extern "C" int mrg_gemm(const mrg_gemm_desc* d, hipStream_t stream) {
     if (d->variant == MRG_GEMM_GLDS3) { use_pipe = false; occ4 = false; }
     else if (d->variant == MRG_GEMM_GLDS4) { use_pipe = false; occ4 = true; }
     else if (d->variant == MRG_GEMM_PIPE128) { use_pipe = true; }
-    else if (d->variant == MRG_GEMM_PIPE256 || d->variant == MRG_GEMM_PIPE256X3) { use_big = fast && !mapped && d->M > 128; use_pipe = true; }
+    else if (d->variant == MRG_GEMM_PIPE256) { use_big = fast && !mapped && d->M > 128; use_pipe = true; }
     if (d->colsum_out) {      // only the single-stage 128 x 128 kernel (dgrad layout) is instantiated with the column-sum epilogue
         MRG_REQUIRE(fast && splitk == 1 && !d->row_map && d->a_mode == MRG_OP_KCONTIG && d->b_mode == MRG_OP_KSTRIDED, MRG_ERR_UNSUPPORTED,
                     "mrg_gemm: colsum_out needs the dgrad layout (A k-contiguous, B k-strided), aligned unmapped operands and no split-K");
@@ -1397,23 +1265,10 @@ extern "C" int mrg_gemm(const mrg_gemm_desc* d, hipStream_t stream) {
         }
         return 0;
     };
-    const bool will_sq = !d->colsum_out && fast && !mapped && d->variant == MRG_GEMM_PIPE256SQ && d->M > 128 && d->N > 128;
     const bool will_ws = !d->colsum_out && fast && !mapped && d->variant == MRG_GEMM_WS256 && d->M > 128;
     const bool will_g256 = fast && d->variant == MRG_GEMM_G256 && kf && !d->colsum_out && d->M > 128;
-    inkernel = splitk > 1 && d->splitk_counters && !d->defer_reduce && !d->colsum_out && !will_sq && !will_g256 && !(use_big && !will_ws);
+    inkernel = splitk > 1 && d->splitk_counters && !d->defer_reduce && !d->colsum_out && !will_g256 && !(use_big && !will_ws);
     g.tile_cnt = inkernel ? d->splitk_counters : nullptr;
-    if (d->variant == MRG_GEMM_P8SK) {     // stream-K schedule of the 8-phase kernel: an explicit request, so an unmet precondition is an error
-        MRG_REQUIRE(fast && !mapped && !d->colsum_out && splitk == 1 && d->K % BK == 0 && !d->m_dev && !d->k_dev, MRG_ERR_UNSUPPORTED,
-                    "mrg_gemm: MRG_GEMM_P8SK needs aligned unmapped operands, K %% 64 == 0, no split-K / column sums / device counts");
-        MRG_REQUIRE(d->ws && d->splitk_counters && (((uintptr_t)d->ws) & 15) == 0, MRG_ERR_ARG,
-                    "mrg_gemm: MRG_GEMM_P8SK needs ws (mrg_streamk_ws_bytes) and zeroed splitk_counters");
-        MRG_REQUIRE(d->sk_grid >= 0 && d->sk_grid <= 4096, MRG_ERR_ARG, "mrg_gemm: bad sk_grid %d", d->sk_grid);
-        g.tile_cnt = nullptr; g.ws = nullptr;
-        MRG_REQUIRE(mrg_gemm8p_sk_launch(g, d->a_mode, d->b_mode, vec, d->ws, d->splitk_counters, d->sk_grid, stream), MRG_ERR_UNSUPPORTED,
-                    "mrg_gemm: MRG_GEMM_P8SK cannot run this operand layout");
-        if (d->ev_stop) (void)hipEventRecord((hipEvent_t)d->ev_stop, stream);
-        return mrg_check_launch("mrg_gemm");
-    }
     if (fast && !mapped && d->variant == MRG_GEMM_P8 && !d->colsum_out && d->M > 128 && d->N > 128 &&
         mrg_gemm8p_launch(g, d->a_mode, d->b_mode, vec, splitk, stream)) {
         if (d->ev_stop) (void)hipEventRecord((hipEvent_t)d->ev_stop, stream);
@@ -1425,7 +1280,6 @@ extern "C" int mrg_gemm(const mrg_gemm_desc* d, hipStream_t stream) {
         int rcd = mrg_check_launch("mrg_gemm");
         return rcd ? rcd : finish_splitk();
     }
-    const bool use_sq = !d->colsum_out && fast && !mapped && d->variant == MRG_GEMM_PIPE256SQ && d->M > 128 && d->N > 128;
     const bool use_ws = !d->colsum_out && fast && !mapped && d->variant == MRG_GEMM_WS256 && d->M > 128;
     if (fast && d->variant == MRG_GEMM_G256 && kf && !d->colsum_out && d->M > 128) {
         const dim3 gg(cdiv(d->M, 256) * g.tiles_n, splitk);
@@ -1447,23 +1301,16 @@ extern "C" int mrg_gemm(const mrg_gemm_desc* d, hipStream_t stream) {
         if (d->ev_stop) (void)hipEventRecord((hipEvent_t)d->ev_stop, stream);
         return mrg_check_launch("mrg_gemm");
     }
-    const bool big3 = d->variant == MRG_GEMM_PIPE256X3;
-#define MRG_BIG(AM, BM_, V) do { if (big3) { const void* fn = (const void*)gemm_pipe256_kernel<AM, BM_, V, 3>; \
-        (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 9 * TILE_BYTES); \
-        hipLaunchKernelGGL((gemm_pipe256_kernel<AM, BM_, V, 3>), dim3(cdiv(d->M, 256) * g.tiles_n, splitk), dim3(512), (size_t)(9 * TILE_BYTES), stream, g); } \
-      else { const void* fn = (const void*)gemm_pipe256_kernel<AM, BM_, V, 2>; \
+#define MRG_BIG(AM, BM_, V) do { const void* fn = (const void*)gemm_pipe256_kernel<AM, BM_, V, 2>; \
         (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 6 * TILE_BYTES); \
-        hipLaunchKernelGGL((gemm_pipe256_kernel<AM, BM_, V, 2>), dim3(cdiv(d->M, 256) * g.tiles_n, splitk), dim3(512), (size_t)(6 * TILE_BYTES), stream, g); } } while (0)
-#define MRG_SQ(AM, BM_, V) do { const void* fn = (const void*)gemm_pipe256sq_kernel<AM, BM_, V>; \
-        (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 8 * TILE_BYTES); \
-        hipLaunchKernelGGL((gemm_pipe256sq_kernel<AM, BM_, V>), dim3(cdiv(d->M, 256) * cdiv(d->N, 256), splitk), dim3(512), (size_t)(8 * TILE_BYTES), stream, g); } while (0)
+        hipLaunchKernelGGL((gemm_pipe256_kernel<AM, BM_, V, 2>), dim3(cdiv(d->M, 256) * g.tiles_n, splitk), dim3(512), (size_t)(6 * TILE_BYTES), stream, g); } while (0)
 #define MRG_WS(AM, BM_, V) do { if (kf && V) { const void* fn = (const void*)gemm_ws256_kernel<AM, BM_, true, true>; \
         (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 9 * TILE_BYTES); \
         hipLaunchKernelGGL((gemm_ws256_kernel<AM, BM_, true, true>), dim3(cdiv(d->M, 256) * g.tiles_n, splitk), dim3(768), (size_t)(9 * TILE_BYTES), stream, g); } else { \
         const void* fn = (const void*)gemm_ws256_kernel<AM, BM_, V>; \
         (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 9 * TILE_BYTES); \
         hipLaunchKernelGGL((gemm_ws256_kernel<AM, BM_, V>), dim3(cdiv(d->M, 256) * g.tiles_n, splitk), dim3(768), (size_t)(9 * TILE_BYTES), stream, g); } } while (0)
-#define MRG_FAST(AM, BM_, V) do { if (use_ws) MRG_WS(AM, BM_, V); else if (use_sq) MRG_SQ(AM, BM_, V); else if (use_big) MRG_BIG(AM, BM_, V); else if (use_pipe && kf && V) hipLaunchKernelGGL((gemm_pipe_kernel<AM, BM_, true, true>), grid, block, (size_t)(4 * TILE_BYTES), stream, g); \
+#define MRG_FAST(AM, BM_, V) do { if (use_ws) MRG_WS(AM, BM_, V); else if (use_big) MRG_BIG(AM, BM_, V); else if (use_pipe && kf && V) hipLaunchKernelGGL((gemm_pipe_kernel<AM, BM_, true, true>), grid, block, (size_t)(4 * TILE_BYTES), stream, g); \
                                   else if (use_pipe) hipLaunchKernelGGL((gemm_pipe_kernel<AM, BM_, V>), grid, block, (size_t)(4 * TILE_BYTES), stream, g); \
                                   else if (occ4 && kf && V && epi_direct) hipLaunchKernelGGL((gemm_glds_kernel<AM, BM_, true, 4, false, true, true>), grid, block, (size_t)(2 * TILE_BYTES), stream, g); \
                                   else if (kf && V && epi_direct) hipLaunchKernelGGL((gemm_glds_kernel<AM, BM_, true, 3, false, true, true>), grid, block, (size_t)(2 * TILE_BYTES), stream, g); \
@@ -1483,7 +1330,6 @@ extern "C" int mrg_gemm(const mrg_gemm_desc* d, hipStream_t stream) {
 #undef MRG_LAUNCH2
 #undef MRG_FAST
 #undef MRG_BIG
-#undef MRG_SQ
 #undef MRG_WS
     if (d->ev_stop) (void)hipEventRecord((hipEvent_t)d->ev_stop, stream);
     int rc = mrg_check_launch("mrg_gemm");
@@ -1532,7 +1378,7 @@ extern "C" int mrg_wgrad_group(const mrg_wgrad_group_desc* d, hipStream_t stream
     ga.af = AdamFuseArgs();
     if (d->fuse) {
         const mrg_adamw_fuse* f = d->fuse;
-        MRG_REQUIRE(splitk == 1 && !d->streamk, MRG_ERR_UNSUPPORTED, "mrg_wgrad_group: the fused AdamW update needs splitk <= 1 and no stream-K");
+        MRG_REQUIRE(splitk == 1, MRG_ERR_UNSUPPORTED, "mrg_wgrad_group: the fused AdamW update needs splitk <= 1");
         MRG_REQUIRE(f->g0 && f->p && f->m && f->v && f->hp && f->n_decay >= 0, MRG_ERR_ARG, "mrg_wgrad_group: fuse: null arena / hp pointer");
         MRG_REQUIRE((((uintptr_t)f->g0 | (uintptr_t)f->p | (uintptr_t)f->m | (uintptr_t)f->v) & 15) == 0 && (((uintptr_t)f->shadow_bf16) & 7) == 0,
                     MRG_ERR_ARG, "mrg_wgrad_group: fuse: arenas must be 16-B aligned");
@@ -1548,23 +1394,8 @@ extern "C" int mrg_wgrad_group(const mrg_wgrad_group_desc* d, hipStream_t stream
     for (int p = d->count; p <= P8_GROUP_MAX; ++p) ga.tile_start[p] = tiles;
     for (int p = d->count; p < P8_GROUP_MAX; ++p) { ga.A[p] = nullptr; ga.B[p] = nullptr; ga.C[p] = nullptr; ga.M[p] = ga.N[p] = ga.lda[p] = ga.ldb[p] = ga.ldc[p] = 0; ga.ws_off[p] = 0; }
     if (splitk > 1) vec = vec && (((uintptr_t)d->ws) % 16 == 0);
-    if (d->streamk) {
-        MRG_REQUIRE(splitk == 1 && d->ws && d->counters && (((uintptr_t)d->ws) & 15) == 0, MRG_ERR_ARG,
-                    "mrg_wgrad_group: stream-K needs splitk <= 1, ws (mrg_streamk_ws_bytes) and zeroed counters");
-        MRG_REQUIRE(d->sk_grid >= 0 && d->sk_grid <= 4096, MRG_ERR_ARG, "mrg_wgrad_group: bad sk_grid %d", d->sk_grid);
-        g.ws = nullptr;
-        if (d->ev_start) (void)hipEventRecord((hipEvent_t)d->ev_start, stream);
-        MRG_REQUIRE(mrg_gemm8p_sk_group_launch(ga, vec, d->ws, d->counters, d->sk_grid, stream), MRG_ERR_SHAPE, "mrg_wgrad_group: nothing to launch");
-        if (d->ev_stop) (void)hipEventRecord((hipEvent_t)d->ev_stop, stream);
-        return mrg_check_launch("mrg_wgrad_group");
-    }
     if (d->ev_start) (void)hipEventRecord((hipEvent_t)d->ev_start, stream);
     MRG_REQUIRE(mrg_gemm8p_group_launch(ga, vec, stream), MRG_ERR_SHAPE, "mrg_wgrad_group: nothing to launch");
     if (d->ev_stop) (void)hipEventRecord((hipEvent_t)d->ev_stop, stream);
     return mrg_check_launch("mrg_wgrad_group");
-}
-
-extern "C" long mrg_streamk_ws_bytes(int sk_grid) {
-    const long P = sk_grid > 0 ? sk_grid : mrg_num_cus();
-    return P * 2 * 256 * 256 * (long)sizeof(float);
 }

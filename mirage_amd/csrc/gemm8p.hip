@@ -424,177 +424,6 @@ __global__ __launch_bounds__(512) void gemm_p8_group_kernel(const P8GroupArgs ga
     }
 }
 
-
-// ------------------------------------------------------------------------------------------------------------------------------
-// Stream-K schedule of the same tile code (Osama et al., "Stream-K: work-centric parallel decomposition for dense matrix-matrix
-// multiplication on the GPU", PPoPP'23, restated for one persistent workgroup per CU).  The launch has P workgroups; the iteration
-// space (tile, k-tile) of all `tiles` output tiles, tile-major, is cut into P equal contiguous ranges, so every CU performs the same
-// number of MAC iterations whatever tiles / P is (C2 fc1 forward: 396 tiles = 1.55 rounds of 256 CUs -> 18.6 k-tiles per CU).
-// A range covers the tail of one tile, whole tiles, and the head of another; a tile whose k-range is shared by s workgroups
-// (s <= 3 when a range is at least half a tile) is finished by its LAST ARRIVER, which keeps its own partial sums in registers:
-//   contributor:  peek the tile's arrival counter -- if the s - 1 others have arrived it is the finisher and stores nothing;
-//                 otherwise store the 256 KiB accumulator image (fragment order, 16 B per lane, write-through), drain, take a ticket
-//                 (the ticket may still make it the finisher: it then reads back nothing of its own either);
-//   finisher:     agent-scope acquire, sum the s partial images in SLICE order (its own slice from registers), fused epilogue, reset
-//                 the counter (zero on entry, zero on exit: graph-replayable without a memset).
-// Nobody waits for anybody, so the result and termination are independent of dispatch order, residency and the number of launches
-// sharing the chip; the sum order is fixed, so the result is a pure function of (operands, P).  A range walks its LAST tile first
-// and its FIRST tile last: the head part of a tile (owned by the lower workgroup) is published at the start of a launch and its
-// tail owner arrives at the end, i.e. in the common case exactly one image per split point travels (P - 1 per launch).
-// Workgroup -> range uses the XCD band order (consecutive ranges share an L2).
-struct P8SkArgs { float* slabs; int* cnt; int tiles; int nk; unsigned long long* trace; };
-// mrg_debug_sk_trace: per workgroup 32 x u64 = {start, then per segment: main loop end, exchange end, role (0 whole tile, 1 stored,
-// 2 finisher without a store, 3 finisher after storing) << 32 | tile, epilogue end} in wall_clock64 ticks (100 MHz); slots 30 / 31:
-// clock64() (shader clock) at the start and after the first main loop -> the clock the CU ran that loop at
-#define SK_TRACE(slot, val) do { if (sk.trace && tid == 0) sk.trace[(long)blockIdx.x * 32 + (slot)] = (val); } while (0)
-constexpr int P8_SLAB_FLOATS = 256 * 256;
-
-__device__ __forceinline__ int sk_owner(long x, int P, long I) { return (int)(((x + 1) * P - 1) / I); }   // workgroup whose range holds iteration x
-
-template <int AMODE, int BMODE, bool VEC, int PHASES, typename ProblemOf>
-__device__ __forceinline__ void p8_streamk(const P8SkArgs& sk, char* smem, ProblemOf problem_of) {
-    const int P = gridDim.x;
-    int lin;
-    {
-        const int b = blockIdx.x, q = P >> 3, r = P & 7, xcd = b & 7, idx = b >> 3;
-        lin = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-    }
-    const int nk = sk.nk;
-    const long I = (long)sk.tiles * nk;
-    const int S = (int)((long)lin * I / P), E = (int)((long)(lin + 1) * I / P);
-    if (S >= E) return;
-    const int tf = S / nk, tl = (E - 1) / nk;
-    const int nseg = tl - tf + 1;
-    volatile int* flag = reinterpret_cast<volatile int*>(smem);
-    { const int tid = threadIdx.x; SK_TRACE(0, wall_clock64()); SK_TRACE(30, clock64()); }
-    for (int si = 0; si < nseg; ++si) {
-        // the lane id is made opaque per segment: everything per-lane below (loader offsets, fragment addresses, epilogue columns,
-        // partial-image offsets) would otherwise be loop-invariant, hoisted out of this loop and kept in registers across the main loop
-        int tid = threadIdx.x;
-        asm volatile("" : "+v"(tid));
-        const int lane = tid & 63;
-        const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-        const int t = nseg == 1 ? tf : (si == 0 ? tl : (si == nseg - 1 ? tf : tf + si));
-        const int k0 = max(S, t * nk) - t * nk, k1 = min(E, (t + 1) * nk) - t * nk;
-        GemmArgs gl;
-        int bid;
-        const GemmArgs& g = problem_of(t, gl, bid);
-        int m0, n0;
-        p8_tile_origin(g, bid, m0, n0);
-        float bv[4];
-        p8_bias(g, n0, true, bv, tid);
-        f32x16 acc[4][2];
-        p8_mainloop<AMODE, BMODE, PHASES>(g, m0, n0, k0, k1 - k0, acc, smem, tid);
-        if (si < 7) SK_TRACE(1 + 4 * si, wall_clock64());
-        if (si == 0) SK_TRACE(31, clock64());     // with slot 30: shader-clock cycles of the first main loop (slots 0 -> 1 are its wall time)
-        bool finish = true;
-        int role = 0;
-        if (k1 - k0 < nk) {
-            const int w0 = sk_owner((long)t * nk, P, I), w1 = sk_owner((long)(t + 1) * nk - 1, P, I);
-            const int s = w1 - w0 + 1, z = lin - w0;
-            auto slab_of = [&](int w) -> float* {
-                const int tfw = (int)((long)w * I / P) / nk;
-                return sk.slabs + ((long)w * 2 + (tfw == t ? 0 : 1)) * P8_SLAB_FLOATS;
-            };
-            int* cnt = sk.cnt + t;
-            if (tid == 0) *flag = (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == s - 1) ? 1 : 0;
-            __syncthreads();
-            bool last = *flag != 0;
-            __syncthreads();
-            if (!last) {
-                float* mine = slab_of(lin) + ((long)wave * 32 * 64 + lane) * 4;
-#pragma unroll
-                for (int i = 0; i < 4; ++i)
-#pragma unroll
-                    for (int j = 0; j < 2; ++j)
-#pragma unroll
-                        for (int q4 = 0; q4 < 4; ++q4)
-                            st_slab(mine + ((i * 2 + j) * 4 + q4) * 256,
-                                    make_float4(acc[i][j][4 * q4], acc[i][j][4 * q4 + 1], acc[i][j][4 * q4 + 2], acc[i][j][4 * q4 + 3]), true);
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                __syncthreads();
-                if (tid == 0) *flag = (__hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == s - 1) ? 1 : 0;
-                __syncthreads();
-                last = *flag != 0;
-                __syncthreads();
-                role = last ? 3 : 1;
-            } else role = 2;
-            finish = last;
-            if (last) {
-                if (tid == 0) {
-                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-                    __hip_atomic_store(cnt, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                }
-                __syncthreads();
-                const long lane_off = ((long)wave * 32 * 64 + lane) * 4;
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    // row tile i of the accumulators: 8 x 16 B per lane.  Canonical order ((p_0 + p_1) + ...) + p_{s-1} with the own
-                    // slice taken from registers at position z.
-                    float4 pre[8];
-                    for (int zz = 0; zz < z; ++zz) {
-                        const float* p = slab_of(w0 + zz) + lane_off + i * 8 * 256;
-                        float4 ld[8];
-#pragma unroll
-                        for (int e = 0; e < 8; ++e) ld[e] = *reinterpret_cast<const float4*>(p + e * 256);
-#pragma unroll
-                        for (int e = 0; e < 8; ++e) {
-                            if (zz == 0) pre[e] = ld[e];
-                            else { pre[e].x += ld[e].x; pre[e].y += ld[e].y; pre[e].z += ld[e].z; pre[e].w += ld[e].w; }
-                        }
-                    }
-                    if (z > 0) {
-#pragma unroll
-                        for (int e = 0; e < 8; ++e) {
-                            f32x16& a = acc[i][e >> 2];
-                            const int b4 = (e & 3) * 4;
-                            a[b4] = pre[e].x + a[b4]; a[b4 + 1] = pre[e].y + a[b4 + 1]; a[b4 + 2] = pre[e].z + a[b4 + 2]; a[b4 + 3] = pre[e].w + a[b4 + 3];
-                        }
-                    }
-                    for (int zz = z + 1; zz < s; ++zz) {
-                        const float* p = slab_of(w0 + zz) + lane_off + i * 8 * 256;
-                        float4 ld[8];
-#pragma unroll
-                        for (int e = 0; e < 8; ++e) ld[e] = *reinterpret_cast<const float4*>(p + e * 256);
-#pragma unroll
-                        for (int e = 0; e < 8; ++e) {
-                            f32x16& a = acc[i][e >> 2];
-                            const int b4 = (e & 3) * 4;
-                            a[b4] += ld[e].x; a[b4 + 1] += ld[e].y; a[b4 + 2] += ld[e].z; a[b4 + 3] += ld[e].w;
-                        }
-                    }
-                }
-            }
-        }
-        if (si < 7) { SK_TRACE(2 + 4 * si, wall_clock64()); SK_TRACE(3 + 4 * si, ((unsigned long long)role << 32) | (unsigned)t | ((unsigned long long)(k1 - k0) << 48)); }
-        if (finish) p8_epilogue<VEC>(g, m0, n0, acc, smem, nullptr, bv, tid, (sk.trace && si == nseg - 1 && nseg <= 4) ? sk.trace + (long)blockIdx.x * 32 + 20 : nullptr);
-        __syncthreads();                         // the staging tile is the next segment's operand ring
-        if (si < 7) SK_TRACE(4 + 4 * si, wall_clock64());
-    }
-}
-
-template <int AMODE, int BMODE, bool VEC, int PHASES>
-__global__ __launch_bounds__(512) void gemm_p8sk_kernel(const GemmArgs g, const P8SkArgs sk) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    p8_streamk<AMODE, BMODE, VEC, PHASES>(sk, smem, [&](int t, GemmArgs&, int& bid) -> const GemmArgs& { bid = t; return g; });
-}
-
-// grouped weight gradients (gemm_p8_group_kernel's problem list) on the stream-K schedule: the concatenated tile lists of all problems
-// form one iteration space (K is common), so a group of 432 tiles is 1.69 "rounds" of work per CU instead of two rounds
-template <bool VEC, int PHASES>
-__global__ __launch_bounds__(512) void gemm_p8sk_group_kernel(const P8GroupArgs ga, const P8SkArgs sk) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    p8_streamk<MRG_OP_KSTRIDED, MRG_OP_KSTRIDED, VEC, PHASES>(sk, smem, [&](int t, GemmArgs& gl, int& bid) -> const GemmArgs& {
-        int p = 0;
-        while (p + 1 < ga.nprob && t >= ga.tile_start[p + 1]) ++p;
-        gl = ga.base;
-        gl.A = ga.A[p]; gl.B = ga.B[p]; gl.C = ga.C[p];
-        gl.M = ga.M[p]; gl.N = ga.N[p]; gl.lda = ga.lda[p]; gl.ldb = ga.ldb[p]; gl.ldc = ga.ldc[p];
-        bid = t - ga.tile_start[p];
-        return gl;
-    });
-}
-
 }  // namespace
 
 bool mrg_gemm8p_group_launch(const mrg_detail::P8GroupArgs& ga, bool vec, hipStream_t stream) {
@@ -630,9 +459,6 @@ bool mrg_gemm8p_launch(const mrg_detail::GemmArgs& g, int a_mode, int b_mode, bo
     return true;
 }
 
-static unsigned long long* g_sk_trace = nullptr;
-extern "C" int mrg_debug_sk_trace(unsigned long long* buf) { g_sk_trace = buf; return 0; }
-
 int mrg_num_cus() {
     static const int n = [] {
         int dev = 0, cus = 256;
@@ -641,47 +467,4 @@ int mrg_num_cus() {
         return cus;
     }();
     return n;
-}
-
-// stream-K launch: grid workgroups (0: one per CU), slabs = grid * 2 * 256 KiB of fp32 workspace, cnt = one zero int per 256 x 256 tile
-bool mrg_gemm8p_sk_launch(const mrg_detail::GemmArgs& g, int a_mode, int b_mode, bool vec, float* slabs, int* cnt, int grid, hipStream_t stream) {
-    if (g.K % BK != 0 || g.a_map || g.b_map || g.m_dev || g.k_dev || g.colsum || g.splitk > 1) return false;
-    if (!g.a_aligned || !g.b_aligned || !slabs || !cnt) return false;
-    if (a_mode == MRG_OP_KSTRIDED && (g.M % 8 != 0)) return false;
-    if (b_mode == MRG_OP_KSTRIDED && (g.N % 8 != 0)) return false;
-    P8SkArgs sk;
-    sk.slabs = slabs; sk.cnt = cnt; sk.tiles = cdiv(g.M, 256) * cdiv(g.N, 256); sk.nk = g.K / BK; sk.trace = g_sk_trace;
-    const long iters = (long)sk.tiles * sk.nk;
-    int P = grid > 0 ? grid : mrg_num_cus();
-    if (P > iters) P = (int)iters;
-    static const int phases = [] { const char* e = getenv("MRG_P8_PHASES"); return e ? atoi(e) : 2; }();
-#define MRG_P8SK_(AM, BM_, V, PH) do { const void* fn = (const void*)gemm_p8sk_kernel<AM, BM_, V, PH>; \
-        (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, P8_LDS); \
-        hipLaunchKernelGGL((gemm_p8sk_kernel<AM, BM_, V, PH>), dim3(P), dim3(512), (size_t)P8_LDS, stream, g, sk); } while (0)
-#define MRG_P8SK(AM, BM_, V) do { if (phases == 4) MRG_P8SK_(AM, BM_, V, 4); else MRG_P8SK_(AM, BM_, V, 2); } while (0)
-    if (a_mode == MRG_OP_KCONTIG && b_mode == MRG_OP_KCONTIG) { if (vec) MRG_P8SK(0, 0, true); else MRG_P8SK(0, 0, false); }
-    else if (a_mode == MRG_OP_KCONTIG && b_mode == MRG_OP_KSTRIDED) { if (vec) MRG_P8SK(0, 1, true); else MRG_P8SK(0, 1, false); }
-    else if (a_mode == MRG_OP_KSTRIDED && b_mode == MRG_OP_KSTRIDED) { if (vec) MRG_P8SK(1, 1, true); else MRG_P8SK(1, 1, false); }
-    else return false;
-#undef MRG_P8SK
-#undef MRG_P8SK_
-    return true;
-}
-
-bool mrg_gemm8p_sk_group_launch(const mrg_detail::P8GroupArgs& ga, bool vec, float* slabs, int* cnt, int grid, hipStream_t stream) {
-    const int total = ga.tile_start[ga.nprob];
-    if (total <= 0 || !slabs || !cnt || ga.base.splitk > 1) return false;
-    P8SkArgs sk;
-    sk.slabs = slabs; sk.cnt = cnt; sk.tiles = total; sk.nk = ga.base.K / BK; sk.trace = g_sk_trace;
-    const long iters = (long)sk.tiles * sk.nk;
-    int P = grid > 0 ? grid : mrg_num_cus();
-    if (P > iters) P = (int)iters;
-    static const int phases = [] { const char* e = getenv("MRG_P8_PHASES"); return e ? atoi(e) : 2; }();
-#define MRG_P8SKG(V, PH) do { const void* fn = (const void*)gemm_p8sk_group_kernel<V, PH>; \
-        (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, P8_LDS); \
-        hipLaunchKernelGGL((gemm_p8sk_group_kernel<V, PH>), dim3(P), dim3(512), (size_t)P8_LDS, stream, ga, sk); } while (0)
-    if (vec) { if (phases == 4) MRG_P8SKG(true, 4); else MRG_P8SKG(true, 2); }
-    else { if (phases == 4) MRG_P8SKG(false, 4); else MRG_P8SKG(false, 2); }
-#undef MRG_P8SKG
-    return true;
 }

@@ -71,10 +71,6 @@ using namespace mrg_detail;
 // launcher of the 256 x 256 8-phase kernel (gemm8p.hip); returns false when the problem is outside its domain
 bool mrg_gemm8p_launch(const mrg_detail::GemmArgs& g, int a_mode, int b_mode, bool vec, int splitk, hipStream_t stream);
 bool mrg_gemm8p_group_launch(const mrg_detail::P8GroupArgs& ga, bool vec, hipStream_t stream);
-// stream-K schedule of the same kernel (gemm8p.hip): persistent grid (0 = one workgroup per CU), slabs = grid * 2 * 256 KiB fp32, cnt = zeroed
-// int per 256 x 256 tile (left zero)
-bool mrg_gemm8p_sk_launch(const mrg_detail::GemmArgs& g, int a_mode, int b_mode, bool vec, float* slabs, int* cnt, int grid, hipStream_t stream);
-bool mrg_gemm8p_sk_group_launch(const mrg_detail::P8GroupArgs& ga, bool vec, float* slabs, int* cnt, int grid, hipStream_t stream);
 int mrg_num_cus();
 // launcher of the 128 x 256 two-workgroups-per-CU kernel (gemm_duo.hip); returns false when the problem is outside its domain
 bool mrg_gemm_duo_launch(const mrg_detail::GemmArgs& g, int a_mode, int b_mode, bool vec, int splitk, hipStream_t stream);

@@ -165,7 +165,7 @@ class _Side:
 
     @classmethod
     def join(cls):
-        K.WgradGroup.exposed = True              # the caller waits for this group: it may take the whole chip (stream-K schedule)
+        K.WgradGroup.exposed = True              # the caller waits for this group: it may take the whole chip
         try:
             cls.flush()
             K.WgradGroup.flush()                 # side stream off: what the last blocks queued

@@ -185,28 +185,11 @@ def _splitk_counters(ntiles: int, device):
     return buf.data_ptr() + 4 * pos
 
 
-# Stream-K launches (MRG_GEMM_P8SK, mrg_wgrad_group streamk): persistent grid of SK_GRID workgroups (0 = one per CU); the scratch for the
-# partial accumulator images is the per-stream workspace, the per-tile arrival counters come from the zero ring above
-SK_GRID = int(os.environ.get("MRG_SK_GRID", "0"))
-STREAMK = os.environ.get("MRG_STREAMK", "1") != "0"          # A/B: 0 keeps the stream-K variant out of the tuner and the groups
-
-
-def _streamk_scratch(d, tiles256: int, dev):
-    d.ws = _workspace(lib.mrg_streamk_ws_bytes(SK_GRID), dev).data_ptr()
-    d.sk_grid = SK_GRID
-    return _splitk_counters(tiles256, dev)
-
-
 def _gemm_launch(d, splitk, variant, dev, defer_out=None):
     d.splitk = splitk
     d.variant = variant
     d.defer_reduce = 0
     d.splitk_counters = None
-    if variant == L.MRG_GEMM_P8SK:
-        d.splitk = 1
-        d.splitk_counters = _streamk_scratch(d, ((d.M + 255) // 256) * ((d.N + 255) // 256), dev)
-        check(lib.mrg_gemm(C.byref(d), _s()), "mrg_gemm")
-        return
     if splitk > 1:
         if (SPLITK_INKERNEL and not d.colsum_out and splitk <= SPLITK_INKERNEL_MAX
                 and ((d.M + 127) // 128) * ((d.N + 127) // 128) >= SPLITK_INKERNEL_MIN_TILES):
@@ -233,10 +216,8 @@ def _autotune(d, key, splitk, allow_split, dev):
     if allow_split:
         kt = (d.K + 63) // 64
         splits = sorted({s for s in (1, 2, 4, 8, 16, 32) if s == 1 or kt // s >= 4})
-    for v in (L.MRG_GEMM_GLDS3, L.MRG_GEMM_GLDS4, L.MRG_GEMM_PIPE128, L.MRG_GEMM_PIPE256, L.MRG_GEMM_PIPE256SQ, L.MRG_GEMM_WS256):
-        if v in (L.MRG_GEMM_PIPE256, L.MRG_GEMM_PIPE256SQ, L.MRG_GEMM_WS256) and d.M <= 128:
-            continue
-        if v == L.MRG_GEMM_PIPE256SQ and (d.N <= 128 or ((d.M + 255) // 256) * ((d.N + 255) // 256) < 64):
+    for v in (L.MRG_GEMM_GLDS3, L.MRG_GEMM_GLDS4, L.MRG_GEMM_PIPE128, L.MRG_GEMM_PIPE256, L.MRG_GEMM_WS256):
+        if v in (L.MRG_GEMM_PIPE256, L.MRG_GEMM_WS256) and d.M <= 128:
             continue
         for s_ in splits:
             cands.append((v, s_))
@@ -251,8 +232,9 @@ def _autotune(d, key, splitk, allow_split, dev):
         for s_ in splits:
             if t8 * s_ >= 192:
                 cands.append((L.MRG_GEMM_P8, s_))
-        if STREAMK and t8 * (d.K // 64) >= 1024:                   # stream-K: at least ~4 k-tiles per CU
-            cands.append((L.MRG_GEMM_P8SK, 1))
+    # 128 x 256 duo kernel (gemm_duo.hip): two workgroups per CU, forward / dgrad layouts
+    if d.K % 64 == 0 and d.a_mode == L.MRG_OP_KCONTIG and d.N > 128 and not d.colsum_out and not d.k_dev and not d.a_map and not d.b_map and not d.m_dev:
+        cands.append((L.MRG_GEMM_DUO, 1))
     best, best_t = (L.MRG_GEMM_AUTO, splitk), float("inf")
     for v, s_ in cands:
         _gemm_launch(d, s_, v, dev)
@@ -376,13 +358,6 @@ class WgradGroup:
     split_below = int(os.environ.get("MRG_WGRAD_GROUP_SPLIT_BELOW", "0"))
     split_max_k = int(os.environ.get("MRG_WGRAD_GROUP_SPLIT_MAX_K", "12288"))
     max_k = int(os.environ.get("MRG_WGRAD_GROUP_MAX_K", "16384"))
-    # groups on the stream-K schedule: 0 (default) never, 1 always, 2 only the groups launched from a join (engine._Side.join sets
-    # `exposed`: the calling stream waits for those, nothing else wants the CUs).  Measured same box (profiles/r04_streamk.md): all groups
-    # C2 9.53 -> 10.04 ms, C4 20.58 -> 22.41 (a persistent launch holds every CU until its last range ends and starves the dgrad chain
-    # beside it); exposed groups only C2 9.42 -> 9.55, C4 20.44 -> 20.46: isolated, 432 tiles take 456 us as two rounds of tiles and
-    # 538 us as 1.69 rounds of work -- the second round of a one-tile-per-workgroup launch runs on a two-thirds empty chip at a higher
-    # rate, while every stream-K range pays a partial-image store, a read and a split main loop
-    streamk_mode = int(os.environ.get("MRG_WGRAD_GROUP_STREAMK", "0"))
     exposed = False
     collecting = False
     tasks = []
@@ -450,29 +425,19 @@ class WgradGroup:
                 wgrad_group(chunk, K_, sk, fuse=fz)
 
 
-def wgrad_group(ts, K: int, splitk: int = 1, streamk: Optional[bool] = None, fuse=None):
+def wgrad_group(ts, K: int, splitk: int = 1, fuse=None):
     """one mrg_wgrad_group launch: ts = [(A, B, M, N, K, lda, ldb, out, ldc, _)], out_p[M_p, N_p] = A_p^T B_p (fp32, overwritten);
-    splitk > 1: slabs + deferred batched reduction (only inside a backward pass: Deferred.active); streamk (default: on for groups
-    that do not fill a whole number of rounds): the concatenated tile lists on the stream-K schedule"""
+    splitk > 1: slabs + deferred batched reduction (only inside a backward pass: Deferred.active)"""
     d = L.WgradGroupDesc()
     d.count, d.K = len(ts), K
     fl = 0.0
-    tiles_all = sum(((t[2] + 255) // 256) * ((t[3] + 255) // 256) for t in ts)
     fz = None
     if fuse is not None and splitk == 1:
         # AdamW applied by the launch (mrg_wgrad_group_desc.fuse): every output must be a contiguous view into the optimizer's gradient arena
         fz = fuse.descriptor(ts)
         if fz is not None:
-            streamk = False
             d.fuse = C.cast(C.pointer(fz), C.c_void_p)
             d._fz = fz
-    if streamk is None:
-        streamk = STREAMK and (WgradGroup.streamk_mode == 1 or (WgradGroup.streamk_mode == 2 and WgradGroup.exposed))
-    if streamk and splitk == 1:
-        d.streamk = 1
-        d.ws = _workspace(lib.mrg_streamk_ws_bytes(SK_GRID), ts[0][0].device).data_ptr()
-        d.sk_grid = SK_GRID
-        d.counters = _splitk_counters(tiles_all, ts[0][0].device)
     if splitk > 1:
         ws = torch.empty(splitk * sum(t[2] * t[3] for t in ts), dtype=F32, device=ts[0][0].device)
         d.splitk, d.ws = splitk, ws.data_ptr()

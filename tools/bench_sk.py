@@ -1,12 +1,13 @@
 #!/usr/bin/env python3
-"""Stream-K schedule of the 8-phase kernel (variant 12) against the one-tile-per-workgroup 8-phase kernel (11), the tuned table entry
-and the vendor BLAS on the encoder shapes of C2 / C4 / C5 WITH the production epilogues (bias -> bf16, bias + fp32 residual,
-bias + GELU + fp16 GELU' side output, multiply by the GELU' side input).  Every variant is timed as a captured graph of `reps`
-launches that rotate through `nrot` operand / output sets (cold-ish operands as inside the step), interleaved rounds, median.
+"""The encoder GEMM shapes of C2 / C4 / C5 WITH their production epilogues (bias -> bf16, bias + fp32 residual, bias + GELU + fp16 GELU' side
+output, multiply by the GELU' side input): the tuned table entry, the 8-phase kernel (variant 11), the duo kernel (13) and the vendor BLAS
+(plain epilogue).  Every variant is timed as a captured graph of `reps` launches that rotate through `nrot` operand / output sets (cold-ish
+operands as inside the step), interleaved rounds, median.  (Round 4 used this tool for the stream-K schedule, hence the name.)
 
-"duo" = the 128 x 256 two-workgroups-per-CU kernel (variant 13, gemm_duo.hip, round 5).
-
-usage: bench_sk.py [c2|c4|c5|all] [grid ...]      grid: stream-K grids to time as well (0 = one workgroup per CU)"""
+usage: bench_sk.py [c2|c4|c5|all|epi|fill|under]
+  epi    one shape per configuration under every epilogue kind: what the epilogue costs on top of the main loop (MRG_BENCH_ZERO=1: zero operands)
+  fill   main-loop-dominated shapes, for the MRG_DUO_FILL experiment build (tools/debug/run_duo_fill.sh)
+  under  shapes with fewer tiles than workgroup slots (MRG_BENCH_DUO_SPLITK=2,3: split-K inside the duo kernel)"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -71,7 +72,7 @@ def case(tag, mode, epi, M, N, Kd, grids, reps=16, nrot=4, rounds=5):
         for A, B, kw in sets:
             A.zero_(); B.zero_()
 
-    def runner(variant, grid=0, splitk=1):
+    def runner(variant, splitk=1):
         def f(i):
             A, B, kw = sets[i % nrot]
             if splitk > 1:
@@ -80,7 +81,6 @@ def case(tag, mode, epi, M, N, Kd, grids, reps=16, nrot=4, rounds=5):
                 torch.mm(A, B.t() if mode == "fwd" else B)
                 return
             K.TUNE["force"] = variant
-            K.SK_GRID = grid
             was = K.TUNE["enabled"]
             if splitk > 1:
                 K.TUNE["enabled"] = False          # the table would overwrite the split factor
@@ -88,15 +88,12 @@ def case(tag, mode, epi, M, N, Kd, grids, reps=16, nrot=4, rounds=5):
                 K.gemm(A, B, M, N, Kd, **kw)
             finally:
                 K.TUNE["force"] = None
-                K.SK_GRID = 0
                 K.TUNE["enabled"] = was
         return f
 
     fns = {"vendor": runner("vendor"), "tuned": runner(None), "p8": runner(L.MRG_GEMM_P8), "duo": runner(L.MRG_GEMM_DUO)}
     for sk_ in [int(x) for x in os.environ.get("MRG_BENCH_DUO_SPLITK", "").split(",") if x]:
-        fns[f"duo/{sk_}"] = runner(L.MRG_GEMM_DUO, 0, sk_)
-    for gr in grids:
-        fns[f"sk{gr}"] = runner(L.MRG_GEMM_P8SK, gr)
+        fns[f"duo/{sk_}"] = runner(L.MRG_GEMM_DUO, sk_)
     graphs = {k: graph_of(f, reps) for k, f in fns.items()}
     res = {k: [] for k in fns}
     for _ in range(rounds):
@@ -120,7 +117,7 @@ def shapes(M, D):
 
 if __name__ == "__main__":
     which = sys.argv[1] if len(sys.argv) > 1 else "all"
-    grids = [int(x) for x in sys.argv[2:]]        # stream-K grids to time as well (none by default: round 4 measured it, profiles/r04_streamk.md)
+    grids = []
     if which == "under":        # shapes with fewer 128 x 256 tiles than workgroup slots: split-K inside the duo kernel (MRG_BENCH_DUO_SPLITK=2,3,4)
         for tag, mode, epi, M, N, Kd in (("c2 proj", "fwd", "resid", 8256, 768, 768), ("c2 fc2", "fwd", "resid", 8256, 768, 3072),
                                          ("c2 fc1", "dgrad", "plain", 8256, 768, 3072), ("c2 qkv", "dgrad", "plain", 8256, 768, 2304),

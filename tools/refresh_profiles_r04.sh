@@ -1,4 +1,5 @@
 #!/bin/bash
+# (round-4 script, kept for the record: it calls the stream-K tools that round 5 removed -- tools/debug/patches/streamk_r04.patch restores them)
 # Round-4 profile refresh on one MI355X box: the driver's default bench line (C2 headline + C4 / C5 as other_configs), rocprofv3 kernel-trace
 # summaries (production schedule = two forward chains, and MRG_TWO_CHAINS=1 = the launch shapes bench.py's instrumented roofline step times),
 # device-timestamp phase tables, PMC traffic (with the fetch / operand ratio table) and the MFMA-busy cross-check.  Summaries only: the

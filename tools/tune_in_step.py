@@ -74,9 +74,8 @@ if os.environ.get("MRG_TUNE_ONLY"):
 cur = base
 for key in used:
     v0, s0 = K._tune_cache[key]
-    trials = [(v, 1 if v == L.MRG_GEMM_P8SK else s0) for v in cands if v != v0 and not (v in (L.MRG_GEMM_PIPE256, L.MRG_GEMM_WS256, L.MRG_GEMM_G256, L.MRG_GEMM_P8, L.MRG_GEMM_P8SK) and key[2] <= 128) and not (v in (L.MRG_GEMM_G256, L.MRG_GEMM_P8, L.MRG_GEMM_P8SK, L.MRG_GEMM_DUO) and key[4] % 64)
+    trials = [(v, s0) for v in cands if v != v0 and not (v in (L.MRG_GEMM_PIPE256, L.MRG_GEMM_WS256, L.MRG_GEMM_G256, L.MRG_GEMM_P8) and key[2] <= 128) and not (v in (L.MRG_GEMM_G256, L.MRG_GEMM_P8, L.MRG_GEMM_DUO) and key[4] % 64)
               and not (v == L.MRG_GEMM_DUO and (key[0] != 0 or key[3] <= 128 or key[8]))
-              and not (v == L.MRG_GEMM_P8SK and (key[3] <= 128 or key[8] or ((key[2] + 255) // 256) * ((key[3] + 255) // 256) * (key[4] // 64) < 1024))
               and not (v == L.MRG_GEMM_P8 and (key[3] <= 128 or ((key[2] + 255) // 256) * ((key[3] + 255) // 256) * s0 < 192))]
     if key[8]:                                   # split-K tunable (wgrad): also neighbours of the split factor
         trials += [(v0, s) for s in (max(1, s0 // 2), s0 * 2) if s != s0 and (key[4] // 64) // s >= 4]
