@@ -424,7 +424,7 @@ def test_two_engine_ranks_on_one_gpu(tmp_path, comm, wire, update):
 
 def _rank_env(**extra):
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MRG_SHARE_GPU="1", MRG_DIST_BACKEND="gloo", **extra)
-    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "MRG_DP_COMM", "MRG_DP_DTYPE", "MRG_FORCE_DP"):
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "MRG_DP_COMM", "MRG_DP_DTYPE", "MRG_DP_UPDATE", "MRG_FORCE_DP"):
         if k not in extra:
             env.pop(k, None)
     return env
@@ -520,3 +520,36 @@ def test_run_pretraining_two_ranks_two_epochs(tmp_path):
     ck = torch.load(os.path.join(d, "checkpoint-1.pth"), map_location="cpu", weights_only=False)
     assert ck["optimizer"]["mrg_iteration"] == 80
     T.report("run_pretraining_dp2", loss_first=losses[0], loss_last=losses[-1], grad_norm_first=norms[0], grad_norm_last=norms[-1])
+
+
+def test_run_pretraining_sharded_update_matches_replicated(tmp_path):
+    """mirage_amd.run_pretraining under two ranks with MRG_DP_UPDATE=sharded (reduce-scatter -> AdamW on the owned shard -> all-gather of the
+    parameters) against the replicated update: the same loss and gradient-norm log line for line (the element updates are the same
+    arithmetic on the same averaged gradients), and a checkpoint whose optimizer state is complete -- the moments of the OTHER rank's
+    shards reach rank 0 through GradReducer.gather_moments before the file is written."""
+    def run(update, out):
+        port = _free_port()
+        argv = ["-m", "mirage_amd.run_pretraining", "--blr", "1e-2", "--data_path", "synthetic", "--in_domains", "bscan-slo", "--out_domains", "bscan-slo",
+                "--input_size", "128", "--patch_size", "8", "--batch_size", "2", "--num_encoded_tokens", "98", "--epochs", "1",
+                "--steps_per_epoch", "12", "--warmup_epochs", "1", "--save_ckpt_freq", "1", "--base_output_dir", out, "--print_freq", "1"]
+        procs = []
+        for r in range(2):
+            env = _rank_env(RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), MRG_DP_UPDATE=update)
+            procs.append(subprocess.Popen([sys.executable] + argv, env=env, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
+        logs = _wait_ranks(procs, 600)
+        for p, lg in zip(procs, logs):
+            assert p.returncode == 0, lg[-3000:]
+        steps = [l for l in logs[0].splitlines() if l.startswith("Epoch: [")]
+        vals = [dict(zip(l.split()[3::2], l.split()[4::2])) for l in steps]
+        ck = torch.load(os.path.join(out, "miragepre_base", "checkpoint-0.pth"), map_location="cpu", weights_only=False)
+        return [(v["loss:"], v["grad_norm:"]) for v in vals], ck
+    rep, ck_rep = run("replicated", str(tmp_path / "rep"))
+    sh, ck_sh = run("sharded", str(tmp_path / "sh"))
+    assert len(rep) == len(sh) == 12
+    assert rep == sh, list(zip(rep, sh))
+    st_r, st_s = ck_rep["optimizer"]["state"], ck_sh["optimizer"]["state"]
+    assert st_r.keys() == st_s.keys() and len(st_s) > 100
+    for i in st_s:
+        assert torch.equal(st_s[i]["exp_avg"], st_r[i]["exp_avg"]) and torch.equal(st_s[i]["exp_avg_sq"], st_r[i]["exp_avg_sq"]), i
+    for k in ck_rep["model"]:
+        assert torch.equal(ck_rep["model"][k], ck_sh["model"][k]), k
