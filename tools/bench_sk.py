@@ -59,6 +59,8 @@ def case(tag, mode, epi, M, N, Kd, grids, reps=16, nrot=4, rounds=5):
         elif epi == "gelu":
             kw.update(bias=torch.randn(N, device=dev), out=torch.empty(M, N, dtype=BF16, device=dev), act=L.MRG_ACT_GELU_SAVE_GRAD,
                       aux_out=torch.empty(M, N, dtype=torch.float16, device=dev))
+        elif epi == "resid0":      # experiment: the residual is ONE row broadcast (row stride 0: always cache-resident) -- what the residual READ costs
+            kw.update(bias=torch.randn(N, device=dev), out=torch.empty(M, N, dtype=F32, device=dev), resid=torch.randn(1, N, device=dev).expand(M, N))
         elif epi == "gelu5":
             kw.update(bias=torch.randn(N, device=dev), out=torch.empty(M, N, dtype=BF16, device=dev), act=L.MRG_ACT_GELU)
         elif epi == "f32":
@@ -126,6 +128,10 @@ if __name__ == "__main__":
                                          ("dec fc2", "fwd", "resid", 16384, 256, 1024), ("dec fc1", "dgrad", "plain", 16384, 256, 1024),
                                          ("c2h fc2", "fwd", "resid", 4128, 768, 3072), ("c2h fc1", "fwd", "gelu", 4128, 3072, 768)):
             case(tag, mode, epi, M, N, Kd, grids)
+    if which == "resid":        # what bounds the fp32-residual epilogue: the residual read (resid0 = cache-resident broadcast row), the fp32 write (f32), or neither
+        for tag, M, N, Kd in (("c5h proj", 32896, 1024, 1024), ("c5h fc2", 32896, 1024, 4096), ("c2 fc2", 8256, 768, 3072), ("c4 fc2", 6336, 1024, 4096), ("c4 proj", 6336, 1024, 1024)):
+            for epi in ("bias", "f32", "resid0", "resid"):
+                case(tag, "fwd", epi, M, N, Kd, grids, reps=(6 if M > 30000 else 16), nrot=(2 if M > 30000 else 4))
     if which == "fill":         # tools/debug/run_duo_fill.sh: main-loop-dominated shapes with the cheapest epilogue
         for tag, M, N, Kd in (("c2 fc1", 8256, 3072, 768), ("c5h fc1", 32896, 4096, 1024), ("square4k", 8192, 8192, 4096)):
             case(tag, "fwd", "bias", M, N, Kd, grids, reps=(6 if M > 30000 or Kd > 2000 else 16), nrot=(2 if M > 30000 or Kd > 2000 else 4))
