@@ -230,6 +230,9 @@ __global__ __launch_bounds__(512, 4) void attn_fwd_kernel(const AttnArgs a0) {  
     const int nqt = (a.Nq + 31) >> 5;
     const int nchunks = (a.Nk + ROWS - 1) / ROWS;
     const float sc = a.scale * LOG2E;
+#ifdef MRG_ATTN_TS      // debug build: phase timestamps of this workgroup's wave 0 (100 MHz wall clock), written over its lse rows at the end
+    unsigned long long fts0 = wall_clock64(), fts1 = 0, fts2 = 0, fts3 = 0;
+#endif
 
     // TAIL: the last token's q, k and v rows (HD bf16 each, plain layout) in front of the exchange area -- read several times below, and a
     // global round trip in front of every tile and of the last query's row is what made the path lose at N = 129
@@ -243,6 +246,9 @@ __global__ __launch_bounds__(512, 4) void attn_fwd_kernel(const AttnArgs a0) {  
         load_rows2<HD, SWZ_ROW, SWZ_TR>(ldsK, kp, a.k_rs, ldsV, vp, a.v_rs, lds_rows, a.Nk, tid, nthr);
         __syncthreads();
     }
+#ifdef MRG_ATTN_TS
+    fts1 = wall_clock64();
+#endif
     // uniform rounds so that every wave takes part in the staging barriers of the multi-chunk path
     const int rounds = (nqt + nwav - 1) / nwav;
     for (int rd = 0; rd < rounds; ++rd) {
@@ -391,74 +397,108 @@ __global__ __launch_bounds__(512, 4) void attn_fwd_kernel(const AttnArgs a0) {  
         if (a.lse && lane < 32 && q0 + lane < a.Nq)
             a.lse[((long)b * a.H + h) * a0.Nq + q0 + lane] = m_run * a.scale + __logf(l_run);
     }
+#ifdef MRG_ATTN_TS
+    fts2 = wall_clock64();
+#endif
     if (TAIL) {
-        // ---- the last query row (index a.Nq): scores with lane = key (half of the head dimension per lane of a pair), P V with lane = column
+        // ---- the last query row (index a.Nq), as a query tile with ONE valid row on the matrix units: every wave takes the key blocks kb = wave,
+        // wave + nwav, ... with the tiles' own block step (S^T = K q^T -> online softmax -> P V, transposed accumulators: lanes 0 and 32 own the
+        // row), wave 0 adds the last key, and the waves' partial softmax states are merged through LDS.  (Round 4 did this row with scalar
+        // reads -- 32 readlane + LDS + FMA steps per key block -- which cost 4.3 us of a workgroup's 20 at N = 257, profiles/r05_attn_fwd.md.)
         float* xch = reinterpret_cast<float*>(smem + a.tail_off + 3 * HD * 2);
         const bf16_t* qt = tl;
+        bf16x8 qf2[KS];
         int hf = lane >> 5;
-        asm volatile("" : "+v"(hf));          // opaque: the loads below depend on it and cannot be hoisted above the tiles (16 + VGPRs live there)
-        const int kl = lane & 31;
-        uint32_t qw[HD / 4];                                  // this half's HD / 2 query values, packed pairs
+        asm volatile("" : "+v"(hf));          // opaque: the loads below depend on it and cannot be hoisted above the tiles (the register budget is theirs)
 #pragma unroll
-        for (int c = 0; c < HD / 16; ++c) {
-            const uint4 v = *reinterpret_cast<const uint4*>(qt + (HD / 2) * hf + 8 * c);
-            qw[4 * c] = v.x; qw[4 * c + 1] = v.y; qw[4 * c + 2] = v.z; qw[4 * c + 3] = v.w;
+        for (int kk = 0; kk < KS; ++kk) {
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if ((lane & 31) == 0) v = *reinterpret_cast<const uint4*>(qt + kk * 16 + 8 * hf);
+            qf2[kk] = *reinterpret_cast<bf16x8*>(&v);
         }
-        float mrun = -INFINITY, lrun = 0.f, od = 0.f;        // od: column `lane` of the (unnormalised) output row
+        f32x16 ot[DJ];
+#pragma unroll
+        for (int dj = 0; dj < DJ; ++dj)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) ot[dj][r] = 0.f;
+        float mrun = -INFINITY, lrun = 0.f;
         const int nkb = a.Nk >> 5;
         for (int kb = wave; kb < nkb; kb += nwav) {
-            const int r = kb * 32 + kl;
-            float part = 0.f;
+            f32x16 st;
 #pragma unroll
-            for (int c = 0; c < HD / 16; ++c) {
-                const uint4 v = *reinterpret_cast<const uint4*>(ldsK + tile_off<HD, SWZ_ROW>(r, (HD / 16) * hf + c));
-                const uint32_t kw[4] = {v.x, v.y, v.z, v.w};
+            for (int r = 0; r < 16; ++r) st[r] = 0.f;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    part = fmaf(__uint_as_float(qw[4 * c + e] << 16), __uint_as_float(kw[e] << 16), part);
-                    part = fmaf(__uint_as_float(qw[4 * c + e] & 0xffff0000u), __uint_as_float(kw[e] & 0xffff0000u), part);
-                }
-            }
-            const float sj = part + __shfl_xor(part, 32, 64);
-            const float mn = fmaxf(mrun, wave_max(sj));
+            for (int kk = 0; kk < KS; ++kk)
+                st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows_cl<HD, SWZ_ROW>(ldsK, kb * 32, kk, lane, a.rmax), qf2[kk], st, 0, 0, 0);
+            float mx = -INFINITY;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) mx = fmaxf(mx, st[r]);
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            const float mn = fmaxf(mrun, mx);
             const float alpha = fast_exp2((mrun - mn) * sc);
-            const float p = fast_exp2((sj - mn) * sc);
-            lrun = lrun * alpha + 0.5f * wave_sum(p);        // both lanes of a pair hold the key's p
-            od *= alpha;
-            mrun = mn;
-            const float pb = __uint_as_float(pack_bf2(p, 0.f) << 16);      // P enters the P V product rounded to bf16, as in the tiles
-            const uint32_t pbits = __float_as_uint(pb);
+            float ls = 0.f;
 #pragma unroll
-            for (int j = 0; j < 32; ++j) {                    // lane j (first half) holds key j's weight: a scalar read per key
-                const float pj = __uint_as_float(__builtin_amdgcn_readlane(pbits, j));
-                const int rr = kb * 32 + j;
-                const bf16_t vv = *reinterpret_cast<const bf16_t*>(ldsV + tile_off<HD, SWZ_TR>(rr, lane >> 3) + ((lane & 7) << 1));
-                od = fmaf(pj, __uint_as_float((uint32_t)vv << 16), od);
+            for (int r = 0; r < 16; ++r) {
+                const float pp = fast_exp2((st[r] - mn) * sc);
+                st[r] = pp;
+                ls += pp;
+            }
+            ls += __shfl_xor(ls, 32, 64);
+            lrun = lrun * alpha + ls;
+            mrun = mn;
+#pragma unroll
+            for (int dj = 0; dj < DJ; ++dj)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) ot[dj][r] *= alpha;
+#pragma unroll
+            for (int mf = 0; mf < 2; ++mf) {
+                const bf16x8 pa = pack8(st, mf);
+#pragma unroll
+                for (int dj = 0; dj < DJ; ++dj)
+                    ot[dj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_cols_tr_cl<HD, SWZ_TR>(ldsV_u, kb * 32, mf, dj, lane, a.rmax), pa, ot[dj], 0, 0, 0);
             }
         }
-        if (wave == 0) {                                      // the last key, for the last query: one more single-key block
+        if (wave == 0) {                                      // the last key, for the last query: one more single-key block (lanes 0 and 32 hold the row)
             const bf16_t* kt = tl + HD;
             float part = 0.f;
 #pragma unroll
-            for (int c = 0; c < HD / 16; ++c) {
-                const uint4 v = *reinterpret_cast<const uint4*>(kt + (HD / 2) * hf + 8 * c);
-                const uint32_t kw[4] = {v.x, v.y, v.z, v.w};
+            for (int kk = 0; kk < KS; ++kk) {
+                const uint4 kv4 = *reinterpret_cast<const uint4*>(kt + kk * 16 + 8 * (lane >> 5));
+                const uint32_t kw[4] = {kv4.x, kv4.y, kv4.z, kv4.w};
+                const uint32_t* qw = reinterpret_cast<const uint32_t*>(&qf2[kk]);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    part = fmaf(__uint_as_float(qw[4 * c + e] << 16), __uint_as_float(kw[e] << 16), part);
-                    part = fmaf(__uint_as_float(qw[4 * c + e] & 0xffff0000u), __uint_as_float(kw[e] & 0xffff0000u), part);
+                    part = fmaf(__uint_as_float(qw[e] << 16), __uint_as_float(kw[e] << 16), part);
+                    part = fmaf(__uint_as_float(qw[e] & 0xffff0000u), __uint_as_float(kw[e] & 0xffff0000u), part);
                 }
             }
-            const float sj = part + __shfl_xor(part, 32, 64);      // the same value in every lane
+            const float sj = part + __shfl_xor(part, 32, 64);
             const float mn = fmaxf(mrun, sj);
             const float alpha = fast_exp2((mrun - mn) * sc);
-            const float p = fast_exp2((sj - mn) * sc);
-            lrun = lrun * alpha + p;
-            const float pb = __uint_as_float(pack_bf2(p, 0.f) << 16);
-            od = fmaf(pb, bf2f(tl[2 * HD + lane]), od * alpha);
+            const float pp = fast_exp2((sj - mn) * sc);
+            lrun = lrun * alpha + pp;
             mrun = mn;
+            const float pb = __uint_as_float(pack_bf2(pp, 0.f) << 16);      // P enters the P V product rounded to bf16, as in the tiles
+            const bf16_t* vt = tl + 2 * HD;
+#pragma unroll
+            for (int dj = 0; dj < DJ; ++dj)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {                 // registers 4 g .. 4 g + 3 = columns dj 32 + 8 g + 4 (lane >> 5) + 0 .. 3
+                    const uint2 v2 = *reinterpret_cast<const uint2*>(vt + dj * 32 + 8 * g + 4 * (lane >> 5));
+                    ot[dj][4 * g + 0] = fmaf(pb, __uint_as_float(v2.x << 16), ot[dj][4 * g + 0] * alpha);
+                    ot[dj][4 * g + 1] = fmaf(pb, __uint_as_float(v2.x & 0xffff0000u), ot[dj][4 * g + 1] * alpha);
+                    ot[dj][4 * g + 2] = fmaf(pb, __uint_as_float(v2.y << 16), ot[dj][4 * g + 2] * alpha);
+                    ot[dj][4 * g + 3] = fmaf(pb, __uint_as_float(v2.y & 0xffff0000u), ot[dj][4 * g + 3] * alpha);
+                }
         }
-        xch[wave * 66 + lane] = od;
+        if ((lane & 31) == 0) {                               // lanes 0 and 32 hold the row: 32 of its 64 columns each
+#pragma unroll
+            for (int dj = 0; dj < DJ; ++dj)
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) xch[wave * 66 + dj * 32 + 8 * g + 4 * (lane >> 5) + e] = ot[dj][4 * g + e];
+        }
         if (lane == 0) { xch[wave * 66 + 64] = mrun; xch[wave * 66 + 65] = lrun; }
         __syncthreads();
         if (wave == 0) {
@@ -474,6 +514,14 @@ __global__ __launch_bounds__(512, 4) void attn_fwd_kernel(const AttnArgs a0) {  
             if (a.lse && lane == 0) a.lse[((long)b * a.H + h) * a0.Nq + a.Nq] = M * a.scale + __logf(L);
         }
     }
+#ifdef MRG_ATTN_TS
+    __syncthreads();
+    fts3 = wall_clock64();
+    if (a.lse && tid == 0) {
+        unsigned long long* tsp = reinterpret_cast<unsigned long long*>(a.lse + ((long)b * a.H + h) * a0.Nq);
+        tsp[0] = fts0; tsp[1] = fts1; tsp[2] = fts2; tsp[3] = fts3;
+    }
+#endif
 }
 
 // ================================================ backward ==============================================
