@@ -319,8 +319,14 @@ __global__ __launch_bounds__(512, 4) void attn_fwd_kernel(const AttnArgs a0) {  
                 for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[kb][r]);
             }
             mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-            const float m_new = fmaxf(m_run, mx);
-            const float alpha = fast_exp2((m_run - m_new) * sc);   // first chunk: exp2(-inf) = 0
+            // Thresholded rescale: while no query of the wave sees its running maximum grow by more than 2^8 (in the exponent's units),
+            // the stale maximum stays the reference point -- p <= 256 instead of <= 1, the normalisation by l at the end is the same --
+            // and the block skips the rescale of the 32 output registers and its exponential: ~70 of the ~550 issue cycles of a block
+            // step on a SIMD-issue-bound kernel (profiles/r05_attn_fwd.md).  The first block of a row always rescales (m_run = -inf).
+            const bool grow = (fmaxf(m_run, mx) - m_run) * sc > 8.0f;         // -inf start: inf > 8
+            const bool rescale = __builtin_amdgcn_ballot_w64(grow) != 0;
+            const float m_new = rescale ? fmaxf(m_run, mx) : m_run;
+            const float alpha = rescale ? fast_exp2((m_run - m_new) * sc) : 1.0f;   // first chunk: exp2(-inf) = 0
             float ls = 0.f;
 #pragma unroll
             for (int kb = 0; kb < CB; ++kb)
@@ -333,7 +339,7 @@ __global__ __launch_bounds__(512, 4) void attn_fwd_kernel(const AttnArgs a0) {  
             ls += __shfl_xor(ls, 32, 64);
             l_run = l_run * alpha + ls;
             m_run = m_new;
-            if (ch > 0 || TAIL) {                    // o is accumulated transposed (lane = query): the row factor is lane-local
+            if ((ch > 0 || TAIL) && rescale) {       // o is accumulated transposed (lane = query): the row factor is lane-local
 #pragma unroll
                 for (int r = 0; r < 16; ++r)
 #pragma unroll
