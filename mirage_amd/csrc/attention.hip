@@ -311,7 +311,8 @@ __global__ __launch_bounds__(512, 4) void attn_fwd_kernel(const AttnArgs a0) {  
                     for (int kk = 0; kk < KS; ++kk)
                         s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows_cl<HD, SWZ_ROW>(ldsK, lbase + kb * 32, kk, lane, a.rmax), qf[kk], s[kb], 0, 0, 0);
                 }
-                if (kb * 32 + 32 > kvalid) {         // only the last, partial key block needs the key-range test
+                if (!TAIL && kb * 32 + 32 > kvalid) {   // only the last, partial key block needs the key-range test (TAIL: the tiles cover 32 m keys)
+                    asm volatile("" ::: "memory");        // keeps this a BRANCH: if-converted it cost every block 58 compare / select instructions
 #pragma unroll
                     for (int r = 0; r < 16; ++r) if (kb * 32 + acc_row(r, lane) >= kvalid) s[kb][r] = -INFINITY;
                 }
@@ -328,11 +329,12 @@ __global__ __launch_bounds__(512, 4) void attn_fwd_kernel(const AttnArgs a0) {  
             const float m_new = rescale ? fmaxf(m_run, mx) : m_run;
             const float alpha = rescale ? fast_exp2((m_run - m_new) * sc) : 1.0f;   // first chunk: exp2(-inf) = 0
             float ls = 0.f;
+            const float nms = -m_new * sc;               // p = 2^(s sc - m sc): one FMA per score instead of a subtract and a multiply
 #pragma unroll
             for (int kb = 0; kb < CB; ++kb)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const float p = fast_exp2((s[kb][r] - m_new) * sc);
+                    const float p = fast_exp2(fmaf(s[kb][r], sc, nms));
                     s[kb][r] = p;
                     ls += p;
                 }
