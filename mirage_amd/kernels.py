@@ -95,7 +95,9 @@ _TUNE_REPS = 6
 # hits: optional set collecting the table keys a run actually uses; table_entries / table_used: size of the committed table and the
 # distinct shapes of this process that were served from it (everything else was tuned at warm-up and is in "log") -- reported by
 # bench.py / run_pretraining so that a run says which variant table it ran on
-TUNE = {"enabled": True, "log": [], "hits": None, "table_entries": 0, "table_used": set()}
+# MRG_TUNE=0: no table, no first-use autotuning -- every GEMM takes the heuristic kernel choice of mrg_gemm (runs that must pick the same
+# kernels in separate processes: first-use autotuning is a timing, and two processes may time differently)
+TUNE = {"enabled": os.environ.get("MRG_TUNE", "1") != "0", "log": [], "hits": None, "table_entries": 0, "table_used": set()}
 _table_keys = set()
 _TUNE_FILE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "gemm_tune_gfx950.json")
 

@@ -524,7 +524,7 @@ def test_run_pretraining_two_ranks_two_epochs(tmp_path):
 
 def test_run_pretraining_sharded_update_matches_replicated(tmp_path):
     """mirage_amd.run_pretraining under two ranks with MRG_DP_UPDATE=sharded (reduce-scatter -> AdamW on the owned shard -> all-gather of the
-    parameters) against the replicated update: the same loss and gradient-norm log line for line (the element updates are the same
+    parameters) against the replicated update: the same loss log line for line, the gradient norm to fp32 roundoff (the element updates are the same
     arithmetic on the same averaged gradients), and a checkpoint whose optimizer state is complete -- the moments of the OTHER rank's
     shards reach rank 0 through GradReducer.gather_moments before the file is written."""
     def run(update, out):
@@ -534,7 +534,10 @@ def test_run_pretraining_sharded_update_matches_replicated(tmp_path):
                 "--steps_per_epoch", "12", "--warmup_epochs", "1", "--save_ckpt_freq", "1", "--base_output_dir", out, "--print_freq", "1"]
         procs = []
         for r in range(2):
-            env = _rank_env(RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), MRG_DP_UPDATE=update)
+            # MRG_TUNE=0: the shapes of this small model are not in the tuning table, and first-use autotuning is a timing -- two separate runs
+            # may pick different kernels (different rounding); the heuristic choice is the same in every process
+            env = _rank_env(RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), MRG_DP_UPDATE=update,
+                            MRG_TUNE="0")
             procs.append(subprocess.Popen([sys.executable] + argv, env=env, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
         logs = _wait_ranks(procs, 600)
         for p, lg in zip(procs, logs):
@@ -546,7 +549,10 @@ def test_run_pretraining_sharded_update_matches_replicated(tmp_path):
     rep, ck_rep = run("replicated", str(tmp_path / "rep"))
     sh, ck_sh = run("sharded", str(tmp_path / "sh"))
     assert len(rep) == len(sh) == 12
-    assert rep == sh, list(zip(rep, sh))
+    # the losses are the same computation; the logged norm is assembled from the per-rank partial sums in another order (root of the
+    # all-reduced sums instead of one sum over the arena): equal to fp32 roundoff
+    assert [a for a, _ in rep] == [a for a, _ in sh], list(zip(rep, sh))
+    assert all(abs(float(a) - float(b)) <= 2e-5 * float(a) + 2e-4 for (_, a), (_, b) in zip(rep, sh)), list(zip(rep, sh))
     st_r, st_s = ck_rep["optimizer"]["state"], ck_sh["optimizer"]["state"]
     assert st_r.keys() == st_s.keys() and len(st_s) > 100
     for i in st_s:
