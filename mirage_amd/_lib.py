@@ -74,7 +74,7 @@ class LossDesc(C.Structure):
     _fields_ = [("kind", ci), ("pred", vp), ("pred_dtype", ci), ("target", vp), ("mask", vp),
                 ("B", ci), ("C", ci), ("H", ci), ("W", ci), ("P", ci),
                 ("partial", vp), ("loss", vp), ("coef", vp), ("per_sample", vp), ("gout", vp), ("dpred", vp),
-                ("target_slot", vp), ("pred_tokens", ci), ("label_smoothing", cf), ("norm_pix", ci), ("stats", vp)]
+                ("target_slot", vp), ("pred_tokens", ci), ("label_smoothing", cf), ("norm_pix", ci), ("stats", vp), ("mask_bs", cl)]
 
 
 class AdamWDesc(C.Structure):
@@ -114,6 +114,9 @@ SIGNATURES = {
     "mrg_loss_partial_floats": (ci, [ci]),
     "mrg_masked_loss_fwd": (ci, [C.POINTER(LossDesc), vp]),
     "mrg_masked_loss_bwd": (ci, [C.POINTER(LossDesc), vp]),
+    "mrg_loss_coef": (ci, [vp, cl, ci, ci, ci, vp, vp]),
+    "mrg_masked_loss_fused": (ci, [C.POINTER(LossDesc), vp]),
+    "mrg_masked_loss_finish": (ci, [C.POINTER(LossDesc), vp]),
     "mrg_patch_rearrange": (ci, [vp, vp, ci, ci, ci, ci, ci, ci, vp]),
     "mrg_maskgen": (ci, [vp, vp, vp, ci, ci, ci, ci, C.POINTER(ci), vp, vp, vp, vp]),
     "mrg_maskgen_rng": (ci, [vp, vp, ci, ci, ci, ci, C.POINTER(ci), vp, vp, vp, vp, vp, vp, vp]),
@@ -147,7 +150,7 @@ for _name, (_res, _args) in SIGNATURES.items():
     _fn.argtypes = _args
 
 ABI_VERSION = lib.mrg_version()
-EXPECTED_ABI_VERSION = 13      # must match MRG_ABI_VERSION in include/mirage_hip.h: the ctypes structs above mirror that layout
+EXPECTED_ABI_VERSION = 14      # must match MRG_ABI_VERSION in include/mirage_hip.h: the ctypes structs above mirror that layout
 if ABI_VERSION != EXPECTED_ABI_VERSION:
     raise ImportError(f"{LIB_PATH} reports ABI version {ABI_VERSION}, the Python bindings expect {EXPECTED_ABI_VERSION}: rebuild it "
                       "(python -c 'import __graft_entry__ as g; g.build()')")

@@ -67,22 +67,73 @@ __global__ __launch_bounds__(256) void patch_stats_kernel(const float* __restric
     }
 }
 
-// grid (LOSS_CHUNKS, B); partial [B][LOSS_CHUNKS][2] = (sum of masked per-pixel loss, masked pixel count)
-template <typename T, bool CE>
+// The batch statistics of a loss: per-sample loss, nanmean, and (coef != nullptr) the backward coefficients coef[b] = 1 / (count_b * n_valid).
+// One workgroup of NT threads; sl / sn = NT floats of LDS each.  The sums run in sample order whatever NT is (bit-identical results from
+// the finish launch whatever its width).
+template <int NT>
+__device__ __forceinline__ void loss_finish_block(const float* __restrict__ partial, int B, float* __restrict__ loss, float* __restrict__ coef,
+                                                  float* __restrict__ per_sample, float* sl, float* sn, float* s_nvalid) {
+    auto ld = [&](long i) -> float { return partial[i]; };
+    const int t = threadIdx.x;
+    float tot = 0.f;
+    int nvalid = 0;
+    float total_cnt = 0.f;
+    for (int base = 0; base < B; base += NT) {
+        const int b = base + t;
+        float s = 0.f, n = 0.f;
+        if (b < B)
+            for (int c = 0; c < LOSS_CHUNKS; ++c) { s += ld(((long)b * LOSS_CHUNKS + c) * 2); n += ld(((long)b * LOSS_CHUNKS + c) * 2 + 1); }
+        sl[t] = s; sn[t] = n;
+        __syncthreads();
+        if (t == 0) {
+            for (int i = 0; i < min(NT, B - base); ++i) {
+                total_cnt += sn[i];
+                if (sn[i] > 0.f) { tot += sl[i] / sn[i]; ++nvalid; }
+            }
+        }
+        __syncthreads();
+    }
+    if (t == 0) {
+        // criterion.py:36,103: mask.sum() == 0 -> 0 ; otherwise nanmean over samples (0/0 samples dropped)
+        loss[0] = (total_cnt > 0.f && nvalid > 0) ? tot / (float)nvalid : 0.f;
+        *s_nvalid = (float)nvalid;
+    }
+    __syncthreads();
+    if (!coef && !per_sample) return;
+    for (int b = t; b < B; b += NT) {
+        float n = 0.f, s = 0.f;
+        for (int c = 0; c < LOSS_CHUNKS; ++c) { s += ld(((long)b * LOSS_CHUNKS + c) * 2); n += ld(((long)b * LOSS_CHUNKS + c) * 2 + 1); }
+        if (coef) coef[b] = (n > 0.f && *s_nvalid > 0.f) ? 1.f / (n * *s_nvalid) : 0.f;
+        if (per_sample) per_sample[b] = n > 0.f ? s / n : NAN;
+    }
+}
+
+// grid (LOSS_CHUNKS, B); partial [B][LOSS_CHUNKS][2] = (sum of masked per-pixel loss, masked pixel count).
+// FUSED: the same pass writes dpred = gout * dloss / dpred with the backward coefficients `coef` that mrg_loss_coef formed from the mask
+// alone (the expressions of loss_bwd_kernel on the same mx / se: bit-identical to the two-launch path).  The batch statistics stay a launch of
+// their own (mrg_masked_loss_finish): a last-workgroup-retires finish needs a device-scope release per workgroup, i.e. an L2 write-back
+// on a part whose L2s are per XCD -- measured 4x the whole kernel.
+template <typename T, bool CE, bool FUSED>
 __global__ __launch_bounds__(256) void loss_fwd_kernel(const T* __restrict__ pred, const void* __restrict__ target,
                                                        const void* const* __restrict__ tslot,
-                                                       const long* __restrict__ mask, int B, int C, int H, int W, int P, int tok,
-                                                       float smooth, const float* __restrict__ stats, float* __restrict__ partial) {
+                                                       const long* __restrict__ mask, long mbs, int B, int C, int H, int W, int P, int tok,
+                                                       float smooth, const float* __restrict__ stats, float* __restrict__ partial,
+                                                       const float* __restrict__ coef, const float* __restrict__ gout, T* __restrict__ dpred) {
     if (tslot) target = *tslot;                              // input slot: the batch is read where it lies (mirage_hip.h, "Input slots")
     __shared__ float red[4];
     const int b = blockIdx.y, chunk = blockIdx.x;
     const int nw = W / P;
     const long HW = (long)H * W;
+    const float kb = FUSED ? (gout ? gout[0] : 1.f) * coef[b] : 0.f;
     float s = 0.f, n = 0.f;
     for (long px = (long)chunk * 256 + threadIdx.x; px < HW; px += (long)LOSS_CHUNKS * 256) {
         const int y = (int)(px / W), x = (int)(px - (long)y * W);
-        const float m = mask ? (float)mask[(long)b * (H / P) * nw + (y / P) * nw + x / P] : 1.f;
-        if (m == 0.f) continue;
+        const float m = mask ? (float)mask[(long)b * mbs + (y / P) * nw + x / P] : 1.f;
+        if (m == 0.f) {
+            if (FUSED) for (int c = 0; c < C; ++c) stf<T>(dpred, pred_index(tok, b, c, y, x, C, H, W, P), 0.f);
+            continue;
+        }
+        const float k = kb * m;
         float l;
         if (CE) {
             const int t = (int)reinterpret_cast<const long*>(target)[(long)b * HW + px];
@@ -92,14 +143,29 @@ __global__ __launch_bounds__(256) void loss_fwd_kernel(const T* __restrict__ pre
             for (int c = 0; c < C; ++c) se += __expf(ldf<T>(pred, pred_index(tok, b, c, y, x, C, H, W, P)) - mx);
             // F.cross_entropy(label_smoothing = e) = (1 - e) nll + e mean_c(-log p_c) = lse - (1 - e) z_t - e mean_c z_c  (criterion.py:33)
             l = mx + __logf(se) - (1.f - smooth) * zt - smooth * zs / (float)C;
+            if (FUSED) {
+                if (k == 0.f) { for (int c = 0; c < C; ++c) stf<T>(dpred, pred_index(tok, b, c, y, x, C, H, W, P), 0.f); }
+                else {
+                    const float inv = 1.f / se;
+                    for (int c = 0; c < C; ++c) {
+                        const long j = pred_index(tok, b, c, y, x, C, H, W, P);
+                        const float p = __expf(ldf<T>(pred, j) - mx) * inv;
+                        stf<T>(dpred, j, k * (p - (c == t ? 1.f - smooth : 0.f) - smooth / (float)C));
+                    }
+                }
+            }
         } else {
             float q = 0.f;
             const float* st = stats ? stats + ((long)b * (H / P) * nw + (y / P) * nw + x / P) * 2 : nullptr;
+            const float kk = k * 2.f / (float)C;
             for (int c = 0; c < C; ++c) {
                 float tv = reinterpret_cast<const float*>(target)[((long)b * C + c) * HW + px];
                 if (st) tv = (tv - st[0]) * st[1];
-                const float d = ldf<T>(pred, pred_index(tok, b, c, y, x, C, H, W, P)) - tv;
+                const long jp = pred_index(tok, b, c, y, x, C, H, W, P);
+                const float pv = ldf<T>(pred, jp);
+                const float d = pv - tv;
                 q += d * d;
+                if (FUSED) stf<T>(dpred, jp, kk * (pv - tv));
             }
             l = q / (float)C;
         }
@@ -115,48 +181,41 @@ __global__ __launch_bounds__(256) void loss_fwd_kernel(const T* __restrict__ pre
 }
 
 // single block: per-sample loss, nanmean, backward coefficients coef[b] = 1 / (count_b * n_valid)
-__global__ void loss_finish_kernel(const float* __restrict__ partial, int B, float* __restrict__ loss, float* __restrict__ coef,
-                                   float* __restrict__ per_sample) {
-    __shared__ float sl[1024], sn[1024];
-    const int t = threadIdx.x;
-    float tot = 0.f;
-    int nvalid = 0;
-    // B <= 1024 per pass; loop passes for larger B
-    float total_cnt = 0.f;
-    for (int base = 0; base < B; base += 1024) {
-        const int b = base + t;
-        float s = 0.f, n = 0.f;
-        if (b < B)
-            for (int c = 0; c < LOSS_CHUNKS; ++c) { s += partial[((long)b * LOSS_CHUNKS + c) * 2]; n += partial[((long)b * LOSS_CHUNKS + c) * 2 + 1]; }
-        sl[t] = s; sn[t] = n;
-        __syncthreads();
-        if (t == 0) {
-            for (int i = 0; i < min(1024, B - base); ++i) {
-                total_cnt += sn[i];
-                if (sn[i] > 0.f) { tot += sl[i] / sn[i]; ++nvalid; }
-            }
+__global__ __launch_bounds__(1024) void loss_finish_kernel(const float* __restrict__ partial, int B, float* __restrict__ loss, float* __restrict__ coef,
+                                                           float* __restrict__ per_sample) {
+    __shared__ float sl[1024], sn[1024], s_nvalid;
+    loss_finish_block<1024>(partial, B, loss, coef, per_sample, sl, sn, &s_nvalid);
+}
+
+// The backward coefficients from the mask alone (they do not depend on the predictions): n_b = masked pixels of sample b = ppt * sum of its
+// token mask (mask == nullptr: every pixel), coef[b] = 1 / (n_b * #{b: n_b > 0}) -- the values loss_finish_kernel derives from the forward
+// pass's pixel counts (both are exact integers in fp32).  One workgroup, one wave per sample at a time.
+__global__ __launch_bounds__(1024) void loss_coef_kernel(const long* __restrict__ mask, long mbs, int B, int ntok, int ppt, float* __restrict__ coef) {
+    __shared__ int s_nvalid;
+    if (threadIdx.x == 0) s_nvalid = 0;
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int b = wave; b < B; b += 16) {
+        float n;
+        if (mask) {
+            float c = 0.f;
+            for (int t = lane; t < ntok; t += 64) c += (float)mask[(long)b * mbs + t];
+            n = wave_sum(c) * (float)ppt;
+        } else {
+            n = (float)ntok * (float)ppt;
         }
-        __syncthreads();
-    }
-    __shared__ float s_nvalid;
-    if (t == 0) {
-        // criterion.py:36,103: mask.sum() == 0 -> 0 ; otherwise nanmean over samples (0/0 samples dropped)
-        loss[0] = (total_cnt > 0.f && nvalid > 0) ? tot / (float)nvalid : 0.f;
-        s_nvalid = (float)nvalid;
+        if (lane == 0) { coef[b] = n; if (n > 0.f) atomicAdd(&s_nvalid, 1); }
     }
     __syncthreads();
-    for (int b = t; b < B; b += blockDim.x) {
-        float n = 0.f, s = 0.f;
-        for (int c = 0; c < LOSS_CHUNKS; ++c) { s += partial[((long)b * LOSS_CHUNKS + c) * 2]; n += partial[((long)b * LOSS_CHUNKS + c) * 2 + 1]; }
-        coef[b] = (n > 0.f && s_nvalid > 0.f) ? 1.f / (n * s_nvalid) : 0.f;
-        if (per_sample) per_sample[b] = n > 0.f ? s / n : NAN;
-    }
+    const float nv = (float)s_nvalid;
+    for (int b = wave; b < B; b += 16)
+        if (lane == 0) { const float n = coef[b]; coef[b] = (n > 0.f && nv > 0.f) ? 1.f / (n * nv) : 0.f; }
 }
 
 template <typename T, bool CE>
 __global__ __launch_bounds__(256) void loss_bwd_kernel(const T* __restrict__ pred, const void* __restrict__ target,
                                                        const void* const* __restrict__ tslot,
-                                                       const long* __restrict__ mask, const float* __restrict__ coef,
+                                                       const long* __restrict__ mask, long mbs, const float* __restrict__ coef,
                                                        const float* __restrict__ gout, int B, int C, int H, int W, int P, int tok,
                                                        float smooth, const float* __restrict__ stats, T* __restrict__ dpred) {
     if (tslot) target = *tslot;
@@ -168,7 +227,7 @@ __global__ __launch_bounds__(256) void loss_bwd_kernel(const T* __restrict__ pre
         const int b = (int)(i / HW);
         const long px = i - (long)b * HW;
         const int y = (int)(px / W), x = (int)(px - (long)y * W);
-        const float m = mask ? (float)mask[(long)b * (H / P) * nw + (y / P) * nw + x / P] : 1.f;
+        const float m = mask ? (float)mask[(long)b * mbs + (y / P) * nw + x / P] : 1.f;
         const float k = go * coef[b] * m;
         if (CE) {
             if (k == 0.f) { for (int c = 0; c < C; ++c) stf<T>(dpred, pred_index(tok, b, c, y, x, C, H, W, P), 0.f); continue; }
@@ -197,22 +256,31 @@ __global__ __launch_bounds__(256) void loss_bwd_kernel(const T* __restrict__ pre
 }
 
 // ---- single-channel bf16 MSE fast path: 8 consecutive pixels (16 B of predictions, 32 B of targets) per thread
+// FUSED: see loss_fwd_kernel (the gradient expressions are mse1_bwd_vec_kernel's)
+template <bool FUSED>
 __global__ __launch_bounds__(256) void mse1_fwd_vec_kernel(const bf16_t* __restrict__ pred, const float* __restrict__ target,
                                                            const void* const* __restrict__ tslot,
-                                                           const long* __restrict__ mask, int B, int H, int W, int P, int tok,
-                                                           float* __restrict__ partial) {
+                                                           const long* __restrict__ mask, long mbs, int B, int H, int W, int P, int tok,
+                                                           float* __restrict__ partial,
+                                                           const float* __restrict__ coef, const float* __restrict__ gout, bf16_t* __restrict__ dpred) {
     if (tslot) target = static_cast<const float*>(*tslot);
     __shared__ float red[4];
     const int b = blockIdx.y, chunk = blockIdx.x;
     const int nw = W / P;
     const long HW8 = (long)H * W / 8;
+    const float go = FUSED ? (gout ? gout[0] : 1.f) : 0.f;
+    const float cb = FUSED ? coef[b] : 0.f;
     float s = 0.f, n = 0.f;
     for (long v = (long)chunk * 256 + threadIdx.x; v < HW8; v += (long)LOSS_CHUNKS * 256) {
         const long px = v * 8;
         const int y = (int)(px / W), x = (int)(px - (long)y * W);
-        const float m = mask ? (float)mask[(long)b * (H / P) * nw + (y / P) * nw + x / P] : 1.f;
-        if (m == 0.f) continue;
-        const uint4 p = *reinterpret_cast<const uint4*>(pred + pred_index(tok, b, 0, y, x, 1, H, W, P));     // P % 8 == 0: 8 pixels stay inside a patch row
+        const float m = mask ? (float)mask[(long)b * mbs + (y / P) * nw + x / P] : 1.f;
+        const long ip = pred_index(tok, b, 0, y, x, 1, H, W, P);                                             // P % 8 == 0: 8 pixels stay inside a patch row
+        if (m == 0.f) {
+            if (FUSED) *reinterpret_cast<uint4*>(dpred + ip) = make_uint4(0, 0, 0, 0);
+            continue;
+        }
+        const uint4 p = *reinterpret_cast<const uint4*>(pred + ip);
         const float4 t0 = *reinterpret_cast<const float4*>(target + (long)b * H * W + px);
         const float4 t1 = *reinterpret_cast<const float4*>(target + (long)b * H * W + px + 4);
         const float d0 = __uint_as_float(p.x << 16) - t0.x, d1 = __uint_as_float(p.x & 0xffff0000u) - t0.y;
@@ -221,6 +289,15 @@ __global__ __launch_bounds__(256) void mse1_fwd_vec_kernel(const bf16_t* __restr
         const float d6 = __uint_as_float(p.w << 16) - t1.z, d7 = __uint_as_float(p.w & 0xffff0000u) - t1.w;
         s += ((d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3)) + ((d4 * d4 + d5 * d5) + (d6 * d6 + d7 * d7));
         n += 8.f;
+        if (FUSED) {
+            const float k = 2.f * go * cb * m;
+            uint4 o = make_uint4(0, 0, 0, 0);
+            if (k != 0.f) {
+                o.x = pack_bf2(k * d0, k * d1); o.y = pack_bf2(k * d2, k * d3);
+                o.z = pack_bf2(k * d4, k * d5); o.w = pack_bf2(k * d6, k * d7);
+            }
+            *reinterpret_cast<uint4*>(dpred + ip) = o;
+        }
     }
     const float ts = block_sum(s, red);
     const float tn = block_sum(n, red);
@@ -232,7 +309,7 @@ __global__ __launch_bounds__(256) void mse1_fwd_vec_kernel(const bf16_t* __restr
 
 __global__ __launch_bounds__(256) void mse1_bwd_vec_kernel(const bf16_t* __restrict__ pred, const float* __restrict__ target,
                                                            const void* const* __restrict__ tslot,
-                                                           const long* __restrict__ mask, const float* __restrict__ coef,
+                                                           const long* __restrict__ mask, long mbs, const float* __restrict__ coef,
                                                            const float* __restrict__ gout, int B, int H, int W, int P, int tok,
                                                            bf16_t* __restrict__ dpred) {
     if (tslot) target = static_cast<const float*>(*tslot);
@@ -245,7 +322,7 @@ __global__ __launch_bounds__(256) void mse1_bwd_vec_kernel(const bf16_t* __restr
         const int b = (int)(i / HW);
         const long px = i - (long)b * HW;
         const int y = (int)(px / W), x = (int)(px - (long)y * W);
-        const float m = mask ? (float)mask[(long)b * (H / P) * nw + (y / P) * nw + x / P] : 1.f;
+        const float m = mask ? (float)mask[(long)b * mbs + (y / P) * nw + x / P] : 1.f;
         const float k = 2.f * go * coef[b] * m;
         uint4 o = make_uint4(0, 0, 0, 0);
         const long ip = pred_index(tok, b, 0, y, x, 1, H, W, P);
@@ -282,6 +359,8 @@ __global__ void patch_rearrange_kernel(const T* __restrict__ src, T* __restrict_
     }
 }
 
+long mask_stride(const mrg_loss_desc* d) { return d->mask_bs > 0 ? d->mask_bs : (long)(d->H / d->P) * (d->W / d->P); }
+
 int check(const mrg_loss_desc* d, const char* who) {
     MRG_REQUIRE(d != nullptr, MRG_ERR_ARG, "%s: null descriptor", who);
     MRG_REQUIRE(d->pred && (d->target || d->target_slot) && d->partial && d->coef, MRG_ERR_ARG, "%s: null pointer", who);
@@ -295,40 +374,75 @@ int check(const mrg_loss_desc* d, const char* who) {
 
 extern "C" int mrg_loss_partial_floats(int B) { return B * LOSS_CHUNKS * 2; }
 
+namespace {
+// forward launches of a loss; fused: + gradient and batch statistics in the same pass (mrg_masked_loss_fused)
+int launch_loss_fwd(const mrg_loss_desc* d, bool fused, hipStream_t stream, const char* who) {
+    int rc;
+    const long mbs = mask_stride(d);
+    dim3 grid(LOSS_CHUNKS, d->B), block(256);
+    const bool vec_mse = d->kind == MRG_LOSS_MSE && d->C == 1 && d->pred_dtype == MRG_DT_BF16 && d->P % 8 == 0 && d->W % 8 == 0 && !d->norm_pix &&
+                         (((uintptr_t)d->pred | (uintptr_t)d->target | (fused ? (uintptr_t)d->dpred : 0)) & 15) == 0;
+    if (d->norm_pix) {
+        MRG_REQUIRE(d->kind == MRG_LOSS_MSE && d->stats != nullptr && d->C * d->P * d->P > 1, MRG_ERR_ARG,
+                    "%s: norm_pix needs the MSE kind, a stats workspace and more than one element per patch", who);
+        hipLaunchKernelGGL(patch_stats_kernel, dim3((d->H / d->P) * (d->W / d->P), d->B), dim3(256), 0, stream, (const float*)d->target, d->target_slot,
+                           d->C, d->H, d->W, d->P, d->stats);
+        rc = mrg_check_launch("mrg_masked_loss/norm_pix");
+        if (rc) return rc;
+    }
+    const float* coef = fused ? d->coef : nullptr;
+    if (vec_mse) {
+#define MRG_V(F) hipLaunchKernelGGL(mse1_fwd_vec_kernel<F>, grid, block, 0, stream, (const bf16_t*)d->pred, (const float*)d->target, d->target_slot, d->mask, mbs, d->B, d->H, \
+                           d->W, d->P, d->pred_tokens, d->partial, coef, d->gout, (bf16_t*)d->dpred)
+        if (fused) MRG_V(true); else MRG_V(false);
+#undef MRG_V
+    } else {
+#define MRG_L(T, CE, F) hipLaunchKernelGGL((loss_fwd_kernel<T, CE, F>), grid, block, 0, stream, (const T*)d->pred, d->target, d->target_slot, d->mask, mbs, d->B, d->C, d->H, d->W, d->P, d->pred_tokens, d->label_smoothing, d->norm_pix ? d->stats : nullptr, d->partial, coef, d->gout, (T*)d->dpred)
+#define MRG_LF(T, CE) do { if (fused) MRG_L(T, CE, true); else MRG_L(T, CE, false); } while (0)
+    if (d->pred_dtype == MRG_DT_BF16) { if (d->kind == MRG_LOSS_CE) MRG_LF(bf16_t, true); else MRG_LF(bf16_t, false); }
+    else { if (d->kind == MRG_LOSS_CE) MRG_LF(float, true); else MRG_LF(float, false); }
+#undef MRG_LF
+#undef MRG_L
+    }
+    return mrg_check_launch(who);
+}
+}  // namespace
+
 extern "C" int mrg_masked_loss_fwd(const mrg_loss_desc* d, hipStream_t stream) {
     int rc = check(d, "mrg_masked_loss_fwd");
     if (rc) return rc;
     MRG_REQUIRE(d->loss, MRG_ERR_ARG, "mrg_masked_loss_fwd: null loss pointer");
-    dim3 grid(LOSS_CHUNKS, d->B), block(256);
-    const bool vec_mse = d->kind == MRG_LOSS_MSE && d->C == 1 && d->pred_dtype == MRG_DT_BF16 && d->P % 8 == 0 && d->W % 8 == 0 && !d->norm_pix &&
-                         (((uintptr_t)d->pred | (uintptr_t)d->target) & 15) == 0;
-    if (d->norm_pix) {
-        MRG_REQUIRE(d->kind == MRG_LOSS_MSE && d->stats != nullptr && d->C * d->P * d->P > 1, MRG_ERR_ARG,
-                    "mrg_masked_loss_fwd: norm_pix needs the MSE kind, a stats workspace and more than one element per patch");
-        hipLaunchKernelGGL(patch_stats_kernel, dim3((d->H / d->P) * (d->W / d->P), d->B), dim3(256), 0, stream, (const float*)d->target, d->target_slot,
-                           d->C, d->H, d->W, d->P, d->stats);
-        rc = mrg_check_launch("mrg_masked_loss_fwd/norm_pix");
-        if (rc) return rc;
-    }
-    if (vec_mse) {
-        hipLaunchKernelGGL(mse1_fwd_vec_kernel, grid, block, 0, stream, (const bf16_t*)d->pred, (const float*)d->target, d->target_slot, d->mask, d->B, d->H,
-                           d->W, d->P, d->pred_tokens, d->partial);
-    } else {
-#define MRG_L(T, CE) hipLaunchKernelGGL((loss_fwd_kernel<T, CE>), grid, block, 0, stream, (const T*)d->pred, d->target, d->target_slot, d->mask, d->B, d->C, d->H, d->W, d->P, d->pred_tokens, d->label_smoothing, d->norm_pix ? d->stats : nullptr, d->partial)
-    if (d->pred_dtype == MRG_DT_BF16) { if (d->kind == MRG_LOSS_CE) MRG_L(bf16_t, true); else MRG_L(bf16_t, false); }
-    else { if (d->kind == MRG_LOSS_CE) MRG_L(float, true); else MRG_L(float, false); }
-#undef MRG_L
-    }
-    rc = mrg_check_launch("mrg_masked_loss_fwd");
+    rc = launch_loss_fwd(d, false, stream, "mrg_masked_loss_fwd");
     if (rc) return rc;
     hipLaunchKernelGGL(loss_finish_kernel, dim3(1), dim3(1024), 0, stream, d->partial, d->B, d->loss, d->coef, d->per_sample);
     return mrg_check_launch("mrg_masked_loss_fwd/finish");
+}
+
+extern "C" int mrg_loss_coef(const long* mask, long mask_bs, int B, int ntok, int ppt, float* coef, hipStream_t stream) {
+    MRG_REQUIRE(coef != nullptr && B > 0 && ntok > 0 && ppt > 0 && mask_bs >= 0, MRG_ERR_ARG, "mrg_loss_coef: bad argument");
+    MRG_REQUIRE((double)ntok * ppt < 16777216.0, MRG_ERR_SHAPE, "mrg_loss_coef: %d x %d pixels per sample are not exact in fp32", ntok, ppt);
+    hipLaunchKernelGGL(loss_coef_kernel, dim3(1), dim3(1024), 0, stream, mask, mask_bs > 0 ? mask_bs : (long)ntok, B, ntok, ppt, coef);
+    return mrg_check_launch("mrg_loss_coef");
+}
+
+extern "C" int mrg_masked_loss_fused(const mrg_loss_desc* d, hipStream_t stream) {
+    int rc = check(d, "mrg_masked_loss_fused");
+    if (rc) return rc;
+    MRG_REQUIRE(d->dpred, MRG_ERR_ARG, "mrg_masked_loss_fused: null dpred pointer");
+    return launch_loss_fwd(d, true, stream, "mrg_masked_loss_fused");
+}
+
+extern "C" int mrg_masked_loss_finish(const mrg_loss_desc* d, hipStream_t stream) {
+    MRG_REQUIRE(d != nullptr && d->partial && d->loss && d->B > 0, MRG_ERR_ARG, "mrg_masked_loss_finish: null descriptor / partial / loss pointer");
+    hipLaunchKernelGGL(loss_finish_kernel, dim3(1), dim3(1024), 0, stream, d->partial, d->B, d->loss, (float*)nullptr, d->per_sample);
+    return mrg_check_launch("mrg_masked_loss_finish");
 }
 
 extern "C" int mrg_masked_loss_bwd(const mrg_loss_desc* d, hipStream_t stream) {
     int rc = check(d, "mrg_masked_loss_bwd");
     if (rc) return rc;
     MRG_REQUIRE(d->dpred, MRG_ERR_ARG, "mrg_masked_loss_bwd: null dpred");
+    const long mbs = mask_stride(d);
     const long total = (long)d->B * d->H * d->W;
     dim3 grid((unsigned)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096)), block(256);
     const bool vec_mse = d->kind == MRG_LOSS_MSE && d->C == 1 && d->pred_dtype == MRG_DT_BF16 && d->P % 8 == 0 && d->W % 8 == 0 && !d->norm_pix &&
@@ -336,10 +450,10 @@ extern "C" int mrg_masked_loss_bwd(const mrg_loss_desc* d, hipStream_t stream) {
     MRG_REQUIRE(!d->norm_pix || d->stats != nullptr, MRG_ERR_ARG, "mrg_masked_loss_bwd: norm_pix needs the stats the forward call filled");
     if (vec_mse) {
         hipLaunchKernelGGL(mse1_bwd_vec_kernel, dim3((unsigned)((total / 8 + 255) / 256 < 4096 ? (total / 8 + 255) / 256 : 4096)), block, 0, stream,
-                           (const bf16_t*)d->pred, (const float*)d->target, d->target_slot, d->mask, d->coef, d->gout, d->B, d->H, d->W, d->P, d->pred_tokens, (bf16_t*)d->dpred);
+                           (const bf16_t*)d->pred, (const float*)d->target, d->target_slot, d->mask, mbs, d->coef, d->gout, d->B, d->H, d->W, d->P, d->pred_tokens, (bf16_t*)d->dpred);
         return mrg_check_launch("mrg_masked_loss_bwd");
     }
-#define MRG_L(T, CE) hipLaunchKernelGGL((loss_bwd_kernel<T, CE>), grid, block, 0, stream, (const T*)d->pred, d->target, d->target_slot, d->mask, d->coef, d->gout, d->B, d->C, d->H, d->W, d->P, d->pred_tokens, d->label_smoothing, d->norm_pix ? d->stats : nullptr, (T*)d->dpred)
+#define MRG_L(T, CE) hipLaunchKernelGGL((loss_bwd_kernel<T, CE>), grid, block, 0, stream, (const T*)d->pred, d->target, d->target_slot, d->mask, mbs, d->coef, d->gout, d->B, d->C, d->H, d->W, d->P, d->pred_tokens, d->label_smoothing, d->norm_pix ? d->stats : nullptr, (T*)d->dpred)
     if (d->pred_dtype == MRG_DT_BF16) { if (d->kind == MRG_LOSS_CE) MRG_L(bf16_t, true); else MRG_L(bf16_t, false); }
     else { if (d->kind == MRG_LOSS_CE) MRG_L(float, true); else MRG_L(float, false); }
 #undef MRG_L

@@ -835,6 +835,15 @@ class PredLayout:
         return K.patch_rearrange(pred.contiguous(), True, pred.shape[0], ad.num_channels, g, ad.P_H)
 
 
+def loss_mask(m):
+    """a task's token mask as the loss kernels read it: int64 [B, tokens], rows possibly strided (the task's columns of the step's mask, in place)"""
+    if m is None:
+        return None
+    if m.dtype != torch.int64:
+        m = m.long()
+    return m if m.dim() == 2 and m.stride(1) == 1 else m.contiguous()
+
+
 class LaneLosses:
     """Masked losses computed ON the output adapters' lane streams (set by trainer.TrainStep around its forward pass).  The reference
     computes the task losses after the model call (run_pretraining.py:713-721); as separate autograd nodes they run one after the other
@@ -851,6 +860,12 @@ class LaneLosses:
     # both passes.  The caller seeds the backward with the constant gradient of each task loss (d sum / d loss_t = 1) instead of
     # differentiating the sum, and reads the loss scalars only after the backward pass.
     defer_join = False
+    # fuse_bwd (trainer.TrainStep): every lane forms its loss AND the loss gradient in one pass over the predictions (mrg_masked_loss_fused;
+    # the backward coefficients come from the mask at the head of the lane, mrg_loss_coef) under the contract that the caller seeds each
+    # task loss with the constant `unit` (d sum / d loss_t = 1).  A backward pass seeded with anything else runs the separate gradient launch.
+    fuse_bwd = False
+    unit = None
+    fused_hits = 0      # backward passes (per adapter) that took the forward lane's gradient as it was (tests)
 
 
 class _Lanes:
@@ -921,14 +936,24 @@ class DecodersFn(torch.autograd.Function):
             enc16 = to_bf16(enc32)
         doms_l, start_l = list(dom_names), list(dom_start)
 
+        fuse = loss_spec is not None and LaneLosses.fuse_bwd and LaneLosses.unit is not None and save
+
         def job(i, ad):
+            coef = None
+            if fuse:
+                kind, patch, target, mask, smooth, npix = loss_spec[i]
+                H, W = target.shape[-2:]
+                coef = K.loss_coef(mask, target.shape[0], (H // patch) * (W // patch), patch * patch, enc32.device)
             img, sv = decoder_fwd(ad, enc32, enc16, ids_keep, ids_restore, doms_l, start_l, ng, save)
             if loss_spec is None:
                 return img, sv, None
             kind, patch, target, mask, smooth, npix = loss_spec[i]
             d = K.loss_desc(kind, img, target, mask, patch, smoothing=smooth, norm_pix=npix)
+            if fuse:
+                loss, partial, dpred, finish = K.masked_loss_fused(d, coef, img.device)
+                return loss, sv, (d, coef, partial, img, dpred, finish)
             loss, coef, partial = K.masked_loss_fwd(d, img.device)
-            return loss, sv, (d, coef, partial, img)
+            return loss, sv, (d, coef, partial, img, None, None)
         jobs = [(lambda i=i, ad=ad: job(i, ad)) for i, ad in enumerate(adapters)]
         res = _Lanes.run_all(jobs, enc32.device, enabled=_Lanes.enabled and _Lanes.fwd,
                              join=not (loss_spec is not None and LaneLosses.defer_join and _Lanes.bwd))
@@ -950,7 +975,12 @@ class DecodersFn(torch.autograd.Function):
             todo = [(ad, sv, (g, ls)) for ad, sv, g, ls in zip(ctx.adapters, ctx.saved, d_imgs, ctx.loss_saved) if g is not None]
 
             def bwd(ad, sv, gl):
-                g, (d, coef, partial, img) = gl
+                g, (d, coef, partial, img, dpred, finish) = gl
+                if finish is not None:
+                    _Side.run(finish, partial)                 # the loss VALUE: nobody waits for it before the step ends
+                if dpred is not None and LaneLosses.unit is not None and g.data_ptr() == LaneLosses.unit.data_ptr():
+                    LaneLosses.fused_hits += 1
+                    return decoder_bwd(ad, sv, dpred)          # the forward lane has written the gradient already (seed = 1)
                 return decoder_bwd(ad, sv, K.masked_loss_bwd(d, coef, partial, g.contiguous().float(), img))
             jobs = [(lambda ad=ad, sv=sv, gl=gl: bwd(ad, sv, gl)) for ad, sv, gl in todo]
             ctx.loss_saved = None

@@ -788,6 +788,11 @@ def loss_desc(kind, pred, target, mask, P, smoothing: float = 0.0, norm_pix: boo
     d.kind, d.pred, d.pred_dtype = kind, pred.data_ptr(), (L.MRG_DT_BF16 if pred.dtype == BF16 else L.MRG_DT_F32)
     d.target, d.mask, d.target_slot = target.data_ptr(), _p(mask), slot_of(target)
     d.B, d.C, d.H, d.W, d.P = B, Cc, H, W, P
+    if mask is not None:
+        # a task's columns of the step's [B, all tokens] mask are read in place (mrg_loss_desc.mask_bs)
+        if mask.dtype != torch.int64 or mask.dim() != 2 or mask.stride(1) != 1 or tuple(mask.shape) != (B, (H // P) * (W // P)):
+            raise ValueError(f"loss_desc: mask must be int64 [B, tokens] with unit token stride, got {mask.dtype} {tuple(mask.shape)} strides {mask.stride()}")
+        d.mask_bs = mask.stride(0)
     stats = None
     if norm_pix and kind == L.MRG_LOSS_MSE:
         stats = torch.empty(B * (H // P) * (W // P) * 2, dtype=F32, device=pred.device)
@@ -810,6 +815,33 @@ def masked_loss_bwd(d: "L.LossDesc", coef, partial, gout, pred):
     d.coef, d.partial, d.gout, d.dpred = coef.data_ptr(), partial.data_ptr(), _p(gout), dpred.data_ptr()
     check(lib.mrg_masked_loss_bwd(C.byref(d), _s()), "mrg_masked_loss_bwd")
     return dpred
+
+
+def loss_coef(mask, B: int, ntok: int, ppt: int, device):
+    """Backward coefficients of a masked loss from the token mask alone (mrg_loss_coef): available as soon as the masks are.
+    mask: int64 [B, ntok] (rows may be strided) or None (every pixel counts)."""
+    coef = torch.empty(B, dtype=F32, device=device)
+    if mask is not None and (mask.dtype != torch.int64 or mask.stride(1) != 1 or tuple(mask.shape) != (B, ntok)):
+        raise ValueError(f"loss_coef: mask must be int64 [{B}, {ntok}] with unit token stride")
+    check(lib.mrg_loss_coef(_p(mask), mask.stride(0) if mask is not None else 0, B, ntok, ppt, coef.data_ptr(), _s()), "mrg_loss_coef")
+    return coef
+
+
+def masked_loss_fused(d: "L.LossDesc", coef, device, gout=None):
+    """The gradient of a masked loss (seeded with gout, None = 1) and the partial sums of its value in one pass over the predictions
+    (mrg_masked_loss_fused).  Returns (loss, partial, dpred, finish): `loss` holds the value once finish() -- the batch statistics, a tiny
+    launch nothing in a training step waits for -- has run on some stream ordered behind this call."""
+    partial = torch.empty(lib.mrg_loss_partial_floats(d.B), dtype=F32, device=device)
+    loss = torch.empty((), dtype=F32, device=device)
+    pred = d._refs[0]
+    dpred = torch.empty_like(pred)
+    d.partial, d.loss, d.coef, d.gout, d.dpred = partial.data_ptr(), loss.data_ptr(), coef.data_ptr(), _p(gout), dpred.data_ptr()
+    check(lib.mrg_masked_loss_fused(C.byref(d), _s()), "mrg_masked_loss_fused")
+
+    def finish():
+        d.partial, d.loss = partial.data_ptr(), loss.data_ptr()
+        check(lib.mrg_masked_loss_finish(C.byref(d), _s()), "mrg_masked_loss_finish")
+    return loss, partial, dpred, finish
 
 
 def patch_rearrange(src: torch.Tensor, to_image: bool, B: int, Cc: int, g: int, P: int) -> torch.Tensor:

@@ -390,7 +390,7 @@ class MIRAGEModel(nn.Module):
                 kind, patch, target, use_mask, *rest = E.LaneLosses.spec[name]
                 m = task_masks.get(name) if use_mask else None
                 loss_spec.append((kind, patch, target.contiguous() if kind != E.L.MRG_LOSS_MSE else target.contiguous().float(),
-                                  m.contiguous().long() if m is not None else None, float(rest[0]) if rest else 0.0,
+                                  E.loss_mask(m), float(rest[0]) if rest else 0.0,
                                   bool(rest[1]) if len(rest) > 1 else False))
         imgs = E.DecodersFn.apply(enc32, enc16, ads, doms, dom_start, self.num_global_tokens, ids_keep.contiguous(),
                                   ids_restore.contiguous(), save, True, loss_spec, *self._decoder_params())

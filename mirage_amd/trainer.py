@@ -24,6 +24,8 @@ IN_PLACE_INPUTS = os.environ.get("MRG_INPUT_SLOTS", "1") != "0"   # step(batch) 
 FUSE_OPT = os.environ.get("MRG_FUSE_OPT", "1") != "0"
 LANE_DEFER_JOIN = os.environ.get("MRG_LANE_DEFER_JOIN", "0") != "0"
 LANE_LOSSES = os.environ.get("MRG_LANE_LOSSES", "1") != "0"   # the masked losses run on the output adapters' lane streams (engine.LaneLosses)
+LOSS_SEED_ONES = os.environ.get("MRG_LOSS_SEED_ONES", "1") != "0"   # with the lane losses: the backward pass is seeded with d(sum)/d(loss_t) = 1 per task and the logged sum is formed after it
+LOSS_FUSED = os.environ.get("MRG_LOSS_FUSED", "1") != "0"     # ... and every lane forms loss + loss gradient in one pass over its predictions (engine.LaneLosses.fuse_bwd)
 TOKEN_PREDS = os.environ.get("MRG_TOKEN_PREDS", "1") != "0"   # predictions stay in the decoders' token layout inside the step (engine.PredLayout)
 
 
@@ -201,6 +203,9 @@ class TrainStep:
         if self._lane_losses:
             from . import _lib as L
             E.LaneLosses.defer_join = self._defer_join = bool(LANE_DEFER_JOIN and self.reducer is None)
+            if getattr(self, "_one", None) is None:
+                self._one = torch.ones((), dtype=torch.float32, device=self.static_x[self.in_domains[0]].device)
+            E.LaneLosses.fuse_bwd, E.LaneLosses.unit = LOSS_FUSED and LOSS_SEED_ONES, self._one
             E.LaneLosses.spec = {t: (L.MRG_LOSS_MSE if isinstance(self.loss_fns[t], MaskedMSELoss) else L.MRG_LOSS_CE, self.loss_fns[t].scale_factor,
                                      x[t], not self.loss_on_unmasked, float(getattr(self.loss_fns[t], "label_smoothing", 0.0)),
                                      bool(getattr(self.loss_fns[t], "norm_pix", False)))
@@ -212,6 +217,7 @@ class TrainStep:
             E.PredLayout.tokens = False
             E.LaneLosses.spec = None
             E.LaneLosses.defer_join = False
+            E.LaneLosses.fuse_bwd = False
 
     def _losses(self, preds, masks, x):
         """task losses of a forward pass: computed by the adapters' lanes already (engine.LaneLosses) or here, as the reference does"""
@@ -235,13 +241,13 @@ class TrainStep:
         self.task_losses = self._losses(preds, masks, x)
         self.masks = masks                            # static tensors of the captured step (parity tests read them and self.preds after a replay)
         self.opt.zero_grad()
-        deferred = self._lane_losses and getattr(self, "_defer_join", False)
-        if deferred:
-            # the loss scalars still live on the adapters' lanes (engine.LaneLosses.defer_join): seed each with d(sum)/d(loss_t) = 1 --
-            # the gradient the sum's backward would hand it -- and form the logged sum after the backward pass has joined the lanes
+        seeded = self._lane_losses and LOSS_SEED_ONES
+        if seeded:
+            # the task losses come from the adapters' lanes (engine.LaneLosses): each is seeded with d(sum)/d(loss_t) = 1 -- the gradient
+            # the sum's backward would hand it, as one constant tensor (the lanes have formed their loss gradients under that contract
+            # already, LaneLosses.fuse_bwd) -- and the logged sum is formed after the backward pass, off the critical chain
             ls = list(self.task_losses.values())
-            one = self._one if getattr(self, "_one", None) is not None else torch.ones((), dtype=ls[0].dtype, device=ls[0].device)
-            self._one = one
+            one = self._one
             run_backward = lambda: torch.autograd.backward(ls, [one] * len(ls))
         else:
             self.loss = sum(self.task_losses.values())
@@ -262,7 +268,7 @@ class TrainStep:
                 raise RuntimeError(f"early optimizer: {self._early_seen} of {len(self._early)} encoder blocks were updated")
         else:
             run_backward()
-        if deferred:
+        if seeded:
             self.loss = sum(t.detach() for t in self.task_losses.values())
 
     def _fwd_bwd_upper(self):
@@ -271,10 +277,14 @@ class TrainStep:
         x = self.static_x
         preds, masks = self._forward(x)
         self.task_losses = self._losses(preds, masks, x)
-        self.loss = sum(self.task_losses.values())
         self.opt.zero_grad()
         self._hs = list(self.model._mrg_h_cuts)
-        self._g = torch.autograd.grad(self.loss, self._hs[-1], retain_graph=True)[0]
+        if self._lane_losses and LOSS_SEED_ONES:             # seeded with the constant 1 per task (see _fwd_bwd)
+            ls = list(self.task_losses.values())
+            self._g = torch.autograd.grad(ls, self._hs[-1], grad_outputs=[self._one] * len(ls), retain_graph=True)[0]
+        else:
+            self.loss = sum(self.task_losses.values())
+            self._g = torch.autograd.grad(self.loss, self._hs[-1], retain_graph=True)[0]
         E.join_side_stream()
 
     def _bwd_mid(self, k):
@@ -285,6 +295,8 @@ class TrainStep:
 
     def _bwd_lower(self):
         self._hs[0].backward(self._g)
+        if self._lane_losses and LOSS_SEED_ONES:
+            self.loss = sum(t.detach() for t in self.task_losses.values())
         self._hs = self._g = None
         self.model._mrg_h_cuts = None
         self.model._mrg_h_mid = None

@@ -722,6 +722,55 @@ def test_masked_mse_and_ce(K, dtype):
 
 
 @pytest.mark.parametrize("dtype", [F32, BF16])
+def test_loss_and_gradient_in_one_pass(K, dtype):
+    """mrg_loss_coef + mrg_masked_loss_fused (the training step's form: backward coefficients from the mask alone, loss value + gradient in one
+    pass, mrg_masked_loss_finish for the value) == mrg_masked_loss_fwd + mrg_masked_loss_bwd bit for bit: MSE (1 channel = the vector path,
+    3 channels, norm_pix), CE with label smoothing, image and token layouts, the task's columns of a wider mask read in place, a sample with
+    nothing masked, no mask at all, a seed != 1."""
+    from mirage_amd import _lib as L
+    torch.manual_seed(5)
+    B = 6
+
+    def both(kind, pred, tgt, mask, P, gout=None, **kw):
+        d = K.loss_desc(kind, pred, tgt, mask, P, **kw)
+        loss, coef, part = K.masked_loss_fwd(d, dev())
+        dp = K.masked_loss_bwd(d, coef, part, gout, pred)
+        H, W = tgt.shape[-2:]
+        d2 = K.loss_desc(kind, pred, tgt, mask, P, **kw)
+        coef2 = K.loss_coef(mask, B, (H // P) * (W // P), P * P, dev())
+        loss2, part2, dp2, finish = K.masked_loss_fused(d2, coef2, dev(), gout=gout)
+        finish()
+        torch.cuda.synchronize()
+        assert torch.equal(coef, coef2)
+        assert torch.equal(part, part2)
+        assert torch.equal(loss, loss2), (float(loss), float(loss2))
+        assert torch.equal(dp, dp2)
+        return loss2
+
+    wide = (torch.rand(B, 3 * 64, device=dev()) < 0.7).long()
+    wide[3] = 0
+    for mask in (wide[:, 64:128], wide[:, 64:128].contiguous(), None):
+        for C in (1, 3):
+            pred = torch.randn(B, C, 64, 64, device=dev()).to(dtype)
+            tgt = torch.rand(B, C, 64, 64, device=dev())
+            both(L.MRG_LOSS_MSE, pred, tgt, mask, 8)
+            tok = pred.reshape(B, C, 8, 8, 8, 8).permute(0, 2, 4, 1, 3, 5).reshape(B, 64, C * 64).contiguous()
+            both(L.MRG_LOSS_MSE, tok, tgt, mask, 8, gout=torch.tensor(0.25, device=dev()))
+            both(L.MRG_LOSS_MSE, tok, tgt, mask, 8, norm_pix=True)
+        logits = (torch.randn(B, 13, 16, 16, device=dev()) * 2).to(dtype)
+        t = torch.randint(0, 13, (B, 16, 16), device=dev())
+        m2 = None if mask is None else wide[:, 32:96]
+        both(L.MRG_LOSS_CE, logits, t, m2, 2, smoothing=0.1)
+        ltok = logits.reshape(B, 13, 8, 2, 8, 2).permute(0, 2, 4, 1, 3, 5).reshape(B, 64, 13 * 4).contiguous()
+        both(L.MRG_LOSS_CE, ltok, t, m2, 2)
+    pred = torch.randn(B, 1, 64, 64, device=dev()).to(BF16)
+    tgt = torch.rand(B, 1, 64, 64, device=dev())
+    both(L.MRG_LOSS_MSE, pred, tgt, wide[:, :64], 8)
+    with pytest.raises(ValueError):
+        K.loss_desc(L.MRG_LOSS_MSE, pred, tgt, wide[:, :64].float(), 8)
+
+
+@pytest.mark.parametrize("dtype", [F32, BF16])
 def test_cross_entropy_label_smoothing(K, dtype):
     """mrg_loss_desc.label_smoothing against the REFERENCE's MaskedCrossEntropyLoss(label_smoothing = e) on the committed problem
     (tests/golden/loss_smoothing.npz: losses + logit gradients, e in {0.1, 0.3}, masked / plain), image and token layout; and through the

@@ -696,9 +696,13 @@ def test_losses_on_the_adapter_lanes_are_the_same_step(monkeypatch):
     x = {d: t.to(DEV) for d, t in O.synthetic_batch(cfg, B, seed=177).items()}
     noise, _, _ = _noise_dev(cfg, B, Kk, 178)
 
-    def run(lanes, graph, unmasked, defer=False, options=False):
+    from mirage_amd import engine as E
+
+    def run(lanes, graph, unmasked, defer=False, options=False, fused=True):
         monkeypatch.setattr(trainer, "LANE_LOSSES", lanes)
         monkeypatch.setattr(trainer, "LANE_DEFER_JOIN", defer)
+        monkeypatch.setattr(trainer, "LOSS_FUSED", fused)
+        hits0 = E.LaneLosses.fused_hits
         model, args, _ = T._build(cfg)
         model.train()
         opt = optim.FusedAdamW(model, [1e-3] * 8, [0.05] * 8)
@@ -716,8 +720,16 @@ def test_losses_on_the_adapter_lanes_are_the_same_step(monkeypatch):
         ts.step(noise=noise)
         torch.cuda.synchronize()
         assert ts._lane_losses == lanes
+        # the lanes form loss + loss gradient in one pass (mrg_masked_loss_fused) and the backward pass takes that gradient as it is
+        assert (E.LaneLosses.fused_hits > hits0) == (lanes and fused), (lanes, fused, E.LaneLosses.fused_hits - hits0)
         return (float(ts.loss), {k: float(v) for k, v in ts.task_losses.items()}, opt.arena.flat_g.clone(), opt.arena.flat_p.clone(),
                 {k: v.clone() for k, v in ts.pred_images().items()})
+    a, b = run(True, True, False), run(True, True, False, fused=False)
+    assert a[0] == b[0] and a[1] == b[1] and torch.equal(a[2], b[2]) and torch.equal(a[3], b[3])
+    monkeypatch.setattr(trainer, "LOSS_SEED_ONES", False)          # the sum's own backward seeds the lanes: no fused gradient, same step
+    b = run(True, True, False, fused=False)
+    monkeypatch.setattr(trainer, "LOSS_SEED_ONES", True)
+    assert a[0] == b[0] and a[1] == b[1] and torch.equal(a[2], b[2]) and torch.equal(a[3], b[3])
     for graph, unmasked in ((True, False), (False, False), (True, True)):
         # losses on the lanes (default) / lanes running on into the backward pass without a join (MRG_LANE_DEFER_JOIN=1) / reference placement
         a, c, b = run(True, graph, unmasked), run(True, graph, unmasked, defer=True), run(False, graph, unmasked)
