@@ -524,6 +524,7 @@ class EncoderFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, blocks, save, want_bf16, defer_join, dps, *params):
         ctx.defer_join = defer_join
+        ctx.set_materialize_grads(False)         # the bf16 twin's "gradient" stays None instead of a zero-filled [B, N, D] tensor per backward pass
         K.timestamp("enc_fwd_start")
         x32 = x
         saved_all = []
@@ -547,7 +548,7 @@ class EncoderFn(torch.autograd.Function):
         _Side.begin_backward()
         K.timestamp("enc_bwd_start")
         dx32 = dout.contiguous()
-        dx16 = None
+        dx16 = _twin_of(dx32)                    # the output adapters' last proj_context dgrad writes it beside the fp32 sum
         n = len(ctx.blocks)
         for i, (blk, sv) in enumerate(zip(reversed(ctx.blocks), reversed(ctx.saved))):
             dx32, dx16 = block_bwd(blk, sv, dx32, dx16, remaining=(n - 1 - i) if _Side.taper else None)
@@ -814,10 +815,12 @@ def decoder_bwd(ad, saved, d_img: torch.Tensor):
     return d_ctx16
 
 
-def decoder_bwd_finish(ad, d_ctx16: torch.Tensor, d_enc32: torch.Tensor, first: bool):
+def decoder_bwd_finish(ad, d_ctx16: torch.Tensor, d_enc32: torch.Tensor, acc32: Optional[torch.Tensor], twin16: Optional[torch.Tensor] = None):
+    """d_enc32 = acc32 (the other adapters' sum so far, or None) + proj_context dgrad of this adapter; twin16 (last adapter): the bf16 copy
+    of the finished sum that the encoder's backward pass reads"""
     B, N, Dd = d_ctx16.shape
     D = d_enc32.shape[-1]
-    K.gemm(d_ctx16, shadow(ad.proj_context.weight), B * N, D, Dd, b_mode=KS, lda=Dd, ldb=D, out=d_enc32, ldc=D, accumulate=not first)
+    K.gemm(d_ctx16, shadow(ad.proj_context.weight), B * N, D, Dd, b_mode=KS, lda=Dd, ldb=D, out=d_enc32, ldc=D, resid=acc32, out2=twin16)
 
 
 class PredLayout:
@@ -988,8 +991,17 @@ class DecodersFn(torch.autograd.Function):
             todo = [(ad, sv, d_img) for ad, sv, d_img in zip(ctx.adapters, ctx.saved, d_imgs) if d_img is not None]
             jobs = [(lambda ad=ad, sv=sv, d_img=d_img: decoder_bwd(ad, sv, d_img)) for ad, sv, d_img in todo]
         d_ctxs = _Lanes.run_all(jobs, dev, enabled=_Lanes.enabled and _Lanes.bwd)
+        # the adapters' proj_context dgrads form one sum: each launch adds the sum so far as its fp32 residual and writes the other of two
+        # buffers (no aliasing: a launch stays repeatable for the autotuner); the last one also writes the bf16 twin the encoder reads
+        d_enc16 = torch.empty(ctx.shape, dtype=BF16, device=dev) if len(todo) > 1 else None
+        bufs, acc = [d_enc, torch.empty_like(d_enc) if len(todo) > 1 else None], None
         for i, ((ad, _, _), d_ctx16) in enumerate(zip(todo, d_ctxs)):
-            decoder_bwd_finish(ad, d_ctx16, d_enc, i == 0)
+            decoder_bwd_finish(ad, d_ctx16, bufs[i % 2], acc, d_enc16 if i == len(todo) - 1 else None)
+            acc = bufs[i % 2]
+        d_enc = acc
+        if d_enc16 is not None:
+            _TWINS.clear()
+            _TWINS[d_enc.data_ptr()] = (d_enc, d_enc16)
         ctx.saved = None
         if _Side.early_opt is not None:          # every output-adapter gradient is final after the next reduction flush
             if _Side.enabled:
