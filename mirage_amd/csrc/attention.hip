@@ -1073,6 +1073,365 @@ int launch_bwd_fused(const AttnArgs& a0, hipStream_t stream) {
     return mrg_check_launch("mrg_attn_bwd/fused");
 }
 
+// ------------------------------------------------ fused backward, N = 32 NT + 1: the patches and the global token ---------------
+// The MIRAGE encoder rows are 32 m kept patches + ONE global token appended last (mirage/model.py:391): as a fifth 32-row tile that token
+// costs the general kernel a fifth wave (whose tile holds one row), 9 of 25 padded tile products, 111 KiB of LDS and with them the second
+// workgroup of the CU (five-wave workgroups do not pair up even at 80 KiB: the dispatcher wants waves 0 and 4 of both on the same SIMD,
+// i.e. <= 128 registers -- measured, profiles/r05_attn_bwd.md).  Here the NT tiles cover the patches only and the global token's row and
+// column are plain vector arithmetic in fp32:
+//   column (every query against the global token's key): one dot-product pair per query, 2 lanes each -> p, ds per query (LDS); their
+//       contribution to dQ is a rank-1 update of the finished accumulators, dK[g] / dV[g] are vector-matrix products with lane = column;
+//   row (the global token's query against every key): each key lane forms its scores from the K / V fragments it holds for phase A,
+//       adds p dO[g] / ds Q[g] to its dV / dK accumulators, and dQ[g] is a vector-matrix product against K once K is in LDS.
+// K and V never meet Q and dO in LDS (the owner waves hold them in registers through phase A and write K out for phase B): 73 KiB at N = 129,
+// four waves -> two workgroups per CU, whose memory and matrix phases overlap.
+template <int NT>
+__global__ __launch_bounds__(64 * NT, 2) void attn_bwd_fused_gt_kernel(const AttnArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int HD = 64, KS = 4, DJ = 2, NM = NT * 32, NTHR = 64 * NT, G = NM;
+    constexpr int TB = NM * 64;                        // bytes of one T block: [NM keys][32 queries] bf16
+    constexpr int REG_A = 2 * NM * 128, REG_B = NM * 128 + NT * 32 * FUSED_SP, REG = REG_A > REG_B ? REG_A : REG_B;
+    char* ldsT = smem;
+    char* reg = smem + NT * TB;                        // phase A: Q, dO; afterwards: K, the per-wave staging tiles
+    char* ldsQ = reg;
+    char* ldsDO = reg + NM * 128;
+    char* ldsK = reg;
+    float* ldsL = reinterpret_cast<float*>(reg + REG); // log-sum-exp (x log2 e) and dsum per query, [NM + 4] each
+    float* ldsD = ldsL + (NM + 4);
+    float* ldsPG = ldsD + (NM + 4);                    // p and ds of (query, global key)
+    float* ldsDSG = ldsPG + (NM + 4);
+    float* ldsDSQ = ldsDSG + (NM + 4);                 // ds of (global query, key), [NM]
+    float* kg = ldsDSQ + NM;                           // the global token's K, V, Q, dO rows in fp32
+    float* vg = kg + HD;
+    float* qg = vg + HD;
+    float* dog = qg + HD;
+    float* redKV = dog + HD;                           // [NT][2][HD] partial dK[g] / dV[g]
+    float* redQ = redKV + NT * 2 * HD;                 // [NT][HD] partial dQ[g]
+    const uint32_t ldsQ_u = lds_addr(ldsQ), ldsDO_u = lds_addr(ldsDO), ldsK_u = lds_addr(ldsK), ldsT_u = lds_addr(ldsT);
+    const int h = blockIdx.x, b = blockIdx.y;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hf = lane >> 5;
+    const float sc = a.scale * LOG2E;
+    const int row = wave * 32 + (lane & 31);           // this lane's key row in phase A, its query row in phase B
+#ifdef MRG_ATTN_TS      // debug build: phase timestamps of every workgroup (100 MHz wall clock) into the unused dsum workspace
+    unsigned long long* ts = reinterpret_cast<unsigned long long*>(a.dsum) + ((long)b * a.H + h) * 8;
+#define MRG_TS(i) do { if (tid == 0) ts[i] = wall_clock64(); } while (0)
+#else
+#define MRG_TS(i) do { } while (0)
+#endif
+    MRG_TS(0);
+    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+    auto lo = [](uint32_t w) { return __uint_as_float(w << 16); };
+    auto hi = [](uint32_t w) { return __uint_as_float(w & 0xffff0000u); };
+    // dot product of 8 packed bf16 with 8 floats
+    auto dot8 = [&](const uint32_t* w, const float* f) {
+        const float4 f0 = *reinterpret_cast<const float4*>(f), f1 = *reinterpret_cast<const float4*>(f + 4);
+        return ((lo(w[0]) * f0.x + hi(w[0]) * f0.y) + (lo(w[1]) * f0.z + hi(w[1]) * f0.w)) + ((lo(w[2]) * f1.x + hi(w[2]) * f1.y) + (lo(w[3]) * f1.z + hi(w[3]) * f1.w));
+    };
+
+    // ---- this wave's key tile: K / V fragments (lane = key row, 8 consecutive columns per k-slot group) straight from global memory
+    bf16x8 kf[KS], vf[KS];
+    {
+        const bf16_t* kp = a.k + (long)b * a.k_bs + h * HD + (long)row * a.k_rs;
+        const bf16_t* vp = a.v + (long)b * a.v_bs + h * HD + (long)row * a.v_rs;
+#pragma unroll
+        for (int kk = 0; kk < KS; ++kk) {
+            kf[kk] = *reinterpret_cast<const bf16x8*>(kp + (kk * 2 + hf) * 8);
+            vf[kk] = *reinterpret_cast<const bf16x8*>(vp + (kk * 2 + hf) * 8);
+        }
+    }
+    // ---- staging: Q, dO rows [0, NM) with 16-B loads, 8 lanes per 128-B row; dsum[q] = sum_d dO * O on the way; the global token's rows -> fp32
+    {
+        const bf16_t* qp = a.q + (long)b * a.q_bs + h * HD;
+        const bf16_t* dop = a.d_o + (long)b * a.do_bs + h * HD;
+        const bf16_t* op = a.o + (long)b * a.o_bs + h * HD;
+        const float lse_v = (tid <= NM) ? a.lse[((long)b * a.H + h) * (NM + 1) + tid] : 0.f;
+        u32x4 vq[4], vdo[4], vo[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int q = tid + j * NTHR, r = q >> 3, c = q & 7;          // 4 NTHR / 8 = NM rows exactly
+            vq[j] = *reinterpret_cast<const u32x4*>(qp + (long)r * a.q_rs + c * 8);
+            vdo[j] = *reinterpret_cast<const u32x4*>(dop + (long)r * a.do_rs + c * 8);
+            vo[j] = *reinterpret_cast<const u32x4*>(op + (long)r * a.o_rs + c * 8);
+        }
+        u32x4 gq = {0u, 0u, 0u, 0u}, gdo = gq, go = gq, gk = gq, gv = gq;
+        if (tid < 8) {
+            gq = *reinterpret_cast<const u32x4*>(qp + (long)G * a.q_rs + tid * 8);
+            gdo = *reinterpret_cast<const u32x4*>(dop + (long)G * a.do_rs + tid * 8);
+            go = *reinterpret_cast<const u32x4*>(op + (long)G * a.o_rs + tid * 8);
+            gk = *reinterpret_cast<const u32x4*>(a.k + (long)b * a.k_bs + h * HD + (long)G * a.k_rs + tid * 8);
+            gv = *reinterpret_cast<const u32x4*>(a.v + (long)b * a.v_bs + h * HD + (long)G * a.v_rs + tid * 8);
+        }
+        MRG_TS(1);
+        if (tid <= NM) ldsL[tid] = lse_v * LOG2E;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int q = tid + j * NTHR, r = q >> 3, c = q & 7;
+            float dsm = 0.f;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) dsm += lo(vo[j][e]) * lo(vdo[j][e]) + hi(vo[j][e]) * hi(vdo[j][e]);
+            dsm += __shfl_xor(dsm, 1, 64);
+            dsm += __shfl_xor(dsm, 2, 64);
+            dsm += __shfl_xor(dsm, 4, 64);
+            const int off = tile_off<HD, SWZ_ROW>(r, c);
+            *reinterpret_cast<u32x4*>(ldsQ + off) = vq[j];
+            *reinterpret_cast<u32x4*>(ldsDO + off) = vdo[j];
+            if (c == 0) ldsD[r] = dsm;
+        }
+        {
+            float dsm = 0.f;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) dsm += lo(go[e]) * lo(gdo[e]) + hi(go[e]) * hi(gdo[e]);
+            dsm += __shfl_xor(dsm, 1, 64);
+            dsm += __shfl_xor(dsm, 2, 64);
+            dsm += __shfl_xor(dsm, 4, 64);
+            if (tid < 8) {
+                if (tid == 0) ldsD[G] = dsm;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    qg[tid * 8 + 2 * e] = lo(gq[e]); qg[tid * 8 + 2 * e + 1] = hi(gq[e]);
+                    dog[tid * 8 + 2 * e] = lo(gdo[e]); dog[tid * 8 + 2 * e + 1] = hi(gdo[e]);
+                    kg[tid * 8 + 2 * e] = lo(gk[e]); kg[tid * 8 + 2 * e + 1] = hi(gk[e]);
+                    vg[tid * 8 + 2 * e] = lo(gv[e]); vg[tid * 8 + 2 * e + 1] = hi(gv[e]);
+                }
+            }
+        }
+    }
+    __syncthreads();
+    MRG_TS(2);
+
+    // ---- the global token's KEY against every query: two lanes per query
+    {
+        const int q = tid >> 1, half = tid & 1;        // NTHR / 2 = NM queries
+        float s = 0.f, dp = 0.f;
+#pragma unroll
+        for (int c4 = 0; c4 < 4; ++c4) {
+            const int c = half * 4 + c4;
+            const u32x4 qv = *reinterpret_cast<const u32x4*>(ldsQ + tile_off<HD, SWZ_ROW>(q, c));
+            const u32x4 dv = *reinterpret_cast<const u32x4*>(ldsDO + tile_off<HD, SWZ_ROW>(q, c));
+            const uint32_t qw[4] = {qv.x, qv.y, qv.z, qv.w}, dw[4] = {dv.x, dv.y, dv.z, dv.w};
+            s += dot8(qw, kg + c * 8);
+            dp += dot8(dw, vg + c * 8);
+        }
+        s += __shfl_xor(s, 1, 64);
+        dp += __shfl_xor(dp, 1, 64);
+        const float p = fast_exp2(s * sc - ldsL[q]);
+        if (half == 0) { ldsPG[q] = p; ldsDSG[q] = p * (dp - ldsD[q]) * a.scale; }
+        if (wave == 0) {                               // (global query, global key)
+            const float sg = wave_sum(qg[lane] * kg[lane]), dpg = wave_sum(dog[lane] * vg[lane]);
+            const float pg = fast_exp2(sg * sc - ldsL[G]);
+            if (lane == 0) { ldsPG[G] = pg; ldsDSG[G] = pg * (dpg - ldsD[G]) * a.scale; }
+        }
+    }
+    __syncthreads();
+    // dK[g] = sum_q ds[q, g] Q[q], dV[g] = sum_q p[q, g] dO[q]: lane = column, this wave's 32 queries
+    {
+        float ak = 0.f, av = 0.f;
+        const int cb = tile_off<HD, SWZ_ROW>(0, 0);
+        (void)cb;
+#pragma unroll 8
+        for (int i = 0; i < 32; ++i) {
+            const int q = wave * 32 + i;
+            const int off = tile_off<HD, SWZ_ROW>(q, lane >> 3) + (lane & 7) * 2;
+            ak += ldsDSG[q] * bf2f(*reinterpret_cast<const bf16_t*>(ldsQ + off));
+            av += ldsPG[q] * bf2f(*reinterpret_cast<const bf16_t*>(ldsDO + off));
+        }
+        if (wave == 0) { ak += ldsDSG[G] * qg[lane]; av += ldsPG[G] * dog[lane]; }
+        redKV[(wave * 2 + 0) * HD + lane] = ak;
+        redKV[(wave * 2 + 1) * HD + lane] = av;
+    }
+
+    // ---- phase A: this wave's key tile against every query block, two blocks at a time (attn_bwd_fused_kernel's, without row clamps)
+    f32x16 dvT[DJ], dkT[DJ];
+#pragma unroll
+    for (int dj = 0; dj < DJ; ++dj)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { dvT[dj][r] = 0.f; dkT[dj][r] = 0.f; }
+    {
+        char* tw = ldsT + row * 64;
+        const int tws = (row >> 2) & 7;
+#define MRG_SDP(QB, S, DP) { \
+            _Pragma("unroll") for (int r = 0; r < 16; ++r) { S[r] = 0.f; DP[r] = 0.f; } \
+            _Pragma("unroll") for (int kk = 0; kk < KS; ++kk) { \
+                S = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fz_rows(false, ldsQ, (QB) * 32, kk, lane, 0), kf[kk], S, 0, 0, 0); \
+                DP = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fz_rows(false, ldsDO, (QB) * 32, kk, lane, 0), vf[kk], DP, 0, 0, 0); } }
+#define MRG_TAIL(QB, S, DP) { \
+            _Pragma("unroll") for (int mf = 0; mf < 2; ++mf) { \
+                f32x16 pr; \
+                _Pragma("unroll") for (int g = 2 * mf; g < 2 * mf + 2; ++g) { \
+                    const int qrow = (QB) * 32 + 8 * g + 4 * hf; \
+                    const float4 l4 = *reinterpret_cast<const float4*>(ldsL + qrow); \
+                    const float4 d4 = *reinterpret_cast<const float4*>(ldsD + qrow); \
+                    const float ls[4] = {l4.x, l4.y, l4.z, l4.w}, ds[4] = {d4.x, d4.y, d4.z, d4.w}; \
+                    _Pragma("unroll") for (int e = 0; e < 4; ++e) { \
+                        const int r = g * 4 + e; \
+                        const float p = fast_exp2(S[r] * sc - ls[e]); \
+                        pr[r] = p; \
+                        S[r] = p * (DP[r] - ds[e]) * a.scale; } } \
+                const bf16x8 pa = pack8(pr, mf); \
+                const bf16x8 da = pack8(S, mf); \
+                { \
+                    const uint2* w2 = reinterpret_cast<const uint2*>(&da); \
+                    _Pragma("unroll") for (int x = 0; x < 2; ++x) \
+                        *reinterpret_cast<uint2*>(tw + (QB) * TB + (((4 * mf + 2 * x + hf) ^ tws) << 3)) = w2[x]; } \
+                _Pragma("unroll") for (int dj = 0; dj < DJ; ++dj) { \
+                    dvT[dj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fz_cols_tr(false, ldsDO_u, (QB) * 32, mf, dj, lane, 0), pa, dvT[dj], 0, 0, 0); \
+                    dkT[dj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fz_cols_tr(false, ldsQ_u, (QB) * 32, mf, dj, lane, 0), da, dkT[dj], 0, 0, 0); } } }
+#pragma unroll
+        for (int qp2 = 0; qp2 < NT / 2; ++qp2) {
+            __builtin_amdgcn_sched_barrier(0);
+            f32x16 s0, dp0, s1, dp1;
+            MRG_SDP(2 * qp2, s0, dp0)
+            MRG_SDP(2 * qp2 + 1, s1, dp1)
+            MRG_TAIL(2 * qp2, s0, dp0)
+            MRG_TAIL(2 * qp2 + 1, s1, dp1)
+        }
+        if (NT & 1) {
+            __builtin_amdgcn_sched_barrier(0);
+            f32x16 s0, dp0;
+            MRG_SDP(NT - 1, s0, dp0)
+            MRG_TAIL(NT - 1, s0, dp0)
+        }
+#undef MRG_SDP
+#undef MRG_TAIL
+        // ---- the global token's QUERY against this lane's key: scores from the fragments (a lane pair holds the key's 64 columns)
+        __builtin_amdgcn_sched_barrier(0);
+        float sp = 0.f, dpp = 0.f;
+#pragma unroll
+        for (int kk = 0; kk < KS; ++kk) {
+            const int d0 = kk * 16 + hf * 8;
+            sp += dot8(reinterpret_cast<const uint32_t*>(&kf[kk]), qg + d0);
+            dpp += dot8(reinterpret_cast<const uint32_t*>(&vf[kk]), dog + d0);
+        }
+        sp += __shfl_xor(sp, 32, 64);
+        dpp += __shfl_xor(dpp, 32, 64);
+        const float pk = fast_exp2(sp * sc - ldsL[G]);
+        const float dsk = pk * (dpp - ldsD[G]) * a.scale;
+        if (hf == 0) ldsDSQ[row] = dsk;
+        // dV[k] += p dO[g], dK[k] += ds Q[g]: register r of block dj is column 32 dj + 8 (r >> 2) + 4 hf + (r & 3)
+#pragma unroll
+        for (int dj = 0; dj < DJ; ++dj)
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                const int c0 = 32 * dj + 8 * g4 + 4 * hf;
+                const float4 o4 = *reinterpret_cast<const float4*>(dog + c0), q4 = *reinterpret_cast<const float4*>(qg + c0);
+                dvT[dj][4 * g4 + 0] += pk * o4.x; dvT[dj][4 * g4 + 1] += pk * o4.y; dvT[dj][4 * g4 + 2] += pk * o4.z; dvT[dj][4 * g4 + 3] += pk * o4.w;
+                dkT[dj][4 * g4 + 0] += dsk * q4.x; dkT[dj][4 * g4 + 1] += dsk * q4.y; dkT[dj][4 * g4 + 2] += dsk * q4.z; dkT[dj][4 * g4 + 3] += dsk * q4.w;
+            }
+    }
+    MRG_TS(3);
+    __syncthreads();                                   // T complete; Q and dO are dead: their area takes K and the per-wave staging tiles
+    MRG_TS(4);
+#pragma unroll
+    for (int kk = 0; kk < KS; ++kk)                    // this wave's K rows, from the registers, in the layout the transposed reads of phase B expect
+        *reinterpret_cast<bf16x8*>(ldsK + tile_off<HD, SWZ_ROW>(row, kk * 2 + hf)) = kf[kk];
+    char* stg = reg + NM * 128 + wave * (32 * FUSED_SP);
+    float cs[3][8];
+    fused_stage<2>(stg, dvT, lane);
+    fused_flush<2, true>(stg, a.dv + (long)b * a.dv_bs + h * HD, a.dv_rs, wave * 32, NM, lane, cs[2]);
+    fused_stage<2>(stg, dkT, lane);
+    fused_flush<2, true>(stg, a.dk + (long)b * a.dk_bs + h * HD, a.dk_rs, wave * 32, NM, lane, cs[1]);
+    MRG_TS(5);
+    __syncthreads();                                   // every wave's K rows are in LDS
+
+    // ---- phase B: this wave's query tile (T block `wave`), contraction over the patch keys; then the global key as a rank-1 update
+    {
+        f32x16 dqT[DJ];
+#pragma unroll
+        for (int dj = 0; dj < DJ; ++dj)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) dqT[dj][r] = 0.f;
+        const int i16 = lane & 15;
+        const int chunk = ((lane & 16) >> 2) + (i16 & 3);
+        const uint32_t tb = ldsT_u + wave * TB;
+#pragma unroll
+        for (int kb = 0; kb < NT; ++kb)
+#pragma unroll
+            for (int mf = 0; mf < 2; ++mf) {
+                const int r0 = kb * 32 + 16 * mf + 4 * hf + (i16 >> 2), r1 = r0 + 8;
+                const s16x4 l4 = lds_read_tr16(tb + t_off(r0, chunk));
+                const s16x4 h4 = lds_read_tr16(tb + t_off(r1, chunk));
+                bf16x8 da;
+                da[0] = l4[0]; da[1] = l4[1]; da[2] = l4[2]; da[3] = l4[3];
+                da[4] = h4[0]; da[5] = h4[1]; da[6] = h4[2]; da[7] = h4[3];
+#pragma unroll
+                for (int dj = 0; dj < DJ; ++dj)
+                    dqT[dj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fz_cols_tr(false, ldsK_u, kb * 32, mf, dj, lane, 0), da, dqT[dj], 0, 0, 0);
+            }
+        MRG_TS(6);
+        const float dsg = ldsDSG[row];
+#pragma unroll
+        for (int dj = 0; dj < DJ; ++dj)
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                const float4 k4 = *reinterpret_cast<const float4*>(kg + 32 * dj + 8 * g4 + 4 * hf);
+                dqT[dj][4 * g4 + 0] += dsg * k4.x; dqT[dj][4 * g4 + 1] += dsg * k4.y; dqT[dj][4 * g4 + 2] += dsg * k4.z; dqT[dj][4 * g4 + 3] += dsg * k4.w;
+            }
+        fused_stage<2>(stg, dqT, lane);
+        fused_flush<2, true>(stg, a.dq + (long)b * a.dq_bs + h * HD, a.dq_rs, wave * 32, NM, lane, cs[0]);
+    }
+    // dQ[g] = sum_k ds[g, k] K[k]: lane = column, this wave's 32 keys
+    {
+        float aq = 0.f;
+#pragma unroll 8
+        for (int i = 0; i < 32; ++i) {
+            const int k = wave * 32 + i;
+            aq += ldsDSQ[k] * bf2f(*reinterpret_cast<const bf16_t*>(ldsK + tile_off<HD, SWZ_ROW>(k, lane >> 3) + (lane & 7) * 2));
+        }
+        if (wave == 0) aq += ldsDSG[G] * kg[lane];
+        redQ[wave * HD + lane] = aq;
+    }
+    MRG_TS(7);
+    __syncthreads();                                   // partial sums complete; every wave is done with K and T
+    float* red = reinterpret_cast<float*>(ldsK);
+    if (wave == 0) {                                   // the global token's three output rows
+        float tq = 0.f, tk = 0.f, tv = 0.f;
+#pragma unroll
+        for (int w = 0; w < NT; ++w) { tq += redQ[w * HD + lane]; tk += redKV[(w * 2 + 0) * HD + lane]; tv += redKV[(w * 2 + 1) * HD + lane]; }
+        const bf16_t q16 = f2bf(tq), k16 = f2bf(tk), v16 = f2bf(tv);
+        a.dq[(long)b * a.dq_bs + (long)G * a.dq_rs + h * HD + lane] = q16;
+        a.dk[(long)b * a.dk_bs + (long)G * a.dk_rs + h * HD + lane] = k16;
+        a.dv[(long)b * a.dv_bs + (long)G * a.dv_rs + h * HD + lane] = v16;
+        if (a.cs_q) { red[(NT * 3 + 0) * HD + lane] = bf2f(q16); red[(NT * 3 + 1) * HD + lane] = bf2f(k16); red[(NT * 3 + 2) * HD + lane] = bf2f(v16); }
+    }
+    if (a.cs_q) {   // per-(batch, head) column sums of dQ / dK / dV: the bias gradients before the reduction over the batch
+        if (lane < 8) {
+#pragma unroll
+            for (int m = 0; m < 3; ++m)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) red[(wave * 3 + m) * HD + lane * 8 + e] = cs[m][e];
+        }
+        __syncthreads();
+        for (int c = tid; c < 3 * HD; c += NTHR) {
+            float t = 0.f;
+            for (int w = 0; w <= NT; ++w) t += red[w * 3 * HD + c];
+            float* dst = c < HD ? a.cs_q : (c < 2 * HD ? a.cs_k : a.cs_v);
+            dst[(long)b * a.cs_bs + h * HD + (c % HD)] = t;
+        }
+    }
+}
+#undef MRG_TS
+
+template <int NT>
+int launch_bwd_fused_gt(const AttnArgs& a, hipStream_t stream) {
+    constexpr int NM = NT * 32;
+    constexpr size_t REG_A = 2 * NM * 128, REG_B = NM * 128 + NT * 32 * FUSED_SP;
+    const size_t sh = (size_t)NT * NM * 64 + (REG_A > REG_B ? REG_A : REG_B) + sizeof(float) * (4 * (NM + 4) + NM + 4 * 64 + NT * 3 * 64);
+    static bool attr_set = false;
+    if (sh > 65536 && !attr_set) {
+        (void)hipFuncSetAttribute((const void*)attn_bwd_fused_gt_kernel<NT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(attn_bwd_fused_gt_kernel<NT>, dim3(a.H, a.B), dim3(64 * NT), sh, stream, a);
+    return mrg_check_launch("mrg_attn_bwd/fused_gt");
+}
+
+// MRG_ATTN_GT=0: N = 32 m + 1 goes through the general fused kernel (five tiles) like any other length (A/B knob)
+bool fused_gt_enabled() {
+    static int on = -1;
+    if (on < 0) { const char* e = getenv("MRG_ATTN_GT"); on = (e && e[0] == '0') ? 0 : 1; }
+    return on == 1;
+}
+
 // MRG_ATTN_FUSED=0 selects the query-owner + key-owner pair of kernels for every shape (A/B knob; the fused kernel is the default)
 bool fused_enabled() {
     static int on = -1;
@@ -1183,8 +1542,11 @@ extern "C" int mrg_attn_bwd(const mrg_attn_desc* d, hipStream_t stream) {
     AttnArgs a;
     fill(a, d);
     const int HD = d->head_dim;
-    if (HD == 64 && a.Nq == a.Nk && a.Nq > 96 && a.Nq <= 160 && fused_enabled())
+    if (HD == 64 && a.Nq == a.Nk && a.Nq > 96 && a.Nq <= 160 && fused_enabled()) {
+        if (a.Nq == 129 && fused_gt_enabled()) return launch_bwd_fused_gt<4>(a, stream);
+        if (a.Nq == 97 && fused_gt_enabled()) return launch_bwd_fused_gt<3>(a, stream);
         return a.Nq > 128 ? launch_bwd_fused<5>(a, stream) : launch_bwd_fused<4>(a, stream);
+    }
     dim3 grid(a.H, a.B);
     {   // dQ: K,V chunk in LDS
         dim3 block(64 * waves_for((a.Nq + 31) / 32));

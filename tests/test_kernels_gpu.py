@@ -505,6 +505,41 @@ def test_self_attention_fwd_bwd(K, B, H, N, hd):
     assert (gb - dqkv.float().reshape(B * N, 3 * D).sum(0)).abs().max() <= 2e-2 * dqkv.float().abs().sum(dim=(0, 1)).max()
 
 
+@pytest.mark.parametrize("B,H,N", [(3, 12, 129), (2, 4, 97), (5, 3, 129)])
+def test_attention_backward_global_token_rows(K, B, H, N):
+    """N = 32 m + 1 (patches + the global token): the fused backward kernel tiles the patches and treats the global token's row and column
+    as vector arithmetic (attn_bwd_fused_gt_kernel).  The gradients of THAT token (row N - 1 of dQ, dK, dV) and of the patches alone are each
+    checked against fp32 autograd, with large-magnitude scores for the token so that its column dominates some rows."""
+    hd, D = 64, H * 64
+    qkv = rnd(B, N, 3 * D, dtype=BF16, seed=70)
+    qkv[:, N - 1, D:2 * D] *= 3.0                       # the global token's key: every query attends to it strongly
+    qkv[:, N - 1, :D] *= 2.0                            # and its query row is peaked
+    scale = hd ** -0.5
+    q, k, v = qkv[..., :D], qkv[..., D:2 * D], qkv[..., 2 * D:]
+    st = (N * 3 * D, 3 * D)
+    o, lse = K.attn_fwd(q, k, v, B, H, N, N, hd, scale, st, st, st)
+    qf, kf, vf = [t.float().reshape(B, N, H, hd).permute(0, 2, 1, 3).detach().requires_grad_(True) for t in (q, k, v)]
+    ref, _ = _attn_ref(qf, kf, vf, scale)
+    d_o = rnd(B, N, D, dtype=BF16, seed=71)
+    ref.backward(d_o.float().reshape(B, N, H, hd).permute(0, 2, 1, 3))
+    dqkv = torch.zeros_like(qkv)
+    gb = torch.full((3 * D,), float("nan"), device=dev())
+    K.attn_bwd(q, k, v, o, lse, d_o, dqkv[..., :D], dqkv[..., D:2 * D], dqkv[..., 2 * D:], B, H, N, N, hd, scale, st, st, st, st, st, st,
+               bias_grads=(gb[:D], gb[D:2 * D], gb[2 * D:]))
+    for name, got, want in (("dq", dqkv[..., :D], qf.grad), ("dk", dqkv[..., D:2 * D], kf.grad), ("dv", dqkv[..., 2 * D:], vf.grad)):
+        want_m = want.permute(0, 2, 1, 3).reshape(B, N, D)
+        for part, sl in (("token", slice(N - 1, N)), ("patches", slice(0, N - 1))):
+            e = rel_rms(got.float()[:, sl], want_m[:, sl])
+            assert e < 1.5e-2, (name, part, e)
+    want_b = torch.cat([g.permute(0, 2, 1, 3).reshape(B * N, D).sum(0) for g in (qf.grad, kf.grad, vf.grad)])
+    assert rel_rms(gb, want_b) < 1.5e-2, rel_rms(gb, want_b)
+    assert (gb - dqkv.float().reshape(B * N, 3 * D).sum(0)).abs().max() <= 2e-2 * dqkv.float().abs().sum(dim=(0, 1)).max()
+    # the same call again: bit-identical (no atomics, fixed summation orders)
+    again = torch.zeros_like(qkv)
+    K.attn_bwd(q, k, v, o, lse, d_o, again[..., :D], again[..., D:2 * D], again[..., 2 * D:], B, H, N, N, hd, scale, st, st, st, st, st, st)
+    assert torch.equal(again, dqkv)
+
+
 @pytest.mark.parametrize("B,H,Nq,Nk,hd", [(2, 8, 256, 99, 32), (2, 8, 256, 129, 32), (2, 2, 64, 25, 32), (1, 2, 64, 33, 64)])
 def test_cross_attention_fwd_bwd(K, B, H, Nq, Nk, hd):
     D = H * hd
