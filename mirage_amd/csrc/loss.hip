@@ -255,6 +255,99 @@ __global__ __launch_bounds__(256) void loss_bwd_kernel(const T* __restrict__ pre
     }
 }
 
+// ---- cross entropy on token-layout bf16 logits with C classes known at compile time: a thread owns 8 consecutive elements of a token's
+// [P][P] block (one 16-B chunk per class: the class blocks of a token are contiguous, so 8 lanes cover 128 B and every line is read once),
+// keeps the C chunks packed in registers and walks them three times (max / target / sum, sum of exponentials, gradient) -- instead of the
+// scalar kernel's three 2-byte loads per class and pixel with their index arithmetic (52 us for the 27 MB of C4's layer-map logits, 5x
+// its traffic time).  grid (LOSS_CHUNKS, B) and partial sums like the scalar kernel's; the forward-only and the one-pass launch are the
+// same code, so their partial sums agree bit for bit.
+template <bool FUSED, int C>
+__global__ __launch_bounds__(256) void ce_tok_vec_kernel(const bf16_t* __restrict__ pred, const long* __restrict__ target,
+                                                         const void* const* __restrict__ tslot, const long* __restrict__ mask, long mbs,
+                                                         int B, int H, int W, int P, float smooth, float* __restrict__ partial,
+                                                         const float* __restrict__ coef, const float* __restrict__ gout, bf16_t* __restrict__ dpred) {
+    if (tslot) target = static_cast<const long*>(*tslot);
+    __shared__ float red[4];
+    const int b = blockIdx.y, chunk = blockIdx.x;
+    const int nw = W / P, PP = P * P, q8 = PP / 8, ntok = (H / P) * nw;
+    const long total = (long)ntok * q8;                        // 16-B chunks of one class plane of the sample
+    const float kb = FUSED ? (gout ? gout[0] : 1.f) * coef[b] : 0.f;
+    const float sm_c = smooth / (float)C, hit = 1.f - smooth;
+    auto lo = [](uint32_t w) { return __uint_as_float(w << 16); };
+    auto hi = [](uint32_t w) { return __uint_as_float(w & 0xffff0000u); };
+    float s = 0.f, n = 0.f;
+    for (long v = (long)chunk * 256 + threadIdx.x; v < total; v += (long)LOSS_CHUNKS * 256) {
+        const int tk = (int)(v / q8), q = (int)(v - (long)tk * q8);
+        const float m = mask ? (float)mask[(long)b * mbs + tk] : 1.f;
+        const long base = ((long)b * ntok + tk) * ((long)C * PP) + q * 8;
+        if (m == 0.f) {
+            if (FUSED) {
+#pragma unroll
+                for (int c = 0; c < C; ++c) *reinterpret_cast<uint4*>(dpred + base + (long)c * PP) = make_uint4(0, 0, 0, 0);
+            }
+            continue;
+        }
+        uint32_t w[C][4];
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+            const uint4 u = *reinterpret_cast<const uint4*>(pred + base + (long)c * PP);
+            w[c][0] = u.x; w[c][1] = u.y; w[c][2] = u.z; w[c][3] = u.w;
+        }
+        const int ty = tk / nw, tx = tk - ty * nw, py = (q * 8) / P, px = q * 8 - py * P;
+        int t[8];
+        {
+            const long* tp = target + ((long)b * H + ty * P + py) * W + tx * P + px;
+#pragma unroll
+            for (int i = 0; i < 8; i += 2) {
+                const longlong2 t2 = *reinterpret_cast<const longlong2*>(tp + i);
+                t[i] = (int)t2.x; t[i + 1] = (int)t2.y;
+            }
+        }
+        const float k = kb * m;
+        uint32_t o[C][4];
+        // two pixels (one packed word per class) at a time: the C x 2 target compares stay in scalar registers
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float mx0 = -INFINITY, mx1 = -INFINITY, zt0 = 0.f, zt1 = 0.f, zs0 = 0.f, zs1 = 0.f;
+#pragma unroll
+            for (int c = 0; c < C; ++c) {
+                const float z0 = lo(w[c][j]), z1 = hi(w[c][j]);
+                mx0 = fmaxf(mx0, z0); mx1 = fmaxf(mx1, z1);
+                zt0 = (c == t[2 * j]) ? z0 : zt0; zt1 = (c == t[2 * j + 1]) ? z1 : zt1;
+                zs0 += z0; zs1 += z1;
+            }
+            float se0 = 0.f, se1 = 0.f;
+#pragma unroll
+            for (int c = 0; c < C; ++c) { se0 += __expf(lo(w[c][j]) - mx0); se1 += __expf(hi(w[c][j]) - mx1); }
+            // F.cross_entropy(label_smoothing = e) = lse - (1 - e) z_t - e mean_c z_c  (criterion.py:33)
+            const float l0 = mx0 + __logf(se0) - hit * zt0 - smooth * zs0 / (float)C;
+            const float l1 = mx1 + __logf(se1) - hit * zt1 - smooth * zs1 / (float)C;
+            s += l0 * m; n += m;
+            s += l1 * m; n += m;
+            if (FUSED) {
+                const float i0 = 1.f / se0, i1 = 1.f / se1;
+#pragma unroll
+                for (int c = 0; c < C; ++c) {
+                    const float p0 = __expf(lo(w[c][j]) - mx0) * i0, p1 = __expf(hi(w[c][j]) - mx1) * i1;
+                    const float g0 = k == 0.f ? 0.f : k * (p0 - (c == t[2 * j] ? hit : 0.f) - sm_c);
+                    const float g1 = k == 0.f ? 0.f : k * (p1 - (c == t[2 * j + 1] ? hit : 0.f) - sm_c);
+                    o[c][j] = pack_bf2(g0, g1);
+                }
+            }
+        }
+        if (FUSED) {
+#pragma unroll
+            for (int c = 0; c < C; ++c) *reinterpret_cast<uint4*>(dpred + base + (long)c * PP) = make_uint4(o[c][0], o[c][1], o[c][2], o[c][3]);
+        }
+    }
+    const float ts = block_sum(s, red);
+    const float tn = block_sum(n, red);
+    if (threadIdx.x == 0) {
+        partial[((long)b * LOSS_CHUNKS + chunk) * 2 + 0] = ts;
+        partial[((long)b * LOSS_CHUNKS + chunk) * 2 + 1] = tn;
+    }
+}
+
 // ---- single-channel bf16 MSE fast path: 8 consecutive pixels (16 B of predictions, 32 B of targets) per thread
 // FUSED: see loss_fwd_kernel (the gradient expressions are mse1_bwd_vec_kernel's)
 template <bool FUSED>
@@ -391,7 +484,15 @@ int launch_loss_fwd(const mrg_loss_desc* d, bool fused, hipStream_t stream, cons
         if (rc) return rc;
     }
     const float* coef = fused ? d->coef : nullptr;
-    if (vec_mse) {
+    // the layer maps' 13 classes (mirage/output_adapters.py: num_channels of the semseg adapter); other class counts take the scalar kernel
+    const bool vec_ce = d->kind == MRG_LOSS_CE && d->pred_tokens && d->pred_dtype == MRG_DT_BF16 && d->P % 8 == 0 && d->C == 13 && d->W % 8 == 0 &&
+                        (((uintptr_t)d->pred | (uintptr_t)d->target | (fused ? (uintptr_t)d->dpred : 0)) & 15) == 0;
+    if (vec_ce) {
+#define MRG_C(F) hipLaunchKernelGGL((ce_tok_vec_kernel<F, 13>), grid, block, 0, stream, (const bf16_t*)d->pred, (const long*)d->target, d->target_slot, d->mask, mbs, d->B, \
+                           d->H, d->W, d->P, d->label_smoothing, d->partial, coef, d->gout, (bf16_t*)d->dpred)
+        if (fused) MRG_C(true); else MRG_C(false);
+#undef MRG_C
+    } else if (vec_mse) {
 #define MRG_V(F) hipLaunchKernelGGL(mse1_fwd_vec_kernel<F>, grid, block, 0, stream, (const bf16_t*)d->pred, (const float*)d->target, d->target_slot, d->mask, mbs, d->B, d->H, \
                            d->W, d->P, d->pred_tokens, d->partial, coef, d->gout, (bf16_t*)d->dpred)
         if (fused) MRG_V(true); else MRG_V(false);
