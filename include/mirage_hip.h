@@ -26,7 +26,7 @@ extern "C" {
 typedef struct ihipStream_t* hipStream_t;
 #endif
 
-#define MRG_ABI_VERSION 14   /* 14: mrg_loss_coef, mrg_masked_loss_fused, mrg_masked_loss_finish (loss forward + gradient in one pass), mrg_loss_desc.mask_bs; 13: the stream-K schedule of round 4 is gone (measured slower everywhere it was meant to win and selected nowhere: profiles/r04_streamk.md; the code is tools/debug/patches/streamk_r04.patch) -- variant 12 reserved, mrg_gemm_desc.sk_grid, mrg_wgrad_group_desc.streamk / counters / sk_grid, mrg_streamk_ws_bytes and mrg_debug_sk_trace removed; 12: MRG_GEMM_DUO (mrg_gemm_desc.variant 13: the 128 x 256 two-workgroups-per-CU kernel, csrc/gemm_duo.hip); 11: mrg_attn_desc.drop_rng / drop_p / drop_stream (dropout on the attention probabilities), mrg_posemb_grad, mrg_loss_desc.label_smoothing / norm_pix / stats, mrg_wgrad_group_desc.fuse + mrg_adamw_hp (AdamW in the weight-gradient epilogue), mrg_debug_clock_monitor; 10: MRG_GEMM_P8SK (stream-K schedule of the 8-phase kernel), mrg_gemm_desc.sk_grid, mrg_wgrad_group_desc.streamk / counters / sk_grid, mrg_streamk_ws_bytes; 9: mrg_maskgen_rng, input slots (mrg_set_slots, *_slot parameters, mrg_loss_desc.target_slot); 8: mrg_gemm_desc.drop_rng / drop_p / drop_stream, mrg_dropout_bwd_bf16; 7: mrg_wgrad_group, mrg_debug_timestamp; 2: mrg_gemm_desc grew row_scale / defer_reduce, act codes 3, 4, reduce_batch / augment / row_scale entry points; 3: colsum_out, attention colsum_*; 4: step = int[2], mrg_step_inc takes the skip decision; 5: splitk_counters, MRG_GEMM_P8, resize entry points; 6: mrg_adamw_desc.sumsq_out, mrg_sumsq_finish */
+#define MRG_ABI_VERSION 14   /* 14: mrg_loss_coef, mrg_masked_loss_fused, mrg_masked_loss_finish (loss forward + gradient in one pass), mrg_loss_desc.nvalid / mask_bs; 13: the stream-K schedule of round 4 is gone (measured slower everywhere it was meant to win and selected nowhere: profiles/r04_streamk.md; the code is tools/debug/patches/streamk_r04.patch) -- variant 12 reserved, mrg_gemm_desc.sk_grid, mrg_wgrad_group_desc.streamk / counters / sk_grid, mrg_streamk_ws_bytes and mrg_debug_sk_trace removed; 12: MRG_GEMM_DUO (mrg_gemm_desc.variant 13: the 128 x 256 two-workgroups-per-CU kernel, csrc/gemm_duo.hip); 11: mrg_attn_desc.drop_rng / drop_p / drop_stream (dropout on the attention probabilities), mrg_posemb_grad, mrg_loss_desc.label_smoothing / norm_pix / stats, mrg_wgrad_group_desc.fuse + mrg_adamw_hp (AdamW in the weight-gradient epilogue), mrg_debug_clock_monitor; 10: MRG_GEMM_P8SK (stream-K schedule of the 8-phase kernel), mrg_gemm_desc.sk_grid, mrg_wgrad_group_desc.streamk / counters / sk_grid, mrg_streamk_ws_bytes; 9: mrg_maskgen_rng, input slots (mrg_set_slots, *_slot parameters, mrg_loss_desc.target_slot); 8: mrg_gemm_desc.drop_rng / drop_p / drop_stream, mrg_dropout_bwd_bf16; 7: mrg_wgrad_group, mrg_debug_timestamp; 2: mrg_gemm_desc grew row_scale / defer_reduce, act codes 3, 4, reduce_batch / augment / row_scale entry points; 3: colsum_out, attention colsum_*; 4: step = int[2], mrg_step_inc takes the skip decision; 5: splitk_counters, MRG_GEMM_P8, resize entry points; 6: mrg_adamw_desc.sumsq_out, mrg_sumsq_finish */
 
 enum { MRG_DT_BF16 = 0, MRG_DT_F32 = 1 };
 enum { MRG_OP_KCONTIG = 0, MRG_OP_KSTRIDED = 1 };
@@ -282,6 +282,9 @@ typedef struct mrg_loss_desc {
     int norm_pix; float* stats;       /* MSE only: MaskedMSELoss(norm_pix=True) (criterion.py:92-98): the target is normalised per patch over its
                                          C*P*P elements ((t - mean) / sqrt(unbiased var + 1e-6)); stats = workspace fp32 [B*(H/P)*(W/P)*2] that the
                                          forward call fills ({mean, 1/sqrt(var + eps)} per patch) and the backward call reads */
+    int nvalid;                       /* mrg_masked_loss_fused with coef == NULL: the caller's GUARANTEE that exactly nvalid samples have masked pixels (the
+                                         training step: all B, because fewer tokens are kept than a modality has); the launch then forms each sample's
+                                         coefficient 1 / (its masked pixels x nvalid) from its own mask row and no mrg_loss_coef launch is needed */
     long mask_bs;                     /* elements between the mask rows of consecutive samples (0 = tokens per sample: a contiguous mask); lets a
                                          task's columns of the step's [B, all tokens] mask be read in place */
 } mrg_loss_desc;

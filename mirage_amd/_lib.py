@@ -74,7 +74,7 @@ class LossDesc(C.Structure):
     _fields_ = [("kind", ci), ("pred", vp), ("pred_dtype", ci), ("target", vp), ("mask", vp),
                 ("B", ci), ("C", ci), ("H", ci), ("W", ci), ("P", ci),
                 ("partial", vp), ("loss", vp), ("coef", vp), ("per_sample", vp), ("gout", vp), ("dpred", vp),
-                ("target_slot", vp), ("pred_tokens", ci), ("label_smoothing", cf), ("norm_pix", ci), ("stats", vp), ("mask_bs", cl)]
+                ("target_slot", vp), ("pred_tokens", ci), ("label_smoothing", cf), ("norm_pix", ci), ("stats", vp), ("nvalid", ci), ("mask_bs", cl)]
 
 
 class AdamWDesc(C.Structure):

@@ -108,6 +108,24 @@ __device__ __forceinline__ void loss_finish_block(const float* __restrict__ part
     }
 }
 
+// Backward coefficient of sample b inside a fused launch: coef[b] when the caller formed the coefficients (mrg_loss_coef), otherwise
+// 1 / (masked pixels of the sample x nvalid) from the sample's own mask row -- the caller guarantees that nvalid samples have masked
+// pixels (in the training step: every one, because fewer tokens are kept than a modality has).  Same expression as loss_finish_kernel's.
+__device__ __forceinline__ float fused_coef(const float* __restrict__ coef, const long* __restrict__ mask, long mbs, int b, int ntok, int ppt,
+                                            int nvalid, float* red) {
+    if (coef) return coef[b];
+    __shared__ float s_cb;
+    float c = 0.f;
+    if (mask) for (int t = threadIdx.x; t < ntok; t += blockDim.x) c += (float)mask[(long)b * mbs + t];
+    const float tot = block_sum(c, red);
+    if (threadIdx.x == 0) {
+        const float n = mask ? tot * (float)ppt : (float)ntok * (float)ppt;
+        s_cb = (n > 0.f && nvalid > 0) ? 1.f / (n * (float)nvalid) : 0.f;
+    }
+    __syncthreads();
+    return s_cb;
+}
+
 // grid (LOSS_CHUNKS, B); partial [B][LOSS_CHUNKS][2] = (sum of masked per-pixel loss, masked pixel count).
 // FUSED: the same pass writes dpred = gout * dloss / dpred with the backward coefficients `coef` that mrg_loss_coef formed from the mask
 // alone (the expressions of loss_bwd_kernel on the same mx / se: bit-identical to the two-launch path).  The batch statistics stay a launch of
@@ -118,13 +136,13 @@ __global__ __launch_bounds__(256) void loss_fwd_kernel(const T* __restrict__ pre
                                                        const void* const* __restrict__ tslot,
                                                        const long* __restrict__ mask, long mbs, int B, int C, int H, int W, int P, int tok,
                                                        float smooth, const float* __restrict__ stats, float* __restrict__ partial,
-                                                       const float* __restrict__ coef, const float* __restrict__ gout, T* __restrict__ dpred) {
+                                                       const float* __restrict__ coef, const float* __restrict__ gout, T* __restrict__ dpred, int nvalid) {
     if (tslot) target = *tslot;                              // input slot: the batch is read where it lies (mirage_hip.h, "Input slots")
     __shared__ float red[4];
     const int b = blockIdx.y, chunk = blockIdx.x;
     const int nw = W / P;
     const long HW = (long)H * W;
-    const float kb = FUSED ? (gout ? gout[0] : 1.f) * coef[b] : 0.f;
+    const float kb = FUSED ? (gout ? gout[0] : 1.f) * fused_coef(coef, mask, mbs, b, (H / P) * nw, P * P, nvalid, red) : 0.f;
     float s = 0.f, n = 0.f;
     for (long px = (long)chunk * 256 + threadIdx.x; px < HW; px += (long)LOSS_CHUNKS * 256) {
         const int y = (int)(px / W), x = (int)(px - (long)y * W);
@@ -265,13 +283,13 @@ template <bool FUSED, int C>
 __global__ __launch_bounds__(256) void ce_tok_vec_kernel(const bf16_t* __restrict__ pred, const long* __restrict__ target,
                                                          const void* const* __restrict__ tslot, const long* __restrict__ mask, long mbs,
                                                          int B, int H, int W, int P, float smooth, float* __restrict__ partial,
-                                                         const float* __restrict__ coef, const float* __restrict__ gout, bf16_t* __restrict__ dpred) {
+                                                         const float* __restrict__ coef, const float* __restrict__ gout, bf16_t* __restrict__ dpred, int nvalid) {
     if (tslot) target = static_cast<const long*>(*tslot);
     __shared__ float red[4];
     const int b = blockIdx.y, chunk = blockIdx.x;
     const int nw = W / P, PP = P * P, q8 = PP / 8, ntok = (H / P) * nw;
     const long total = (long)ntok * q8;                        // 16-B chunks of one class plane of the sample
-    const float kb = FUSED ? (gout ? gout[0] : 1.f) * coef[b] : 0.f;
+    const float kb = FUSED ? (gout ? gout[0] : 1.f) * fused_coef(coef, mask, mbs, b, ntok, PP, nvalid, red) : 0.f;
     const float sm_c = smooth / (float)C, hit = 1.f - smooth;
     auto lo = [](uint32_t w) { return __uint_as_float(w << 16); };
     auto hi = [](uint32_t w) { return __uint_as_float(w & 0xffff0000u); };
@@ -355,14 +373,14 @@ __global__ __launch_bounds__(256) void mse1_fwd_vec_kernel(const bf16_t* __restr
                                                            const void* const* __restrict__ tslot,
                                                            const long* __restrict__ mask, long mbs, int B, int H, int W, int P, int tok,
                                                            float* __restrict__ partial,
-                                                           const float* __restrict__ coef, const float* __restrict__ gout, bf16_t* __restrict__ dpred) {
+                                                           const float* __restrict__ coef, const float* __restrict__ gout, bf16_t* __restrict__ dpred, int nvalid) {
     if (tslot) target = static_cast<const float*>(*tslot);
     __shared__ float red[4];
     const int b = blockIdx.y, chunk = blockIdx.x;
     const int nw = W / P;
     const long HW8 = (long)H * W / 8;
     const float go = FUSED ? (gout ? gout[0] : 1.f) : 0.f;
-    const float cb = FUSED ? coef[b] : 0.f;
+    const float cb = FUSED ? fused_coef(coef, mask, mbs, b, (H / P) * nw, P * P, nvalid, red) : 0.f;
     float s = 0.f, n = 0.f;
     for (long v = (long)chunk * 256 + threadIdx.x; v < HW8; v += (long)LOSS_CHUNKS * 256) {
         const long px = v * 8;
@@ -456,7 +474,7 @@ long mask_stride(const mrg_loss_desc* d) { return d->mask_bs > 0 ? d->mask_bs : 
 
 int check(const mrg_loss_desc* d, const char* who) {
     MRG_REQUIRE(d != nullptr, MRG_ERR_ARG, "%s: null descriptor", who);
-    MRG_REQUIRE(d->pred && (d->target || d->target_slot) && d->partial && d->coef, MRG_ERR_ARG, "%s: null pointer", who);
+    MRG_REQUIRE(d->pred && (d->target || d->target_slot) && d->partial && (d->coef || d->nvalid > 0), MRG_ERR_ARG, "%s: null pointer", who);
     MRG_REQUIRE(d->kind == MRG_LOSS_MSE || d->kind == MRG_LOSS_CE, MRG_ERR_ARG, "%s: bad kind", who);
     MRG_REQUIRE(d->B > 0 && d->C > 0 && d->P > 0 && d->H % d->P == 0 && d->W % d->P == 0, MRG_ERR_SHAPE, "%s: bad geometry", who);
     MRG_REQUIRE(d->pred_dtype == MRG_DT_BF16 || d->pred_dtype == MRG_DT_F32, MRG_ERR_ARG, "%s: bad dtype", who);
@@ -484,21 +502,22 @@ int launch_loss_fwd(const mrg_loss_desc* d, bool fused, hipStream_t stream, cons
         if (rc) return rc;
     }
     const float* coef = fused ? d->coef : nullptr;
+    const int nvalid = d->nvalid;
     // the layer maps' 13 classes (mirage/output_adapters.py: num_channels of the semseg adapter); other class counts take the scalar kernel
     const bool vec_ce = d->kind == MRG_LOSS_CE && d->pred_tokens && d->pred_dtype == MRG_DT_BF16 && d->P % 8 == 0 && d->C == 13 && d->W % 8 == 0 &&
                         (((uintptr_t)d->pred | (uintptr_t)d->target | (fused ? (uintptr_t)d->dpred : 0)) & 15) == 0;
     if (vec_ce) {
 #define MRG_C(F) hipLaunchKernelGGL((ce_tok_vec_kernel<F, 13>), grid, block, 0, stream, (const bf16_t*)d->pred, (const long*)d->target, d->target_slot, d->mask, mbs, d->B, \
-                           d->H, d->W, d->P, d->label_smoothing, d->partial, coef, d->gout, (bf16_t*)d->dpred)
+                           d->H, d->W, d->P, d->label_smoothing, d->partial, coef, d->gout, (bf16_t*)d->dpred, nvalid)
         if (fused) MRG_C(true); else MRG_C(false);
 #undef MRG_C
     } else if (vec_mse) {
 #define MRG_V(F) hipLaunchKernelGGL(mse1_fwd_vec_kernel<F>, grid, block, 0, stream, (const bf16_t*)d->pred, (const float*)d->target, d->target_slot, d->mask, mbs, d->B, d->H, \
-                           d->W, d->P, d->pred_tokens, d->partial, coef, d->gout, (bf16_t*)d->dpred)
+                           d->W, d->P, d->pred_tokens, d->partial, coef, d->gout, (bf16_t*)d->dpred, nvalid)
         if (fused) MRG_V(true); else MRG_V(false);
 #undef MRG_V
     } else {
-#define MRG_L(T, CE, F) hipLaunchKernelGGL((loss_fwd_kernel<T, CE, F>), grid, block, 0, stream, (const T*)d->pred, d->target, d->target_slot, d->mask, mbs, d->B, d->C, d->H, d->W, d->P, d->pred_tokens, d->label_smoothing, d->norm_pix ? d->stats : nullptr, d->partial, coef, d->gout, (T*)d->dpred)
+#define MRG_L(T, CE, F) hipLaunchKernelGGL((loss_fwd_kernel<T, CE, F>), grid, block, 0, stream, (const T*)d->pred, d->target, d->target_slot, d->mask, mbs, d->B, d->C, d->H, d->W, d->P, d->pred_tokens, d->label_smoothing, d->norm_pix ? d->stats : nullptr, d->partial, coef, d->gout, (T*)d->dpred, nvalid)
 #define MRG_LF(T, CE) do { if (fused) MRG_L(T, CE, true); else MRG_L(T, CE, false); } while (0)
     if (d->pred_dtype == MRG_DT_BF16) { if (d->kind == MRG_LOSS_CE) MRG_LF(bf16_t, true); else MRG_LF(bf16_t, false); }
     else { if (d->kind == MRG_LOSS_CE) MRG_LF(float, true); else MRG_LF(float, false); }
@@ -530,6 +549,7 @@ extern "C" int mrg_masked_loss_fused(const mrg_loss_desc* d, hipStream_t stream)
     int rc = check(d, "mrg_masked_loss_fused");
     if (rc) return rc;
     MRG_REQUIRE(d->dpred, MRG_ERR_ARG, "mrg_masked_loss_fused: null dpred pointer");
+    MRG_REQUIRE(d->coef || (d->nvalid > 0 && d->nvalid <= d->B), MRG_ERR_ARG, "mrg_masked_loss_fused: neither coef nor a sample count 0 < nvalid <= B");
     return launch_loss_fwd(d, true, stream, "mrg_masked_loss_fused");
 }
 
@@ -542,7 +562,7 @@ extern "C" int mrg_masked_loss_finish(const mrg_loss_desc* d, hipStream_t stream
 extern "C" int mrg_masked_loss_bwd(const mrg_loss_desc* d, hipStream_t stream) {
     int rc = check(d, "mrg_masked_loss_bwd");
     if (rc) return rc;
-    MRG_REQUIRE(d->dpred, MRG_ERR_ARG, "mrg_masked_loss_bwd: null dpred");
+    MRG_REQUIRE(d->dpred && d->coef, MRG_ERR_ARG, "mrg_masked_loss_bwd: null dpred / coef");
     const long mbs = mask_stride(d);
     const long total = (long)d->B * d->H * d->W;
     dim3 grid((unsigned)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096)), block(256);

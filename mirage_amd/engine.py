@@ -941,12 +941,18 @@ class DecodersFn(torch.autograd.Function):
 
         fuse = loss_spec is not None and LaneLosses.fuse_bwd and LaneLosses.unit is not None and save
 
+        # fewer tokens are kept than a modality has => every sample has masked tokens in every modality: the fused launch then forms each
+        # sample's coefficient from its own mask row (mrg_loss_desc.nvalid) and the lane needs no mrg_loss_coef launch at its head
+        n_keep = ids_keep.shape[1]
+
         def job(i, ad):
             coef = None
             if fuse:
                 kind, patch, target, mask, smooth, npix = loss_spec[i]
                 H, W = target.shape[-2:]
-                coef = K.loss_coef(mask, target.shape[0], (H // patch) * (W // patch), patch * patch, enc32.device)
+                ntok_i = (H // patch) * (W // patch)
+                if not (mask is None or n_keep < ntok_i):
+                    coef = K.loss_coef(mask, target.shape[0], ntok_i, patch * patch, enc32.device)
             img, sv = decoder_fwd(ad, enc32, enc16, ids_keep, ids_restore, doms_l, start_l, ng, save)
             if loss_spec is None:
                 return img, sv, None
@@ -984,6 +990,8 @@ class DecodersFn(torch.autograd.Function):
                 if dpred is not None and LaneLosses.unit is not None and g.data_ptr() == LaneLosses.unit.data_ptr():
                     LaneLosses.fused_hits += 1
                     return decoder_bwd(ad, sv, dpred)          # the forward lane has written the gradient already (seed = 1)
+                if coef is None:                               # (the fused launch formed its coefficients itself)
+                    coef = K.loss_coef(d._refs[2], d.B, (d.H // d.P) * (d.W // d.P), d.P * d.P, img.device)
                 return decoder_bwd(ad, sv, K.masked_loss_bwd(d, coef, partial, g.contiguous().float(), img))
             jobs = [(lambda ad=ad, sv=sv, gl=gl: bwd(ad, sv, gl)) for ad, sv, gl in todo]
             ctx.loss_saved = None

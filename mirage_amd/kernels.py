@@ -829,13 +829,15 @@ def loss_coef(mask, B: int, ntok: int, ppt: int, device):
 
 def masked_loss_fused(d: "L.LossDesc", coef, device, gout=None):
     """The gradient of a masked loss (seeded with gout, None = 1) and the partial sums of its value in one pass over the predictions
-    (mrg_masked_loss_fused).  Returns (loss, partial, dpred, finish): `loss` holds the value once finish() -- the batch statistics, a tiny
+    (mrg_masked_loss_fused).  coef: mrg_loss_coef's coefficients, or None under the caller's guarantee that EVERY sample has masked pixels
+    (the launch then forms them from each sample's own mask row).  Returns (loss, partial, dpred, finish): `loss` holds the value once finish() -- the batch statistics, a tiny
     launch nothing in a training step waits for -- has run on some stream ordered behind this call."""
     partial = torch.empty(lib.mrg_loss_partial_floats(d.B), dtype=F32, device=device)
     loss = torch.empty((), dtype=F32, device=device)
     pred = d._refs[0]
     dpred = torch.empty_like(pred)
-    d.partial, d.loss, d.coef, d.gout, d.dpred = partial.data_ptr(), loss.data_ptr(), coef.data_ptr(), _p(gout), dpred.data_ptr()
+    d.partial, d.loss, d.coef, d.gout, d.dpred = partial.data_ptr(), loss.data_ptr(), _p(coef), _p(gout), dpred.data_ptr()
+    d.nvalid = 0 if coef is not None else d.B      # coef None: the caller guarantees that every sample has masked pixels
     check(lib.mrg_masked_loss_fused(C.byref(d), _s()), "mrg_masked_loss_fused")
 
     def finish():
