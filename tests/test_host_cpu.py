@@ -216,3 +216,33 @@ def test_gelu_cdf_rational_coefficients():
     assert float(np.abs(phi - ref).max()) <= 1e-6
     assert float(np.abs(x.astype(np.float64) * phi - x.astype(np.float64) * ref).max()) <= 1e-5
     assert float(phi.min()) >= -1e-6 and float(phi.max()) <= 1.0 + 1e-6
+
+
+def test_task_mask_columns_are_read_in_place_and_masked_pixel_coefficients():
+    """engine.loss_mask hands the loss kernels a task's columns of the step's [B, all tokens] mask without a copy (mrg_loss_desc.mask_bs) and
+    copies only what they cannot address; the backward coefficients the fused loss launch forms are 1 / (masked pixels x samples with any)
+    (criterion.py:36-51, 103-117: per-sample mean over the masked pixels, nanmean over the samples) -- restated here against torch autograd
+    of the oracle's masked MSE, which is what mrg_loss_coef / mrg_loss_desc.nvalid are tested against on the GPU."""
+    from mirage_amd import engine as E
+    from oracle import mirage_oracle as O
+    m = (torch.rand(4, 48) < 0.6).long()
+    v = E.loss_mask(m[:, 16:32])
+    assert v.data_ptr() == m[:, 16:32].data_ptr() and v.stride() == (48, 1)
+    assert E.loss_mask(None) is None
+    assert E.loss_mask(m.t()[:16].t()[:, ::2]).is_contiguous()                      # strided tokens: copied
+    assert E.loss_mask(m[:, :16].bool()).dtype == torch.int64
+    # coefficients: d loss / d pred = 2 (pred - target) mask coef[b] / C for the MSE
+    torch.manual_seed(3)
+    B, g, P = 4, 4, 2
+    pred = torch.randn(B, 1, g * P, g * P, requires_grad=True)
+    tgt = torch.rand(B, 1, g * P, g * P)
+    mask = (torch.rand(B, g * g) < 0.5).long()
+    mask[2] = 0
+    O.masked_mse(pred, tgt, mask, P).backward()
+    n = mask.sum(1).float() * P * P
+    nvalid = float((n > 0).sum())
+    coef = torch.where(n > 0, 1.0 / (n * nvalid), torch.zeros_like(n))
+    up = mask.view(B, 1, g, g).repeat_interleave(P, 2).repeat_interleave(P, 3).float()
+    want = 2.0 * (pred.detach() - tgt) * up * coef.view(B, 1, 1, 1)
+    keep = [0, 1, 3]                                                                # (the reference back-propagates NaN into sample 2)
+    torch.testing.assert_close(pred.grad[keep], want[keep], rtol=1e-5, atol=1e-7)
