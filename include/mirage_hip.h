@@ -26,7 +26,7 @@ extern "C" {
 typedef struct ihipStream_t* hipStream_t;
 #endif
 
-#define MRG_ABI_VERSION 14   /* 14: mrg_loss_coef, mrg_masked_loss_fused, mrg_masked_loss_finish (loss forward + gradient in one pass), mrg_loss_desc.nvalid / mask_bs; 13: the stream-K schedule of round 4 is gone (measured slower everywhere it was meant to win and selected nowhere: profiles/r04_streamk.md; the code is tools/debug/patches/streamk_r04.patch) -- variant 12 reserved, mrg_gemm_desc.sk_grid, mrg_wgrad_group_desc.streamk / counters / sk_grid, mrg_streamk_ws_bytes and mrg_debug_sk_trace removed; 12: MRG_GEMM_DUO (mrg_gemm_desc.variant 13: the 128 x 256 two-workgroups-per-CU kernel, csrc/gemm_duo.hip); 11: mrg_attn_desc.drop_rng / drop_p / drop_stream (dropout on the attention probabilities), mrg_posemb_grad, mrg_loss_desc.label_smoothing / norm_pix / stats, mrg_wgrad_group_desc.fuse + mrg_adamw_hp (AdamW in the weight-gradient epilogue), mrg_debug_clock_monitor; 10: MRG_GEMM_P8SK (stream-K schedule of the 8-phase kernel), mrg_gemm_desc.sk_grid, mrg_wgrad_group_desc.streamk / counters / sk_grid, mrg_streamk_ws_bytes; 9: mrg_maskgen_rng, input slots (mrg_set_slots, *_slot parameters, mrg_loss_desc.target_slot); 8: mrg_gemm_desc.drop_rng / drop_p / drop_stream, mrg_dropout_bwd_bf16; 7: mrg_wgrad_group, mrg_debug_timestamp; 2: mrg_gemm_desc grew row_scale / defer_reduce, act codes 3, 4, reduce_batch / augment / row_scale entry points; 3: colsum_out, attention colsum_*; 4: step = int[2], mrg_step_inc takes the skip decision; 5: splitk_counters, MRG_GEMM_P8, resize entry points; 6: mrg_adamw_desc.sumsq_out, mrg_sumsq_finish */
+#define MRG_ABI_VERSION 14   /* 14: mrg_gemm_multi; mrg_loss_coef, mrg_masked_loss_fused, mrg_masked_loss_finish (loss forward + gradient in one pass), mrg_loss_desc.nvalid / mask_bs; 13: the stream-K schedule of round 4 is gone (measured slower everywhere it was meant to win and selected nowhere: profiles/r04_streamk.md; the code is tools/debug/patches/streamk_r04.patch) -- variant 12 reserved, mrg_gemm_desc.sk_grid, mrg_wgrad_group_desc.streamk / counters / sk_grid, mrg_streamk_ws_bytes and mrg_debug_sk_trace removed; 12: MRG_GEMM_DUO (mrg_gemm_desc.variant 13: the 128 x 256 two-workgroups-per-CU kernel, csrc/gemm_duo.hip); 11: mrg_attn_desc.drop_rng / drop_p / drop_stream (dropout on the attention probabilities), mrg_posemb_grad, mrg_loss_desc.label_smoothing / norm_pix / stats, mrg_wgrad_group_desc.fuse + mrg_adamw_hp (AdamW in the weight-gradient epilogue), mrg_debug_clock_monitor; 10: MRG_GEMM_P8SK (stream-K schedule of the 8-phase kernel), mrg_gemm_desc.sk_grid, mrg_wgrad_group_desc.streamk / counters / sk_grid, mrg_streamk_ws_bytes; 9: mrg_maskgen_rng, input slots (mrg_set_slots, *_slot parameters, mrg_loss_desc.target_slot); 8: mrg_gemm_desc.drop_rng / drop_p / drop_stream, mrg_dropout_bwd_bf16; 7: mrg_wgrad_group, mrg_debug_timestamp; 2: mrg_gemm_desc grew row_scale / defer_reduce, act codes 3, 4, reduce_batch / augment / row_scale entry points; 3: colsum_out, attention colsum_*; 4: step = int[2], mrg_step_inc takes the skip decision; 5: splitk_counters, MRG_GEMM_P8, resize entry points; 6: mrg_adamw_desc.sumsq_out, mrg_sumsq_finish */
 
 enum { MRG_DT_BF16 = 0, MRG_DT_F32 = 1 };
 enum { MRG_OP_KCONTIG = 0, MRG_OP_KSTRIDED = 1 };
@@ -108,6 +108,11 @@ typedef struct mrg_gemm_desc {
 enum { MRG_GEMM_AUTO = 0, MRG_GEMM_GLDS3 = 1, MRG_GEMM_GLDS4 = 2, MRG_GEMM_PIPE128 = 3, MRG_GEMM_PIPE256 = 4, /* 5, 6, 9 reserved: a three-stage 256 x 128 kernel, a two-stage 256 x 256 kernel and a persistent one, measured and dropped */ MRG_GEMM_WS256 = 7, MRG_GEMM_GLDS64 = 8, MRG_GEMM_G256 = 10, MRG_GEMM_P8 = 11, /* 12 reserved */ MRG_GEMM_DUO = 13 };
 
 int mrg_gemm(const mrg_gemm_desc* d, hipStream_t stream);
+/* n <= MRG_MAX_DOMAINS independent forward-layout products (descriptors ds[0 .. n-1], results identical to n mrg_gemm calls) in ONE launch:
+ * the patch projections of a step's modalities (mirage/input_adapters.py:101,229 run once per modality) are each a chain of k-tiles on fewer
+ * tiles than the chip has CUs; side by side their chains overlap.  Accepted: both operands k-contiguous and 16-byte aligned, K % 64 == 0,
+ * N % 4 == 0, act none, optional bias, m_dev, row_map + add_tab / add_row, fp32 or bf16 C; anything else is refused (MRG_ERR_UNSUPPORTED). */
+int mrg_gemm_multi(const mrg_gemm_desc* ds, int n, hipStream_t stream);
 
 /* Grouped weight gradients: C_p[M_p, N_p] (fp32, row stride ldc_p, OVERWRITTEN) = A_p^T B_p for p < count, with A_p = dY bf16 [K, M_p]
  * (row stride lda_p) and B_p = X bf16 [K, N_p] (row stride ldb_p): both operands contracted over their leading (token) axis, i.e.

@@ -111,6 +111,7 @@ SIGNATURES = {
     "mrg_dec_assemble_fwd": (ci, [C.POINTER(DecAssembleDesc), vp]),
     "mrg_dec_assemble_bwd_nblocks": (ci, [ci, ci, ci]),
     "mrg_dec_assemble_bwd": (ci, [C.POINTER(DecAssembleDesc), vp]),
+    "mrg_gemm_multi": (ci, [vp, ci, vp]),
     "mrg_loss_partial_floats": (ci, [ci]),
     "mrg_masked_loss_fwd": (ci, [C.POINTER(LossDesc), vp]),
     "mrg_masked_loss_bwd": (ci, [C.POINTER(LossDesc), vp]),

@@ -170,7 +170,7 @@ __device__ __forceinline__ void glds_setup(const bf16_t* P, int ld, int row0, in
 // 16 B (fp32 x 4) per quad -- no fp32 round trip of the tile through LDS (64 ds_write_b32 + 16 ds_read_b128 per lane, at the LDS's
 // ~64-80 B/clk store rate about 1000 cycles per tile) and none of its four barriers.
 template <int AMODE, int BMODE, bool VEC, int OCC, bool CSUM = false, bool KF = false, bool DIRECT = false, bool DROP = false>
-__global__ __launch_bounds__(256, OCC) void gemm_glds_kernel(const GemmArgs g) {
+__device__ __forceinline__ void gemm_glds_body(const GemmArgs& g) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int nwg = g.tiles_m * g.tiles_n;
     int bid, ksplit;
@@ -385,6 +385,23 @@ __global__ __launch_bounds__(256, OCC) void gemm_glds_kernel(const GemmArgs g) {
             g.colsum[(long)tm * g.N + n0 + tid] = t;
         }
     }
+}
+
+template <int AMODE, int BMODE, bool VEC, int OCC, bool CSUM = false, bool KF = false, bool DIRECT = false, bool DROP = false>
+__global__ __launch_bounds__(256, OCC) void gemm_glds_kernel(const GemmArgs g) {
+    gemm_glds_body<AMODE, BMODE, VEC, OCC, CSUM, KF, DIRECT, DROP>(g);
+}
+
+// Several independent problems in ONE launch (mrg_gemm_multi: the patch projections of a step's modalities, mirage/input_adapters.py:101,229):
+// blockIdx.z selects the problem, the grid's x extent is the largest tile count rounded up to a multiple of 8 (so that a block's XCD is
+// blockIdx.x & 7 for every z, as wg_remap assumes), surplus blocks leave.  Each problem alone is a latency chain over its k-tiles on
+// fewer tiles than CUs; side by side their chains overlap (2 x 31 us -> one launch).
+struct GemmMultiArgs { GemmArgs g[MRG_MAX_DOMAINS]; };
+template <int AMODE, int BMODE, bool VEC, int OCC, bool KF>
+__global__ __launch_bounds__(256, OCC) void gemm_glds_multi_kernel(const GemmMultiArgs m) {
+    const GemmArgs& g = m.g[blockIdx.z];
+    if ((int)blockIdx.x >= g.tiles_m * g.tiles_n) return;
+    gemm_glds_body<AMODE, BMODE, VEC, OCC, false, KF, false, false>(g);
 }
 
 // LDS-DMA issued from inline asm: invisible to hipcc's s_waitcnt bookkeeping, so the compiler does not drain the
@@ -1335,6 +1352,49 @@ extern "C" int mrg_gemm(const mrg_gemm_desc* d, hipStream_t stream) {
     int rc = mrg_check_launch("mrg_gemm");
     if (rc) return rc;
     return finish_splitk();
+}
+
+// n independent forward-layout products in one launch of the single-stage 128 x 128 kernel (gemm_glds_multi_kernel).  The narrow case the
+// step needs: both operands k-contiguous and 16-B aligned, K a multiple of 64, no split-K / maps on the operands / device-side K /
+// column sums / dropout / accumulate; every fused epilogue of that layout (bias, table row at a mapped output row, fp32 or bf16 C, m_dev).
+extern "C" int mrg_gemm_multi(const mrg_gemm_desc* ds, int n, hipStream_t stream) {
+    MRG_REQUIRE(ds != nullptr && n >= 1 && n <= MRG_MAX_DOMAINS, MRG_ERR_ARG, "mrg_gemm_multi: %d problems (1 .. %d)", n, MRG_MAX_DOMAINS);
+    GemmMultiArgs m;
+    int gx = 0;
+    for (int p = 0; p < n; ++p) {
+        const mrg_gemm_desc* d = ds + p;
+        GemmArgs& g = m.g[p];
+        MRG_REQUIRE(d->A && d->B && d->C && d->M > 0 && d->N > 0 && d->K > 0, MRG_ERR_ARG, "mrg_gemm_multi: problem %d: null operand or empty shape", p);
+        MRG_REQUIRE(d->a_mode == MRG_OP_KCONTIG && d->b_mode == MRG_OP_KCONTIG && d->K % BK == 0 && d->splitk <= 1 && !d->a_map && !d->b_map && !d->k_dev &&
+                    !d->colsum_out && !d->accumulate && !(d->drop_rng && d->drop_p > 0.f) && !d->resid && !d->row_scale && !d->C2 && d->act == MRG_ACT_NONE,
+                    MRG_ERR_UNSUPPORTED, "mrg_gemm_multi: problem %d is outside the forward-layout case this entry point launches", p);
+        MRG_REQUIRE(!d->add_tab || d->add_row, MRG_ERR_ARG, "mrg_gemm_multi: add_tab needs add_row");
+        g = GemmArgs{};
+        g.A = (const bf16_t*)d->A; g.B = (const bf16_t*)d->B;
+        g.M = d->M; g.N = d->N; g.K = d->K; g.lda = d->lda; g.ldb = d->ldb;
+        g.m_dev = d->m_dev;
+        g.a_aligned = (((uintptr_t)d->A & 15) == 0) && (d->lda % 8 == 0);
+        g.b_aligned = (((uintptr_t)d->B & 15) == 0) && (d->ldb % 8 == 0);
+        g.C = d->C; g.ldc = d->ldc; g.c_f32 = (d->c_dtype == MRG_DT_F32);
+        g.bias = d->bias; g.act = d->act;
+        g.row_map = d->row_map; g.add_tab = d->add_tab; g.add_row = d->add_row; g.ldt = d->ldt;
+        g.splitk = 1; g.drop.scale = 1.f;
+        g.tiles_m = cdiv(d->M, BM); g.tiles_n = cdiv(d->N, BN);
+        g.nt = 2; g.xcd_split = 1; g.side_drain = 3;
+        auto al4 = [](const void* q, int ld, int bytes) { return q == nullptr || ((((uintptr_t)q) % (4 * bytes) == 0) && (ld % 4 == 0)); };
+        const bool vec = (d->N % 4 == 0) && al4(d->C, d->ldc, g.c_f32 ? 4 : 2) && al4(d->add_tab, d->ldt, 4);
+        MRG_REQUIRE(g.a_aligned && g.b_aligned && vec, MRG_ERR_UNSUPPORTED, "mrg_gemm_multi: problem %d: operands / outputs must be 16-B aligned with N %% 4 == 0", p);
+        // lean epilogues of this layout (mrg_gemm's selection): bias -> bf16 (1), bias + table row -> fp32 C at a mapped row (6); else generic
+        g.epi_kind = 0;
+        if (!d->add_tab && !d->row_map && !g.c_f32) g.epi_kind = 1;
+        else if (d->add_tab && d->add_row && d->row_map && g.c_f32) g.epi_kind = 6;
+        const int nt = g.tiles_m * g.tiles_n;
+        gx = nt > gx ? nt : gx;
+    }
+    for (int p = n; p < MRG_MAX_DOMAINS; ++p) m.g[p] = m.g[0];
+    const dim3 grid((unsigned)((gx + 7) & ~7), 1, (unsigned)n), block(256);
+    hipLaunchKernelGGL((gemm_glds_multi_kernel<0, 0, true, 3, true>), grid, block, (size_t)(2 * TILE_BYTES), stream, m);
+    return mrg_check_launch("mrg_gemm_multi");
 }
 
 // Grouped weight gradients (gemm8p.hip gemm_p8_group_kernel): C_p[M_p, N_p] (fp32, overwritten) = A_p^T B_p, A_p = dY [K, M_p],

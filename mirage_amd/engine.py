@@ -22,6 +22,7 @@ BF16, F32 = torch.bfloat16, torch.float32
 KS = L.MRG_OP_KSTRIDED
 FUSE_EPI_COLSUM = True    # bias gradient of the producing layer from the dgrad GEMM's epilogue (column sums of dx per tile)
 EMBED_WGRAD_GATHER = True # patch-embedding weight gradient: compact the gradient rows, then a plain k-strided GEMM (A/B: MRG_EMBED_GATHER=0)
+EMBED_MULTI = os.environ.get("MRG_EMBED_MULTI", "1") != "0"   # the modalities' patch projections in one launch (mrg_gemm_multi)
 EMBED_LANES = os.environ.get("MRG_EMBED_LANES", "0") != "0"   # the modalities' patch projections side by side on lane streams: measured neutral (C2 9.52 / 9.54 vs 9.54 / 9.51 ms, C4 20.46 vs 20.53), the two cross-stream edges cost what the shared round saves
 CHAIN_END_FLUSH = os.environ.get("MRG_CHAIN_END_FLUSH", "0") != "0"   # experiment: side-stream fork at the end of the encoder's dgrad chain (neutral)
 FUSE_ATTN_BIAS = True     # q / k / v bias gradients from inside the attention-backward kernels (else: a column-sum pass over d_qkv)
@@ -616,13 +617,26 @@ def embed_fwd(model, x: Dict[str, torch.Tensor], ids_keep: torch.Tensor, save: b
             A = K.im2col_image(inp.contiguous().float(), srcb[d], toks[d], counts[d:d + 1], cap, ad.P_H)
         W = shadow(ad.proj.weight)
         Kp = A.shape[1]
-        K.gemm(A, W, cap, D, Kp, lda=Kp, ldb=Kp, out=x0, ldc=D, bias=ad.proj.bias, row_map=rows[d], add_tab=_pos_tokens(ad),
-               add_row=toks[d], m_dev=counts[d:d + 1])
+        pr = dict(A=A, B=W, M=cap, N=D, K=Kp, lda=Kp, ldb=Kp, out=x0, ldc=D, bias=ad.proj.bias, row_map=rows[d], add_tab=_pos_tokens(ad),
+                  add_row=toks[d], m_dev=counts[d:d + 1])
+        if group is not None:
+            group.append(pr)
+        else:
+            K.gemm_multi([pr])
         return A if save else None
-    # the modalities' patch projections are independent (disjoint rows of x0) and each fills about 1 / ndom of its capacity-sized
-    # grid: MRG_EMBED_LANES=1 runs them side by side on lane streams (one shared round of the chip instead of one each)
+    # the modalities' patch projections are independent (disjoint rows of x0), each a latency chain over its 16 k-tiles on fewer tiles than
+    # CUs: they leave as ONE launch (mrg_gemm_multi, MRG_EMBED_MULTI=0: one launch each).  (MRG_EMBED_LANES=1, side by side on lane
+    # streams, was measured neutral: the two cross-stream edges cost what the shared round saves.)
+    group = [] if (EMBED_MULTI and not EMBED_LANES and len(doms) > 1 and all(x[dom].shape[-1] % 8 == 0 for dom in doms)) else None
     saved = _Lanes.run_all([(lambda d=d, dom=dom: embed_one(d, dom)) for d, dom in enumerate(doms)], dev,
                            enabled=_Lanes.enabled and EMBED_LANES)
+    if group:
+        ok = all(pr["K"] % 64 == 0 and pr["A"].data_ptr() % 16 == 0 and pr["B"].data_ptr() % 16 == 0 for pr in group)
+        if ok:
+            K.gemm_multi(group)
+        else:
+            for pr in group:
+                K.gemm_multi([pr])
     K.fill_global(x0, model.global_tokens, B, N, Kk)
     plan = (rows, toks, srcb, counts)
     return x0, (plan, saved, {k: x[k] for k in doms}) if save else None

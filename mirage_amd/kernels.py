@@ -340,6 +340,34 @@ def gemm(A: torch.Tensor, B: torch.Tensor, M: int, N: int, K: int, *, a_mode=L.M
     return out
 
 
+def gemm_multi(problems):
+    """Several independent forward-layout products y = A W^T (+ bias) (+ table row at a mapped output row) in ONE launch (mrg_gemm_multi).
+    problems: list of dicts with the keyword arguments of gemm() that this entry point accepts (A, B, M, N, K, lda, ldb, out, ldc, bias,
+    row_map, add_tab, add_row, m_dev).  Results are those of the separate gemm() calls."""
+    n = len(problems)
+    if TIMING["on"] or n == 1 or n > L.MRG_MAX_DOMAINS:          # (the instrumented roofline step times every product on its own)
+        for pr in problems:
+            gemm(pr["A"], pr["B"], pr["M"], pr["N"], pr["K"], lda=pr.get("lda"), ldb=pr.get("ldb"), out=pr["out"], ldc=pr.get("ldc"), bias=pr.get("bias"),
+                 row_map=pr.get("row_map"), add_tab=pr.get("add_tab"), add_row=pr.get("add_row"), m_dev=pr.get("m_dev"))
+        return
+    arr = (L.GemmDesc * n)()
+    for d, pr in zip(arr, problems):
+        A, B, out = pr["A"], pr["B"], pr["out"]
+        _need_cuda(A, "GEMM operand")
+        d.A, d.B, d.C = A.data_ptr(), B.data_ptr(), out.data_ptr()
+        d.M, d.N, d.K = pr["M"], pr["N"], pr["K"]
+        d.lda = pr.get("lda") or A.stride(0)
+        d.ldb = pr.get("ldb") or B.stride(0)
+        d.ldc = pr.get("ldc") or out.stride(-2)
+        d.a_mode = d.b_mode = L.MRG_OP_KCONTIG
+        d.c_dtype = L.MRG_DT_F32 if out.dtype == F32 else L.MRG_DT_BF16
+        d.bias, d.row_map, d.m_dev = _p(pr.get("bias")), _p(pr.get("row_map")), _p(pr.get("m_dev"))
+        if pr.get("add_tab") is not None:
+            d.add_tab, d.add_row, d.ldt = pr["add_tab"].data_ptr(), pr["add_row"].data_ptr(), pr["add_tab"].stride(0)
+        d.act, d.splitk = L.MRG_ACT_NONE, 1
+    check(lib.mrg_gemm_multi(C.cast(arr, C.c_void_p), n, _s()), "mrg_gemm_multi")
+
+
 class WgradGroup:
     """Weight gradients of several Linears in ONE launch without split-K (mrg_wgrad_group, gemm8p.hip).  While `collecting`
     (engine._Side: the side-stream jobs of a flush), gemm() calls that are plain weight gradients -- both operands contracted over

@@ -347,6 +347,52 @@ def test_gemm_epilogues(K):
     torch.testing.assert_close(acc, res + A.float() @ W.float().t(), rtol=2e-3, atol=2e-3 * float(lin.abs().max()))
 
 
+def test_gemm_multi_is_the_separate_launches(K):
+    """mrg_gemm_multi: the patch projections of a step's modalities in one launch (different weights, row maps, positional tables, device-side
+    row counts per problem -- a count of zero and a full one included; then three bf16-output products of different widths) == one mrg_gemm
+    launch each, bit for bit; what the entry point does not launch is refused."""
+    from mirage_amd import _lib as L
+    torch.manual_seed(11)
+    B, Kk, D, Kp, ntok = 8, 48, 256, 192, 64
+    cap = B * Kk
+    x_ref = torch.full((B, Kk + 1, D), float("nan"), device=dev())
+    x_new = x_ref.clone()
+    perm = torch.randperm(B * (Kk + 1), device=dev())[:cap].int()
+    counts = [150, 0, cap - 150 - 60]
+    problems = []
+    start = 0
+    for d, cnt in enumerate(counts):
+        A = rnd(cap, Kp, dtype=BF16, seed=200 + d)
+        W = rnd(D, Kp, dtype=BF16, seed=210 + d) * 0.05
+        bias = rnd(D, seed=220 + d)
+        rows = torch.zeros(cap, dtype=torch.int32, device=dev())
+        rows[:cnt] = perm[start:start + cnt]
+        start += cnt
+        toks = torch.randint(0, ntok, (cap,), device=dev()).int()
+        tab = rnd(ntok, D, seed=230 + d)
+        m_dev = torch.tensor([cnt], dtype=torch.int32, device=dev())
+        problems.append(dict(A=A, B=W, M=cap, N=D, K=Kp, lda=Kp, ldb=Kp, ldc=D, bias=bias, row_map=rows, add_tab=tab, add_row=toks, m_dev=m_dev))
+    for pr in problems:
+        K.gemm(pr["A"], pr["B"], pr["M"], pr["N"], pr["K"], lda=Kp, ldb=Kp, out=x_ref, ldc=D, bias=pr["bias"], row_map=pr["row_map"], add_tab=pr["add_tab"],
+               add_row=pr["add_row"], m_dev=pr["m_dev"])
+    K.gemm_multi([dict(pr, out=x_new) for pr in problems])
+    torch.cuda.synchronize()
+    written = ~torch.isnan(x_ref)
+    assert int(written.sum()) == (counts[0] + counts[2]) * D and torch.equal(written, ~torch.isnan(x_new))
+    assert torch.equal(x_ref[written], x_new[written])
+    # plain bias -> bf16 products of different shapes
+    plain = []
+    for i, (M, N, Kd) in enumerate(((300, 128, 64), (77, 384, 256), (1000, 260, 128))):
+        plain.append(dict(A=rnd(M, Kd, dtype=BF16, seed=240 + i), B=rnd(N, Kd, dtype=BF16, seed=250 + i) * 0.1, M=M, N=N, K=Kd, bias=rnd(N, seed=260 + i)))
+    ref = [K.gemm(pr["A"], pr["B"], pr["M"], pr["N"], pr["K"], bias=pr["bias"]) for pr in plain]
+    outs = [torch.empty_like(r) for r in ref]
+    K.gemm_multi([dict(pr, out=o) for pr, o in zip(plain, outs)])
+    for r, o in zip(ref, outs):
+        assert torch.equal(r, o)
+    with pytest.raises(RuntimeError):                                   # K % 64 != 0
+        K.gemm_multi([dict(A=rnd(64, 40, dtype=BF16), B=rnd(64, 40, dtype=BF16), M=64, N=64, K=40, out=torch.empty(64, 64, dtype=BF16, device=dev()))] * 2)
+
+
 def test_gemm_maps_and_device_counts(K):
     from mirage_amd import _lib as L
     cap, Kd, D, count = 700, 1024, 256, 413
