@@ -631,11 +631,13 @@ def embed_fwd(model, x: Dict[str, torch.Tensor], ids_keep: torch.Tensor, save: b
     saved = _Lanes.run_all([(lambda d=d, dom=dom: embed_one(d, dom)) for d, dom in enumerate(doms)], dev,
                            enabled=_Lanes.enabled and EMBED_LANES)
     if group:
-        ok = all(pr["K"] % 64 == 0 and pr["A"].data_ptr() % 16 == 0 and pr["B"].data_ptr() % 16 == 0 for pr in group)
-        if ok:
-            K.gemm_multi(group)
-        else:
-            for pr in group:
+        # one launch for the problems the single-stage kernel is the choice for (< 24 k-tiles, mrg_gemm's own rule); a long-K projection
+        # (the layer maps' class-embedding patches) keeps its pipelined launch: inside the shared launch it would set the pace (C4: 110 vs 66 us)
+        fits = lambda pr: pr["K"] % 64 == 0 and pr["K"] < 24 * 64 and pr["A"].data_ptr() % 16 == 0 and pr["B"].data_ptr() % 16 == 0
+        short = [pr for pr in group if fits(pr)]
+        K.gemm_multi(short) if len(short) > 1 else [K.gemm_multi([pr]) for pr in short]
+        for pr in group:
+            if not fits(pr):
                 K.gemm_multi([pr])
     K.fill_global(x0, model.global_tokens, B, N, Kk)
     plan = (rows, toks, srcb, counts)
