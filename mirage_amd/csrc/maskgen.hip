@@ -72,7 +72,7 @@ __device__ __forceinline__ int rank_of(const u64* key, int lo, int hi, u64 mine)
 }
 
 template <bool RNG>
-__global__ __launch_bounds__(512) void maskgen_kernel(const MaskArgs a) {
+__global__ __launch_bounds__(1024) void maskgen_kernel(const MaskArgs a) {
     __shared__ __attribute__((aligned(16))) u64 key[MAXT];
     __shared__ float tie[MAXT];
     __shared__ int perm[MAXT];
@@ -163,7 +163,7 @@ extern "C" int mrg_maskgen(const float* p, const float* u, const float* g, int B
     a.p = p; a.u = u; a.g = g; a.B = B; a.T = T; a.K = K; a.ndom = ndom;
     for (int i = 0; i <= MAXDOM; ++i) a.dom_start[i] = i <= ndom ? dom_start_host[i] : T;
     a.task_mask = task_mask; a.ids_keep = ids_keep; a.ids_restore = ids_restore;
-    hipLaunchKernelGGL(maskgen_kernel<false>, dim3(B), dim3(512), 0, stream, a);
+    hipLaunchKernelGGL(maskgen_kernel<false>, dim3(B), dim3(T > 512 ? 1024 : 512), 0, stream, a);      // one token per thread (the rank loops are O(T) per token)
     return mrg_check_launch("mrg_maskgen");
 }
 
@@ -177,6 +177,6 @@ extern "C" int mrg_maskgen_rng(const float* conc, unsigned long long* rng, int B
     a.B = B; a.T = T; a.K = K; a.ndom = ndom;
     for (int i = 0; i <= MAXDOM; ++i) a.dom_start[i] = i <= ndom ? dom_start_host[i] : T;
     a.task_mask = task_mask; a.ids_keep = ids_keep; a.ids_restore = ids_restore;
-    hipLaunchKernelGGL(maskgen_kernel<true>, dim3(B), dim3(512), 0, stream, a);
+    hipLaunchKernelGGL(maskgen_kernel<true>, dim3(B), dim3(T > 512 ? 1024 : 512), 0, stream, a);
     return mrg_check_launch("mrg_maskgen_rng");
 }
