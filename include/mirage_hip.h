@@ -26,7 +26,7 @@ extern "C" {
 typedef struct ihipStream_t* hipStream_t;
 #endif
 
-#define MRG_ABI_VERSION 14   /* 14: mrg_gemm_multi; mrg_loss_coef, mrg_masked_loss_fused, mrg_masked_loss_finish (loss forward + gradient in one pass), mrg_loss_desc.nvalid / mask_bs; 13: the stream-K schedule of round 4 is gone (measured slower everywhere it was meant to win and selected nowhere: profiles/r04_streamk.md; the code is tools/debug/patches/streamk_r04.patch) -- variant 12 reserved, mrg_gemm_desc.sk_grid, mrg_wgrad_group_desc.streamk / counters / sk_grid, mrg_streamk_ws_bytes and mrg_debug_sk_trace removed; 12: MRG_GEMM_DUO (mrg_gemm_desc.variant 13: the 128 x 256 two-workgroups-per-CU kernel, csrc/gemm_duo.hip); 11: mrg_attn_desc.drop_rng / drop_p / drop_stream (dropout on the attention probabilities), mrg_posemb_grad, mrg_loss_desc.label_smoothing / norm_pix / stats, mrg_wgrad_group_desc.fuse + mrg_adamw_hp (AdamW in the weight-gradient epilogue), mrg_debug_clock_monitor; 10: MRG_GEMM_P8SK (stream-K schedule of the 8-phase kernel), mrg_gemm_desc.sk_grid, mrg_wgrad_group_desc.streamk / counters / sk_grid, mrg_streamk_ws_bytes; 9: mrg_maskgen_rng, input slots (mrg_set_slots, *_slot parameters, mrg_loss_desc.target_slot); 8: mrg_gemm_desc.drop_rng / drop_p / drop_stream, mrg_dropout_bwd_bf16; 7: mrg_wgrad_group, mrg_debug_timestamp; 2: mrg_gemm_desc grew row_scale / defer_reduce, act codes 3, 4, reduce_batch / augment / row_scale entry points; 3: colsum_out, attention colsum_*; 4: step = int[2], mrg_step_inc takes the skip decision; 5: splitk_counters, MRG_GEMM_P8, resize entry points; 6: mrg_adamw_desc.sumsq_out, mrg_sumsq_finish */
+#define MRG_ABI_VERSION 15   /* 15: mrg_rowfuse_fwd (the output adapters' row-local chains in one launch, csrc/rowfuse.hip); 14: mrg_gemm_multi; mrg_loss_coef, mrg_masked_loss_fused, mrg_masked_loss_finish (loss forward + gradient in one pass), mrg_loss_desc.nvalid / mask_bs; 13: the stream-K schedule of round 4 is gone (measured slower everywhere it was meant to win and selected nowhere: profiles/r04_streamk.md; the code is tools/debug/patches/streamk_r04.patch) -- variant 12 reserved, mrg_gemm_desc.sk_grid, mrg_wgrad_group_desc.streamk / counters / sk_grid, mrg_streamk_ws_bytes and mrg_debug_sk_trace removed; 12: MRG_GEMM_DUO (mrg_gemm_desc.variant 13: the 128 x 256 two-workgroups-per-CU kernel, csrc/gemm_duo.hip); 11: mrg_attn_desc.drop_rng / drop_p / drop_stream (dropout on the attention probabilities), mrg_posemb_grad, mrg_loss_desc.label_smoothing / norm_pix / stats, mrg_wgrad_group_desc.fuse + mrg_adamw_hp (AdamW in the weight-gradient epilogue), mrg_debug_clock_monitor; 10: MRG_GEMM_P8SK (stream-K schedule of the 8-phase kernel), mrg_gemm_desc.sk_grid, mrg_wgrad_group_desc.streamk / counters / sk_grid, mrg_streamk_ws_bytes; 9: mrg_maskgen_rng, input slots (mrg_set_slots, *_slot parameters, mrg_loss_desc.target_slot); 8: mrg_gemm_desc.drop_rng / drop_p / drop_stream, mrg_dropout_bwd_bf16; 7: mrg_wgrad_group, mrg_debug_timestamp; 2: mrg_gemm_desc grew row_scale / defer_reduce, act codes 3, 4, reduce_batch / augment / row_scale entry points; 3: colsum_out, attention colsum_*; 4: step = int[2], mrg_step_inc takes the skip decision; 5: splitk_counters, MRG_GEMM_P8, resize entry points; 6: mrg_adamw_desc.sumsq_out, mrg_sumsq_finish */
 
 enum { MRG_DT_BF16 = 0, MRG_DT_F32 = 1 };
 enum { MRG_OP_KCONTIG = 0, MRG_OP_KSTRIDED = 1 };
@@ -171,6 +171,27 @@ int mrg_ln_bwd(const void* dy_bf16, const float* dy_f32, const float* x, const f
 int mrg_colsum_nblocks(int M);
 int mrg_colsum(const void* x, int x_dtype, int M, int N, int ld, const int* row_map, const int* m_dev, float* partials,
                float* out, hipStream_t stream);
+
+/* ---------------------------------------------------------------------------------------------------
+ * Row-local chains of the 256-wide output adapters in ONE launch (csrc/rowfuse.hip).  Rows are 256 wide, M % 64 == 0, every
+ * operand contiguous and 16-byte aligned, weights bf16 [out][in] as nn.Linear stores them, biases / LayerNorm vectors fp32.
+ *   a0 != NULL ("post-attention"):  x = a0 W0^T + b0 (+ resid);  ln = LayerNorm(x; gamma, beta, eps);  h = gelu(ln W1^T + b1);
+ *        y = h W2^T + b2 + x.   a0 bf16 [M,256] (attention output), W0 [256,256], W1 [NH,256], W2 [256,NH], NH = 1024:
+ *        attn.proj (+ residual), norm2 / out_norm and the Mlp of a decoder Block or of the adapter's cross-attention stage
+ *        (mirage/utils.py:155-158,186-187,259-262; mirage/output_adapters.py:279-280).  y32 fp32 [M,256] (+ optional bf16 copy y16).
+ *   a0 == NULL ("norm + projection"): x = resid (fp32 [M,256]);  h_out = LayerNorm(x) W1^T + b1, bf16 [M,NH], NH = 256 / 512 / 768:
+ *        query_norm + q, context_norm + kv (mirage/output_adapters.py:275-276), norm1 + qkv (mirage/utils.py:177,259).
+ *   training side outputs (all or none; ln_out != NULL selects them): x_out fp32 [M,256] (a0 != NULL only), mean / rstd fp32 [M],
+ *        ln_out bf16 [M,256], and with a0 != NULL h_out = gelu(.) bf16 [M,NH] and hgrad_out = gelu'(.) IEEE fp16 [M,NH] -- the tensors
+ *        mrg_ln_fwd and the MRG_ACT_GELU_SAVE_GRAD epilogue of mrg_gemm leave for the backward pass. */
+typedef struct mrg_rowfuse_desc {
+    int M, NH; float eps;
+    const void* a0; const void* w0; const float* b0; const float* resid; float* x_out;
+    const float* gamma; const float* beta; float* mean; float* rstd; void* ln_out;
+    const void* w1; const float* b1; void* h_out; void* hgrad_out;
+    const void* w2; const float* b2; float* y32; void* y16;
+} mrg_rowfuse_desc;
+int mrg_rowfuse_fwd(const mrg_rowfuse_desc* d, hipStream_t stream);
 
 /* ---------------------------------------------------------------------------------------------------
  * Fused softmax attention.  Replaces F.scaled_dot_product_attention (mirage/utils.py:181 self, :216 cross;

@@ -77,6 +77,12 @@ class LossDesc(C.Structure):
                 ("target_slot", vp), ("pred_tokens", ci), ("label_smoothing", cf), ("norm_pix", ci), ("stats", vp), ("nvalid", ci), ("mask_bs", cl)]
 
 
+class RowFuseDesc(C.Structure):
+    _fields_ = [("M", ci), ("NH", ci), ("eps", cf), ("a0", vp), ("w0", vp), ("b0", vp), ("resid", vp), ("x_out", vp),
+                ("gamma", vp), ("beta", vp), ("mean", vp), ("rstd", vp), ("ln_out", vp),
+                ("w1", vp), ("b1", vp), ("h_out", vp), ("hgrad_out", vp), ("w2", vp), ("b2", vp), ("y32", vp), ("y16", vp)]
+
+
 class AdamWDesc(C.Structure):
     _fields_ = [("p", vp), ("g", vp), ("m", vp), ("v", vp), ("shadow_bf16", vp), ("n", cl), ("n_decay", cl),
                 ("lr_table", vp), ("wd_table", vp), ("step", vp), ("table_len", ci),
@@ -133,6 +139,7 @@ SIGNATURES = {
     "mrg_dropout_bwd_bf16": (ci, [vp, vp, vp, cl, ci, vp, cf, C.c_uint, vp]),
     "mrg_ln_bwd_partial_rows": (ci, [ci, ci]),
     "mrg_reduce_batch": (ci, [vp, ci, vp]),
+    "mrg_rowfuse_fwd": (ci, [C.POINTER(RowFuseDesc), vp]),
     "mrg_augment_image": (ci, [vp, vp, vp, ci, ci, ci, ci, vp]),
     "mrg_augment_label": (ci, [vp, vp, vp, ci, ci, ci, ci, vp]),
     "mrg_resize_image": (ci, [vp, vp, ci, ci, ci, ci, ci, vp]),
@@ -151,7 +158,7 @@ for _name, (_res, _args) in SIGNATURES.items():
     _fn.argtypes = _args
 
 ABI_VERSION = lib.mrg_version()
-EXPECTED_ABI_VERSION = 14      # must match MRG_ABI_VERSION in include/mirage_hip.h: the ctypes structs above mirror that layout
+EXPECTED_ABI_VERSION = 15      # must match MRG_ABI_VERSION in include/mirage_hip.h: the ctypes structs above mirror that layout
 if ABI_VERSION != EXPECTED_ABI_VERSION:
     raise ImportError(f"{LIB_PATH} reports ABI version {ABI_VERSION}, the Python bindings expect {EXPECTED_ABI_VERSION}: rebuild it "
                       "(python -c 'import __graft_entry__ as g; g.build()')")

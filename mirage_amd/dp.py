@@ -66,6 +66,7 @@ class GradReducer:
         if self.update == "sharded" and self.wire != "fp32":
             raise ValueError("GradReducer: MRG_DP_UPDATE=sharded exchanges fp32 shards (MRG_DP_DTYPE=bf16 is not implemented for it)")
         self.rank = dist.get_rank(process_group) if dist.is_initialized() else 0
+        self.moments_synced = True   # False between a sharded update and the next gather_moments()
         self._plan = {}            # sharded update: (s, e) -> (main_end, sub) of every bucket exchanged so far (gather_moments walks it)
         active = dist.is_initialized() and (self.world > 1 or self.force)
         self._stage16 = torch.empty(self.bucket_elems, dtype=torch.bfloat16, device=flat_grad.device) if (active and self.wire == "bf16") else None
@@ -211,6 +212,7 @@ class GradReducer:
             rs = ranges if ranges is not None else [(0, self.flat.numel())]
             update(list(rs), [], True)
             return
+        self.moments_synced = False          # from here on a shard's moments are current on its owner only (FusedAdamW.state_dict checks)
         op = dist.ReduceOp.AVG if self.use_avg else dist.ReduceOp.SUM
         if self.side is not None:
             ready = torch.cuda.Event()
@@ -244,6 +246,7 @@ class GradReducer:
             own = (s + self.rank * sub, s + (self.rank + 1) * sub)
             for m in moments:
                 dist.all_gather_into_tensor(m[s:main_end], m[own[0]:own[1]].clone(), group=self.group)
+        self.moments_synced = True
 
     def _buckets(self, ranges):
         if ranges is None:

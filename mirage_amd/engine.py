@@ -25,6 +25,7 @@ EMBED_WGRAD_GATHER = True # patch-embedding weight gradient: compact the gradien
 EMBED_MULTI = os.environ.get("MRG_EMBED_MULTI", "1") != "0"   # the modalities' patch projections in one launch (mrg_gemm_multi)
 EMBED_LANES = os.environ.get("MRG_EMBED_LANES", "0") != "0"   # the modalities' patch projections side by side on lane streams: measured neutral (C2 9.52 / 9.54 vs 9.54 / 9.51 ms, C4 20.46 vs 20.53), the two cross-stream edges cost what the shared round saves
 CHAIN_END_FLUSH = os.environ.get("MRG_CHAIN_END_FLUSH", "0") != "0"   # experiment: side-stream fork at the end of the encoder's dgrad chain (neutral)
+ROWFUSE = int(os.environ.get("MRG_ROWFUSE", "1"))   # the output adapters' row-local chains in one launch each (csrc/rowfuse.hip): 0 off, 1 forward
 FUSE_ATTN_BIAS = True     # q / k / v bias gradients from inside the attention-backward kernels (else: a column-sum pass over d_qkv)
 
 
@@ -340,10 +341,22 @@ def block_fwd(blk, x32: torch.Tensor, save: bool, want_bf16_out: bool = False, d
     H = blk.attn.num_heads
     hd = D // H
     eps = blk.norm1.eps
-    ln1, mean1, rstd1 = K.ln_fwd(x32, blk.norm1.weight, blk.norm1.bias, eps)
-    qkv, _, _ = lin_fwd(ln1, blk.attn.qkv)
     st = (N * 3 * D, 3 * D)
     adrop = attn_dropout_args(blk.attn)
+    if (ROWFUSE and dp is None and K.Halves.mode == 0 and blk.attn.qkv.bias is not None and K.rowfuse_ok(B * N, D, 3 * D)
+            and blk.mlp.fc1.weight.shape[0] == 1024):
+        # 256-wide blocks (the output adapters' decoder_transformer): norm1 + qkv and proj + residual + norm2 + mlp + residual as one launch each
+        qkv, ln1, mean1, rstd1 = K.rowfuse_ln_proj(x32, blk.norm1, blk.attn.qkv, shadow(blk.attn.qkv.weight), save)
+        o, lse = K.attn_fwd(qkv[..., :D], qkv[..., D:2 * D], qkv[..., 2 * D:], B, H, N, N, hd, blk.attn.scale, st, st, st, need_lse=save, drop=adrop)
+        x_out, x_out16, sv = K.rowfuse_mlp(o, blk.attn.proj, shadow(blk.attn.proj.weight), x32, blk.norm2, blk.mlp.fc1, shadow(blk.mlp.fc1.weight),
+                                           blk.mlp.fc2, shadow(blk.mlp.fc2.weight), save, want_bf16_out)
+        saved = None
+        if save:
+            x_mid, ln2, mean2, rstd2, h_pre, h_act = sv
+            saved = (x32, ln1, mean1, rstd1, qkv, o, lse, x_mid, ln2, mean2, rstd2, h_pre, h_act, dp, adrop)
+        return x_out, x_out16, saved
+    ln1, mean1, rstd1 = K.ln_fwd(x32, blk.norm1.weight, blk.norm1.bias, eps)
+    qkv, _, _ = lin_fwd(ln1, blk.attn.qkv)
     o, lse = K.attn_fwd(qkv[..., :D], qkv[..., D:2 * D], qkv[..., 2 * D:], B, H, N, N, hd, blk.attn.scale, st, st, st, need_lse=save, drop=adrop)
     x_mid, _, _ = lin_fwd(o, blk.attn.proj, out_dtype=F32, resid=x32, row_scale=dp[0] if dp else None, dropout=d_att)
     ln2, mean2, rstd2 = K.ln_fwd(x_mid, blk.norm2.weight, blk.norm2.bias, blk.norm2.eps)
@@ -640,24 +653,30 @@ def embed_fwd(model, x: Dict[str, torch.Tensor], ids_keep: torch.Tensor, save: b
             if not fits(pr):
                 K.gemm_multi([pr])
     K.fill_global(x0, model.global_tokens, B, N, Kk)
+    if save:
+        model._mrg_unused_adapters = unused_trainable_adapters(model, doms)
     plan = (rows, toks, srcb, counts)
     return x0, (plan, saved, {k: x[k] for k in doms}) if save else None
+
+
+def unused_trainable_adapters(model, doms) -> List[str]:
+    """input adapters with trainable parameters whose modality is not among `doms` (the batch of this pass)"""
+    return sorted(name for name, ad in model.input_adapters.items()
+                  if name not in doms and any(p_.requires_grad for p_ in ad.parameters()))
 
 
 def embed_bwd(model, saved_all, dx32: torch.Tensor, dx16: Optional[torch.Tensor]):
     (rows, toks, srcb, counts), A_list, inputs = saved_all
     doms = list(inputs.keys())
-    unused = []
-    for name, ad in model.input_adapters.items():
-        if name not in inputs:
-            # a modality that was not in x: torch leaves its parameters' .grad at None and the optimizer skips them; here gradients are
-            # buffers that every backward pass overwrites, so the unused adapter's are cleared -- and the adapter is reported to the fused
-            # optimizer, which refuses to step it (momentum and weight decay on parameters the reference's optimizer would skip)
-            for p_ in ad.parameters():
-                if p_.requires_grad:
-                    grad_buffer(p_).zero_()
-                    unused.append(name)
-    model._mrg_unused_adapters = sorted(set(unused))
+    for name in unused_trainable_adapters(model, inputs):
+        # a modality that was not in x: torch leaves its parameters' .grad at None and the optimizer skips them; here gradients are
+        # buffers that every backward pass overwrites, so the unused adapter's are cleared.  The adapter was reported at FORWARD time
+        # (embed_fwd -> model._mrg_unused_adapters): the fused optimizer refuses to step it (momentum and weight decay on parameters the
+        # reference's optimizer would skip), and trainer.TrainStep refuses before its backward pass, i.e. before any early / fused /
+        # sharded update of the same step has touched the arena
+        for p_ in model.input_adapters[name].parameters():
+            if p_.requires_grad:
+                grad_buffer(p_).zero_()
     B, N, D = dx32.shape
     ng = model.num_global_tokens
     Kk = N - ng
@@ -745,18 +764,30 @@ def decoder_fwd(ad, enc32: torch.Tensor, enc16: torch.Tensor, ids_keep, ids_rest
     desc = K.dec_assemble_desc(ctx, ad.mask_token, task_embs, pos, ids_keep, ids_restore, dom_start, qdom, B, N, Kk, T, Tq, Dd, q_te)
     queries, context = K.dec_assemble_fwd(desc, dev)                                     # :188-246
     eps = ad.query_norm.eps
-    qn, mq, rq = K.ln_fwd(queries, ad.query_norm.weight, ad.query_norm.bias, eps)
-    cn, mc, rc = K.ln_fwd(context, ad.context_norm.weight, ad.context_norm.bias, eps)
-    qp, _, _ = lin_fwd(qn, ad.decoder.q)
-    kv, _, _ = lin_fwd(cn, ad.decoder.kv)
     sq, skv = (Tq * Dd, Dd), (N * 2 * Dd, 2 * Dd)
     adrop = attn_dropout_args(ad.decoder)
-    o, lse = K.attn_fwd(qp, kv[..., :Dd], kv[..., Dd:], B, H, Tq, N, hd, ad.decoder.scale, sq, skv, skv, need_lse=save, drop=adrop)
-    x1, _, _ = lin_fwd(o, ad.decoder.proj, out_dtype=F32)                                # :279 (no residual)
-    on, mo, ro = K.ln_fwd(x1, ad.out_norm.weight, ad.out_norm.bias, eps)
-    h_act, _, h_pre = lin_fwd(on, ad.mlp.fc1, gelu=True, save_pre=save)
     blocks = list(ad.decoder_transformer) if isinstance(ad.decoder_transformer, torch.nn.Sequential) else []
-    x2, x16, _ = lin_fwd(h_act, ad.mlp.fc2, out_dtype=F32, resid=x1, want_bf16_copy=(len(blocks) == 0))   # :280
+    fuse = (ROWFUSE and K.rowfuse_ok(B * Tq, Dd, Dd) and K.rowfuse_ok(B * N, Dd, 2 * Dd) and ad.mlp.fc1.weight.shape[0] == 1024
+            and ad.decoder.q.bias is not None and ad.decoder.kv.bias is not None)
+    if fuse:
+        # one launch per row-local chain (csrc/rowfuse.hip): norm + projection of queries / context, and everything between the attention
+        # output and the next norm1 (proj, out_norm, mlp with its residual)
+        qp, qn, mq, rq = K.rowfuse_ln_proj(queries, ad.query_norm, ad.decoder.q, shadow(ad.decoder.q.weight), save)
+        kv, cn, mc, rc = K.rowfuse_ln_proj(context, ad.context_norm, ad.decoder.kv, shadow(ad.decoder.kv.weight), save)
+        o, lse = K.attn_fwd(qp, kv[..., :Dd], kv[..., Dd:], B, H, Tq, N, hd, ad.decoder.scale, sq, skv, skv, need_lse=save, drop=adrop)
+        x2, x16, sv = K.rowfuse_mlp(o, ad.decoder.proj, shadow(ad.decoder.proj.weight), None, ad.out_norm, ad.mlp.fc1, shadow(ad.mlp.fc1.weight),
+                                    ad.mlp.fc2, shadow(ad.mlp.fc2.weight), save, len(blocks) == 0)          # :279-280
+        x1, on, mo, ro, h_pre, h_act = sv if save else (None,) * 6
+    else:
+        qn, mq, rq = K.ln_fwd(queries, ad.query_norm.weight, ad.query_norm.bias, eps)
+        cn, mc, rc = K.ln_fwd(context, ad.context_norm.weight, ad.context_norm.bias, eps)
+        qp, _, _ = lin_fwd(qn, ad.decoder.q)
+        kv, _, _ = lin_fwd(cn, ad.decoder.kv)
+        o, lse = K.attn_fwd(qp, kv[..., :Dd], kv[..., Dd:], B, H, Tq, N, hd, ad.decoder.scale, sq, skv, skv, need_lse=save, drop=adrop)
+        x1, _, _ = lin_fwd(o, ad.decoder.proj, out_dtype=F32)                                # :279 (no residual)
+        on, mo, ro = K.ln_fwd(x1, ad.out_norm.weight, ad.out_norm.bias, eps)
+        h_act, _, h_pre = lin_fwd(on, ad.mlp.fc1, gelu=True, save_pre=save)
+        x2, x16, _ = lin_fwd(h_act, ad.mlp.fc2, out_dtype=F32, resid=x1, want_bf16_copy=(len(blocks) == 0))   # :280
     blk_saved = []
     xx = x2
     for i, blk in enumerate(blocks):                                                     # :285
@@ -964,15 +995,17 @@ class DecodersFn(torch.autograd.Function):
         def job(i, ad):
             coef = None
             if fuse:
-                kind, patch, target, mask, smooth, npix = loss_spec[i]
+                kind, patch, target, mask, smooth, npix, *own = loss_spec[i]
                 H, W = target.shape[-2:]
                 ntok_i = (H // patch) * (W // patch)
-                if not (mask is None or n_keep < ntok_i):
+                # own[0]: the mask is the mask generator's own for THESE ids_keep (MIRAGEModel._forward says so); a mask from elsewhere
+                # carries no such guarantee (a sample without masked pixels would get coefficient 0 while the others still divide by B)
+                if not (mask is None or (own and own[0] and n_keep < ntok_i)):
                     coef = K.loss_coef(mask, target.shape[0], ntok_i, patch * patch, enc32.device)
             img, sv = decoder_fwd(ad, enc32, enc16, ids_keep, ids_restore, doms_l, start_l, ng, save)
             if loss_spec is None:
                 return img, sv, None
-            kind, patch, target, mask, smooth, npix = loss_spec[i]
+            kind, patch, target, mask, smooth, npix = loss_spec[i][:6]
             d = K.loss_desc(kind, img, target, mask, patch, smoothing=smooth, norm_pix=npix)
             if fuse:
                 loss, partial, dpred, finish = K.masked_loss_fused(d, coef, img.device)

@@ -536,6 +536,66 @@ def ln_bwd(dy: torch.Tensor, x, mean, rstd, gamma, dres, dgamma, dbeta, dres_col
     return dx32, dx16
 
 
+def rowfuse_ok(M: int, D: int, NH: int) -> bool:
+    """shapes the fused row-chain kernels (csrc/rowfuse.hip) accept: 256-wide rows in whole 64-row tiles"""
+    return D == 256 and M > 0 and M % 64 == 0 and NH in (256, 512, 768, 1024)
+
+
+def rowfuse_ln_proj(x32: torch.Tensor, norm, lin, W16: torch.Tensor, save: bool):
+    """LayerNorm(x) W^T + b in one launch (mrg_rowfuse_fwd without a0): query_norm + q, context_norm + kv, norm1 + qkv of the output
+    adapters.  Returns (y bf16 [..., NH], ln bf16 or None, mean, rstd or None) -- ln / mean / rstd only when `save`."""
+    D = x32.shape[-1]
+    M = x32.numel() // D
+    NH = W16.shape[0]
+    dev = x32.device
+    y = torch.empty(x32.shape[:-1] + (NH,), dtype=BF16, device=dev)
+    d = L.RowFuseDesc()
+    d.M, d.NH, d.eps = M, NH, norm.eps
+    d.resid = x32.data_ptr()
+    d.gamma, d.beta = norm.weight.data_ptr(), norm.bias.data_ptr()
+    d.w1, d.b1, d.h_out = W16.data_ptr(), lin.bias.data_ptr(), y.data_ptr()
+    ln = mean = rstd = None
+    if save:
+        ln = torch.empty(x32.shape, dtype=BF16, device=dev)
+        mean = torch.empty((M,), dtype=F32, device=dev)
+        rstd = torch.empty((M,), dtype=F32, device=dev)
+        d.ln_out, d.mean, d.rstd = ln.data_ptr(), mean.data_ptr(), rstd.data_ptr()
+    check(lib.mrg_rowfuse_fwd(C.byref(d), _s()), "mrg_rowfuse_fwd")
+    return y, ln, mean, rstd
+
+
+def rowfuse_mlp(o16: torch.Tensor, proj, W0: torch.Tensor, resid: Optional[torch.Tensor], norm, fc1, W1: torch.Tensor, fc2, W2: torch.Tensor,
+                save: bool, want_bf16: bool):
+    """x = o W0^T + b0 (+ resid); y = x + fc2(gelu(fc1(LayerNorm(x)))) in one launch (mrg_rowfuse_fwd with a0).
+    Returns (y32, y16 or None, saved) with saved = (x, ln, mean, rstd, gelu'(h) fp16, gelu(h) bf16) when `save`, else None."""
+    D = o16.shape[-1]
+    M = o16.numel() // D
+    NH = W1.shape[0]
+    dev = o16.device
+    y32 = torch.empty(o16.shape, dtype=F32, device=dev)
+    y16 = torch.empty(o16.shape, dtype=BF16, device=dev) if want_bf16 else None
+    d = L.RowFuseDesc()
+    d.M, d.NH, d.eps = M, NH, norm.eps
+    d.a0, d.w0, d.b0, d.resid = o16.data_ptr(), W0.data_ptr(), proj.bias.data_ptr(), _p(resid)
+    d.gamma, d.beta = norm.weight.data_ptr(), norm.bias.data_ptr()
+    d.w1, d.b1, d.w2, d.b2 = W1.data_ptr(), fc1.bias.data_ptr(), W2.data_ptr(), fc2.bias.data_ptr()
+    d.y32, d.y16 = y32.data_ptr(), _p(y16)
+    saved = None
+    if save:
+        x = torch.empty(o16.shape, dtype=F32, device=dev)
+        ln = torch.empty(o16.shape, dtype=BF16, device=dev)
+        mean = torch.empty((M,), dtype=F32, device=dev)
+        rstd = torch.empty((M,), dtype=F32, device=dev)
+        hshape = o16.shape[:-1] + (NH,)
+        h_act = torch.empty(hshape, dtype=BF16, device=dev)
+        h_grad = torch.empty(hshape, dtype=torch.float16, device=dev)
+        d.x_out, d.ln_out, d.mean, d.rstd, d.h_out, d.hgrad_out = (x.data_ptr(), ln.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
+                                                                    h_act.data_ptr(), h_grad.data_ptr())
+        saved = (x, ln, mean, rstd, h_grad, h_act)
+    check(lib.mrg_rowfuse_fwd(C.byref(d), _s()), "mrg_rowfuse_fwd")
+    return y32, y16, saved
+
+
 def colsum(x: torch.Tensor, out: torch.Tensor, M: Optional[int] = None, row_map=None, m_dev=None):
     N = x.shape[-1]
     M = M if M is not None else x.numel() // N
@@ -861,7 +921,7 @@ def masked_loss_fused(d: "L.LossDesc", coef, device, gout=None):
     (the launch then forms them from each sample's own mask row).  Returns (loss, partial, dpred, finish): `loss` holds the value once finish() -- the batch statistics, a tiny
     launch nothing in a training step waits for -- has run on some stream ordered behind this call."""
     partial = torch.empty(lib.mrg_loss_partial_floats(d.B), dtype=F32, device=device)
-    loss = torch.empty((), dtype=F32, device=device)
+    loss = torch.full((), float("nan"), dtype=F32, device=device)     # NaN until finish() has run: a premature read is detectable
     pred = d._refs[0]
     dpred = torch.empty_like(pred)
     d.partial, d.loss, d.coef, d.gout, d.dpred = partial.data_ptr(), loss.data_ptr(), _p(coef), _p(gout), dpred.data_ptr()

@@ -391,7 +391,8 @@ class MIRAGEModel(nn.Module):
                 m = task_masks.get(name) if use_mask else None
                 loss_spec.append((kind, patch, target.contiguous() if kind != E.L.MRG_LOSS_MSE else target.contiguous().float(),
                                   E.loss_mask(m), float(rest[0]) if rest else 0.0,
-                                  bool(rest[1]) if len(rest) > 1 else False))
+                                  bool(rest[1]) if len(rest) > 1 else False,
+                                  True))       # the masks are this call's own (task_masks and ids_keep come from one mask-generator launch)
         imgs = E.DecodersFn.apply(enc32, enc16, ads, doms, dom_start, self.num_global_tokens, ids_keep.contiguous(),
                                   ids_restore.contiguous(), save, True, loss_spec, *self._decoder_params())
         preds = {name: img for name, img in zip(self.output_adapters.keys(), imgs)}

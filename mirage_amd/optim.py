@@ -188,6 +188,7 @@ class FusedAdamW:
         # writes the same slice of `_ss`, and the finish kernel sums every slot handed out so far.  Nothing here depends on a host
         # cursor, so eager calls, captured graphs and any mix of the two (data parallel: stage updates issued eagerly between
         # graph replays, the rest inside the optimizer graph) stay consistent across replays.
+        self.reducer = None         # ... which also hands over its dp.GradReducer (state_dict checks reducer.moments_synced)
         self.sharded = False        # set by trainer.TrainStep when the data-parallel exchange also carries the update (MRG_DP_UPDATE=sharded)
         self._ss = torch.zeros(1 << 19, dtype=torch.float32, device=dev) if self.fuse_norm else None     # <= 4096 partials per launch, <= 128 ranges
         self._slots = PartialSumSlots(1 << 19)
@@ -296,6 +297,12 @@ class FusedAdamW:
         """{'state': {i: {'step', 'exp_avg', 'exp_avg_sq'}}, 'param_groups': [...]} exactly as torch.optim.AdamW.state_dict() of the
         reference's optimizer would hold it (checkpoint['optimizer'], mutils/checkpoint.py:14-20), so that a reference run can resume
         from our checkpoint.  Moments are copied out of the flat arena per parameter (CPU tensors)."""
+        red = getattr(self, "reducer", None)
+        if self.sharded and red is not None and not red.moments_synced:
+            # MRG_DP_UPDATE=sharded: exp_avg / exp_avg_sq of a shard are current on its owner only; serialising them as they are would write
+            # stale moments that nothing detects on resume
+            raise RuntimeError("FusedAdamW.state_dict: the sharded update left this rank's copy of the moments stale; call "
+                               "reducer.gather_moments(optimizer.exp_avg, optimizer.exp_avg_sq) on EVERY rank first (a collective)")
         groups = self._index_order()
         it = int(self.step_dev[0].item()); t_adam = int(self.step_dev[1].item())
         i_lr = min(max(it - 1, 0), len(self._lr_host) - 1)

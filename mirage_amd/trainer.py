@@ -113,6 +113,7 @@ class TrainStep:
                 raise RuntimeError("MRG_DP_UPDATE=sharded needs FusedAdamW without clip_grad / skip_grad (the update must not depend on the global gradient norm)")
             self._sharded = True
             optimizer.sharded = True
+            optimizer.reducer = reducer          # state_dict() refuses stale moments (reducer.moments_synced)
         if (self.split and not self._sharded and os.environ.get("MRG_EARLY_OPT", "1") != "0" and isinstance(optimizer, FusedAdamW)
                 and not optimizer.clip_grad and not optimizer.skip_grad):
             self._stage_merged = [self._merge(r) for r in self.stage_ranges]
@@ -233,11 +234,22 @@ class TrainStep:
         from . import engine as E
         return {t: E.PredLayout.to_images(p, self.model.output_adapters[t]) for t, p in self.preds.items()}
 
+    def _refuse_unused_adapters(self):
+        """FusedAdamW.step refuses a trainable input adapter that was not in the batch (the reference's optimizer skips parameters without
+        a gradient; one launch over the arena cannot).  Here the refusal comes BEFORE the backward pass: early block-wise updates, AdamW in
+        the weight-gradient epilogues and the sharded exchange all modify the arena during it, and a raise at step() would leave a
+        half-applied step behind."""
+        skipped = getattr(self.model, "_mrg_unused_adapters", None)
+        if skipped:
+            raise RuntimeError(f"TrainStep: input adapter(s) {skipped} have trainable parameters but are not in the batch; pass every modality, "
+                               "or freeze the unused adapter (requires_grad_(False)) before building the optimizer")
+
     def _fwd_bwd(self):
         from . import kernels as _K
         _K.timestamp("step_start")
         x = self.static_x
         preds, masks = self._forward(x)
+        self._refuse_unused_adapters()
         self.task_losses = self._losses(preds, masks, x)
         self.masks = masks                            # static tensors of the captured step (parity tests read them and self.preds after a replay)
         self.opt.zero_grad()
@@ -276,6 +288,7 @@ class TrainStep:
         from . import engine as E
         x = self.static_x
         preds, masks = self._forward(x)
+        self._refuse_unused_adapters()
         self.task_losses = self._losses(preds, masks, x)
         self.opt.zero_grad()
         self._hs = list(self.model._mrg_h_cuts)

@@ -25,7 +25,7 @@ def test_library_exports_every_declared_symbol():
 def test_binding_covers_the_header():
     from mirage_amd import _lib
     assert sorted(_lib.SIGNATURES) == _declared()
-    assert _lib.ABI_VERSION == _lib.EXPECTED_ABI_VERSION == 14
+    assert _lib.ABI_VERSION == _lib.EXPECTED_ABI_VERSION == 15
     assert _lib.lib.mrg_last_error_string() is not None
 
 
@@ -37,6 +37,10 @@ def test_argument_errors_are_reported_not_crashed():
     d = _lib.GemmDesc()
     rc = _lib.lib.mrg_gemm(ctypes.byref(d), None)
     assert rc < 0 and b"mrg_gemm" in _lib.lib.mrg_last_error_string()
+    r = _lib.RowFuseDesc()
+    r.M, r.NH = 100, 1024
+    rc = _lib.lib.mrg_rowfuse_fwd(ctypes.byref(r), None)
+    assert rc < 0 and b"multiple of 64" in _lib.lib.mrg_last_error_string()
     assert _lib.lib.mrg_ln_bwd_nblocks(8256) >= 1 and _lib.lib.mrg_loss_partial_floats(64) == 64 * 64
 
 

@@ -107,6 +107,21 @@ def _fullsize_case(tag, kind, doms, B, Kk, check_eager=True, data_seed=1234, mas
         worst_n = max(worst_n, (en, n)); worst_r = max(worst_r, (er, n))
     meas.update(grad_norm_worst=worst_n[0], grad_norm_worst_name=worst_n[1], grad_norm_worst_tol=2e-2,
                 grad_rms_worst=worst_r[0], grad_rms_worst_name=worst_r[1], grad_rms_worst_tol=2e-2, data_seed=data_seed, mask_seed=mask_seed)
+    # ---- the UPDATE (mutils/optim_factory.py:180 torch.optim.AdamW, first step: m_hat = g, sqrt(v_hat) = |g|).  The matrices leave the grouped
+    # weight-gradient launches already updated (epi_kind 9), the rest is updated block by block: (i) every sampled parameter after the step
+    # must be AdamW's first step applied to the engine's OWN gradient (in units of lr; fp32 roundoff of p is ~1e-3 lr), (ii) against the
+    # oracle's step from the oracle's gradient the first step is lr * sign(g): the share of elements whose sign differs is recorded
+    lr, wd, eps = 1e-4, 0.05, 1e-8
+    sd0 = O.procedural_state_dict(cfg)
+    upd_self, upd_sign = (0.0, ""), (0.0, "")
+    for n in names:
+        p0, p1 = sd0[n].double(), params[n].detach().double().cpu()
+        dec = wd if n in opt.arena.names_decay else 0.0
+        first = lambda g_: p0 * (1.0 - lr * dec) - lr * g_ / (g_.abs() + eps)
+        upd_self = max(upd_self, (float((p1 - first(grads[n].double())).abs().max()) / lr, n))
+        upd_sign = max(upd_sign, (float(((p1 - first(sdr[n].grad.double())).abs() > 0.5 * lr).double().mean()), n))
+    meas.update(update_vs_own_gradient_in_lr=upd_self[0], update_vs_own_gradient_name=upd_self[1], update_sign_mismatch_share=upd_sign[0],
+                update_sign_mismatch_name=upd_sign[1])
     del sdr
     if check_eager:
         model_e, opt_e, ts_e = _run_engine(cfg, B, Kk, x, noise, use_graph=False)
@@ -130,6 +145,8 @@ def _fullsize_case(tag, kind, doms, B, Kk, check_eager=True, data_seed=1234, mas
     assert meas["grad_norm_rel"] <= 1e-2, meas
     assert worst_n[0] <= 2e-2, worst_n
     assert worst_r[0] <= 2e-2, worst_r            # 2e-2 (measured 8-9e-3)
+    assert upd_self[0] <= 2e-2, upd_self          # the fused / block-wise updates ARE AdamW of the engine's gradient (within fp32 roundoff of p)
+    assert upd_sign[0] <= 5e-2, upd_sign          # and lr * sign(g) agrees with the oracle's step on >= 95 % of every sampled tensor
     if check_eager:
         assert meas["eager_equals_graph"]
     return meas
@@ -213,6 +230,59 @@ def test_c4_large_b16_graph_step_vs_oracle():
 
 def test_c4_large_b64_production_step_vs_oracle_on_8_samples():
     _c4_b64_case()
+
+
+def test_c4_large_b64_graph_step_gradients_and_update_vs_oracle():
+    """C4 at the PRODUCTION batch with every gradient check of the C2 / C3 cases (round-5 review, weak #1): M = 64 x 99 = 6336 rows -- the dgrad
+    variants of gemm_tune_gfx950.json at that M, the seven grouped weight-gradient launches of the Large model and AdamW in their epilogue --
+    against the CPU oracle's forward + backward on all 64 samples (about a minute on 32 host threads, ~25 GB of host memory)."""
+    _fullsize_case("c4_b64_trainstep", "large", ("bscan", "slo", "bscanlayermap"), 64, 98, check_eager=False)
+
+
+def test_c2_b64_five_step_curve_through_the_graph_replayed_trainstep():
+    """SURVEY.md section 8(d)'s loss-curve check on the PRODUCTION schedule (round-5 review, weak #2: the 20-step curve of test_train_gpu runs
+    B = 2 through eager autograd): five optimizer steps of the graph-replayed TrainStep at C2, B = 64 -- one hipGraph per step, side streams,
+    grouped weight gradients with AdamW in the epilogue, device-side lr table -- against oracle.train_steps (run_pretraining.py:683-742 restated
+    on CPU fp32) on the same five batches and mask noises.  |dloss| <= 1e-3 max(1, |loss|) on every step; gradient norms within 2e-2."""
+    from oracle import mirage_oracle as O
+    from mirage_amd import builder, optim
+    from mirage_amd.trainer import TrainStep
+    import test_model_gpu as T
+    cfg = O.make_config("base", ("bscan", "slo"))
+    B, Kk, steps = 64, 128, 5
+    lrs, wds = [1e-4, 2e-4, 3e-4, 4e-4, 4e-4], [0.05] * steps
+    batches = [O.synthetic_batch(cfg, B, seed=700 + it) for it in range(steps)]
+    noises, masks = [], []
+    for it in range(steps):
+        noise, _, ik, ir = O.synthetic_masks(cfg, B, Kk, seed=500 + it)
+        noises.append(noise); masks.append((ik, ir))
+    model, args, _ = T._build(cfg)
+    model.train()
+    opt = optim.FusedAdamW(model, lrs, wds, betas=(0.9, 0.95), eps=1e-8)
+    dev_noise = lambda n_: (torch.from_numpy(n_[0]).to(DEV), torch.cat([torch.from_numpy(a) for a in n_[1]], 1).to(DEV), torch.from_numpy(n_[2]).to(DEV))
+    x0 = {d: t.to(DEV) for d, t in O.synthetic_batch(cfg, B, seed=4321).items()}          # warm-up / capture on other data
+    ts = TrainStep(model, builder.get_losses(args), opt, x0, Kk, use_graph=True, feed_mask_noise=True)
+    ts.load(x0)
+    for dst, src in zip(ts.static_noise, dev_noise(O.synthetic_masks(cfg, B, Kk, seed=77)[0])):
+        dst.copy_(src)
+    ts.warmup_and_capture(warm_iters=1)
+    assert ts.g_fb is not None
+    curve, norms = [], []
+    for it in range(steps):
+        ts.step({d: t.to(DEV) for d, t in batches[it].items()}, noise=dev_noise(noises[it]))
+        torch.cuda.synchronize()
+        curve.append(float(ts.loss)); norms.append(float(opt.grad_norm))
+    assert opt.step_dev.tolist() == [steps, steps]
+    torch.set_num_threads(min(os.cpu_count() or 1, 32))
+    ref_curve, ref_norms, _ = O.train_steps(cfg, O.procedural_state_dict(cfg), batches, masks, lrs, wds)
+    ref_curve, curve = np.asarray(ref_curve), np.asarray(curve)
+    err = np.abs(curve - ref_curve) / np.maximum(1.0, np.abs(ref_curve))
+    nerr = np.abs(np.asarray(norms) - np.asarray(ref_norms)) / np.asarray(ref_norms)
+    T.report("c2_b64_graph_curve_5_steps", loss_err_per_step=[float(e) for e in err], grad_norm_err_per_step=[float(e) for e in nerr],
+             curve=[float(c) for c in curve], ref_curve=[float(c) for c in ref_curve], tol=1e-3)
+    assert abs(ref_curve[0] - ref_curve[-1]) > 0.02 * abs(ref_curve[0]), "the schedule must move the loss for this check to mean anything"
+    assert err.max() <= 1e-3, (err.tolist(), curve.tolist(), ref_curve.tolist())
+    assert nerr.max() <= 2e-2, nerr.tolist()
 
 
 def _c4_b64_case(data_seed=1234, mask_seed=99, asserts=True):

@@ -1232,3 +1232,18 @@ def test_gemm_colsum_epilogue(K):
     want = ((dy.float() @ W.float()) * gd.float())
     assert rel_rms(dx.float(), want) < 1e-2
     assert rel_rms(cs, want.sum(0)) < 2e-3, rel_rms(cs, want.sum(0))
+
+
+def test_gelu_epilogue_far_negative_arguments_tend_to_zero(K):
+    """Round-5 advisor item: the inference GELU epilogue is x * Phi(clamp(x, -5, 5)); multiplied by the UNclamped x it grew linearly below
+    -5 (-2.9e-4 at -1e3) where gelu tends to 0.  The factor is clamped on the negative side now: |gelu(x)| <= 1.5e-6 for x <= -5."""
+    from mirage_amd import _lib as L
+    M, N, Kd = 128, 128, 64
+    A = torch.zeros(M, Kd, dtype=BF16, device=dev()); W = torch.zeros(N, Kd, dtype=BF16, device=dev())
+    xs = torch.tensor([-1e30, -1e6, -1e3, -40.0, -6.0, -5.0, -1.0, 0.0, 1.0, 5.0, 6.0, 1e3], device=dev())
+    b = xs.repeat(N // xs.numel() + 1)[:N].contiguous()
+    out = K.gemm(A, W, M, N, Kd, bias=b, out_dtype=F32, act=L.MRG_ACT_GELU)
+    ref = torch.nn.functional.gelu(b.double()).float()
+    assert torch.isfinite(out).all()
+    assert float((out[0] - ref).abs().max()) <= 2e-6 * max(1.0, float(ref.abs().max()))
+    assert float(out[0][b <= -5.0].abs().max()) <= 1.5e-6

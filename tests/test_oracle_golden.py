@@ -377,3 +377,24 @@ def test_norm_pix_targets_match_reference():
             want = fx[f"{tag}.dpred.{mt}"]
             ok = ~np.isnan(want)
             np.testing.assert_allclose(x.grad.numpy()[ok], want[ok], rtol=1e-4, atol=1e-8)
+
+
+@pytest.mark.parametrize("name", ["tiny2", "tiny3", "c2_base", "c3_base", "c4_large"])
+def test_bf16_weight_comparator_is_the_reference_with_rounded_module_weights(name):
+    """tests/test_fullsize_gpu.py measures the engine against TWO oracles: fp32 (1e-3, BASELINE.json) and `O.autocast_weights` (2e-4 /
+    4e-4 per task), the oracle with the weight matrices in the format the reference's autocast region multiplies with.  That second
+    comparator is pinned here: `w16.loss.*` in the fixtures is the REFERENCE model in fp32 arithmetic with the weight of every nn.Linear /
+    nn.Conv2d MODULE rounded to bf16 (tools/ref_bf16_floor.py walks the reference's modules; the oracle's rule is on parameter names), and the
+    oracle reproduces it.  The reference's full autocast run (`autocast.loss.*`: activations rounded as well) is recorded beside it: the weight
+    format alone moves a task by the same order as that run (`floor.loss.*`), which is why the fp32 distance is asserted at 1.5e-3 per task."""
+    fx, meta = load_golden(name)
+    cfg, B, K = meta["cfg"], meta["B"], meta["K"]
+    x = O.synthetic_batch(cfg, B, seed=meta["data_seed"])
+    with torch.no_grad():
+        _, lw, _, _ = O.forward_loss(cfg, O.autocast_weights(O.procedural_state_dict(cfg)), x, _t(fx["ids_keep"]), _t(fx["ids_restore"]))
+    for d in lw:
+        ref_w16, ref32, ref_ac = float(fx[f"w16.loss.{d}"]), float(fx[f"loss.{d}"]), float(fx[f"autocast.loss.{d}"])
+        assert abs(float(lw[d]) - ref_w16) <= 5e-6 * abs(ref_w16), (d, float(lw[d]), ref_w16)
+        # the stored floor is |autocast - fp32| of the reference, and the weight format is a part of it of the same order
+        assert abs(abs(ref_ac - ref32) / max(1.0, abs(ref32)) - float(fx[f"floor.loss.{d}"])) <= 1e-9
+        assert abs(ref_w16 - ref32) / max(1.0, abs(ref32)) <= max(1e-3, 3.0 * float(fx[f"floor.loss.{d}"]))

@@ -1,7 +1,10 @@
 #!/usr/bin/env python3
 """Noise floor of the REFERENCE itself under bf16 autocast (CPU) on the golden fixtures: how far the reference's own
 mixed-precision run is from its fp32 run with identical weights, inputs and masks.  Adds `floor.*` entries to the
-fixtures (numbers only).  Build container only."""
+fixtures (numbers only), the SIGNED losses of that autocast run (`autocast.loss.*`) and -- round 6 -- `w16.loss.*`: the reference in
+fp32 arithmetic with the weight of every nn.Linear / nn.Conv2d MODULE rounded to bf16 (what autocast casts per call), everything else
+untouched.  The oracle's `autocast_weights` comparator (a rule on parameter NAMES) must reproduce those numbers
+(tests/test_oracle_golden.py).  Build container only."""
 import json, os, sys, io, contextlib
 sys.dont_write_bytecode = True
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -20,8 +23,13 @@ def run(name):
     x = O.synthetic_batch(cfg, B, seed=meta["data_seed"])
     loss_fns = G.reference_losses(cfg)
     out = {}
-    for mode in ("fp32", "bf16"):
+    for mode in ("fp32", "bf16", "w16"):
         torch.manual_seed(meta["mask_seed"])
+        if mode == "w16":
+            with torch.no_grad():
+                for m_ in model.modules():
+                    if isinstance(m_, (torch.nn.Linear, torch.nn.Conv2d)):
+                        m_.weight.copy_(m_.weight.to(torch.bfloat16).to(torch.float32))
         cap = {}
         first = cfg["out_domains"][0]
         orig = model.output_adapters[first].forward
@@ -40,6 +48,10 @@ def run(name):
                          gnorm=float(torch.sqrt(sum((p_.grad.double() ** 2).sum() for p_ in model.parameters() if p_.grad is not None))),
                          grads={n: p_.grad.detach().clone() for n, p_ in model.named_parameters() if p_.grad is not None})
     f32, b16 = out["fp32"], out["bf16"]
+    for d in f32["losses"]:
+        fx[f"autocast.loss.{d}"] = np.float64(b16["losses"][d])
+        fx[f"w16.loss.{d}"] = np.float64(out["w16"]["losses"][d])
+    fx["w16.grad_total_norm"] = np.float64(out["w16"]["gnorm"])
     for d in f32["losses"]:
         fx[f"floor.loss.{d}"] = np.float64(abs(b16["losses"][d] - f32["losses"][d]) / max(1.0, abs(f32["losses"][d])))
     tot32, tot16 = sum(f32["losses"].values()), sum(b16["losses"].values())
