@@ -77,11 +77,45 @@ def synth_batches(doms, B, n, seed, device):
     return pool
 
 
+HBM_ACHIEVABLE = 6.3e12      # B/s: what a streaming kernel sustains of the 8 TB/s HBM3E peak (MI355X_MICROARCH.md)
+
+
+def algorithmic_bytes(model_name, doms, B, K, train):
+    """HBM bytes ONE step has to move with the present dataflow (every operand read once, every result written once; fp32 residual stream,
+    bf16 GEMM operands, activations saved for the backward pass), per GPU.  Encoder block at M = B (K + 1) rows of width D
+    (profiles/history.md section 6.1, per row and column: forward 72 B = LN in 4 / out 2, qkv 2 + 6, attention 6 + 2, proj 2 + 4 + 4, LN 4 + 2,
+    fc1 2 + 8 + 8, fc2 8 + 4 + 4; backward 141.9 B = dgrad chain, both LayerNorm backwards at 16 B, attention backward, the weight gradients'
+    operand reads) + 30 B per weight for AdamW inside the weight-gradient epilogues (gradient, parameter, two moments read / written, bf16
+    shadow); output adapters, patch embedding, losses and the rest of the optimizer: 2.0 GB per adapter at B = 64 (C2: 19.0 GB encoder + 4.0 =
+    the 23.0 GB of DESIGN section 6).  Forward-only (C5): 64 B per row and column (no GELU' side tensor), weights once per block."""
+    D, L, _ = DIMS[model_name]
+    M = B * (K + 1)
+    if not train:
+        return L * (64.0 * M * D + 24.0 * D * D)
+    return L * ((72.0 + 141.9) * M * D + 30.0 * 12 * D * D) + 2.0e9 * len(doms) * B / 64.0
+
+
+def step_hbm(model_name, doms, B, K, train, ms_per_step, fpi, measured=None):
+    """the whole step against BOTH of its floors: algorithmic bytes / achievable HBM bandwidth and algorithmic flops / bf16 MFMA peak"""
+    by = algorithmic_bytes(model_name, doms, B, K, train)
+    t = ms_per_step * 1e-3
+    hbm_floor, mfma_floor = by / HBM_ACHIEVABLE, B * fpi / MFMA_BF16_PEAK
+    out = {"algorithmic_gb": round(by / 1e9, 2), "measured_gb": measured["measured_gb"] if measured else None,
+           "achieved_tbps": round(by / t / 1e12, 3), "achievable_tbps": HBM_ACHIEVABLE / 1e12, "frac_of_6.3TBps": round(by / t / HBM_ACHIEVABLE, 4),
+           "hbm_floor_ms": round(hbm_floor * 1e3, 3), "mfma_floor_ms": round(mfma_floor * 1e3, 3),
+           "binding_floor": "hbm" if hbm_floor > mfma_floor else "mfma", "frac_of_binding_floor": round(max(hbm_floor, mfma_floor) / t, 4),
+           "flop_per_byte": round(B * fpi / by, 1), "ridge_flop_per_byte": round(MFMA_BF16_PEAK / HBM_ACHIEVABLE, 1)}
+    if measured:
+        out["measured_frac_of_6.3TBps"] = round(measured["measured_gb"] * 1e9 / t / HBM_ACHIEVABLE, 4)
+        out["measured_source"] = measured["source"]
+    return out
+
+
 def step_traffic(cfg_name):
     """{'measured_gb', 'algorithmic_gb', 'ratio', 'source'} of one C2 step, or None (other configurations / no committed PMC pass)"""
     if cfg_name != "c2":
         return None
-    for tname in ("r05_c2_step_traffic.json",):
+    for tname in ("r06_c2_step_traffic.json", "r05_c2_step_traffic.json"):
         f = os.path.join(ROOT, "profiles", tname)
         if os.path.exists(f):
             t = json.load(open(f))
@@ -150,9 +184,10 @@ def cpu_baseline(model_name, doms, K, train, budget_s=25.0):
                       f"{n_threads} threads of {os.cpu_count()} host cores"}
 
 
-def measure(a, cfg_name, steps, warmup, batch, rank, world, dev, force_dp, ranks_seen):
+def measure(a, cfg_name, steps, warmup, batch, rank, world, dev, force_dp, ranks_seen, light=False):
     """Build one configuration from scratch, warm it up, capture it, time `steps` steps (barrier + synchronize on both sides, max over
-    ranks) and run the instrumented roofline step.  Returns the JSON-ready result dict (rank 0; None elsewhere)."""
+    ranks) and run the instrumented roofline step.  Returns the JSON-ready result dict (rank 0; None elsewhere).
+    light: timing only ({ms_per_step, value}, on every rank) -- the per-rank reference step of an N > 1 run."""
     from mirage_amd import builder, kernels as K, optim
     from mirage_amd import _lib as L
     from mirage_amd.dp import GradReducer, broadcast_params
@@ -256,6 +291,8 @@ def measure(a, cfg_name, steps, warmup, batch, rank, world, dev, force_dp, ranks
     ms_per_step = 1e3 * elapsed / steps
     value = B * world * steps / elapsed
     fpi = flops_per_image(model_name, doms, Kk, train)
+    if light:
+        return {"ms_per_step": round(ms_per_step, 3), "value": round(value, 2)}
 
     result = None
     if rank == 0:
@@ -338,6 +375,9 @@ def measure(a, cfg_name, steps, warmup, batch, rank, world, dev, force_dp, ranks
                     # step's dataflow needs (encoder dataflow 19.0 GB + adapters / optimizer ~4 GB at C2): the family-average
                     # `traffic` above hides the re-fetches, this ratio does not
                     "step_traffic": step_traffic(cfg_name),
+                    # the WHOLE step against both of its floors (round 6): at the algorithmic level C2 and C4 sit below the ridge (215 / 260
+                    # flop per byte against 397), i.e. the step's floor is HBM time, not MFMA time -- both fractions belong in the line
+                    "hbm": step_hbm(model_name, doms, B, Kk, train, ms_per_step, fpi, step_traffic(cfg_name)),
                     "whole_step_achieved": round(value / world * fpi / 1e12, 2),
                     "whole_step_frac": round(value / world * fpi / MFMA_BF16_PEAK, 4)}
         result = {
@@ -504,6 +544,26 @@ def _run(real_stdout: int):
 
     from mirage_amd import kernels as K
     result = measure(a, a.config, a.steps, a.warmup, a.batch, rank, world, dev, force_dp, ranks_seen)
+    if (world > 1 or force_dp) and CONFIGS[a.config][4] and os.environ.get("MRG_DP_LOCAL_REF", "1") != "0":
+        # What the N-rank step is to be compared with, measured by EVERY rank on its own GPU in the same process: the same configuration
+        # without the gradient exchange and with separate update launches (with N > 1 the update cannot ride in the weight-gradient
+        # epilogues; other_configs.c4.unfused_update is the same number on one GPU).  step(N) / this = the cost of
+        # communication that the overlap did not hide, per rank.
+        import gc
+        from mirage_amd import trainer as _T
+        gc.collect(); torch.cuda.empty_cache()
+        was, _T.FUSE_OPT = _T.FUSE_OPT, False
+        try:
+            loc = measure(a, a.config, a.steps, a.warmup, a.batch, rank, 1, dev, False, 1, light=True)
+        finally:
+            _T.FUSE_OPT = was
+        mine = torch.tensor([loc["ms_per_step"]], device=dev, dtype=torch.float64)
+        allr = [torch.zeros_like(mine) for _ in range(dist.get_world_size())]
+        dist.all_gather(allr, mine)
+        if rank == 0 and result is not None and "dp" in result:
+            result["dp"]["local_unfused_ms_per_step"] = [round(float(x[0]), 3) for x in allr]
+            result["dp"]["local_unfused_note"] = ("every rank's own step without the gradient exchange and with separate update launches "
+                                                  "(MRG_FUSE_OPT=0): the per-GPU step the N-rank step is to be read against")
     if rank == 0:
         model_name, doms, _, Kk, train = CONFIGS[a.config]
         # The 40 % target of BASELINE.json is stated on the Large model: the same single line also carries the Large configurations
@@ -526,7 +586,7 @@ def _run(real_stdout: int):
                 rf = r["roofline"]
                 others[name] = {"workload": r["config"]["workload"], "value": r["value"], "unit": r["unit"], "steps": st, "warmup": wu,
                                 "ms_per_step": r["ms_per_step"], "gflop_per_image": r["config"]["gflop_per_image"],
-                                "whole_step_frac": rf["whole_step_frac"],
+                                "whole_step_frac": rf["whole_step_frac"], "hbm": rf["hbm"],
                                 "roofline": {"kernel": rf["kernel"], "achieved": rf["achieved"], "frac": rf["frac"], "unit": rf["unit"],
                                              "launches_per_step": rf["launches_per_step"], "avg_launch_us": rf["avg_launch_us"],
                                              "families": rf["families"]},

@@ -68,7 +68,9 @@ __global__ __launch_bounds__(256, 1) void rowfuse_fwd_kernel(const RowFuseArgs g
     const uint32_t voff_d = (uint32_t)((lane >> 2) * 512) + c16;               // rows of 256 elements
     const uint32_t voff_h = (uint32_t)((lane >> 2) * NH * 2) + c16;            // rows of NH elements (fc2's weight)
     int t_issue = 0, slot_issue = 0, slot_use = 0;
-    auto issue = [&]() {
+    // source / destination of the next tile to request (wave-uniform): scalar base of this wave's 64 weight rows, row pitch, LDS slot
+    struct Tile { const char* sb; long pitch; uint32_t voff, dst; };
+    auto next_tile = [&]() {
         const int T = min(t_issue, Ttot - 1);        // past the end: reload the last tile (keeps the in-flight count constant)
         int s = T >> 3;
         const int kt = T & 7;
@@ -83,30 +85,48 @@ __global__ __launch_bounds__(256, 1) void rowfuse_fwd_kernel(const RowFuseArgs g
                 else { base = reinterpret_cast<const char*>(g.w1) + ((long)c * 65536 + kt * 32) * 2; ld = 256; }
             } else { base = reinterpret_cast<const char*>(g.w1) + ((long)s * 65536 + kt * 32) * 2; ld = 256; }
         }
-        const uint32_t voff = ld == 256 ? voff_d : voff_h;
-        const uint32_t dst = sbase + RF_OFF_W + slot_issue * RF_WT_BYTES + wave * 4096;
-        const char* sb = base + (long)wave * 128 * ld;                          // this wave's 64 weight rows
-#pragma unroll
-        for (int jj = 0; jj < 4; ++jj) glds16_s(uniform_ptr(sb + (long)jj * 32 * ld), voff, dst + jj * 1024);
+        Tile t;
+        t.voff = ld == 256 ? voff_d : voff_h;
+        t.dst = sbase + RF_OFF_W + slot_issue * RF_WT_BYTES + wave * 4096;
+        t.sb = base + (long)wave * 128 * ld;                                    // this wave's 64 weight rows
+        t.pitch = (long)32 * ld;                                                // 16 rows per 1-KiB piece
         ++t_issue;
         slot_issue = slot_issue == RF_RING - 1 ? 0 : slot_issue + 1;
+        return t;
+    };
+    auto dma = [&](const Tile& t, int jj) { glds16_s(uniform_ptr(t.sb + jj * t.pitch), t.voff, t.dst + jj * 1024); };
+    auto issue = [&]() {
+        const Tile t = next_tile();
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) dma(t, jj);
     };
     const uint32_t sw = (uint32_t)((lr >> 2) & 3);
     const uint32_t fb_off[2] = {(uint32_t)(lr * 64) + (((0u + h) ^ sw) << 4), (uint32_t)(lr * 64) + (((2u + h) ^ sw) << 4)};
-    auto mma_tile = [&](const char* A, int kt, f32x16 (&acc)[2][2]) {
+    // one tile: all fragment reads first, then the eight MFMAs with the four DMA pieces of the tile three ahead between them -- a DMA
+    // piece stalls the issuing wave for 60-180 cycles (MI355X_MICROARCH.md price list), which the matrix pipe covers only if it has work
+    // queued; requested up front (the first version) the pieces, the LDS reads and the MFMAs of the only wave of a SIMD ran one after
+    // the other: ~1600 cycles per tile for 256 cycles of matrix work
+    auto step = [&](const char* A, int kt, f32x16 (&acc)[2][2]) {
+        const Tile t = next_tile();
         const char* wb = smem + RF_OFF_W + slot_use * RF_WT_BYTES + wave * 4096;
+        bf16x8 fa[2][2], fb[2][2];
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
-            bf16x8 fa[2], fb[2];
 #pragma unroll
-            for (int i = 0; i < 2; ++i) fa[i] = read_frag<MRG_OP_KCONTIG>(A + (kt >> 1) * 8192, 0u, i * 32, (kt & 1) * 2 + kk, lane);
+            for (int i = 0; i < 2; ++i) fa[kk][i] = read_frag<MRG_OP_KCONTIG>(A + (kt >> 1) * 8192, 0u, i * 32, (kt & 1) * 2 + kk, lane);
 #pragma unroll
-            for (int j = 0; j < 2; ++j) fb[j] = *reinterpret_cast<const bf16x8*>(wb + j * 2048 + fb_off[kk]);
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
+            for (int j = 0; j < 2; ++j) fb[kk][j] = *reinterpret_cast<const bf16x8*>(wb + j * 2048 + fb_off[kk]);
         }
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[kk][j], fa[kk][i], acc[i][j], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                dma(t, kk * 2 + i);
+                __builtin_amdgcn_sched_barrier(0);
+            }
         slot_use = slot_use == RF_RING - 1 ? 0 : slot_use + 1;
     };
     // bf16 quad (4 consecutive columns of one row) into an activation region
@@ -193,8 +213,7 @@ __global__ __launch_bounds__(256, 1) void rowfuse_fwd_kernel(const RowFuseArgs g
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
             if (k > 0) { RF_WAIT(8); RF_BARRIER(); }
-            issue();
-            mma_tile(Areg, k, acc);
+            step(Areg, k, acc);
         }
 #pragma unroll
         for (int i = 0; i < 2; ++i)
@@ -272,17 +291,17 @@ __global__ __launch_bounds__(256, 1) void rowfuse_fwd_kernel(const RowFuseArgs g
                 }
     }
     // ---- the products over the LayerNorm output, 256 output / hidden columns at a time.  vmcnt budget of a tile wait: 8 (the two
-    // younger tiles' DMAs) + the stores issued behind the awaited tile's DMA, i.e. in the three iterations before this one
+    // younger tiles' DMAs) + the stores issued behind the awaited tile's DMA, i.e. in the two iterations before this one (an iteration
+    // issues its stores first, then -- between its MFMAs -- the DMA of the tile three ahead)
     if (MLP) zero_acc(acc2);
     uint32_t gq[2][2][4][2];          // gelu'(h) of the chunk as packed fp16 pairs, until both row halves have gone through the staging area
     for (int c = 0; c < NC; ++c) {
         zero_acc(acc);
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
-            // !MLP: 8 stores in k = 0 (the previous chunk's output)
-            if (!MLP && c > 0 && k >= 1 && k <= 3) RF_WAIT(16); else RF_WAIT(8);
+            // !MLP: 8 stores in k = 0 (the previous chunk's output) count for the waits of k = 1, 2
+            if (!MLP && c > 0 && (k == 1 || k == 2)) RF_WAIT(16); else RF_WAIT(8);
             RF_BARRIER();
-            issue();
             if (k == 0) {
                 if (c == 0) {
                     if (SAVE) {
@@ -294,7 +313,7 @@ __global__ __launch_bounds__(256, 1) void rowfuse_fwd_kernel(const RowFuseArgs g
                     for (int it = 0; it < 8; ++it) copy_out(Hreg, g.h_out + (c - 1) * 256, NH, it);
                 }
             }
-            mma_tile(Areg, k, acc);
+            step(Areg, k, acc);
         }
         // epilogue of the chunk: + b1 -> (GELU) -> bf16 into Hreg
 #pragma unroll
@@ -339,10 +358,9 @@ __global__ __launch_bounds__(256, 1) void rowfuse_fwd_kernel(const RowFuseArgs g
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
                 if (SAVE) {
-                    if (k == 1 || k == 2) RF_WAIT(20); else if (k == 3) RF_WAIT(24); else if (k == 4 || k == 5) RF_WAIT(12); else RF_WAIT(8);
+                    if (k == 1 || k == 2) RF_WAIT(20); else if (k == 3 || k == 4) RF_WAIT(12); else RF_WAIT(8);
                 } else RF_WAIT(8);
                 RF_BARRIER();
-                issue();
                 if (SAVE) {
                     if (k == 0) {
 #pragma unroll
@@ -359,7 +377,7 @@ __global__ __launch_bounds__(256, 1) void rowfuse_fwd_kernel(const RowFuseArgs g
                         for (int it = 0; it < 4; ++it) g_copy_out(g.hgrad_out, 1, c, it);
                     }
                 }
-                mma_tile(Hreg, k, acc2);
+                step(Hreg, k, acc2);
             }
         }
     }
