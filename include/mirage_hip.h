@@ -151,12 +151,12 @@ int mrg_wgrad_group(const mrg_wgrad_group_desc* d, hipStream_t stream);
  *   fwd: x fp32 [M,D] -> y bf16 and/or fp32, mean/rstd fp32 [M].  D % 4 == 0, D <= 1024.
  *   bwd: dx = dres + LN'(dy); writes dx fp32 and/or bf16; dgamma/dbeta fp32 [D]; dres_colsum (optional) = column
  *        sum of dres = bias gradient of the Linear whose output entered the residual stream.
- *        partials: workspace fp32 [mrg_ln_bwd_nblocks(M)][3][D].
+ *        partials: workspace fp32 [mrg_ln_bwd_partial_rows(M, D)][3][D] (one row of partial sums per workgroup of the launch).
  */
 int mrg_ln_fwd(const float* x, const float* gamma, const float* beta, void* y_bf16, float* y_f32, float* mean, float* rstd,
                int M, int D, float eps, hipStream_t stream);
 int mrg_ln_bwd_nblocks(int M);
-int mrg_ln_bwd_partial_rows(int M, int D);   /* rows of `partials` mrg_ln_bwd actually writes (<= mrg_ln_bwd_nblocks(M)) */
+int mrg_ln_bwd_partial_rows(int M, int D);   /* rows of `partials` mrg_ln_bwd writes = its workgroup count (<= mrg_ln_bwd_nblocks(M)) */
 /* Batched slice reduction: for every task dst[i] = sum_{s < nslices} src[s * stride + i], i < n (fp32; n and stride multiples
  * of 4, 16-byte aligned).  One or two launches for the whole table: it finishes the split-K slabs of deferred weight-gradient
  * GEMMs (mrg_gemm defer_reduce) and the partial column sums mrg_ln_bwd / mrg_colsum leave behind when called with null

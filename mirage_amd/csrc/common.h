@@ -87,7 +87,7 @@ __device__ __forceinline__ float gelu_cdf_rational(float x) {
     return fmaf(xc * p, __builtin_amdgcn_rcpf(q), 0.5f);
 }
 // the factor on the negative side is the CLAMPED argument: x * Phi(-5) would grow linearly below -5 (-2.9e-4 at x = -1e3, -inf at -inf)
-// where gelu tends to 0; -5 * Phi(-5) = -1.4e-6 is the bound.  (The training epilogue, GELU_SAVE_GRAD, keeps the erf form of gelu_parts: it
+// where gelu tends to 0; now |gelu_f(x)| <= 5 (Phi(-5) + 8.9e-7) = 6e-6 for every x <= -5.  (The training epilogue, GELU_SAVE_GRAD, keeps the erf form of gelu_parts: it
 // needs the Gaussian factor for the derivative anyway, so train and eval forward differ by the two formulas' < 1e-6.)
 __device__ __forceinline__ float gelu_f(float x) { return fmaxf(x, -5.0f) * gelu_cdf_rational(x); }
 __device__ __forceinline__ float gelu_grad_f(float x) { float c, p; gelu_parts(x, c, p); return c + x * p; }

@@ -177,7 +177,7 @@ __device__ __forceinline__ void gemm_glds_body(const GemmArgs& g) {
     wg_remap(nwg, g.xcd_split, bid, ksplit);
     // grouped rasterisation inside the XCD's band: GROUP_M row panels x all column tiles, column-major within the group,
     // so a B (weight) tile is reused by GROUP_M consecutive workgroups while their A panels stay L2-resident
-    constexpr int GROUP_M = 8;
+    const int GROUP_M = g.group_m;
     int tm, tn;
     {
         const int per_group = GROUP_M * g.tiles_n;
@@ -1194,6 +1194,7 @@ extern "C" int mrg_gemm(const mrg_gemm_desc* d, hipStream_t stream) {
     { static const int abl = [] { const char* e = getenv("MRG_GEMM_ABLATE"); return e ? atoi(e) : 0; }(); g.ablate = abl; }
     { static const int nt = [] { const char* e = getenv("MRG_GEMM_NT"); return e ? atoi(e) : 2; }(); g.nt = nt; }
     { static const int xs = [] { const char* e = getenv("MRG_GEMM_XCD_SPLIT"); return e ? atoi(e) : 1; }(); g.xcd_split = xs; }
+    { static const int gm = [] { const char* e = getenv("MRG_GEMM_GROUP_M"); const int v = e ? atoi(e) : 8; return v >= 1 ? v : 8; }(); g.group_m = gm; }
     { static const int sd = [] { const char* e = getenv("MRG_GEMM_SIDE_DRAIN"); return e ? atoi(e) : 3; }(); g.side_drain = sd; }
     static const int kfast = [] { const char* e = getenv("MRG_GEMM_KFAST"); return e ? atoi(e) : 1; }();
     static const int epi_direct_env = [] { const char* e = getenv("MRG_EPI_DIRECT"); return e ? atoi(e) : 0; }();   // register-direct epilogue of the single-stage 128 x 128 kernel: measured SLOWER (12.95 vs 11.02 ms/step at C2)
@@ -1380,7 +1381,7 @@ extern "C" int mrg_gemm_multi(const mrg_gemm_desc* ds, int n, hipStream_t stream
         g.row_map = d->row_map; g.add_tab = d->add_tab; g.add_row = d->add_row; g.ldt = d->ldt;
         g.splitk = 1; g.drop.scale = 1.f;
         g.tiles_m = cdiv(d->M, BM); g.tiles_n = cdiv(d->N, BN);
-        g.nt = 2; g.xcd_split = 1; g.side_drain = 3;
+        g.nt = 2; g.xcd_split = 1; g.side_drain = 3; g.group_m = 8;
         auto al4 = [](const void* q, int ld, int bytes) { return q == nullptr || ((((uintptr_t)q) % (4 * bytes) == 0) && (ld % 4 == 0)); };
         const bool vec = (d->N % 4 == 0) && al4(d->C, d->ldc, g.c_f32 ? 4 : 2) && al4(d->add_tab, d->ldt, 4);
         MRG_REQUIRE(g.a_aligned && g.b_aligned && vec, MRG_ERR_UNSUPPORTED, "mrg_gemm_multi: problem %d: operands / outputs must be 16-B aligned with N %% 4 == 0", p);
@@ -1412,7 +1413,7 @@ extern "C" int mrg_wgrad_group(const mrg_wgrad_group_desc* d, hipStream_t stream
     const int splitk = d->splitk > 1 ? d->splitk : 1;
     MRG_REQUIRE(splitk == 1 || d->ws, MRG_ERR_ARG, "mrg_wgrad_group: split-K needs a workspace");
     MRG_REQUIRE(splitk <= (d->K / BK), MRG_ERR_SHAPE, "mrg_wgrad_group: split-K factor %d exceeds the %d k-tiles", splitk, d->K / BK);
-    g.c_f32 = 1; g.splitk = splitk; g.ws = d->ws; g.epi_kind = splitk == 1 ? 7 : 0; g.act = MRG_ACT_NONE; g.xcd_split = 1;
+    g.c_f32 = 1; g.splitk = splitk; g.ws = d->ws; g.epi_kind = splitk == 1 ? 7 : 0; g.act = MRG_ACT_NONE; g.xcd_split = 1; g.group_m = 8;
     { static const int nt = [] { const char* e = getenv("MRG_GEMM_NT"); return e ? atoi(e) : 2; }(); g.nt = nt; }
     { static const int sd = [] { const char* e = getenv("MRG_GEMM_SIDE_DRAIN"); return e ? atoi(e) : 3; }(); g.side_drain = sd; }
     ga.nprob = d->count;

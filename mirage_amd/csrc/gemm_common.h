@@ -38,6 +38,7 @@ struct GemmArgs {
                    // 8-phase kernel only, the other kernels take the generic path for it)
     int side_drain; // MRG_GEMM_SIDE_DRAIN (bit 0: batched drain of the lean epilogues, bit 1: of the split-K slab stores; default 3)
     int xcd_split; // MRG_GEMM_XCD_SPLIT (default 1): split-K index slowest in the XCD band order
+    int group_m;   // MRG_GEMM_GROUP_M (default 8; single-stage 128 x 128 kernel only): row panels per rasterisation group inside an XCD's band
     int nt;       // MRG_GEMM_NT: 0 plain stores, 1 streaming (nontemporal) stores for C / C2 / aux_out, 2 (default) for aux_out only
     int ablate;   // MRG_GEMM_ABLATE (256x128 kernel only, for roofline analysis): 1 = no DMA, 2 = DMA only, 3 = DMA + LDS reads, no MFMA
     MrgDropout drop;   // drop.rng != nullptr: (acc + bias) is multiplied by the Philox keep mask / (1 - p) before row_scale / resid --

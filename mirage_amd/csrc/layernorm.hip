@@ -78,6 +78,9 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
 // Templated on the row width (NV float4 chunks per lane) and on the optional operands so that the row loop is
 // straight-line code: all loads of a row are issued back to back and registers are sized for the real D.
 constexpr int LNB_WAVES = 4;
+// (Round 6 tried the opposite trade: no look-ahead row, 3 waves per SIMD and a grid on which every wave owns the same number of rows -- the
+// BASELINE shapes leave 64 / 192 of the 2048 waves a row more than the rest.  Slower: 25.2 / 27.6 us against 23.6 / 24.6 at 8256 x 768 /
+// 6336 x 1024; the look-ahead is worth more than the occupancy.  profiles/r06_experiments.md)
 template <int NV, bool DY16, bool HAS_RES>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const void* __restrict__ dyp, const float* __restrict__ x,
                                                      const float* __restrict__ mean, const float* __restrict__ rstd,

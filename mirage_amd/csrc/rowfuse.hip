@@ -33,7 +33,8 @@ constexpr int RF_OFF_A = 0, RF_OFF_H = RF_A_BYTES, RF_OFF_W = 2 * RF_A_BYTES;
 constexpr int RF_OFF_G = RF_OFF_W + RF_RING * RF_WT_BYTES;      // 16 KiB staging of gelu'(h): [4 k-tiles][32 rows][64 cols] fp16, one row half at a time
 constexpr int RF_OFF_VEC = RF_OFF_G + 16384;                    // fp32 vectors: b0 | gamma | beta | b2 | b1[<= 1024]
 constexpr int RF_OFF_RED = RF_OFF_VEC + 2048 * 4;               // two [4 waves][64 rows] fp32 reduction buffers
-constexpr int RF_LDS_BYTES = RF_OFF_RED + 2 * 4 * 64 * 4;       // 157696
+constexpr int RF_OFF_TS = RF_OFF_RED + 2 * 4 * 64 * 4;          // (debug build -DMRG_RF_TS: 64 phase timestamps)
+constexpr int RF_LDS_BYTES = RF_OFF_TS + 512;                   // 158208
 
 struct RowFuseArgs {
     int M, NH; float eps;
@@ -46,6 +47,11 @@ struct RowFuseArgs {
 #define RF_WAIT(N_) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" :: "n"(N_) : "memory")
 #define RF_BARRIER() do { __builtin_amdgcn_s_barrier(); __builtin_amdgcn_sched_barrier(0); } while (0)
 #define RF_LDS_SYNC() do { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); RF_BARRIER(); } while (0)
+#ifdef MRG_RF_TS      // debug build: shader-clock timestamps of wave 0 at the phase boundaries, returned in rstd[m0 .. m0 + 63] as cycles since the first
+#define RF_TS(i_) do { if (tid == 0) reinterpret_cast<unsigned long long*>(smem + RF_OFF_TS)[i_] = clock64(); } while (0)
+#else
+#define RF_TS(i_) do { } while (0)
+#endif
 
 // PROJ: stage 0 is a projection of a bf16 operand (else the rows come in as fp32); MLP: fc1 + GELU + fc2 (else a plain projection to NH
 // columns); SAVE: training -- x, LayerNorm output / statistics, gelu(h) and gelu'(h) are written for the backward pass
@@ -171,6 +177,7 @@ __global__ __launch_bounds__(256, 1) void rowfuse_fwd_kernel(const RowFuseArgs g
     };
 
     // ---- prologue: stage-0 operand and the first three weight tiles in flight, then the fp32 rows and the small vectors
+    RF_TS(0);
     if (PROJ) {
         const char* sa = uniform_ptr(reinterpret_cast<const char*>(g.a0) + ((long)m0 * 256 + wave * 64) * 2);   // k-tile = wave
 #pragma unroll
@@ -205,6 +212,7 @@ __global__ __launch_bounds__(256, 1) void rowfuse_fwd_kernel(const RowFuseArgs g
         for (int j = 0; j < 2; ++j) asm volatile("" : "+v"(x[i][j]));
     RF_WAIT(0);
     RF_BARRIER();
+    RF_TS(1);
 
     f32x16 acc[2][2], acc2[2][2];
     // ---- stage 0: x = a0 W0^T + b0 (+ resid)
@@ -215,6 +223,7 @@ __global__ __launch_bounds__(256, 1) void rowfuse_fwd_kernel(const RowFuseArgs g
             if (k > 0) { RF_WAIT(8); RF_BARRIER(); }
             step(Areg, k, acc);
         }
+        RF_TS(2);
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -237,6 +246,7 @@ __global__ __launch_bounds__(256, 1) void rowfuse_fwd_kernel(const RowFuseArgs g
         }
     }
     // ---- LayerNorm over the 256 columns of each row (two passes over the registers, like ln_fwd_small_kernel)
+    RF_TS(3);
     float mu[2], rs[2];
     {
         float s[2];
@@ -255,6 +265,7 @@ __global__ __launch_bounds__(256, 1) void rowfuse_fwd_kernel(const RowFuseArgs g
 #pragma unroll
             for (int it = 0; it < 16; ++it) f32_copy_out(g.x_out, it);
         }
+        RF_TS(4);
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int r = i * 32 + lr;
@@ -293,6 +304,7 @@ __global__ __launch_bounds__(256, 1) void rowfuse_fwd_kernel(const RowFuseArgs g
     // ---- the products over the LayerNorm output, 256 output / hidden columns at a time.  vmcnt budget of a tile wait: 8 (the two
     // younger tiles' DMAs) + the stores issued behind the awaited tile's DMA, i.e. in the two iterations before this one (an iteration
     // issues its stores first, then -- between its MFMAs -- the DMA of the tile three ahead)
+    RF_TS(5);
     if (MLP) zero_acc(acc2);
     uint32_t gq[2][2][4][2];          // gelu'(h) of the chunk as packed fp16 pairs, until both row halves have gone through the staging area
     for (int c = 0; c < NC; ++c) {
@@ -315,6 +327,7 @@ __global__ __launch_bounds__(256, 1) void rowfuse_fwd_kernel(const RowFuseArgs g
             }
             step(Areg, k, acc);
         }
+        RF_TS(6 + 4 * c);
         // epilogue of the chunk: + b1 -> (GELU) -> bf16 into Hreg
 #pragma unroll
         for (int i = 0; i < 2; ++i)
@@ -346,6 +359,7 @@ __global__ __launch_bounds__(256, 1) void rowfuse_fwd_kernel(const RowFuseArgs g
                     }
                     a_store(Hreg, i * 32 + lr, j, q, pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]));
                 }
+        RF_TS(7 + 4 * c);
         if (MLP) {
             if (SAVE) {
 #pragma unroll
@@ -378,9 +392,12 @@ __global__ __launch_bounds__(256, 1) void rowfuse_fwd_kernel(const RowFuseArgs g
                     }
                 }
                 step(Hreg, k, acc2);
+                if (k == 3) RF_TS(8 + 4 * c);
             }
+            RF_TS(9 + 4 * c);
         }
     }
+    RF_TS(22);
     RF_WAIT(0);                  // the tail's dummy tiles have landed: the ring is free (and nothing lands after the workgroup has left)
     RF_BARRIER();                // every wave is done with Areg / Hreg
     if (MLP) {
@@ -398,6 +415,7 @@ __global__ __launch_bounds__(256, 1) void rowfuse_fwd_kernel(const RowFuseArgs g
                     f32_stage(i, j, q, o0, o1, o2, o3);
                     if (g.y16) a_store(smem + RF_OFF_W, i * 32 + lr, j, q, pack_bf2(o0, o1), pack_bf2(o2, o3));
                 }
+        RF_TS(23);
         RF_LDS_SYNC();
 #pragma unroll
         for (int it = 0; it < 16; ++it) f32_copy_out(g.y32, it);
@@ -405,6 +423,16 @@ __global__ __launch_bounds__(256, 1) void rowfuse_fwd_kernel(const RowFuseArgs g
 #pragma unroll
             for (int it = 0; it < 8; ++it) copy_out(smem + RF_OFF_W, g.y16, 256, it);
         }
+        RF_TS(24);
+#ifdef MRG_RF_TS
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        RF_TS(25);
+        RF_LDS_SYNC();
+        if (SAVE && tid < 64) {
+            const unsigned long long* t = reinterpret_cast<const unsigned long long*>(smem + RF_OFF_TS);
+            g.rstd[m0 + tid] = (float)(long long)(t[tid] - t[0]);
+        }
+#endif
     } else {
 #pragma unroll
         for (int it = 0; it < 8; ++it) copy_out(Hreg, g.h_out + (NC - 1) * 256, NH, it);

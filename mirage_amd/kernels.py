@@ -451,6 +451,9 @@ class WgradGroup:
                 # end of the step) cuts every tile's k-range in two: slabs + the batched reduction, as the per-GEMM path does
                 sk = 2 if (ctiles <= cls.split_below and K_ // 64 >= 32 and K_ <= cls.split_max_k and Deferred.active
                            and all(t[8] == t[3] and Deferred.ok(t[7], t[2] * t[3], t[2] * t[3]) for t in chunk)) else 1
+                # (round 6: cutting the k-range of the output adapters' 38-tile group -- K = 16384 tokens, ~400 us on 38 CUs beside the encoder's
+                # backward pass -- in four made the launch fuller and the step slower: slabs + reduction, no AdamW in the epilogue; C2 +0.1 ms,
+                # C4 +-0, profiles/r06_experiments.md)
                 fz = cls.fuse if (sk == 1 and cls.fuse is not None and (cls.exposed or not cls.fuse.only_exposed)) else None
                 wgrad_group(chunk, K_, sk, fuse=fz)
 

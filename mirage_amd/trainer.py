@@ -51,6 +51,12 @@ class TrainStep:
         from . import kernels as _K
         self.slots = _K.InputSlots(self.static_x)
         self.in_domains = list(model.input_adapters.keys())
+        missing = [d for d in self.in_domains if d not in batch_example]
+        if missing:
+            # the step drives EVERY input adapter of the model; a trainable adapter without input could not be skipped by the fused /
+            # early / sharded updates anyway (FusedAdamW.step refuses it: the reference's optimizer skips parameters without a gradient)
+            raise ValueError(f"TrainStep: the example batch lacks the modalities {missing} of the model's input adapters; build the model with "
+                             "the adapters in use (or pass every modality)")
         # parity runs: the three random inputs of the mask generator (Dirichlet shares p [B, n], per-task
         # noise u [B, T], tie-break noise g [B, T]) come from static buffers filled by step(noise=...) instead of the device RNG
         self.static_noise = None

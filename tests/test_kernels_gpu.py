@@ -1236,7 +1236,8 @@ def test_gemm_colsum_epilogue(K):
 
 def test_gelu_epilogue_far_negative_arguments_tend_to_zero(K):
     """Round-5 advisor item: the inference GELU epilogue is x * Phi(clamp(x, -5, 5)); multiplied by the UNclamped x it grew linearly below
-    -5 (-2.9e-4 at -1e3) where gelu tends to 0.  The factor is clamped on the negative side now: |gelu(x)| <= 1.5e-6 for x <= -5."""
+    -5 (-2.9e-4 at -1e3) where gelu tends to 0.  The factor is clamped on the negative side now: |gelu(x)| <= 5 (Phi(-5) + the rational's
+    8.9e-7) = 6e-6 for every x <= -5."""
     from mirage_amd import _lib as L
     M, N, Kd = 128, 128, 64
     A = torch.zeros(M, Kd, dtype=BF16, device=dev()); W = torch.zeros(N, Kd, dtype=BF16, device=dev())
@@ -1246,4 +1247,4 @@ def test_gelu_epilogue_far_negative_arguments_tend_to_zero(K):
     ref = torch.nn.functional.gelu(b.double()).float()
     assert torch.isfinite(out).all()
     assert float((out[0] - ref).abs().max()) <= 2e-6 * max(1.0, float(ref.abs().max()))
-    assert float(out[0][b <= -5.0].abs().max()) <= 1.5e-6
+    assert float(out[0][b <= -5.0].abs().max()) <= 6e-6
