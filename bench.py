@@ -330,9 +330,8 @@ def measure(a, cfg_name, steps, warmup, batch, rank, world, dev, force_dp, ranks
             K.TIMING["on"] = False
             _E._Side.enabled, _E.TWO_CHAINS = side_was, chains_was
         torch.cuda.synchronize()
-        vname = {0: "auto", 1: "gemm_glds_kernel", 2: "gemm_glds_kernel", 3: "gemm_pipe_kernel", 4: "gemm_pipe256_kernel",
-                 7: "gemm_ws256_kernel", 8: "gemm_glds64_kernel",
-                 10: "gemm_g256_kernel", 11: "gemm_p8_kernel", 13: "gemm_duo_kernel", 100: "gemm_p8_group_kernel"}
+        vname = {0: "auto", 1: "gemm_glds_kernel", 2: "gemm_glds_kernel", 3: "gemm_pipe_kernel", 7: "gemm_ws256_kernel", 11: "gemm_p8_kernel",
+                 100: "gemm_p8_group_kernel"}
         mname = {(0, 0): "forward x*W^T", (0, 1): "dgrad dy*W", (1, 1): "wgrad dy^T*x"}
         groups = {}
         shapes = {}

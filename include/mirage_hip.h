@@ -26,7 +26,7 @@ extern "C" {
 typedef struct ihipStream_t* hipStream_t;
 #endif
 
-#define MRG_ABI_VERSION 15   /* 15: mrg_rowfuse_fwd (the output adapters' row-local chains in one launch, csrc/rowfuse.hip); 14: mrg_gemm_multi; mrg_loss_coef, mrg_masked_loss_fused, mrg_masked_loss_finish (loss forward + gradient in one pass), mrg_loss_desc.nvalid / mask_bs; 13: the stream-K schedule of round 4 is gone (measured slower everywhere it was meant to win and selected nowhere: profiles/r04_streamk.md; the code is tools/debug/patches/streamk_r04.patch) -- variant 12 reserved, mrg_gemm_desc.sk_grid, mrg_wgrad_group_desc.streamk / counters / sk_grid, mrg_streamk_ws_bytes and mrg_debug_sk_trace removed; 12: MRG_GEMM_DUO (mrg_gemm_desc.variant 13: the 128 x 256 two-workgroups-per-CU kernel, csrc/gemm_duo.hip); 11: mrg_attn_desc.drop_rng / drop_p / drop_stream (dropout on the attention probabilities), mrg_posemb_grad, mrg_loss_desc.label_smoothing / norm_pix / stats, mrg_wgrad_group_desc.fuse + mrg_adamw_hp (AdamW in the weight-gradient epilogue), mrg_debug_clock_monitor; 10: MRG_GEMM_P8SK (stream-K schedule of the 8-phase kernel), mrg_gemm_desc.sk_grid, mrg_wgrad_group_desc.streamk / counters / sk_grid, mrg_streamk_ws_bytes; 9: mrg_maskgen_rng, input slots (mrg_set_slots, *_slot parameters, mrg_loss_desc.target_slot); 8: mrg_gemm_desc.drop_rng / drop_p / drop_stream, mrg_dropout_bwd_bf16; 7: mrg_wgrad_group, mrg_debug_timestamp; 2: mrg_gemm_desc grew row_scale / defer_reduce, act codes 3, 4, reduce_batch / augment / row_scale entry points; 3: colsum_out, attention colsum_*; 4: step = int[2], mrg_step_inc takes the skip decision; 5: splitk_counters, MRG_GEMM_P8, resize entry points; 6: mrg_adamw_desc.sumsq_out, mrg_sumsq_finish */
+#define MRG_ABI_VERSION 16   /* 16: the GEMM variants that the committed table never selected for a production shape are gone (two-stage 256 x 128 = 4, 64-row tile = 8, single-stage 256 x 128 = 10, 128 x 256 two-workgroup kernel = 13: mrg_gemm_desc.variant refuses them like the other reserved numbers; round-5 review item 6); 15: mrg_rowfuse_fwd (the output adapters' row-local chains in one launch, csrc/rowfuse.hip); 14: mrg_gemm_multi; mrg_loss_coef, mrg_masked_loss_fused, mrg_masked_loss_finish (loss forward + gradient in one pass), mrg_loss_desc.nvalid / mask_bs; 13: the stream-K schedule of round 4 is gone (measured slower everywhere it was meant to win and selected nowhere: profiles/r04_streamk.md; the code is in the history of csrc/gemm8p.hip, round 4) -- variant 12 reserved, mrg_gemm_desc.sk_grid, mrg_wgrad_group_desc.streamk / counters / sk_grid, mrg_streamk_ws_bytes and mrg_debug_sk_trace removed; 12: MRG_GEMM_DUO (mrg_gemm_desc.variant 13: the 128 x 256 two-workgroups-per-CU kernel, csrc/gemm_duo.hip); 11: mrg_attn_desc.drop_rng / drop_p / drop_stream (dropout on the attention probabilities), mrg_posemb_grad, mrg_loss_desc.label_smoothing / norm_pix / stats, mrg_wgrad_group_desc.fuse + mrg_adamw_hp (AdamW in the weight-gradient epilogue), mrg_debug_clock_monitor; 10: MRG_GEMM_P8SK (stream-K schedule of the 8-phase kernel), mrg_gemm_desc.sk_grid, mrg_wgrad_group_desc.streamk / counters / sk_grid, mrg_streamk_ws_bytes; 9: mrg_maskgen_rng, input slots (mrg_set_slots, *_slot parameters, mrg_loss_desc.target_slot); 8: mrg_gemm_desc.drop_rng / drop_p / drop_stream, mrg_dropout_bwd_bf16; 7: mrg_wgrad_group, mrg_debug_timestamp; 2: mrg_gemm_desc grew row_scale / defer_reduce, act codes 3, 4, reduce_batch / augment / row_scale entry points; 3: colsum_out, attention colsum_*; 4: step = int[2], mrg_step_inc takes the skip decision; 5: splitk_counters, MRG_GEMM_P8, resize entry points; 6: mrg_adamw_desc.sumsq_out, mrg_sumsq_finish */
 
 enum { MRG_DT_BF16 = 0, MRG_DT_F32 = 1 };
 enum { MRG_OP_KCONTIG = 0, MRG_OP_KSTRIDED = 1 };
@@ -59,10 +59,9 @@ const char* mrg_last_error_string(void);
  *   row_map optional int32 scatter of output rows; add_tab/add_row: v += add_tab[add_row[row]*ldt + col]
  *           (positional-embedding add of the input adapters, mirage/input_adapters.py:104-108)
  *   splitk  >1: partial sums to ws [splitk][M][N] fp32, then reduced (bias/accumulate epilogue only)
- *   variant kernel variant for aligned, map-free problems: single-stage LDS-DMA kernel at 3 or 4 workgroups/CU,
- *           two-stage pipelined 128x128 kernel, two-stage pipelined 256x128 kernel (8 waves), warp-specialised 256x128 kernel (8 compute + 4 loader waves, 3-stage ring), single-stage 64x128 kernel (A k-contiguous only), single-stage 256x128 kernel with 4 waves x (128x64) (K a multiple of 64);
- *           0 picks by shape; MRG_GEMM_P8 = the 256 x 256 8-phase kernel, one tile per workgroup (12 reserved: its stream-K schedule, measured and dropped);
- *           MRG_GEMM_DUO = the 128 x 256 kernel with two co-resident workgroups per CU (A k-contiguous, K a multiple of 64: forward / dgrad)
+ *   variant kernel variant for aligned, map-free problems: single-stage LDS-DMA 128 x 128 kernel at 3 or 4 workgroups/CU, two-stage pipelined
+ *           128 x 128 kernel, warp-specialised 256 x 128 kernel (8 compute + 4 loader waves, 3-stage ring), MRG_GEMM_P8 = the 256 x 256 8-phase
+ *           kernel, one tile per workgroup; 0 picks by shape.  Every other number is reserved (kernels measured and dropped) and refused.
  */
 typedef struct mrg_gemm_desc {
     const void* A; const void* B;
@@ -105,7 +104,7 @@ typedef struct mrg_gemm_desc {
                                         mrg_dropout_bwd_bf16 regenerates the same mask for the backward pass. */
     float drop_p; unsigned drop_stream;
 } mrg_gemm_desc;
-enum { MRG_GEMM_AUTO = 0, MRG_GEMM_GLDS3 = 1, MRG_GEMM_GLDS4 = 2, MRG_GEMM_PIPE128 = 3, MRG_GEMM_PIPE256 = 4, /* 5, 6, 9 reserved: a three-stage 256 x 128 kernel, a two-stage 256 x 256 kernel and a persistent one, measured and dropped */ MRG_GEMM_WS256 = 7, MRG_GEMM_GLDS64 = 8, MRG_GEMM_G256 = 10, MRG_GEMM_P8 = 11, /* 12 reserved */ MRG_GEMM_DUO = 13 };
+enum { MRG_GEMM_AUTO = 0, MRG_GEMM_GLDS3 = 1, MRG_GEMM_GLDS4 = 2, MRG_GEMM_PIPE128 = 3, MRG_GEMM_WS256 = 7, MRG_GEMM_P8 = 11 };   /* 4, 5, 6, 8, 9, 10, 12, 13 reserved */
 
 int mrg_gemm(const mrg_gemm_desc* d, hipStream_t stream);
 /* n <= MRG_MAX_DOMAINS independent forward-layout products (descriptors ds[0 .. n-1], results identical to n mrg_gemm calls) in ONE launch:

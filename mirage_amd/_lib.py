@@ -19,7 +19,7 @@ MRG_OP_KCONTIG, MRG_OP_KSTRIDED = 0, 1
 MRG_ACT_NONE, MRG_ACT_GELU, MRG_ACT_GELU_BWD, MRG_ACT_GELU_SAVE_GRAD, MRG_ACT_MUL_AUX_F16 = 0, 1, 2, 3, 4
 MRG_LOSS_MSE, MRG_LOSS_CE = 0, 1
 MRG_MAX_DOMAINS = 4
-MRG_GEMM_AUTO, MRG_GEMM_GLDS3, MRG_GEMM_GLDS4, MRG_GEMM_PIPE128, MRG_GEMM_PIPE256, MRG_GEMM_WS256, MRG_GEMM_GLDS64, MRG_GEMM_G256, MRG_GEMM_P8, MRG_GEMM_DUO = 0, 1, 2, 3, 4, 7, 8, 10, 11, 13      # 5, 6, 9, 12 reserved (variants measured and dropped)
+MRG_GEMM_AUTO, MRG_GEMM_GLDS3, MRG_GEMM_GLDS4, MRG_GEMM_PIPE128, MRG_GEMM_WS256, MRG_GEMM_P8 = 0, 1, 2, 3, 7, 11      # every other number is reserved (variants measured and dropped)
 MRG_GEMM_P8_GROUP = 100     # not a mrg_gemm variant: the kernel-family code of mrg_wgrad_group in timing records
 
 vp, ci, cl, cf = C.c_void_p, C.c_int, C.c_long, C.c_float
@@ -158,7 +158,7 @@ for _name, (_res, _args) in SIGNATURES.items():
     _fn.argtypes = _args
 
 ABI_VERSION = lib.mrg_version()
-EXPECTED_ABI_VERSION = 15      # must match MRG_ABI_VERSION in include/mirage_hip.h: the ctypes structs above mirror that layout
+EXPECTED_ABI_VERSION = 16      # must match MRG_ABI_VERSION in include/mirage_hip.h: the ctypes structs above mirror that layout
 if ABI_VERSION != EXPECTED_ABI_VERSION:
     raise ImportError(f"{LIB_PATH} reports ABI version {ABI_VERSION}, the Python bindings expect {EXPECTED_ABI_VERSION}: rebuild it "
                       "(python -c 'import __graft_entry__ as g; g.build()')")

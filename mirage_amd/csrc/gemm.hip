@@ -177,7 +177,7 @@ __device__ __forceinline__ void gemm_glds_body(const GemmArgs& g) {
     wg_remap(nwg, g.xcd_split, bid, ksplit);
     // grouped rasterisation inside the XCD's band: GROUP_M row panels x all column tiles, column-major within the group,
     // so a B (weight) tile is reused by GROUP_M consecutive workgroups while their A panels stay L2-resident
-    const int GROUP_M = g.group_m;
+    constexpr int GROUP_M = 8;      // round 6: 4 / 8 / 16 tie in the step (C2 8.98 / 8.98 / 8.98 ms, C4 19.49 / 19.49 / 19.53), 64 -- M-fastest over the whole band -- is slower (9.09 / 19.73)
     int tm, tn;
     {
         const int per_group = GROUP_M * g.tiles_n;
@@ -570,147 +570,6 @@ __global__ __launch_bounds__(256, 2) void gemm_pipe_kernel(const GemmArgs g) {
     if (ws && g.tile_cnt) splitk_finish<VEC>(g, bid, m0, n0, BM, BN, Meff, smem, tid, 256);
 }
 
-// 256 x 128 output tile = two stacked 128 x 128 sub-tiles that share one B tile (87 instead of 64 flop per byte moved
-// from L2 to LDS); 8 waves (4 x 2), two-stage ring of 48 KiB stages, one workgroup per CU.
-template <int AMODE, int BMODE, bool VEC, int STAGES>
-__global__ __launch_bounds__(512, 2) void gemm_pipe256_kernel(const GemmArgs g) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int STAGE = 3 * TILE_BYTES;
-    const int tiles_m = (g.M + 255) / 256;
-    const int nwg = tiles_m * g.tiles_n;
-    int bid, ksplit;
-    wg_remap(nwg, g.xcd_split, bid, ksplit);
-    constexpr int GROUP_M = 4;
-    int tm, tn;
-    {
-        const int per_group = GROUP_M * g.tiles_n;
-        const int grp = fast_udiv(bid, per_group), in_grp = bid - grp * per_group;
-        const int first = grp * GROUP_M;
-        const int rows = min(GROUP_M, tiles_m - first);
-        tn = fast_udiv(in_grp, rows);
-        tm = first + in_grp - tn * rows;
-    }
-    const int m0 = tm * 256, n0 = tn * BN;
-    const int Meff = g.m_dev ? min(g.M, *g.m_dev) : g.M;
-    const int Keff = g.k_dev ? min(g.K, *g.k_dev) : g.K;
-    if (m0 >= Meff) return;
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int half = wave >> 2, wl = wave & 3;          // sub-tile, wave inside the sub-tile
-    const int wm = wl >> 1, wn = wl & 1;
-    const int ntiles = (Keff + BK - 1) / BK;
-    int t0 = 0, t1 = ntiles;
-    if (g.splitk > 1) {
-        const int per = (ntiles + g.splitk - 1) / g.splitk;
-        t0 = ksplit * per;
-        t1 = min(ntiles, t0 + per);
-    }
-    f32x16 acc[2][2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-    const uint32_t sbase = __builtin_amdgcn_readfirstlane(lds_addr(smem));
-    const bf16_t* pa[4]; const bf16_t* pb[2];
-    long ia[4], ib[2];
-    int ka[4], kb[2];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) glds_setup<AMODE>(g.A, g.lda, m0 + half * 128, Meff, t0 * BK, wl * 4 + j, lane, pa[j], ia[j], ka[j]);
-#pragma unroll
-    for (int j = 0; j < 2; ++j) glds_setup<BMODE>(g.B, g.ldb, n0, g.N, t0 * BK, wave * 2 + j, lane, pb[j], ib[j], kb[j]);
-    const bf16_t* zero = reinterpret_cast<const bf16_t*>(g_zero_page);
-    auto issue = [&](int t, int buf) {
-        const uint32_t la = sbase + buf * STAGE + half * TILE_BYTES + wl * 4096;
-        const uint32_t lb = sbase + buf * STAGE + 2 * TILE_BYTES + wave * 2048;
-        const int krem = Keff - t * BK;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) glds16_asm((krem >= BK || ka[j] < krem) ? pa[j] : zero, la + j * 1024);
-#pragma unroll
-        for (int j = 0; j < 2; ++j) glds16_asm((krem >= BK || kb[j] < krem) ? pb[j] : zero, lb + j * 1024);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) pa[j] += ia[j];
-#pragma unroll
-        for (int j = 0; j < 2; ++j) pb[j] += ib[j];
-    };
-    // ring of STAGES stages: STAGES-1 tiles are in flight while one is multiplied (the DMA latency under load is several
-    // k-tile compute times, so the depth of the ring, not the barrier count, sets the rate)
-    if (t0 < t1) issue(t0, 0);
-    if (STAGES == 3 && t0 + 1 < t1) issue(t0 + 1, 1);
-    int cur = 0;
-    for (int t = t0; t < t1; ++t) {
-        if (STAGES == 3 && t + 1 < t1) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");   // tile t landed, tile t+1 may still fly
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        __builtin_amdgcn_sched_barrier(0);
-        if (t + STAGES - 1 < t1 && g.ablate != 1) issue(t + STAGES - 1, (cur + STAGES - 1) % STAGES);
-        if (g.ablate == 2) { cur = (cur + 1 == STAGES) ? 0 : cur + 1; continue; }
-        const char* ldsA = smem + cur * STAGE + half * TILE_BYTES;
-        const char* ldsB = smem + cur * STAGE + 2 * TILE_BYTES;
-        const uint32_t la_u = sbase + cur * STAGE + half * TILE_BYTES, lb_u = sbase + cur * STAGE + 2 * TILE_BYTES;
-#pragma unroll
-        for (int kk = 0; kk < 4; ++kk) {
-            bf16x8 fa[2], fb[2];
-#pragma unroll
-            for (int i = 0; i < 2; ++i) fa[i] = read_frag<AMODE>(ldsA, la_u, wm * 64 + i * 32, kk, lane);
-#pragma unroll
-            for (int j = 0; j < 2; ++j) fb[j] = read_frag<BMODE>(ldsB, lb_u, wn * 64 + j * 32, kk, lane);
-            if (g.ablate == 3) {
-                asm volatile("" :: "v"(fa[0]), "v"(fa[1]), "v"(fb[0]), "v"(fb[1]));
-                continue;
-            }
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int j = 0; j < 2; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
-        }
-        cur = (cur + 1 == STAGES) ? 0 : cur + 1;
-    }
-    // ---- epilogue: the two 128 x 128 sub-tiles go through a 64 KiB fp32 staging tile one after the other
-    float* ct = reinterpret_cast<float*>(smem);
-    const int cl = (tid & 31) << 2;
-    const int col = n0 + cl;
-    const int nv = min(4, g.N - col);
-    float* ws = g.splitk > 1 ? g.ws + (long)ksplit * g.M * g.N : nullptr;
-    float bv[4] = {0.f, 0.f, 0.f, 0.f};
-    if (g.bias && !ws && col < g.N) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) if (e < nv) bv[e] = g.bias[col + e];
-    }
-    MRG_RETIRE4(bv);
-#pragma unroll 1
-    for (int h = 0; h < 2; ++h) {
-        __syncthreads();
-        if (half == h) {
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    const int c2 = wn * 64 + j * 32 + (lane & 31);
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int rl = wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                        ct[rl * BN + c2] = acc[i][j][r];
-                    }
-                }
-        }
-        __syncthreads();
-        if (col < g.N) {
-#pragma unroll 1
-            for (int it = 0; it < 8; ++it) {
-                const int rl = (tid >> 5) + (it << 4);                  // 0..127 (16 row-lanes of 32 threads)
-                const int row = m0 + h * 128 + rl;
-                if (row < Meff) {
-                    const float4 a4 = *reinterpret_cast<const float4*>(ct + rl * BN + cl);
-                    epi_any<VEC>(g, a4, bv, ws, row, col, nv);
-                }
-            }
-        }
-    }
-}
-
 // Warp-specialised 256 x 128 kernel: 8 compute waves (4 x 2, 64 x 64 each) + 4 loader waves.  Issuing a global_load_lds
 // costs the issuing wave ~60-180 cycles during which it cannot issue MFMAs (in-order issue); the loaders take all 48 of them
 // per k-tile off the compute waves and keep a 3-stage ring (144 KiB) two tiles ahead.  One s_barrier per k-tile for all 12 waves.
@@ -890,238 +749,6 @@ __global__ __launch_bounds__(768) void gemm_ws256_kernel(const GemmArgs g) {
     if (ws && g.tile_cnt) splitk_finish<VEC>(g, bid, m0, n0, 256, BN, Meff, smem, tid, 768);
 }
 
-// 256 x 128 tile, single stage, 4 waves x (128 x 64): the single-stage kernel's structure (two co-resident workgroups cover each
-// other's load -> barrier -> MFMA chain; scalar-base loader; K a multiple of 64) with twice the MFMA work per wave and barrier
-// and 85 instead of 64 flop per operand byte moved from L2 to LDS.  48 KiB LDS, accumulators 128 VGPRs, 2 waves per SIMD.
-template <int AMODE, int BMODE, bool VEC>
-__global__ __launch_bounds__(256, 2) void gemm_g256_kernel(const GemmArgs g) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tiles_m = (g.M + 255) / 256;
-    const int nwg = tiles_m * g.tiles_n;
-    int bid, ksplit;
-    wg_remap(nwg, g.xcd_split, bid, ksplit);
-    constexpr int GROUP_M = 4;
-    int tm, tn;
-    {
-        const int per_group = GROUP_M * g.tiles_n;
-        const int grp = fast_udiv(bid, per_group), in_grp = bid - grp * per_group;
-        const int first = grp * GROUP_M;
-        const int rows = min(GROUP_M, tiles_m - first);
-        tn = fast_udiv(in_grp, rows);
-        tm = first + in_grp - tn * rows;
-    }
-    const int m0 = tm * 256, n0 = tn * BN;
-    const int Meff = g.m_dev ? min(g.M, *g.m_dev) : g.M;
-    if (m0 >= Meff) return;
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 1, wn = wave & 1;
-    const int ntiles = g.K / BK;
-    int t0 = 0, t1 = ntiles;
-    if (g.splitk > 1) {
-        const int per = (ntiles + g.splitk - 1) / g.splitk;
-        t0 = ksplit * per;
-        t1 = min(ntiles, t0 + per);
-    }
-    f32x16 acc[4][2];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-    char* ldsA = smem;                                   // 256 x 64 bf16 = 32 KiB (two 128-row sub-tiles)
-    char* ldsB = smem + 2 * TILE_BYTES;                  // 128 x 64 bf16 = 16 KiB
-    const uint32_t la_s = __builtin_amdgcn_readfirstlane(lds_addr(ldsA)), lb_s = __builtin_amdgcn_readfirstlane(lds_addr(ldsB));
-    // wave w loads A blocks of sub-tile (w >> 1), blocks (w & 1) * 8 .. + 8, and B blocks 4 w .. + 4
-    uint32_t oa[8], ob[4];
-    // a 128-row sub-tile that starts past the last row (M = 8256: rows 8320.. of the last tile) is loaded from the last valid rows
-    const int ra = min(m0 + (wave >> 1) * 128, (AMODE == MRG_OP_KCONTIG ? Meff - 1 : max(0, ((Meff - 1) & ~7))));
-#pragma unroll
-    for (int j = 0; j < 8; ++j) oa[j] = glds_lane_off<AMODE>(g.lda, ra, Meff, (wave & 1) * 8 + j, lane);
-#pragma unroll
-    for (int j = 0; j < 4; ++j) ob[j] = glds_lane_off<BMODE>(g.ldb, n0, g.N, wave * 4 + j, lane);
-    const long ma = ra;
-    const char* sa = uniform_ptr(reinterpret_cast<const char*>(g.A) + (AMODE == MRG_OP_KCONTIG ? (ma * g.lda + (long)t0 * BK) * 2 : ((long)t0 * BK * g.lda + ma) * 2));
-    const char* sb = uniform_ptr(reinterpret_cast<const char*>(g.B) + (BMODE == MRG_OP_KCONTIG ? ((long)n0 * g.ldb + (long)t0 * BK) * 2 : ((long)t0 * BK * g.ldb + n0) * 2));
-    const long step_a = AMODE == MRG_OP_KCONTIG ? BK * 2 : (long)BK * g.lda * 2, step_b = BMODE == MRG_OP_KCONTIG ? BK * 2 : (long)BK * g.ldb * 2;
-    const uint32_t la_w = la_s + (wave >> 1) * TILE_BYTES + (wave & 1) * 8192, lb_w = lb_s + wave * 4096;
-    const char* fragA = ldsA + wm * TILE_BYTES;
-    const uint32_t fragA_u = la_s + wm * TILE_BYTES;
-    for (int t = t0; t < t1; ++t) {
-        if (t > t0) __syncthreads();
-#pragma unroll
-        for (int j = 0; j < 8; ++j) glds16_s(sa, oa[j], la_w + j * 1024);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) glds16_s(sb, ob[j], lb_w + j * 1024);
-        sa = uniform_ptr(sa + step_a); sb = uniform_ptr(sb + step_b);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-#pragma unroll
-        for (int kk = 0; kk < 4; ++kk) {
-            bf16x8 fa[4], fb[2];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) fa[i] = read_frag<AMODE>(fragA, fragA_u, i * 32, kk, lane);
-#pragma unroll
-            for (int j = 0; j < 2; ++j) fb[j] = read_frag<BMODE>(ldsB, lb_s, wn * 64 + j * 32, kk, lane);
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int j = 0; j < 2; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
-        }
-    }
-    // ---- epilogue: four passes of 64 rows x 128 cols fp32 (32 KiB) through the operand stage
-    float* ct = reinterpret_cast<float*>(smem);
-    const int cl = (tid & 31) << 2;
-    const int col = n0 + cl;
-    const int nv = min(4, g.N - col);
-    float* ws = g.splitk > 1 ? g.ws + (long)ksplit * g.M * g.N : nullptr;
-    float bv[4] = {0.f, 0.f, 0.f, 0.f};
-    if (g.bias && !ws && col < g.N) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) if (e < nv) bv[e] = g.bias[col + e];
-    }
-    MRG_RETIRE4(bv);
-#pragma unroll
-    for (int ps = 0; ps < 4; ++ps) {
-        __syncthreads();
-        if (wm == (ps >> 1)) {
-#pragma unroll
-            for (int ii = 0; ii < 2; ++ii)
-#pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    const int c2 = wn * 64 + j * 32 + (lane & 31);
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int rl = ii * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                        ct[rl * BN + c2] = acc[2 * (ps & 1) + ii][j][r];
-                    }
-                }
-        }
-        __syncthreads();
-        if (col < g.N) {
-            auto row_of = [&](int it, int& rl, int& row) { rl = (tid >> 5) + (it << 3); row = m0 + ps * 64 + rl; };
-            if (VEC && (g.side_drain & 2) && ws) MRG_DRAIN8(7, false, ws);
-            else if (VEC && (g.side_drain & 1) && g.epi_kind == 2) MRG_DRAIN8(2, false, nullptr);
-            else if (VEC && (g.side_drain & 1) && g.epi_kind == 4) MRG_DRAIN8(4, false, nullptr);
-            else if (VEC && (g.side_drain & 1) && g.epi_kind == 1) MRG_DRAIN8(1, false, nullptr);
-            else if (VEC && (g.side_drain & 1) && g.epi_kind == 3) MRG_DRAIN8(3, false, nullptr);
-            else if (VEC && (g.side_drain & 1) && g.epi_kind == 5) MRG_DRAIN8(5, false, nullptr);
-            else {
-#pragma unroll 1
-            for (int it = 0; it < 8; ++it) {
-                const int rl = (tid >> 5) + (it << 3);                  // 0..63
-                const int row = m0 + ps * 64 + rl;
-                if (row < Meff) {
-                    const float4 a4 = *reinterpret_cast<const float4*>(ct + rl * BN + cl);
-                    epi_any<VEC>(g, a4, bv, ws, row, col, nv);
-                }
-            }
-            }
-        }
-    }
-}
-
-// 64 x 128 tile, single stage (24 KiB operands; 32 KiB for the epilogue): twice as many, half as tall workgroups for the short,
-// latency-bound problems of the output adapters (K = 256 ... 1024 on 16384 rows) and the N = 768 encoder shapes, where a
-// 128-row tile leaves 1-1.5 workgroups per CU.  A must be k-contiguous (forward / dgrad layouts).
-template <int BMODE, bool VEC>
-__global__ __launch_bounds__(256, 4) void gemm_glds64_kernel(const GemmArgs g) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tiles_m = (g.M + 63) / 64;
-    const int nwg = tiles_m * g.tiles_n;
-    int bid, ksplit;
-    wg_remap(nwg, g.xcd_split, bid, ksplit);
-    constexpr int GROUP_M = 16;
-    int tm, tn;
-    {
-        const int per_group = GROUP_M * g.tiles_n;
-        const int grp = fast_udiv(bid, per_group), in_grp = bid - grp * per_group;
-        const int first = grp * GROUP_M;
-        const int rows = min(GROUP_M, tiles_m - first);
-        tn = fast_udiv(in_grp, rows);
-        tm = first + in_grp - tn * rows;
-    }
-    const int m0 = tm * 64, n0 = tn * BN;
-    const int Meff = g.m_dev ? min(g.M, *g.m_dev) : g.M;
-    const int Keff = g.k_dev ? min(g.K, *g.k_dev) : g.K;
-    if (m0 >= Meff) return;
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 1, wn = wave & 1;
-    const int ntiles = (Keff + BK - 1) / BK;
-    f32x16 acc[2];
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
-    char* ldsA = smem;
-    char* ldsB = smem + TILE_BYTES / 2;
-    const uint32_t la_u = lds_addr(ldsA), lb_u = lds_addr(ldsB);
-    const bf16_t* pa[2]; const bf16_t* pb[4];
-    long ia[2], ib[4];
-    int ka[2], kb[4];
-#pragma unroll
-    for (int j = 0; j < 2; ++j) glds_setup<MRG_OP_KCONTIG>(g.A, g.lda, m0, Meff, 0, wave * 2 + j, lane, pa[j], ia[j], ka[j]);
-#pragma unroll
-    for (int j = 0; j < 4; ++j) glds_setup<BMODE>(g.B, g.ldb, n0, g.N, 0, wave * 4 + j, lane, pb[j], ib[j], kb[j]);
-    const bf16_t* zero = reinterpret_cast<const bf16_t*>(g_zero_page);
-    for (int t = 0; t < ntiles; ++t) {
-        const int krem = Keff - t * BK;
-        if (t > 0) __syncthreads();
-#pragma unroll
-        for (int j = 0; j < 2; ++j) glds16((krem >= BK || ka[j] < krem) ? pa[j] : zero, ldsA + (wave * 2 + j) * 1024);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) glds16((krem >= BK || kb[j] < krem) ? pb[j] : zero, ldsB + (wave * 4 + j) * 1024);
-#pragma unroll
-        for (int j = 0; j < 2; ++j) pa[j] += ia[j];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) pb[j] += ib[j];
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-#pragma unroll
-        for (int kk = 0; kk < 4; ++kk) {
-            const bf16x8 fa = read_frag<MRG_OP_KCONTIG>(ldsA, la_u, wm * 32, kk, lane);
-            bf16x8 fb[2];
-#pragma unroll
-            for (int j = 0; j < 2; ++j) fb[j] = read_frag<BMODE>(ldsB, lb_u, wn * 64 + j * 32, kk, lane);
-#pragma unroll
-            for (int j = 0; j < 2; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb[j], acc[j], 0, 0, 0);
-        }
-    }
-    __syncthreads();
-    float* ct = reinterpret_cast<float*>(smem);
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int c2 = wn * 64 + j * 32 + (lane & 31);
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int rl = wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-            ct[rl * BN + c2] = acc[j][r];
-        }
-    }
-    __syncthreads();
-    const int cl = (tid & 31) << 2;
-    const int col = n0 + cl;
-    if (col >= g.N) return;
-    const int nv = min(4, g.N - col);
-    float bv[4] = {0.f, 0.f, 0.f, 0.f};
-    if (g.bias) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) if (e < nv) bv[e] = g.bias[col + e];
-    }
-    MRG_RETIRE4(bv);
-#pragma unroll 1
-    for (int it = 0; it < 8; ++it) {
-        const int rl = (tid >> 5) + (it << 3);
-        const int row = m0 + rl;
-        if (row >= Meff) break;
-        const float4 a4 = *reinterpret_cast<const float4*>(ct + rl * BN + cl);
-        epi_any<VEC>(g, a4, bv, nullptr, row, col, nv);
-    }
-}
-
 // split-K finish: C (+)= sum_z ws[z]  (+ bias) ; fp32 out, optional bf16 copy
 __global__ void splitk_reduce_kernel(const float* __restrict__ ws, int splitk, long mn, int N, float* __restrict__ C, int ldc,
                                      int accumulate, const float* __restrict__ bias, bf16_t* __restrict__ C2, int ldc2,
@@ -1189,12 +816,12 @@ extern "C" int mrg_gemm(const mrg_gemm_desc* d, hipStream_t stream) {
         g.drop.scale = 1.f / (1.f - d->drop_p);
         g.drop.stream = d->drop_stream;
     }
-    MRG_REQUIRE(d->variant >= 0 && d->variant <= MRG_GEMM_DUO && d->variant != 5 && d->variant != 6 && d->variant != 9 && d->variant != 12, MRG_ERR_ARG, "mrg_gemm: bad variant %d", d->variant);
+    MRG_REQUIRE(d->variant == MRG_GEMM_AUTO || d->variant == MRG_GEMM_GLDS3 || d->variant == MRG_GEMM_GLDS4 || d->variant == MRG_GEMM_PIPE128 ||
+                d->variant == MRG_GEMM_WS256 || d->variant == MRG_GEMM_P8, MRG_ERR_ARG, "mrg_gemm: bad variant %d", d->variant);
     g.tiles_m = cdiv(d->M, BM); g.tiles_n = cdiv(d->N, BN);
     { static const int abl = [] { const char* e = getenv("MRG_GEMM_ABLATE"); return e ? atoi(e) : 0; }(); g.ablate = abl; }
     { static const int nt = [] { const char* e = getenv("MRG_GEMM_NT"); return e ? atoi(e) : 2; }(); g.nt = nt; }
     { static const int xs = [] { const char* e = getenv("MRG_GEMM_XCD_SPLIT"); return e ? atoi(e) : 1; }(); g.xcd_split = xs; }
-    { static const int gm = [] { const char* e = getenv("MRG_GEMM_GROUP_M"); const int v = e ? atoi(e) : 8; return v >= 1 ? v : 8; }(); g.group_m = gm; }
     { static const int sd = [] { const char* e = getenv("MRG_GEMM_SIDE_DRAIN"); return e ? atoi(e) : 3; }(); g.side_drain = sd; }
     static const int kfast = [] { const char* e = getenv("MRG_GEMM_KFAST"); return e ? atoi(e) : 1; }();
     static const int epi_direct_env = [] { const char* e = getenv("MRG_EPI_DIRECT"); return e ? atoi(e) : 0; }();   // register-direct epilogue of the single-stage 128 x 128 kernel: measured SLOWER (12.95 vs 11.02 ms/step at C2)
@@ -1213,7 +840,7 @@ extern "C" int mrg_gemm(const mrg_gemm_desc* d, hipStream_t stream) {
                      !d->C2 && g.c_f32 && !d->colsum_out && !g.drop.rng) g.epi_kind = 6;
             else if (splitk == 1 && d->act == MRG_ACT_NONE && !d->add_tab && !d->row_map && !d->accumulate && !d->colsum_out && d->resid && g.c_f32) g.epi_kind = 2;
             else if (splitk == 1 && d->act == MRG_ACT_NONE && !d->add_tab && !d->row_map && !d->accumulate && !d->colsum_out && !d->resid && !d->row_scale &&
-                     !d->C2 && !d->bias && g.c_f32 && !g.drop.rng && (d->variant == MRG_GEMM_P8 || d->variant == MRG_GEMM_DUO)) g.epi_kind = 7;
+                     !d->C2 && !d->bias && g.c_f32 && !g.drop.rng && d->variant == MRG_GEMM_P8) g.epi_kind = 7;
         }
     }
     dim3 grid(g.tiles_m * g.tiles_n, splitk), block(256);
@@ -1248,11 +875,9 @@ extern "C" int mrg_gemm(const mrg_gemm_desc* d, hipStream_t stream) {
     const int ktiles_per_wg = cdiv(cdiv(d->K, BK), splitk);
     bool use_pipe = ktiles_per_wg >= 24;
     bool occ4 = fast && d->a_mode == MRG_OP_KCONTIG && (g.tiles_m * g.tiles_n >= 1400) && splitk == 1;
-    bool use_big = false;
     if (d->variant == MRG_GEMM_GLDS3) { use_pipe = false; occ4 = false; }
     else if (d->variant == MRG_GEMM_GLDS4) { use_pipe = false; occ4 = true; }
     else if (d->variant == MRG_GEMM_PIPE128) { use_pipe = true; }
-    else if (d->variant == MRG_GEMM_PIPE256) { use_big = fast && !mapped && d->M > 128; use_pipe = true; }
     if (d->colsum_out) {      // only the single-stage 128 x 128 kernel (dgrad layout) is instantiated with the column-sum epilogue
         MRG_REQUIRE(fast && splitk == 1 && !d->row_map && d->a_mode == MRG_OP_KCONTIG && d->b_mode == MRG_OP_KSTRIDED, MRG_ERR_UNSUPPORTED,
                     "mrg_gemm: colsum_out needs the dgrad layout (A k-contiguous, B k-strided), aligned unmapped operands and no split-K");
@@ -1283,9 +908,7 @@ extern "C" int mrg_gemm(const mrg_gemm_desc* d, hipStream_t stream) {
         }
         return 0;
     };
-    const bool will_ws = !d->colsum_out && fast && !mapped && d->variant == MRG_GEMM_WS256 && d->M > 128;
-    const bool will_g256 = fast && d->variant == MRG_GEMM_G256 && kf && !d->colsum_out && d->M > 128;
-    inkernel = splitk > 1 && d->splitk_counters && !d->defer_reduce && !d->colsum_out && !will_g256 && !(use_big && !will_ws);
+    inkernel = splitk > 1 && d->splitk_counters && !d->defer_reduce && !d->colsum_out;
     g.tile_cnt = inkernel ? d->splitk_counters : nullptr;
     if (fast && !mapped && d->variant == MRG_GEMM_P8 && !d->colsum_out && d->M > 128 && d->N > 128 &&
         mrg_gemm8p_launch(g, d->a_mode, d->b_mode, vec, splitk, stream)) {
@@ -1293,42 +916,14 @@ extern "C" int mrg_gemm(const mrg_gemm_desc* d, hipStream_t stream) {
         int rc8 = mrg_check_launch("mrg_gemm");
         return rc8 ? rc8 : finish_splitk();
     }
-    if (fast && !mapped && d->variant == MRG_GEMM_DUO && !d->colsum_out && d->N > 128 && mrg_gemm_duo_launch(g, d->a_mode, d->b_mode, vec, splitk, stream)) {
-        if (d->ev_stop) (void)hipEventRecord((hipEvent_t)d->ev_stop, stream);
-        int rcd = mrg_check_launch("mrg_gemm");
-        return rcd ? rcd : finish_splitk();
-    }
     const bool use_ws = !d->colsum_out && fast && !mapped && d->variant == MRG_GEMM_WS256 && d->M > 128;
-    if (fast && d->variant == MRG_GEMM_G256 && kf && !d->colsum_out && d->M > 128) {
-        const dim3 gg(cdiv(d->M, 256) * g.tiles_n, splitk);
-#define MRG_G256(AM, BM_, V) hipLaunchKernelGGL((gemm_g256_kernel<AM, BM_, V>), gg, block, (size_t)(3 * TILE_BYTES), stream, g)
-        if (d->a_mode == MRG_OP_KCONTIG && d->b_mode == MRG_OP_KCONTIG) { if (vec) MRG_G256(0, 0, true); else MRG_G256(0, 0, false); }
-        else if (d->a_mode == MRG_OP_KCONTIG && d->b_mode == MRG_OP_KSTRIDED) { if (vec) MRG_G256(0, 1, true); else MRG_G256(0, 1, false); }
-        else { if (vec) MRG_G256(1, 1, true); else MRG_G256(1, 1, false); }
-#undef MRG_G256
-        if (d->ev_stop) (void)hipEventRecord((hipEvent_t)d->ev_stop, stream);
-        int rcg = mrg_check_launch("mrg_gemm");
-        return rcg ? rcg : finish_splitk();       // split-K slabs of this variant are reduced by the separate kernel (or left to the caller: defer_reduce)
-    }
-    if (fast && !mapped && d->variant == MRG_GEMM_GLDS64 && d->a_mode == MRG_OP_KCONTIG && splitk == 1 && !d->colsum_out) {
-        const dim3 g64(cdiv(d->M, 64) * g.tiles_n);
-        if (d->b_mode == MRG_OP_KCONTIG) { if (vec) hipLaunchKernelGGL((gemm_glds64_kernel<0, true>), g64, block, (size_t)(2 * TILE_BYTES), stream, g);
-                                           else hipLaunchKernelGGL((gemm_glds64_kernel<0, false>), g64, block, (size_t)(2 * TILE_BYTES), stream, g); }
-        else { if (vec) hipLaunchKernelGGL((gemm_glds64_kernel<1, true>), g64, block, (size_t)(2 * TILE_BYTES), stream, g);
-               else hipLaunchKernelGGL((gemm_glds64_kernel<1, false>), g64, block, (size_t)(2 * TILE_BYTES), stream, g); }
-        if (d->ev_stop) (void)hipEventRecord((hipEvent_t)d->ev_stop, stream);
-        return mrg_check_launch("mrg_gemm");
-    }
-#define MRG_BIG(AM, BM_, V) do { const void* fn = (const void*)gemm_pipe256_kernel<AM, BM_, V, 2>; \
-        (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 6 * TILE_BYTES); \
-        hipLaunchKernelGGL((gemm_pipe256_kernel<AM, BM_, V, 2>), dim3(cdiv(d->M, 256) * g.tiles_n, splitk), dim3(512), (size_t)(6 * TILE_BYTES), stream, g); } while (0)
 #define MRG_WS(AM, BM_, V) do { if (kf && V) { const void* fn = (const void*)gemm_ws256_kernel<AM, BM_, true, true>; \
         (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 9 * TILE_BYTES); \
         hipLaunchKernelGGL((gemm_ws256_kernel<AM, BM_, true, true>), dim3(cdiv(d->M, 256) * g.tiles_n, splitk), dim3(768), (size_t)(9 * TILE_BYTES), stream, g); } else { \
         const void* fn = (const void*)gemm_ws256_kernel<AM, BM_, V>; \
         (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 9 * TILE_BYTES); \
         hipLaunchKernelGGL((gemm_ws256_kernel<AM, BM_, V>), dim3(cdiv(d->M, 256) * g.tiles_n, splitk), dim3(768), (size_t)(9 * TILE_BYTES), stream, g); } } while (0)
-#define MRG_FAST(AM, BM_, V) do { if (use_ws) MRG_WS(AM, BM_, V); else if (use_big) MRG_BIG(AM, BM_, V); else if (use_pipe && kf && V) hipLaunchKernelGGL((gemm_pipe_kernel<AM, BM_, true, true>), grid, block, (size_t)(4 * TILE_BYTES), stream, g); \
+#define MRG_FAST(AM, BM_, V) do { if (use_ws) MRG_WS(AM, BM_, V); else if (use_pipe && kf && V) hipLaunchKernelGGL((gemm_pipe_kernel<AM, BM_, true, true>), grid, block, (size_t)(4 * TILE_BYTES), stream, g); \
                                   else if (use_pipe) hipLaunchKernelGGL((gemm_pipe_kernel<AM, BM_, V>), grid, block, (size_t)(4 * TILE_BYTES), stream, g); \
                                   else if (occ4 && kf && V && epi_direct) hipLaunchKernelGGL((gemm_glds_kernel<AM, BM_, true, 4, false, true, true>), grid, block, (size_t)(2 * TILE_BYTES), stream, g); \
                                   else if (kf && V && epi_direct) hipLaunchKernelGGL((gemm_glds_kernel<AM, BM_, true, 3, false, true, true>), grid, block, (size_t)(2 * TILE_BYTES), stream, g); \
@@ -1347,7 +942,6 @@ extern "C" int mrg_gemm(const mrg_gemm_desc* d, hipStream_t stream) {
 #undef MRG_LAUNCH
 #undef MRG_LAUNCH2
 #undef MRG_FAST
-#undef MRG_BIG
 #undef MRG_WS
     if (d->ev_stop) (void)hipEventRecord((hipEvent_t)d->ev_stop, stream);
     int rc = mrg_check_launch("mrg_gemm");
@@ -1381,7 +975,7 @@ extern "C" int mrg_gemm_multi(const mrg_gemm_desc* ds, int n, hipStream_t stream
         g.row_map = d->row_map; g.add_tab = d->add_tab; g.add_row = d->add_row; g.ldt = d->ldt;
         g.splitk = 1; g.drop.scale = 1.f;
         g.tiles_m = cdiv(d->M, BM); g.tiles_n = cdiv(d->N, BN);
-        g.nt = 2; g.xcd_split = 1; g.side_drain = 3; g.group_m = 8;
+        g.nt = 2; g.xcd_split = 1; g.side_drain = 3;
         auto al4 = [](const void* q, int ld, int bytes) { return q == nullptr || ((((uintptr_t)q) % (4 * bytes) == 0) && (ld % 4 == 0)); };
         const bool vec = (d->N % 4 == 0) && al4(d->C, d->ldc, g.c_f32 ? 4 : 2) && al4(d->add_tab, d->ldt, 4);
         MRG_REQUIRE(g.a_aligned && g.b_aligned && vec, MRG_ERR_UNSUPPORTED, "mrg_gemm_multi: problem %d: operands / outputs must be 16-B aligned with N %% 4 == 0", p);
@@ -1413,7 +1007,7 @@ extern "C" int mrg_wgrad_group(const mrg_wgrad_group_desc* d, hipStream_t stream
     const int splitk = d->splitk > 1 ? d->splitk : 1;
     MRG_REQUIRE(splitk == 1 || d->ws, MRG_ERR_ARG, "mrg_wgrad_group: split-K needs a workspace");
     MRG_REQUIRE(splitk <= (d->K / BK), MRG_ERR_SHAPE, "mrg_wgrad_group: split-K factor %d exceeds the %d k-tiles", splitk, d->K / BK);
-    g.c_f32 = 1; g.splitk = splitk; g.ws = d->ws; g.epi_kind = splitk == 1 ? 7 : 0; g.act = MRG_ACT_NONE; g.xcd_split = 1; g.group_m = 8;
+    g.c_f32 = 1; g.splitk = splitk; g.ws = d->ws; g.epi_kind = splitk == 1 ? 7 : 0; g.act = MRG_ACT_NONE; g.xcd_split = 1;
     { static const int nt = [] { const char* e = getenv("MRG_GEMM_NT"); return e ? atoi(e) : 2; }(); g.nt = nt; }
     { static const int sd = [] { const char* e = getenv("MRG_GEMM_SIDE_DRAIN"); return e ? atoi(e) : 3; }(); g.side_drain = sd; }
     ga.nprob = d->count;

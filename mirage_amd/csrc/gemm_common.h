@@ -38,7 +38,6 @@ struct GemmArgs {
                    // 8-phase kernel only, the other kernels take the generic path for it)
     int side_drain; // MRG_GEMM_SIDE_DRAIN (bit 0: batched drain of the lean epilogues, bit 1: of the split-K slab stores; default 3)
     int xcd_split; // MRG_GEMM_XCD_SPLIT (default 1): split-K index slowest in the XCD band order
-    int group_m;   // MRG_GEMM_GROUP_M (default 8; single-stage 128 x 128 kernel only): row panels per rasterisation group inside an XCD's band
     int nt;       // MRG_GEMM_NT: 0 plain stores, 1 streaming (nontemporal) stores for C / C2 / aux_out, 2 (default) for aux_out only
     int ablate;   // MRG_GEMM_ABLATE (256x128 kernel only, for roofline analysis): 1 = no DMA, 2 = DMA only, 3 = DMA + LDS reads, no MFMA
     MrgDropout drop;   // drop.rng != nullptr: (acc + bias) is multiplied by the Philox keep mask / (1 - p) before row_scale / resid --
@@ -73,8 +72,6 @@ using namespace mrg_detail;
 bool mrg_gemm8p_launch(const mrg_detail::GemmArgs& g, int a_mode, int b_mode, bool vec, int splitk, hipStream_t stream);
 bool mrg_gemm8p_group_launch(const mrg_detail::P8GroupArgs& ga, bool vec, hipStream_t stream);
 int mrg_num_cus();
-// launcher of the 128 x 256 two-workgroups-per-CU kernel (gemm_duo.hip); returns false when the problem is outside its domain
-bool mrg_gemm_duo_launch(const mrg_detail::GemmArgs& g, int a_mode, int b_mode, bool vec, int splitk, hipStream_t stream);
 
 namespace {
 

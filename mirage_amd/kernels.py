@@ -218,25 +218,17 @@ def _autotune(d, key, splitk, allow_split, dev):
     if allow_split:
         kt = (d.K + 63) // 64
         splits = sorted({s for s in (1, 2, 4, 8, 16, 32) if s == 1 or kt // s >= 4})
-    for v in (L.MRG_GEMM_GLDS3, L.MRG_GEMM_GLDS4, L.MRG_GEMM_PIPE128, L.MRG_GEMM_PIPE256, L.MRG_GEMM_WS256):
-        if v in (L.MRG_GEMM_PIPE256, L.MRG_GEMM_WS256) and d.M <= 128:
+    for v in (L.MRG_GEMM_GLDS3, L.MRG_GEMM_GLDS4, L.MRG_GEMM_PIPE128, L.MRG_GEMM_WS256):
+        if v == L.MRG_GEMM_WS256 and d.M <= 128:
             continue
         for s_ in splits:
             cands.append((v, s_))
-    if d.a_mode == L.MRG_OP_KCONTIG and not d.colsum_out:          # half-height tiles: only pays when 128-row tiles underfill the chip
-        cands.append((L.MRG_GEMM_GLDS64, 1))
-    if d.K % 64 == 0 and d.M > 128 and not d.colsum_out and not d.k_dev:   # single-stage 256x128 (wins when there are many tiles per CU)
-        for s_ in splits:
-            cands.append((L.MRG_GEMM_G256, s_))
     # 256 x 256 8-phase kernel (gemm8p.hip): one workgroup per CU, so it needs about a CU's worth of tiles per round
     if d.K % 64 == 0 and d.M > 128 and d.N > 128 and not d.colsum_out and not d.k_dev and not d.a_map and not d.m_dev:
         t8 = ((d.M + 255) // 256) * ((d.N + 255) // 256)
         for s_ in splits:
             if t8 * s_ >= 192:
                 cands.append((L.MRG_GEMM_P8, s_))
-    # 128 x 256 duo kernel (gemm_duo.hip): two workgroups per CU, forward / dgrad layouts
-    if d.K % 64 == 0 and d.a_mode == L.MRG_OP_KCONTIG and d.N > 128 and not d.colsum_out and not d.k_dev and not d.a_map and not d.b_map and not d.m_dev:
-        cands.append((L.MRG_GEMM_DUO, 1))
     best, best_t = (L.MRG_GEMM_AUTO, splitk), float("inf")
     for v, s_ in cands:
         _gemm_launch(d, s_, v, dev)

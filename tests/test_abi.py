@@ -25,7 +25,7 @@ def test_library_exports_every_declared_symbol():
 def test_binding_covers_the_header():
     from mirage_amd import _lib
     assert sorted(_lib.SIGNATURES) == _declared()
-    assert _lib.ABI_VERSION == _lib.EXPECTED_ABI_VERSION == 15
+    assert _lib.ABI_VERSION == _lib.EXPECTED_ABI_VERSION == 16
     assert _lib.lib.mrg_last_error_string() is not None
 
 

@@ -46,9 +46,10 @@ def test_gemm_nt_bias(K, M, N, K_):
 
 
 def test_gemm_reserved_variants_are_refused(K):
-    """variants 5, 6, 9 and 12 (kernels that were measured and dropped) are no longer silently mapped to another kernel"""
+    """the variant numbers of kernels that were measured and dropped (round 6: 4, 8, 10, 13 joined 5, 6, 9, 12) are not silently mapped to
+    another kernel"""
     A = rnd(256, 128, dtype=BF16, seed=1); W = rnd(256, 128, scale=0.05, dtype=BF16, seed=2)
-    for v in (5, 6, 9, 12, 14):
+    for v in (4, 5, 6, 8, 9, 10, 12, 13, 14):
         K.TUNE["force"] = v
         try:
             with pytest.raises(RuntimeError, match="bad variant"):
@@ -86,7 +87,7 @@ def test_gemm_wgrad_kstrided_both(K, Mtok, Nout, Kin, splitk):
     torch.testing.assert_close(out, ref, rtol=3e-3, atol=3e-3 * float(ref.abs().max()))
 
 
-@pytest.mark.parametrize("variant", [1, 2, 3, 4, 7, 8, 10])
+@pytest.mark.parametrize("variant", [1, 2, 3, 7])
 def test_gemm_every_variant_same_result(K, variant):
     """Each kernel variant the tuner may pick computes the same forward / dgrad product (ragged M, N and K tails, bias + GELU'
     side output, device row count)."""
@@ -191,80 +192,6 @@ def test_gemm_p8_fused_epilogues_and_repeatability(K):
     torch.testing.assert_close(o, lin + res, rtol=2e-3, atol=2e-3 * float(lin.abs().max()))
     assert torch.equal(o2, o.to(BF16))
     assert rel_rms(act.float(), torch.nn.functional.gelu(lin)) < 5e-3
-    xg = lin.double()
-    gd = 0.5 * (1 + torch.erf(xg / 2 ** 0.5)) + xg * torch.exp(-0.5 * xg * xg) / (2 * 3.141592653589793) ** 0.5
-    assert rel_rms(aux.float(), gd.float()) < 3e-3
-    assert rel_rms(mul.float(), (lin - b) * aux.float()) < 5e-3
-    torch.testing.assert_close(first, lin, rtol=2e-3, atol=2e-3 * float(lin.abs().max()))
-
-
-@pytest.mark.parametrize("M,N,Kd,splitk", [(8256, 768, 768, 1), (8256, 3072, 768, 1), (640, 512, 64, 1), (1000, 328, 128, 1), (512, 256, 1152, 3),
-                                            (300, 264, 192, 1), (129, 1024, 1024, 1), (4128, 2304, 768, 2)])
-def test_gemm_duo_layouts(K, M, N, Kd, splitk):
-    """128 x 256 two-workgroups-per-CU kernel (gemm_duo.hip): forward (x W^T) and dgrad (dy W) operand layouts with ragged M / N edges
-    (tile rows past M, B half-chunks starting past N), 1..18 k-tiles (ring wrap-around over 5 slots), split-K finished inside the
-    launch, against fp32 matmuls of the same bf16 inputs.  Random asymmetric data: a transposed or permuted block cannot pass."""
-    from mirage_amd import _lib as L
-    A = rnd(M, Kd, dtype=BF16, seed=161); W = rnd(N, Kd, scale=0.05, dtype=BF16, seed=162); b = rnd(N, seed=163)
-    Wt = rnd(Kd, N, scale=0.05, dtype=BF16, seed=164)
-    K.TUNE["force"] = L.MRG_GEMM_DUO
-    try:
-        out = K.gemm(A, W, M, N, Kd, bias=b, out_dtype=BF16, splitk=1)
-        o32 = K.gemm(A, W, M, N, Kd, out_dtype=F32, splitk=splitk)
-        dg = K.gemm(A, Wt, M, N, Kd, b_mode=L.MRG_OP_KSTRIDED, out_dtype=F32, splitk=splitk)
-        dg16 = K.gemm(A, Wt, M, N, Kd, b_mode=L.MRG_OP_KSTRIDED, out_dtype=BF16)
-    finally:
-        K.TUNE["force"] = None
-    lin = A.float() @ W.float().t()
-    torch.testing.assert_close(o32, lin, rtol=2e-3, atol=2e-3 * float(lin.abs().max()))
-    assert rel_rms(out.float(), lin + b) < 4e-3
-    ref = A.float() @ Wt.float()
-    torch.testing.assert_close(dg, ref, rtol=2e-3, atol=2e-3 * float(ref.abs().max()))
-    assert rel_rms(dg16.float(), ref) < 4e-3
-
-
-def test_gemm_duo_asymmetric_identity(K):
-    """A = I against a B whose every element is distinct (mod 251): any transposed / permuted / swizzle-mismatched write shows."""
-    from mirage_amd import _lib as L
-    M, N, Kd = 256, 512, 256
-    A = torch.eye(M, Kd, dtype=BF16, device=dev())
-    B = (torch.arange(N * Kd, device=dev()).reshape(N, Kd) % 251).to(BF16)
-    K.TUNE["force"] = L.MRG_GEMM_DUO
-    try:
-        out = K.gemm(A, B, M, N, Kd, out_dtype=F32)
-        outt = K.gemm(A, B.t().contiguous(), M, N, Kd, b_mode=L.MRG_OP_KSTRIDED, out_dtype=F32)
-    finally:
-        K.TUNE["force"] = None
-    torch.testing.assert_close(out, B.float().t().contiguous(), rtol=0, atol=0)
-    torch.testing.assert_close(outt, B.float().t().contiguous(), rtol=0, atol=0)
-
-
-def test_gemm_duo_fused_epilogues_and_repeatability(K):
-    """The lean epilogues through the duo kernel (fp32 residual + bf16 twin, GELU with the fp16 GELU' side output, multiply by the
-    side input, plain GELU) and run-to-run bit-identity over 20 launches (a ring / staging race would show as a rare differing tile)."""
-    from mirage_amd import _lib as L
-    M, N, Kd = 2112, 1024, 768
-    A = rnd(M, Kd, dtype=BF16, seed=171); W = rnd(N, Kd, scale=0.05, dtype=BF16, seed=172); b = rnd(N, seed=173)
-    res = rnd(M, N, seed=174)
-    K.TUNE["force"] = L.MRG_GEMM_DUO
-    try:
-        o = torch.empty(M, N, device=dev()); o2 = torch.empty(M, N, dtype=BF16, device=dev())
-        K.gemm(A, W, M, N, Kd, bias=b, out=o, out2=o2, resid=res)
-        aux = torch.empty(M, N, dtype=torch.float16, device=dev())
-        act = K.gemm(A, W, M, N, Kd, bias=b, act=L.MRG_ACT_GELU_SAVE_GRAD, aux_out=aux)
-        mul = K.gemm(A, W, M, N, Kd, act=L.MRG_ACT_MUL_AUX_F16, aux_in=aux)
-        gl = K.gemm(A, W, M, N, Kd, bias=b, act=L.MRG_ACT_GELU)
-        first = K.gemm(A, W, M, N, Kd, bias=b, out_dtype=F32).clone()
-        for _ in range(20):
-            again = K.gemm(A, W, M, N, Kd, bias=b, out_dtype=F32)
-            assert torch.equal(first, again)
-    finally:
-        K.TUNE["force"] = None
-    lin = A.float() @ W.float().t() + b
-    torch.testing.assert_close(o, lin + res, rtol=2e-3, atol=2e-3 * float(lin.abs().max()))
-    assert torch.equal(o2, o.to(BF16))
-    assert rel_rms(act.float(), torch.nn.functional.gelu(lin)) < 5e-3
-    assert rel_rms(gl.float(), torch.nn.functional.gelu(lin)) < 5e-3
     xg = lin.double()
     gd = 0.5 * (1 + torch.erf(xg / 2 ** 0.5)) + xg * torch.exp(-0.5 * xg * xg) / (2 * 3.141592653589793) ** 0.5
     assert rel_rms(aux.float(), gd.float()) < 3e-3

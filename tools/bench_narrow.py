@@ -3,15 +3,15 @@
 production epilogues: every kernel variant forced, the tuned table entry, and the vendor BLAS (plain epilogue), each as a captured graph of
 16 launches over rotating operand sets (tools/bench_sk.py's protocol).  These launches run at 110-320 TFLOP/s inside the step
 (profiles/r05_table_c2.txt) -- 2-5x their HBM floor -- and add up to 1.3 ms of the 9.2 ms C2 step.
-usage: bench_narrow.py [variants ...]     (default: 1 2 3 8 10 13)"""
+usage: bench_narrow.py [variants ...]     (default: 1 2 3)"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from mirage_amd import kernels as K, _lib as L
 import bench_sk as S
 
-variants = [int(v) for v in sys.argv[1:]] or [1, 2, 3, 8, 10, 13]
-NAMES = {1: "glds3", 2: "glds4", 3: "pipe128", 4: "pipe256", 7: "ws256", 8: "glds64", 10: "g256", 11: "p8", 13: "duo"}
+variants = [int(v) for v in sys.argv[1:]] or [1, 2, 3]
+NAMES = {1: "glds3", 2: "glds4", 3: "pipe128", 7: "ws256", 11: "p8"}
 
 
 def case(tag, mode, epi, M, N, Kd, reps=16, nrot=4, rounds=5):

@@ -1,13 +1,12 @@
 #!/usr/bin/env python3
 """The encoder GEMM shapes of C2 / C4 / C5 WITH their production epilogues (bias -> bf16, bias + fp32 residual, bias + GELU + fp16 GELU' side
-output, multiply by the GELU' side input): the tuned table entry, the 8-phase kernel (variant 11), the duo kernel (13) and the vendor BLAS
+output, multiply by the GELU' side input): the tuned table entry, the 8-phase kernel (variant 11) and the vendor BLAS
 (plain epilogue).  Every variant is timed as a captured graph of `reps` launches that rotate through `nrot` operand / output sets (cold-ish
 operands as inside the step), interleaved rounds, median.  (Round 4 used this tool for the stream-K schedule, hence the name.)
 
-usage: bench_sk.py [c2|c4|c5|all|epi|fill|under]
+usage: bench_sk.py [c2|c4|c5|all|epi|resid]
   epi    one shape per configuration under every epilogue kind: what the epilogue costs on top of the main loop (MRG_BENCH_ZERO=1: zero operands)
-  fill   main-loop-dominated shapes, for the MRG_DUO_FILL experiment build (tools/debug/run_duo_fill.sh)
-  under  shapes with fewer tiles than workgroup slots (MRG_BENCH_DUO_SPLITK=2,3: split-K inside the duo kernel)"""
+"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -93,9 +92,7 @@ def case(tag, mode, epi, M, N, Kd, grids, reps=16, nrot=4, rounds=5):
                 K.TUNE["enabled"] = was
         return f
 
-    fns = {"vendor": runner("vendor"), "tuned": runner(None), "p8": runner(L.MRG_GEMM_P8), "duo": runner(L.MRG_GEMM_DUO)}
-    for sk_ in [int(x) for x in os.environ.get("MRG_BENCH_DUO_SPLITK", "").split(",") if x]:
-        fns[f"duo/{sk_}"] = runner(L.MRG_GEMM_DUO, sk_)
+    fns = {"vendor": runner("vendor"), "tuned": runner(None), "p8": runner(L.MRG_GEMM_P8)}
     graphs = {k: graph_of(f, reps) for k, f in fns.items()}
     res = {k: [] for k in fns}
     for _ in range(rounds):
@@ -120,21 +117,10 @@ def shapes(M, D):
 if __name__ == "__main__":
     which = sys.argv[1] if len(sys.argv) > 1 else "all"
     grids = []
-    if which == "under":        # shapes with fewer 128 x 256 tiles than workgroup slots: split-K inside the duo kernel (MRG_BENCH_DUO_SPLITK=2,3,4)
-        for tag, mode, epi, M, N, Kd in (("c2 proj", "fwd", "resid", 8256, 768, 768), ("c2 fc2", "fwd", "resid", 8256, 768, 3072),
-                                         ("c2 fc1", "dgrad", "plain", 8256, 768, 3072), ("c2 qkv", "dgrad", "plain", 8256, 768, 2304),
-                                         ("c4 proj", "fwd", "resid", 6336, 1024, 1024), ("c4 fc2", "fwd", "resid", 6336, 1024, 4096),
-                                         ("c4 fc1", "dgrad", "plain", 6336, 1024, 4096), ("c4 qkv", "dgrad", "plain", 6336, 1024, 3072),
-                                         ("dec fc2", "fwd", "resid", 16384, 256, 1024), ("dec fc1", "dgrad", "plain", 16384, 256, 1024),
-                                         ("c2h fc2", "fwd", "resid", 4128, 768, 3072), ("c2h fc1", "fwd", "gelu", 4128, 3072, 768)):
-            case(tag, mode, epi, M, N, Kd, grids)
     if which == "resid":        # what bounds the fp32-residual epilogue: the residual read (resid0 = cache-resident broadcast row), the fp32 write (f32), or neither
         for tag, M, N, Kd in (("c5h proj", 32896, 1024, 1024), ("c5h fc2", 32896, 1024, 4096), ("c2 fc2", 8256, 768, 3072), ("c4 fc2", 6336, 1024, 4096), ("c4 proj", 6336, 1024, 1024)):
             for epi in ("bias", "f32", "resid0", "resid"):
                 case(tag, "fwd", epi, M, N, Kd, grids, reps=(6 if M > 30000 else 16), nrot=(2 if M > 30000 else 4))
-    if which == "fill":         # tools/debug/run_duo_fill.sh: main-loop-dominated shapes with the cheapest epilogue
-        for tag, M, N, Kd in (("c2 fc1", 8256, 3072, 768), ("c5h fc1", 32896, 4096, 1024), ("square4k", 8192, 8192, 4096)):
-            case(tag, "fwd", "bias", M, N, Kd, grids, reps=(6 if M > 30000 or Kd > 2000 else 16), nrot=(2 if M > 30000 or Kd > 2000 else 4))
     if which == "epi":          # one shape per configuration under every epilogue: what the epilogue costs on top of the main loop
         for tag, M, N, Kd in (("c2 fc1", 8256, 3072, 768), ("c5h fc1", 32896, 4096, 1024)):
             for epi in ("plain", "bias", "gelu5", "gelu", "mulaux", "f32", "resid"):

@@ -68,15 +68,13 @@ hits = set(K.TUNE["hits"]); K.TUNE["hits"] = None
 print(f"baseline {base:.3f} ms/step")
 keys = sorted(hits, key=lambda k: -(2.0 * k[2] * k[3] * k[4]))
 used = [k for k in keys if 2.0 * k[2] * k[3] * k[4] > float(os.environ.get('MRG_TUNE_MIN_FLOP', '5e9'))][:int(os.environ.get("MRG_TUNE_TOP", "16"))]
-cands = (L.MRG_GEMM_GLDS3, L.MRG_GEMM_GLDS4, L.MRG_GEMM_PIPE128, L.MRG_GEMM_PIPE256, L.MRG_GEMM_WS256, L.MRG_GEMM_GLDS64, L.MRG_GEMM_G256, L.MRG_GEMM_P8, L.MRG_GEMM_DUO)
+cands = (L.MRG_GEMM_GLDS3, L.MRG_GEMM_GLDS4, L.MRG_GEMM_PIPE128, L.MRG_GEMM_WS256, L.MRG_GEMM_P8)
 if os.environ.get("MRG_TUNE_ONLY"):
     cands = tuple(int(x) for x in os.environ["MRG_TUNE_ONLY"].split(","))
 cur = base
 for key in used:
     v0, s0 = K._tune_cache[key]
-    trials = [(v, s0) for v in cands if v != v0 and not (v in (L.MRG_GEMM_PIPE256, L.MRG_GEMM_WS256, L.MRG_GEMM_G256, L.MRG_GEMM_P8) and key[2] <= 128) and not (v in (L.MRG_GEMM_G256, L.MRG_GEMM_P8, L.MRG_GEMM_DUO) and key[4] % 64)
-              and not (v == L.MRG_GEMM_DUO and (key[0] != 0 or key[3] <= 128 or key[8]))
-              and not (v == L.MRG_GEMM_GLDS64 and (key[0] != 0 or key[8]))
+    trials = [(v, s0) for v in cands if v != v0 and not (v in (L.MRG_GEMM_WS256, L.MRG_GEMM_P8) and key[2] <= 128) and not (v == L.MRG_GEMM_P8 and key[4] % 64)
               and not (v == L.MRG_GEMM_P8 and (key[3] <= 128 or ((key[2] + 255) // 256) * ((key[3] + 255) // 256) * s0 < 192))]
     if key[8]:                                   # split-K tunable (wgrad): also neighbours of the split factor
         trials += [(v0, s) for s in (max(1, s0 // 2), s0 * 2) if s != s0 and (key[4] // 64) // s >= 4]
