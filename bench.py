@@ -112,14 +112,15 @@ def step_hbm(model_name, doms, B, K, train, ms_per_step, fpi, measured=None):
 
 
 def step_traffic(cfg_name):
-    """{'measured_gb', 'algorithmic_gb', 'ratio', 'source'} of one C2 step, or None (other configurations / no committed PMC pass)"""
-    if cfg_name != "c2":
-        return None
-    for tname in ("r06_c2_step_traffic.json", "r05_c2_step_traffic.json"):
+    """{'measured_gb', 'algorithmic_gb', 'ratio', 'source'} of one step from the committed PMC pass of the configuration, or None"""
+    alg = {"c2": 23.0}.get(cfg_name)
+    for tname in (f"r06_{cfg_name}_step_traffic.json", f"r05_{cfg_name}_step_traffic.json"):
         f = os.path.join(ROOT, "profiles", tname)
         if os.path.exists(f):
             t = json.load(open(f))
-            alg = 23.0
+            if alg is None:
+                model_name, doms, B, K, train = CONFIGS[cfg_name]
+                alg = round(algorithmic_bytes(model_name, doms, B, K, train) / 1e9, 1)
             return {"measured_gb": round(t["total_gb"], 2), "read_gb": round(t["read_gb"], 2), "written_gb": round(t["written_gb"], 2),
                     "algorithmic_gb": alg, "ratio": round(t["total_gb"] / alg, 3), "source": "profiles/" + tname}
     return None
