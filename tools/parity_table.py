@@ -8,6 +8,8 @@ title = sys.argv[3] if len(sys.argv) > 3 else "measured parity errors next to th
 rows, seen = [], set()
 for line in open(src):
     d = json.loads(line)
+    if "case" not in d:                 # records of recorded skips (e.g. RCCL with two ranks on one GPU) carry no measurements
+        continue
     case = d.pop("case")
     tols = {k[:-4]: v for k, v in d.items() if k.endswith("_tol")}
     tol_all = d.get("tol")
@@ -15,8 +17,12 @@ for line in open(src):
         if k.endswith("_tol") or k == "tol" or k.endswith("_name") or k in ("B", "oracle_samples"):
             continue
         key = (case, k)
-        if key in seen:
+        if key in seen or isinstance(v, (str, bool)) or v is None:
             continue
+        if isinstance(v, list):
+            if not v or k in ("curve", "ref_curve"):
+                continue
+            k, v = k + " (max over steps)", max(v)
         seen.add(key)
         base = k.split(".")[0]
         tol = tols.get(k, tols.get(base, tols.get(k.replace("_rel", ""), tol_all)))
