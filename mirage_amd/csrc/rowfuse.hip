@@ -23,7 +23,6 @@
 // M must be a multiple of 64 (every BASELINE shape is: 16384, 8256 = 129 x 64, 6336 = 99 x 64); the host falls back to the separate
 // launches otherwise.
 #include "gemm_common.h"
-#include <type_traits>
 
 namespace {
 
@@ -441,331 +440,6 @@ __global__ __launch_bounds__(256, 1) void rowfuse_fwd_kernel(const RowFuseArgs g
 }
 
 
-// ===================================================================================================================================
-// Second design (round 6, after the timestamps of the first: profiles/r06_rowfuse_ts.txt).  ROW-OWNER WAVES: a workgroup is 128 rows, wave w
-// owns rows 32 w .. 32 w + 31 with ALL 256 columns of every product (8 accumulator tiles = 128 registers).  With the operands swapped a lane
-// holds row m = lane & 31 and, per accumulator tile nt and register r, column 32 nt + 8 (r >> 2) + 4 (lane >> 5) + (r & 3): registers
-// 8 (s & 1) .. + 7 of tile s >> 1 are, for the lane's own row, eight contraction indices of k-step s of the NEXT product.  The order of the
-// contraction is free as long as both MFMA ports agree, so the next product takes its activation fragment STRAIGHT from the accumulators
-// (convert + pack, two v_permlane32_swap per k-step to bring the lane pair's quads into the standard order; no LDS round trip, no barrier).  Consequences: LDS holds only the weight ring, the fp32 vectors and a 16 KiB private staging tile per
-// wave (every store leaves as full lines); one pass of the weight stream serves 128 rows instead of 64; LayerNorm statistics are in-lane
-// sums + one cross-half shuffle; and a launch occupies M / 128 workgroups -- half the chip at the adapters' 16384 rows, so the lanes of
-// two adapters run side by side instead of queueing behind each other's one-workgroup-per-CU launches.
-constexpr int RC_RING = 4;
-constexpr int RC_OFF_W = 0;
-constexpr int RC_OFF_VEC = RC_RING * RF_WT_BYTES;               // fp32 vectors: b0 | gamma | beta | b2 | b1[<= 1024]
-constexpr int RC_OFF_STG = RC_OFF_VEC + 2048 * 4;               // 4 waves x 16 KiB staging
-constexpr int RC_OFF_TS = RC_OFF_STG + 4 * 16384;               // (debug build -DMRG_RF_TS: 64 phase timestamps)
-constexpr int RC_LDS_BYTES = RC_OFF_TS + 512;                   // 139776
-#ifdef MRG_RF_TS
-#define RC_TS(i_) do { if (tid == 0) reinterpret_cast<unsigned long long*>(smem + RC_OFF_TS)[i_] = clock64(); } while (0)
-#else
-#define RC_TS(i_) do { } while (0)
-#endif
-
-__global__ __launch_bounds__(256, 1) void rowchain_fwd_kernel(const RowFuseArgs g) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tid = threadIdx.x, lane = tid & 63, lr = lane & 31, h = lane >> 5;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int m0 = blockIdx.x * 128 + wave * 32;                 // first row of this wave
-    const long grow = m0 + lr;                                   // this lane's row
-    const uint32_t sbase = __builtin_amdgcn_readfirstlane(lds_addr(smem));
-    float* vec = reinterpret_cast<float*>(smem + RC_OFF_VEC);
-    char* stg = smem + RC_OFF_STG + wave * 16384;
-    const uint32_t stg_u = sbase + RC_OFF_STG + wave * 16384;
-    const int NH = g.NH, NC = NH >> 7;                           // hidden chunks of 128 columns
-    const int Ttot = 8 + NC * 8;
-
-    // ---- weight-tile stream.  Kind B = [256 n][32 k] (stage 0 and fc2: every output column, a 32-wide k slice); kind A = [128 n][64 k]
-    // (fc1: the chunk's 128 hidden columns, a 64-wide k slice).  Both 16 KiB, 4 DMA pieces per wave.
-    const uint32_t c16b = (uint32_t)(((lane & 3) ^ ((lane >> 4) & 3)) << 4);
-    const uint32_t voffB_d = (uint32_t)((lane >> 2) * 512) + c16b, voffB_h = (uint32_t)((lane >> 2) * NH * 2) + c16b;
-    const uint32_t voffA0 = (uint32_t)((lane >> 3) * 512) + (uint32_t)((((lane & 7) ^ ((lane >> 4) & 7))) << 4);
-    const uint32_t voffA1 = (uint32_t)((lane >> 3) * 512) + (uint32_t)((((lane & 7) ^ ((4 + (lane >> 4)) & 7))) << 4);
-    int t_issue = 0, slot_issue = 0, slot_use = 0;
-    struct Tile { const char* sb; long pitch; uint32_t voff0, voff1, dst; };
-    auto next_tile = [&]() {
-        const int T = min(t_issue, Ttot - 1);
-        Tile t;
-        if (T < 8) {
-            t.sb = reinterpret_cast<const char*>(g.w0) + T * 64 + (long)wave * 64 * 512; t.pitch = 16 * 512; t.voff0 = t.voff1 = voffB_d;
-        } else {
-            const int u = T - 8, c = u >> 3, i = u & 7;
-            if (i < 4) { t.sb = reinterpret_cast<const char*>(g.w1) + ((long)c * 128 * 256 + 64 * i) * 2 + (long)wave * 32 * 512; t.pitch = 8 * 512;
-                         t.voff0 = voffA0; t.voff1 = voffA1; }
-            else { t.sb = reinterpret_cast<const char*>(g.w2) + (c * 128 + 32 * (i - 4)) * 2 + (long)wave * 64 * NH * 2; t.pitch = (long)16 * NH * 2;
-                   t.voff0 = t.voff1 = voffB_h; }
-        }
-        t.dst = sbase + RC_OFF_W + slot_issue * RF_WT_BYTES + wave * 4096;
-        ++t_issue;
-        slot_issue = slot_issue == RC_RING - 1 ? 0 : slot_issue + 1;
-        return t;
-    };
-    auto dma = [&](const Tile& t, int jj) { glds16_s(uniform_ptr(t.sb + jj * t.pitch), (jj & 1) ? t.voff1 : t.voff0, t.dst + jj * 1024); };
-    const uint32_t swB = (uint32_t)((lr >> 2) & 3), swA = (uint32_t)((lr >> 1) & 7);
-    typedef unsigned int u32x4v __attribute__((ext_vector_type(4)));
-    auto as_frag = [](u32x4v v) { return __builtin_bit_cast(bf16x8, v); };
-    // f = {A.lo, A.hi, B.lo, B.hi}: the lane's quads 2 (s & 1) and 2 (s & 1) + 1 of k-step s (columns 16 s + 4 h + e and 16 s + 8 + 4 h + e).
-    // Standard order wants columns 16 s + 8 h + 0..7: half-wave 0 keeps A and takes its partner's A, half-wave 1 keeps B and takes its partner's B
-    auto to_std = [](u32x4v f) {
-        const auto r0 = __builtin_amdgcn_permlane32_swap(f[0], f[2], false, false);
-        const auto r1 = __builtin_amdgcn_permlane32_swap(f[1], f[3], false, false);
-        return u32x4v{r0[0], r1[0], r0[1], r1[1]};
-    };
-    // one tile = 16 MFMAs (NT accumulator tiles x KS k-steps), the four DMA pieces of the tile three ahead between them.
-    // KIND 0 / 1: kind-B tile; 2: kind-A tile.  Weight fragments are always ONE ds_read_b128 in the standard k order: 8-byte LDS reads
-    // (the two halves a chained order would need) reach a fifth of their rate from one wave per SIMD -- 1650 cycles per tile measured --,
-    // so the accumulator-layout fragments are brought into the standard order instead, by two v_permlane32_swap per k-step (to_std)
-    auto step = [&](auto kind_c, auto nt_c, f32x16* acc, const u32x4v* af) {
-        constexpr int KIND = decltype(kind_c)::value, NT = decltype(nt_c)::value, KS = 16 / NT;
-        const Tile t = next_tile();
-        const char* wb = smem + RC_OFF_W + slot_use * RF_WT_BYTES;
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt) {
-                bf16x8 wf;
-                if (KIND != 2) wf = *reinterpret_cast<const bf16x8*>(wb + nt * 2048 + lr * 64 + (((2 * ks + h) ^ swB) << 4));
-                else wf = *reinterpret_cast<const bf16x8*>(wb + (nt * 32 + lr) * 128 + (((2 * ks + h) ^ swA) << 4));
-                acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf, as_frag(af[ks]), acc[nt], 0, 0, 0);
-                if (((ks * NT + nt) & 3) == 3) {
-                    __builtin_amdgcn_sched_barrier(0);
-                    dma(t, (ks * NT + nt) >> 2);
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-            }
-        }
-        slot_use = slot_use == RC_RING - 1 ? 0 : slot_use + 1;
-    };
-    // ---- private staging tile -> global, 16 B per lane, whole row segments
-    auto stage_bf_quad = [&](int base, int rowbytes, int chunk, uint32_t lo, uint32_t hi) {  // 4 bf16 / fp16 of this lane's row at 16-B chunk `chunk`, half h
-        *reinterpret_cast<uint2*>(stg + base + lr * rowbytes + ((chunk ^ (lr & 15)) << 4) + 8 * h) = make_uint2(lo, hi);
-    };
-    auto copy_rows8k = [&](int base, void* dst, long ld_bytes, long col_bytes) {               // 32 rows x 256 B (8 stores per lane)
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        // the lane's first address is made opaque here: the eight addresses are loop-invariant up to the chunk offset, and hoisted out of the
-        // chunk loop they cost 32 registers that went to scratch
-        unsigned long long a0 = (unsigned long long)(reinterpret_cast<char*>(dst) + (long)(m0 + (lane >> 4)) * ld_bytes + col_bytes + (lane & 15) * 16);
-        asm volatile("" : "+v"(a0));
-#pragma unroll
-        for (int it = 0; it < 8; ++it) {
-            const int r = it * 4 + (lane >> 4), cc = lane & 15;
-            const uint4 v = *reinterpret_cast<const uint4*>(stg + base + r * 256 + ((cc ^ (r & 15)) << 4));
-            *reinterpret_cast<uint4*>(a0 + (unsigned long long)(it * 4) * (unsigned long long)ld_bytes) = v;
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                     // the tile may be overwritten after this
-    };
-    auto copy_rows32 = [&](void* dst, long ld_bytes, long col_bytes) {                         // 32 rows x 512 B (16 stores per lane)
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#pragma unroll
-        for (int it = 0; it < 16; ++it) {
-            const int u = it * 64 + lane, r = u >> 5, cc = u & 31;
-            const uint4 v = *reinterpret_cast<const uint4*>(stg + r * 512 + ((cc ^ (r & 15)) << 4));
-            *reinterpret_cast<uint4*>(reinterpret_cast<char*>(dst) + (long)(m0 + r) * ld_bytes + col_bytes + cc * 16) = v;
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    };
-
-    RC_TS(0);
-    // ---- prologue: attention-output rows as standard-order fragments, three weight tiles, then the fp32 residual rows and the vectors
-    u32x4v of[16];
-#pragma unroll
-    for (int s = 0; s < 16; ++s) of[s] = *reinterpret_cast<const u32x4v*>(g.a0 + grow * 256 + 16 * s + 8 * h);
-    Tile t0 = next_tile(), t1 = next_tile(), t2 = next_tile();
-#pragma unroll
-    for (int jj = 0; jj < 4; ++jj) dma(t0, jj);
-#pragma unroll
-    for (int jj = 0; jj < 4; ++jj) dma(t1, jj);
-#pragma unroll
-    for (int jj = 0; jj < 4; ++jj) dma(t2, jj);
-    {
-        const float v0 = g.b0[tid], v1 = g.gamma[tid], v2 = g.beta[tid], v3 = g.b2[tid];
-        vec[tid] = v0; vec[256 + tid] = v1; vec[512 + tid] = v2; vec[768 + tid] = v3;
-        for (int i = tid; i < NH; i += 256) vec[1024 + i] = g.b1[i];
-    }
-    // the fp32 residual rows stay in flight through stage 0 (32 loads per lane, requested last: the counted waits below allow for them)
-    f32x16 x[8], rr[8];
-    const bool have_r = g.resid != nullptr;
-#pragma unroll
-    for (int nt = 0; nt < 8; ++nt)
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const float4 t = have_r ? *reinterpret_cast<const float4*>(g.resid + grow * 256 + nt * 32 + q * 8 + h * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
-            rr[nt][4 * q] = t.x; rr[nt][4 * q + 1] = t.y; rr[nt][4 * q + 2] = t.z; rr[nt][4 * q + 3] = t.w;
-        }
-#pragma unroll
-    for (int nt = 0; nt < 8; ++nt)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) x[nt][r] = 0.f;
-    RF_WAIT(48);                 // everything up to the first weight tile has landed (behind it: two tiles, the vectors, the residual rows)
-    RF_BARRIER();
-    RC_TS(1);
-
-    // ---- stage 0: x = a0 W0^T + b0 (+ resid)
-    using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>; using I2 = std::integral_constant<int, 2>;
-    using N8 = std::integral_constant<int, 8>; using N4 = std::integral_constant<int, 4>;
-#pragma unroll
-    for (int k = 0; k < 8; ++k) {
-        if (k > 0) { if (k < 3) RF_WAIT(48); else RF_WAIT(8); RF_BARRIER(); }
-        step(I0{}, N8{}, x, of + 2 * k);
-    }
-    RC_TS(2);
-#pragma unroll
-    for (int nt = 0; nt < 8; ++nt) {
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const float4 b = *reinterpret_cast<const float4*>(vec + nt * 32 + q * 8 + h * 4);
-            x[nt][4 * q] += b.x + rr[nt][4 * q]; x[nt][4 * q + 1] += b.y + rr[nt][4 * q + 1];
-            x[nt][4 * q + 2] += b.z + rr[nt][4 * q + 2]; x[nt][4 * q + 3] += b.w + rr[nt][4 * q + 3];
-        }
-        __builtin_amdgcn_sched_barrier(0);          // one accumulator tile at a time: the scheduler otherwise requests every vector first (spills)
-    }
-    // x -> global through the staging tile, 128 columns at a time
-#pragma unroll
-    for (int p = 0; p < 2; ++p) {
-#pragma unroll
-        for (int nt = 0; nt < 4; ++nt)
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int chunk = nt * 8 + q * 2 + h;
-                *reinterpret_cast<float4*>(stg + lr * 512 + ((chunk ^ (lr & 15)) << 4)) =
-                    make_float4(x[4 * p + nt][4 * q], x[4 * p + nt][4 * q + 1], x[4 * p + nt][4 * q + 2], x[4 * p + nt][4 * q + 3]);
-            }
-        copy_rows32(g.x_out, 1024, p * 512);
-    }
-    RC_TS(3);
-    // ---- LayerNorm: in-lane sums over the lane's 128 columns + the other half-wave's
-    u32x4v lnf[16];
-    {
-        float s = 0.f;
-#pragma unroll
-        for (int nt = 0; nt < 8; ++nt)
-#pragma unroll
-            for (int q = 0; q < 4; ++q) s += (x[nt][4 * q] + x[nt][4 * q + 1]) + (x[nt][4 * q + 2] + x[nt][4 * q + 3]);
-        s += __shfl_xor(s, 32, 64);
-        const float mu = s * (1.f / 256.f);
-        float v = 0.f;
-#pragma unroll
-        for (int nt = 0; nt < 8; ++nt)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) { const float d = x[nt][e] - mu; v = fmaf(d, d, v); }
-        v += __shfl_xor(v, 32, 64);
-        const float rs = rsqrtf(v * (1.f / 256.f) + g.eps);
-        if (h == 0) { g.mean[grow] = mu; g.rstd[grow] = rs; }
-#pragma unroll
-        for (int nt = 0; nt < 8; ++nt) {
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int col = nt * 32 + q * 8 + h * 4;
-                const float4 gm = *reinterpret_cast<const float4*>(vec + 256 + col), bt = *reinterpret_cast<const float4*>(vec + 512 + col);
-                const float o0 = (x[nt][4 * q] - mu) * rs * gm.x + bt.x, o1 = (x[nt][4 * q + 1] - mu) * rs * gm.y + bt.y;
-                const float o2 = (x[nt][4 * q + 2] - mu) * rs * gm.z + bt.z, o3 = (x[nt][4 * q + 3] - mu) * rs * gm.w + bt.w;
-                const uint32_t lo = pack_bf2(o0, o1), hi = pack_bf2(o2, o3);
-                lnf[2 * nt + (q >> 1)][(q & 1) * 2] = lo; lnf[2 * nt + (q >> 1)][(q & 1) * 2 + 1] = hi;
-                stage_bf_quad(0, 512, nt * 4 + q, lo, hi);
-            }
-        }
-        copy_rows32(g.ln_out, 512, 0);
-#pragma unroll
-        for (int s = 0; s < 16; ++s) lnf[s] = to_std(lnf[s]);
-        // the second residual input of the chain: y = x + b2 + fc2(...) accumulates on top of x
-#pragma unroll
-        for (int nt = 0; nt < 8; ++nt) {
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const float4 b = *reinterpret_cast<const float4*>(vec + 768 + nt * 32 + q * 8 + h * 4);
-                x[nt][4 * q] += b.x; x[nt][4 * q + 1] += b.y; x[nt][4 * q + 2] += b.z; x[nt][4 * q + 3] += b.w;
-            }
-            __builtin_amdgcn_sched_barrier(0);
-        }
-    }
-    RC_TS(5);
-    // ---- hidden chunks of 128 columns: fc1 (4 kind-A tiles) -> GELU on the accumulators -> fc2 k-slice (4 kind-B tiles) into x
-#pragma unroll 1
-    for (int c = 0; c < NC; ++c) {
-        f32x16 a1[4];
-#pragma unroll
-        for (int nt = 0; nt < 4; ++nt)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) a1[nt][r] = 0.f;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            // behind the DMAs of this chunk's first three fc1 tiles sit the 16 side-output stores of the previous chunk (chunk 0: the 50 of
-            // the x / LayerNorm outputs -- more, so 24 is safe there too)
-            if (k < 3) RF_WAIT(24); else RF_WAIT(8);
-            RF_BARRIER();
-            step(I2{}, N4{}, a1, lnf + 4 * k);
-        }
-        RC_TS(6 + 3 * c);
-        // fc2's k-slice t needs only accumulator tile t of fc1: GELU of one tile, then the fc2 tile that consumes it (8 fragment registers
-        // alive instead of 32, and the GELU arithmetic of a tile runs while the next weight tile is still in flight)
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            u32x4v hf[2];
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const float4 b = *reinterpret_cast<const float4*>(vec + 1024 + c * 128 + k * 32 + q * 8 + h * 4);
-                float v[4] = {a1[k][4 * q] + b.x, a1[k][4 * q + 1] + b.y, a1[k][4 * q + 2] + b.z, a1[k][4 * q + 3] + b.w}, gd[4];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    float cd, pd;
-                    gelu_parts(v[e], cd, pd);
-                    gd[e] = cd + v[e] * pd;
-                    v[e] = v[e] * cd;
-                }
-                const uint32_t lo = pack_bf2(v[0], v[1]), hi = pack_bf2(v[2], v[3]);
-                hf[q >> 1][(q & 1) * 2] = lo; hf[q >> 1][(q & 1) * 2 + 1] = hi;
-                stage_bf_quad(0, 256, k * 4 + q, lo, hi);                     // gelu(h): first half of the staging tile
-                typedef _Float16 h2 __attribute__((ext_vector_type(2)));
-                const h2 glo = {(_Float16)gd[0], (_Float16)gd[1]}, ghi = {(_Float16)gd[2], (_Float16)gd[3]};
-                stage_bf_quad(8192, 256, k * 4 + q, __builtin_bit_cast(uint32_t, glo), __builtin_bit_cast(uint32_t, ghi));   // gelu'(h): second half
-            }
-            hf[0] = to_std(hf[0]); hf[1] = to_std(hf[1]);
-            RF_WAIT(8); RF_BARRIER();
-            step(I1{}, N8{}, x, hf);
-        }
-        RC_TS(7 + 3 * c);
-        copy_rows8k(0, g.h_out, (long)NH * 2, (long)c * 256);
-        copy_rows8k(8192, g.hgrad_out, (long)NH * 2, (long)c * 256);
-        RC_TS(8 + 3 * c);
-    }
-    RC_TS(22);
-    RF_WAIT(0);
-    // ---- y (fp32, 128 columns at a time) and its bf16 copy through the staging tile
-#pragma unroll
-    for (int p = 0; p < 2; ++p) {
-#pragma unroll
-        for (int nt = 0; nt < 4; ++nt)
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int chunk = nt * 8 + q * 2 + h;
-                *reinterpret_cast<float4*>(stg + lr * 512 + ((chunk ^ (lr & 15)) << 4)) =
-                    make_float4(x[4 * p + nt][4 * q], x[4 * p + nt][4 * q + 1], x[4 * p + nt][4 * q + 2], x[4 * p + nt][4 * q + 3]);
-            }
-        copy_rows32(g.y32, 1024, p * 512);
-    }
-    if (g.y16) {
-#pragma unroll
-        for (int nt = 0; nt < 8; ++nt)
-#pragma unroll
-            for (int q = 0; q < 4; ++q)
-                stage_bf_quad(0, 512, nt * 4 + q, pack_bf2(x[nt][4 * q], x[nt][4 * q + 1]), pack_bf2(x[nt][4 * q + 2], x[nt][4 * q + 3]));
-        copy_rows32(g.y16, 512, 0);
-    }
-    RC_TS(31);
-#ifdef MRG_RF_TS
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    RC_TS(32);
-    RF_LDS_SYNC();
-    if (tid < 64) {
-        const unsigned long long* t = reinterpret_cast<const unsigned long long*>(smem + RC_OFF_TS);
-        g.rstd[blockIdx.x * 128 + tid] = (float)(long long)(t[tid] - t[0]);
-    }
-#endif
-    (void)stg_u;
-}
-
 }  // namespace
 
 extern "C" int mrg_rowfuse_fwd(const mrg_rowfuse_desc* d, hipStream_t stream) {
@@ -790,13 +464,6 @@ extern "C" int mrg_rowfuse_fwd(const mrg_rowfuse_desc* d, hipStream_t stream) {
     g.gamma = d->gamma; g.beta = d->beta; g.mean = d->mean; g.rstd = d->rstd; g.ln_out = (bf16_t*)d->ln_out;
     g.w1 = (const bf16_t*)d->w1; g.b1 = d->b1; g.h_out = (bf16_t*)d->h_out; g.hgrad_out = (_Float16*)d->hgrad_out;
     g.w2 = (const bf16_t*)d->w2; g.b2 = d->b2; g.y32 = d->y32; g.y16 = (bf16_t*)d->y16;
-    static const int chain = [] { const char* e = getenv("MRG_ROWCHAIN"); return e ? atoi(e) : 1; }();
-    if (proj && save && chain && d->M % 128 == 0 && d->NH % 128 == 0) {      // row-owner waves: 128-row workgroups, products chained through registers
-        const void* fn = (const void*)rowchain_fwd_kernel;
-        (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, RC_LDS_BYTES);
-        hipLaunchKernelGGL(rowchain_fwd_kernel, dim3(d->M / 128), dim3(256), (size_t)RC_LDS_BYTES, stream, g);
-        return mrg_check_launch("mrg_rowfuse_fwd");
-    }
     const dim3 grid(d->M / 64), block(256);
 #define MRG_RF(P_, M_, S_) do { const void* fn = (const void*)rowfuse_fwd_kernel<P_, M_, S_>; \
         (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, RF_LDS_BYTES); \

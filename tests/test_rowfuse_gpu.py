@@ -75,7 +75,7 @@ def test_layernorm_plus_projection(K, M, NH, save):
         assert ln is None and mean is None
 
 
-@pytest.mark.parametrize("M", [64, 6336, 256, 16384])       # M % 128 == 0 with the training outputs on: the row-owner-wave kernel (rowchain_fwd_kernel)
+@pytest.mark.parametrize("M", [64, 6336, 16384])
 @pytest.mark.parametrize("resid,save,twin", [(True, True, True), (False, True, False), (True, False, True), (False, False, False)])
 def test_post_attention_chain(K, M, resid, save, twin):
     from mirage_amd import _lib as L
@@ -117,8 +117,8 @@ def test_post_attention_chain(K, M, resid, save, twin):
         assert saved is None
 
 
-@pytest.mark.parametrize("M", [8256, 8192])
-def test_fused_chain_is_repeatable_and_refuses_ragged_tiles(K, M):
+def test_fused_chain_is_repeatable_and_refuses_ragged_tiles(K):
+    M = 8256
     o = rnd(M, 256, dtype=BF16, seed=21)
     r = rnd(M, 256, seed=22)
     proj, n, fc1, fc2 = _lin(256, 256, 23), _norm(25), _lin(1024, 256, 27), _lin(256, 1024, 29)
