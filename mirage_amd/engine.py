@@ -343,34 +343,25 @@ def block_fwd(blk, x32: torch.Tensor, save: bool, want_bf16_out: bool = False, d
     eps = blk.norm1.eps
     st = (N * 3 * D, 3 * D)
     adrop = attn_dropout_args(blk.attn)
-    if (ROWFUSE and dp is None and K.Halves.mode == 0 and blk.attn.qkv.bias is not None and K.rowfuse_ok(B * N, D, 3 * D)
-            and blk.mlp.fc1.weight.shape[0] == 1024):
-        # 256-wide blocks (the output adapters' decoder_transformer): norm1 + qkv and proj + residual + norm2 + mlp + residual as one launch each
-        if ROWFUSE & 1:
-            qkv, ln1, mean1, rstd1 = K.rowfuse_ln_proj(x32, blk.norm1, blk.attn.qkv, shadow(blk.attn.qkv.weight), save)
-        else:
-            ln1, mean1, rstd1 = K.ln_fwd(x32, blk.norm1.weight, blk.norm1.bias, eps)
-            qkv, _, _ = lin_fwd(ln1, blk.attn.qkv)
-        o, lse = K.attn_fwd(qkv[..., :D], qkv[..., D:2 * D], qkv[..., 2 * D:], B, H, N, N, hd, blk.attn.scale, st, st, st, need_lse=save, drop=adrop)
-        if ROWFUSE & 2:
-            x_out, x_out16, sv = K.rowfuse_mlp(o, blk.attn.proj, shadow(blk.attn.proj.weight), x32, blk.norm2, blk.mlp.fc1, shadow(blk.mlp.fc1.weight),
-                                               blk.mlp.fc2, shadow(blk.mlp.fc2.weight), save, want_bf16_out)
-            x_mid, ln2, mean2, rstd2, h_pre, h_act = sv if save else (None,) * 6
-        else:
-            x_mid, _, _ = lin_fwd(o, blk.attn.proj, out_dtype=F32, resid=x32)
-            ln2, mean2, rstd2 = K.ln_fwd(x_mid, blk.norm2.weight, blk.norm2.bias, blk.norm2.eps)
-            h_act, _, h_pre = lin_fwd(ln2, blk.mlp.fc1, gelu=True, save_pre=save)
-            x_out, x_out16, _ = lin_fwd(h_act, blk.mlp.fc2, out_dtype=F32, resid=x_mid, want_bf16_copy=want_bf16_out)
-        saved = (x32, ln1, mean1, rstd1, qkv, o, lse, x_mid, ln2, mean2, rstd2, h_pre, h_act, dp, adrop) if save else None
-        return x_out, x_out16, saved
-    ln1, mean1, rstd1 = K.ln_fwd(x32, blk.norm1.weight, blk.norm1.bias, eps)
-    qkv, _, _ = lin_fwd(ln1, blk.attn.qkv)
+    # 256-wide blocks (the output adapters' decoder_transformer) may run their row-local chains as one launch each (csrc/rowfuse.hip)
+    rf = ROWFUSE if (dp is None and K.Halves.mode == 0 and blk.attn.qkv.bias is not None and K.rowfuse_ok(B * N, D, 3 * D)
+                     and blk.mlp.fc1.weight.shape[0] == 1024) else 0
+    if rf & 1:
+        qkv, ln1, mean1, rstd1 = K.rowfuse_ln_proj(x32, blk.norm1, blk.attn.qkv, shadow(blk.attn.qkv.weight), save)
+    else:
+        ln1, mean1, rstd1 = K.ln_fwd(x32, blk.norm1.weight, blk.norm1.bias, eps)
+        qkv, _, _ = lin_fwd(ln1, blk.attn.qkv)
     o, lse = K.attn_fwd(qkv[..., :D], qkv[..., D:2 * D], qkv[..., 2 * D:], B, H, N, N, hd, blk.attn.scale, st, st, st, need_lse=save, drop=adrop)
-    x_mid, _, _ = lin_fwd(o, blk.attn.proj, out_dtype=F32, resid=x32, row_scale=dp[0] if dp else None, dropout=d_att)
-    ln2, mean2, rstd2 = K.ln_fwd(x_mid, blk.norm2.weight, blk.norm2.bias, blk.norm2.eps)
-    h_act, _, h_pre = lin_fwd(ln2, blk.mlp.fc1, gelu=True, save_pre=save)
-    x_out, x_out16, _ = lin_fwd(h_act, blk.mlp.fc2, out_dtype=F32, resid=x_mid, want_bf16_copy=want_bf16_out,
-                                row_scale=dp[1] if dp else None, dropout=d_mlp)
+    if rf & 2:
+        x_out, x_out16, sv = K.rowfuse_mlp(o, blk.attn.proj, shadow(blk.attn.proj.weight), x32, blk.norm2, blk.mlp.fc1, shadow(blk.mlp.fc1.weight),
+                                           blk.mlp.fc2, shadow(blk.mlp.fc2.weight), save, want_bf16_out)
+        x_mid, ln2, mean2, rstd2, h_pre, h_act = sv if save else (None,) * 6
+    else:
+        x_mid, _, _ = lin_fwd(o, blk.attn.proj, out_dtype=F32, resid=x32, row_scale=dp[0] if dp else None, dropout=d_att)
+        ln2, mean2, rstd2 = K.ln_fwd(x_mid, blk.norm2.weight, blk.norm2.bias, blk.norm2.eps)
+        h_act, _, h_pre = lin_fwd(ln2, blk.mlp.fc1, gelu=True, save_pre=save)
+        x_out, x_out16, _ = lin_fwd(h_act, blk.mlp.fc2, out_dtype=F32, resid=x_mid, want_bf16_copy=want_bf16_out,
+                                    row_scale=dp[1] if dp else None, dropout=d_mlp)
     saved = (x32, ln1, mean1, rstd1, qkv, o, lse, x_mid, ln2, mean2, rstd2, h_pre, h_act, dp, adrop) if save else None
     return x_out, x_out16, saved
 
@@ -775,35 +766,23 @@ def decoder_fwd(ad, enc32: torch.Tensor, enc16: torch.Tensor, ids_keep, ids_rest
     sq, skv = (Tq * Dd, Dd), (N * 2 * Dd, 2 * Dd)
     adrop = attn_dropout_args(ad.decoder)
     blocks = list(ad.decoder_transformer) if isinstance(ad.decoder_transformer, torch.nn.Sequential) else []
-    fuse = (ROWFUSE and K.rowfuse_ok(B * Tq, Dd, Dd) and K.rowfuse_ok(B * N, Dd, 2 * Dd) and ad.mlp.fc1.weight.shape[0] == 1024
-            and ad.decoder.q.bias is not None and ad.decoder.kv.bias is not None)
-    if fuse:
-        # one launch per row-local chain (csrc/rowfuse.hip): norm + projection of queries / context, and everything between the attention
-        # output and the next norm1 (proj, out_norm, mlp with its residual)
-        if ROWFUSE & 1:
-            qp, qn, mq, rq = K.rowfuse_ln_proj(queries, ad.query_norm, ad.decoder.q, shadow(ad.decoder.q.weight), save)
-            kv, cn, mc, rc = K.rowfuse_ln_proj(context, ad.context_norm, ad.decoder.kv, shadow(ad.decoder.kv.weight), save)
-        else:
-            qn, mq, rq = K.ln_fwd(queries, ad.query_norm.weight, ad.query_norm.bias, eps)
-            cn, mc, rc = K.ln_fwd(context, ad.context_norm.weight, ad.context_norm.bias, eps)
-            qp, _, _ = lin_fwd(qn, ad.decoder.q)
-            kv, _, _ = lin_fwd(cn, ad.decoder.kv)
-        o, lse = K.attn_fwd(qp, kv[..., :Dd], kv[..., Dd:], B, H, Tq, N, hd, ad.decoder.scale, sq, skv, skv, need_lse=save, drop=adrop)
-        if ROWFUSE & 2:
-            x2, x16, sv = K.rowfuse_mlp(o, ad.decoder.proj, shadow(ad.decoder.proj.weight), None, ad.out_norm, ad.mlp.fc1, shadow(ad.mlp.fc1.weight),
-                                        ad.mlp.fc2, shadow(ad.mlp.fc2.weight), save, len(blocks) == 0)          # :279-280
-            x1, on, mo, ro, h_pre, h_act = sv if save else (None,) * 6
-        else:
-            x1, _, _ = lin_fwd(o, ad.decoder.proj, out_dtype=F32)
-            on, mo, ro = K.ln_fwd(x1, ad.out_norm.weight, ad.out_norm.bias, eps)
-            h_act, _, h_pre = lin_fwd(on, ad.mlp.fc1, gelu=True, save_pre=save)
-            x2, x16, _ = lin_fwd(h_act, ad.mlp.fc2, out_dtype=F32, resid=x1, want_bf16_copy=(len(blocks) == 0))
+    # the row-local chains as one launch each (csrc/rowfuse.hip; MRG_ROWFUSE bit 0: norm + projection, bit 1: proj + out_norm + mlp)
+    rf = ROWFUSE if (K.rowfuse_ok(B * Tq, Dd, Dd) and K.rowfuse_ok(B * N, Dd, 2 * Dd) and ad.mlp.fc1.weight.shape[0] == 1024
+                     and ad.decoder.q.bias is not None and ad.decoder.kv.bias is not None) else 0
+    if rf & 1:
+        qp, qn, mq, rq = K.rowfuse_ln_proj(queries, ad.query_norm, ad.decoder.q, shadow(ad.decoder.q.weight), save)
+        kv, cn, mc, rc = K.rowfuse_ln_proj(context, ad.context_norm, ad.decoder.kv, shadow(ad.decoder.kv.weight), save)
     else:
         qn, mq, rq = K.ln_fwd(queries, ad.query_norm.weight, ad.query_norm.bias, eps)
         cn, mc, rc = K.ln_fwd(context, ad.context_norm.weight, ad.context_norm.bias, eps)
         qp, _, _ = lin_fwd(qn, ad.decoder.q)
         kv, _, _ = lin_fwd(cn, ad.decoder.kv)
-        o, lse = K.attn_fwd(qp, kv[..., :Dd], kv[..., Dd:], B, H, Tq, N, hd, ad.decoder.scale, sq, skv, skv, need_lse=save, drop=adrop)
+    o, lse = K.attn_fwd(qp, kv[..., :Dd], kv[..., Dd:], B, H, Tq, N, hd, ad.decoder.scale, sq, skv, skv, need_lse=save, drop=adrop)
+    if rf & 2:
+        x2, x16, sv = K.rowfuse_mlp(o, ad.decoder.proj, shadow(ad.decoder.proj.weight), None, ad.out_norm, ad.mlp.fc1, shadow(ad.mlp.fc1.weight),
+                                    ad.mlp.fc2, shadow(ad.mlp.fc2.weight), save, len(blocks) == 0)          # :279-280
+        x1, on, mo, ro, h_pre, h_act = sv if save else (None,) * 6
+    else:
         x1, _, _ = lin_fwd(o, ad.decoder.proj, out_dtype=F32)                                # :279 (no residual)
         on, mo, ro = K.ln_fwd(x1, ad.out_norm.weight, ad.out_norm.bias, eps)
         h_act, _, h_pre = lin_fwd(on, ad.mlp.fc1, gelu=True, save_pre=save)

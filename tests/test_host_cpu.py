@@ -2,6 +2,7 @@
 against fixtures captured from the reference (tools/gen_golden.py)."""
 import json
 import os
+import sys
 
 import numpy as np
 import pytest
@@ -246,3 +247,30 @@ def test_task_mask_columns_are_read_in_place_and_masked_pixel_coefficients():
     want = 2.0 * (pred.detach() - tgt) * up * coef.view(B, 1, 1, 1)
     keep = [0, 1, 3]                                                                # (the reference back-propagates NaN into sample 2)
     torch.testing.assert_close(pred.grad[keep], want[keep], rtol=1e-5, atol=1e-7)
+
+
+def test_bench_step_floors_are_consistent():
+    """bench.py's `roofline.hbm` (round 6): the whole step against its HBM floor (algorithmic bytes / 6.3 TB/s) and its MFMA floor (algorithmic
+    flops / 2.5 PF).  The byte model must reproduce the documented C2 figure (19.0 GB of encoder dataflow + 4.0 GB = 23.0 GB),
+    scale per GPU batch, and name the binding floor: HBM for the training configurations, MFMA (barely) for the encoder-only forward."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    b = importlib.util.module_from_spec(spec)
+    argv, sys.argv = sys.argv, ["bench.py"]
+    try:
+        spec.loader.exec_module(b)
+    finally:
+        sys.argv = argv
+    by = {name: b.algorithmic_bytes(m, doms, B, K, train) for name, (m, doms, B, K, train) in b.CONFIGS.items()}
+    assert abs(by["c2"] / 1e9 - 23.0) < 0.3
+    m, doms, B, K, train = b.CONFIGS["c4"]
+    assert abs(b.algorithmic_bytes(m, doms, 2 * B, K, train) / by["c4"] - 2.0) < 0.2          # activations dominate: ~2x at twice the batch
+    for name, ms in (("c2", 8.77), ("c4", 19.52), ("c5", 47.9)):
+        m, doms, B, K, train = b.CONFIGS[name]
+        fpi = b.flops_per_image(m, doms, K, train)
+        h = b.step_hbm(m, doms, B, K, train, ms, fpi)
+        assert h["binding_floor"] == ("mfma" if name == "c5" else "hbm")
+        floor = max(h["hbm_floor_ms"], h["mfma_floor_ms"])
+        assert abs(h["frac_of_binding_floor"] - floor / ms) < 1e-3 and 0.3 < h["frac_of_binding_floor"] < 0.5
+        assert abs(h["flop_per_byte"] - B * fpi / by[name]) < 0.2 and h["ridge_flop_per_byte"] > 390
+        assert abs(h["achieved_tbps"] - by[name] / (ms * 1e-3) / 1e12) < 2e-3
