@@ -83,6 +83,7 @@ def get_args(argv=None):
     p.add_argument("--data_path", required=True, type=str, help="'synthetic' or a folder with <domain>/*.npy")
     p.add_argument("--steps_per_epoch", default=None, type=int, help="synthetic data only")
     p.add_argument("--no_graph", action="store_true", help="run the step eagerly instead of replaying a hipGraph")
+    p.add_argument("--no_debug_images", action="store_true", help="skip the picture of the first step of every epoch (<output_dir>/debug/)")
     p.add_argument("--print_freq", default=10, type=int)
     a_cfg, remaining = config_parser.parse_known_args(argv)
     if a_cfg.config:
@@ -139,6 +140,58 @@ def npy_folder_loader(args, device, rank, world, seed):
     assert min(len(v) for v in files.values()) > 0, f"no .npy files under {args.data_path}/<domain>/"
     return PrefetchingNpyLoader(files, args.batch_size, device, augment=augment, rank=rank, world=world, seed=seed,
                                 num_workers=getattr(args, "num_workers", 8) or 8, prefetch=2)
+
+
+def debug_image(preds, masks, targets, patch_sizes):
+    """The picture `save_debug_images` of the reference composes at the first step of every epoch (run_pretraining.py:568-645): per task the
+    input on top of the prediction with the UNMASKED patches replaced by the input (mask: 1 = predicted), both resampled to 128 x 128 (nearest),
+    the tasks stacked vertically with an 8-pixel white line between them.  Layer maps: argmax of the class scores, both scaled by their maximum.
+    Returns [B, C, rows, 128] fp32 on the CPU (or None without tasks).  Logging only: plain torch on the host side, off the step."""
+    import torch.nn.functional as F
+    out = None
+    for task, pred in preds.items():
+        if task not in targets or task not in masks:
+            continue
+        p, x, m = pred.detach().float().cpu(), targets[task].detach().cpu(), masks[task].detach().cpu()
+        if x.dim() == 3:                                   # layer maps: class scores -> labels, both to 0..1 for the picture (:597-605)
+            p = F.softmax(p, dim=1).argmax(dim=1, keepdim=True).float()
+            x = x.unsqueeze(1).float()
+            p = p / p.max().clamp_min(1e-12)
+            x = x / x.max().clamp_min(1e-12)
+        else:
+            x = x.float()
+        P = patch_sizes[task] if isinstance(patch_sizes, dict) else patch_sizes
+        ph, pw = (P, P) if isinstance(P, int) else (P[0], P[1])
+        c, h, w = x.shape[1], x.shape[2] // ph, x.shape[3] // pw
+        mask = m.reshape(m.shape[0], c, h, w).float()      # 'b (c h w) -> b c h w' (:617)
+        mask = F.interpolate(mask, size=tuple(x.shape[2:]), mode="nearest")
+        p = p * mask + x * (1.0 - mask)
+        pair = torch.cat([F.interpolate(x, (128, 128), mode="nearest"), F.interpolate(p, (128, 128), mode="nearest")], dim=2)
+        out = pair if out is None else torch.cat([out, torch.ones(pair.shape[0], pair.shape[1], 8, pair.shape[3]), pair], dim=2)
+    return out
+
+
+def save_debug_images(preds, masks, targets, epoch, patch_sizes, output_dir):
+    """<output_dir>/debug/<epoch>_<task-task-...>.jpg, laid out like torchvision.utils.save_image's default grid (8 per row, 2 pixels of
+    padding, values clamped to [0, 1]) -- written with PIL, torchvision is not a dependency of this package."""
+    img = debug_image(preds, masks, targets, patch_sizes)
+    if img is None:
+        return None
+    from PIL import Image
+    B, C, H, W = img.shape
+    nrow = min(8, B)
+    ncol = (B + nrow - 1) // nrow
+    pad = 2
+    grid = torch.zeros(3, ncol * (H + pad) + pad, nrow * (W + pad) + pad)
+    for i in range(B):
+        r, c = divmod(i, nrow)
+        tile = img[i].expand(3, H, W) if C == 1 else img[i][:3]
+        grid[:, pad + r * (H + pad): pad + r * (H + pad) + H, pad + c * (W + pad): pad + c * (W + pad) + W] = tile
+    arr = (grid.clamp(0, 1) * 255 + 0.5).to(torch.uint8).permute(1, 2, 0).numpy()
+    path = Path(output_dir) / "debug" / f"{epoch}_{'-'.join(t for t in preds if t in targets and t in masks)}.jpg"
+    path.parent.mkdir(parents=True, exist_ok=True)
+    Image.fromarray(arr).save(path)
+    return path
 
 
 def save_model(args, epoch, model, optimizer):
@@ -258,6 +311,10 @@ def main(args):
                           f"served from it, {len(tuned)} tuned at warm-up" + (f" ({', '.join(tuned[:12])}{' ...' if len(tuned) > 12 else ''})" if tuned else ""),
                           flush=True)
             step.step(batch)
+            if it == 0 and rank == 0 and args.output_dir and not args.no_debug_images:
+                # the reference's picture of the first step of every epoch (run_pretraining.py:709-712): one host sync per epoch
+                path = save_debug_images(step.pred_images(), step.masks, batch, epoch, args.patch_size, args.output_dir)
+                print(f"Saving debug images: {path}", flush=True)
             if it % args.print_freq == 0 or it == steps_per_epoch - 1:
                 vals = {"loss": all_reduce_scalar_mean(step.loss.detach().clone().reshape(1))}
                 for t, l in step.task_losses.items():

@@ -274,3 +274,39 @@ def test_bench_step_floors_are_consistent():
         assert abs(h["frac_of_binding_floor"] - floor / ms) < 1e-3 and 0.3 < h["frac_of_binding_floor"] < 0.5
         assert abs(h["flop_per_byte"] - B * fpi / by[name]) < 0.2 and h["ridge_flop_per_byte"] > 390
         assert abs(h["achieved_tbps"] - by[name] / (ms * 1e-3) / 1e12) < 2e-3
+
+
+def test_debug_image_composition_matches_the_reference_recipe():
+    """run_pretraining.save_debug_images (reference run_pretraining.py:568-645): unmasked patches of the prediction replaced by the input, input
+    over prediction at 128 x 128 (nearest), tasks separated by an 8-pixel white line, layer maps as argmax / max; the file is the 8-per-row
+    grid torchvision.utils.save_image would write.  Restated independently here with einops, as the reference writes it."""
+    from einops import rearrange
+    import torch.nn.functional as F
+    from mirage_amd import run_pretraining as R
+    g = torch.Generator().manual_seed(5)
+    B = 3
+    x = {"bscan": torch.rand(B, 1, 64, 64, generator=g), "bscanlayermap": torch.randint(0, 13, (B, 16, 16), generator=g)}
+    preds = {"bscan": torch.rand(B, 1, 64, 64, generator=g).bfloat16(), "bscanlayermap": torch.randn(B, 13, 16, 16, generator=g).bfloat16()}
+    masks = {"bscan": torch.randint(0, 2, (B, 64), generator=g), "bscanlayermap": torch.randint(0, 2, (B, 64), generator=g)}
+    patch = {"bscan": (8, 8), "bscanlayermap": (2, 2)}
+    img = R.debug_image(preds, masks, x, patch)
+    rows = []
+    for t in preds:
+        p, inp = preds[t].float(), x[t]
+        if t == "bscanlayermap":
+            p = F.softmax(p, dim=1).argmax(dim=1, keepdim=True).float()
+            inp = inp.unsqueeze(1)
+            p = p / p.max(); inp = inp / inp.max()
+        c, h, w = inp.shape[1], inp.shape[2] // patch[t][0], inp.shape[3] // patch[t][1]
+        m = F.interpolate(rearrange(masks[t], "b (c h w) -> b c h w", c=c, h=h, w=w).float(), size=inp.shape[2:], mode="nearest")
+        p = p * m + inp * (1 - m)
+        rows += [F.interpolate(inp.float(), (128, 128), mode="nearest"), F.interpolate(p, (128, 128), mode="nearest"), torch.ones(B, 1, 8, 128)]
+    want = torch.cat(rows[:-1], dim=2)
+    assert img.shape == (B, 1, 2 * 256 + 8, 128) and torch.equal(img, want)
+    import tempfile
+    from PIL import Image
+    with tempfile.TemporaryDirectory() as d:
+        path = R.save_debug_images(preds, masks, x, 7, patch, d)
+        assert path.name == "7_bscan-bscanlayermap.jpg" and path.parent.name == "debug"
+        im = Image.open(path)
+        assert im.size == (3 * 130 + 2, 522 + 2) and im.mode == "RGB"

@@ -266,6 +266,11 @@ def test_driver_artifacts_and_resume(tmp_path):
     ck = torch.load(os.path.join(d, "checkpoint-1.pth"), map_location="cpu", weights_only=False)
     assert set(ck) >= {"model", "optimizer", "epoch", "scaler", "args"} and ck["epoch"] == 1
     assert "encoder.0.attn.qkv.weight" in ck["model"] and "input_adapters.bscan.proj.weight" in ck["model"]
+    # the picture of the first step of every epoch (reference run_pretraining.py:568-645, 709-712)
+    from PIL import Image
+    for ep in (0, 1):
+        im = Image.open(os.path.join(d, "debug", f"{ep}_bscan-slo.jpg"))
+        assert im.size == (2 * 130 + 2, 2 * 256 + 8 + 4)           # 2 samples side by side; (input over prediction) x 2 tasks + the white line
     # resume: one more epoch starts at epoch 2
     argv2 = [a if a != "2" else "3" for a in argv]
     argv2[argv2.index("--epochs") + 1] = "3"
